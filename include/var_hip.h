@@ -1,0 +1,124 @@
+/*
+ * var_hip.h -- C ABI of libvar_hip.so, the MI355X (gfx950) implementation of the
+ * VAR contrastive-pretext hot path of PeixinC/VoiceControlledRobot-VAR.
+ *
+ * The reference has no FFI: its seam is the class-valued config attribute
+ * `config.pretextModel = VARPretextNet`
+ * (Envs/pybullet/arms/tasks/fourInARow/config.py:30) and the torch calls made by
+ * VAR_Pretext.trainRepresentation (VAR/pretext_VAR.py:55-70).  Each entry point
+ * below names the reference code it stands in for.  INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (e.g. tensor.data_ptr());
+ *     the library owns only its context workspace;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); entries are
+ *     stream-ordered, never synchronise, never allocate (var_plan excepted) and are
+ *     therefore capturable into a HIP graph;
+ *   - return 0 on success, a negative VAR_ERR_* otherwise; var_last_error() gives text;
+ *   - layouts are the reference's: images NCHW (u8 or f32), MFCC (B,1,100,40) f32,
+ *     embeddings (B,3) row-major, parameters = the 26 state_dict() tensors of the Kuka
+ *     VARPretextNet (models/pretext/arm_pretext_model.py:39-56) back to back in
+ *     registration order, each in its PyTorch layout (OIHW / (out,in)): 213478 floats;
+ *   - one context per (process, device); a context is not re-entrant.
+ */
+#ifndef VAR_HIP_H
+#define VAR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VAR_OK 0
+#define VAR_ERR_ARG (-1)        /* bad argument (null pointer, unsupported size) */
+#define VAR_ERR_HIP (-2)        /* a HIP runtime call failed */
+#define VAR_ERR_PLAN (-3)       /* var_plan() not called or too small for this call */
+#define VAR_ERR_STATE (-4)      /* backward without a saved forward, etc. */
+
+#define VAR_N_PARAMS 213478
+#define VAR_EMB_DIM 3
+#define VAR_MFCC_FRAMES 100
+#define VAR_MFCC_COEFFS 40
+
+typedef struct var_ctx var_ctx;
+
+/* Library / context -------------------------------------------------------- */
+
+/* Create a context on `device_id` (replaces `model.to(device)`, pretext.py:306). */
+int var_init(int device_id, var_ctx** out);
+int var_destroy(var_ctx* ctx);
+const char* var_last_error(var_ctx* ctx);   /* ctx may be NULL: last init error */
+int var_param_count(void);                  /* == VAR_N_PARAMS */
+
+/* Size the context workspace (activations, gradient scratch, split-K slabs) for up
+ * to `max_batch` triplets of img_hw x img_hw images (84 or 96).  The only entry that
+ * allocates; call it outside the step loop / graph capture. */
+int var_plan(var_ctx* ctx, int max_batch, int img_hw);
+
+/* Re-derive the kernel-side weight images (conv filters re-laid as [tap][cin][cout]
+ * and [tap][cout][cin]) from the parameter arena.  Must follow every change of the
+ * parameters (load_state_dict, optimiser step); var_adam_step does it itself. */
+int var_pack_weights(var_ctx* ctx, void* stream, const float* params);
+
+/* Encoder ------------------------------------------------------------------
+ * PretextNetBase.VAR_forward (models/pretext/pretext_base.py:10-41) for the Kuka
+ * VARPretextNet: imgBranch -> imgTriplet -> F.normalize, soundCNN -> soundTriplet ->
+ * F.normalize for the positive and the negative clip.
+ *   image            (B,C>=3,H,H) u8 or f32, first 3 channels used (pretext_base.py:22);
+ *                    u8 images are divided by 255 as dataset.py:67-68 does; may be NULL
+ *   image_bstride    elements between consecutive images (C*H*H)
+ *   mfcc_pos/neg     (B,1,100,40) f32, either may be NULL
+ *   outputs          any may be NULL: image_feat/pos_feat/neg_feat (B,3),
+ *                    image_raw (B,576) = image_feat_raw, pos_raw (B,160) = pos_sound_raw
+ *   save_for_bwd     keep activations in the workspace for var_arm_encoder_bwd
+ */
+int var_arm_encoder_fwd(var_ctx* ctx, void* stream, const float* params,
+                        const void* image, int image_is_u8, long image_bstride,
+                        const float* mfcc_pos, const float* mfcc_neg, int B, int H,
+                        float* image_feat, float* pos_feat, float* neg_feat,
+                        float* image_raw, float* pos_raw, int save_for_bwd);
+
+/* autograd backward of the encoder (loss.backward(), VAR/pretext_VAR.py:68) from the
+ * gradients of the three embeddings; writes d(loss)/d(param) for all 213478
+ * parameters into `grads` (overwrites; arena layout).  Any g_* may be NULL (= zeros). */
+int var_arm_encoder_bwd(var_ctx* ctx, void* stream, const float* params,
+                        const float* g_image_feat, const float* g_pos_feat, const float* g_neg_feat,
+                        float* grads);
+
+/* torch.nn.TripletMarginLoss(margin, p=2, eps=1e-6, reduction='mean')
+ * (VAR/pretext_VAR.py:38,64) forward + backward in one launch.
+ * loss_out[0] = sum_i hinge_i * inv_count;  g* = d(loss_out)/d(a|p|n).
+ * inv_count = 1/B for the reference's mean; 1/B_global under data parallelism. */
+int var_triplet_fwd_bwd(var_ctx* ctx, void* stream, const float* a, const float* p, const float* n,
+                        int B, float margin, float inv_count,
+                        float* loss_out, float* ga, float* gp, float* gn);
+
+/* One fused training-step body: zero_grad -> model(image,pos,neg) -> triplet loss ->
+ * backward (VAR/pretext_VAR.py:56-68), everything up to but excluding optimizer.step().
+ * grads (arena) and loss_out[0] are overwritten.  feats_out (B,9) = [a|p|n] or NULL. */
+int var_arm_loss_grad(var_ctx* ctx, void* stream, const float* params,
+                      const void* image, int image_is_u8, long image_bstride,
+                      const float* mfcc_pos, const float* mfcc_neg, int B, int H,
+                      float margin, float inv_count,
+                      float* grads, float* loss_out, float* feats_out);
+
+/* torch.optim.Adam(lr, betas, eps, weight_decay) .step() (VAR/pretext_VAR.py:33-35,69)
+ * on flat arenas; `step` is the 1-based step count.  When n == VAR_N_PARAMS and
+ * params is the model arena the packed weight images are refreshed as well. */
+int var_adam_step(var_ctx* ctx, void* stream, float* params, const float* grads, float* exp_avg,
+                  float* exp_avg_sq, long n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int step);
+
+/* Audio front-end: Envs/audioLoader.py:147-157 (torchaudio MFCC branch) + :241-252
+ * (processSoundFeat).  pcm: nclips rows of `pcm_stride` int16 samples, lens[i] valid
+ * samples each (<= pcm_stride); out: (nclips, 1, out_frames, 40) f32, frames beyond
+ * 1 + len/160 are zero (MFCC-domain padding), frames beyond out_frames are dropped. */
+int var_mfcc(var_ctx* ctx, void* stream, const int16_t* pcm, const int* lens, int nclips,
+             int pcm_stride, int out_frames, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAR_HIP_H */

@@ -1,0 +1,231 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against (1) the golden vectors the reference produced and (2) the CPU oracle on seeded inputs.
+Tolerances: north_star's 1e-3 (fp32) on embeddings and loss; tighter where fp32 allows."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import var_oracle as orc  # noqa: E402  (checker only)
+from oracle import mfcc_np  # noqa: E402
+
+
+def cfg(h):
+    return types.SimpleNamespace(img_dim=(3, h, h), sound_dim=(1, 100, 40), representationDim=3)
+
+
+def load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name)))
+
+
+def rel_err(a, b):
+    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def var_amd():
+    import var_amd as m
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return m
+
+
+def make_model(var_amd, sd, h):
+    m = var_amd.VARPretextNet(cfg(h))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return m.to("cuda")
+
+
+def cuda(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+@pytest.mark.parametrize("h,ffile", [(84, "kuka_h84.npz"), (96, "kuka_h96.npz")])
+def test_conv_stack_layerwise_vs_oracle(var_amd, golden_dir, h, ffile):
+    sd = load(golden_dir, "kuka_weights.npz")
+    fx = load(golden_dir, ffile)
+    m = make_model(var_amd, sd, h)
+    with torch.no_grad():
+        m(cuda(fx['image']), cuda(fx['sound_positive']), cuda(fx['sound_negative']))
+    from var_amd._lib import Context
+    ctx = Context.get(0)
+    B = fx['image'].shape[0]
+    x = fx['image'].astype(np.float32) / np.float32(255.)
+    hs = h
+    chans = [3, 32, 32, 64, 64, 64]
+    for l in range(5):
+        w, b = sd[f'imgBranch.{2 * l}.weight'], sd[f'imgBranch.{2 * l}.bias']
+        y = orc.conv3x3s2_fwd(x, w, b)
+        hs = (hs - 1) // 2 + 1
+        got = ctx.debug_buffer(f"act{l + 1}").cpu().numpy()[:y.size].reshape(y.shape)
+        assert np.max(np.abs(got - y)) < 2e-5 * max(1.0, float(np.max(np.abs(y)))), f"conv{l + 1}"
+        x = y
+
+
+@pytest.mark.parametrize("wfile,ffile,h", [("kuka_weights.npz", "kuka_h84.npz", 84),
+                                           ("kuka_weights.npz", "kuka_h96.npz", 96),
+                                           ("kuka_weights2.npz", "kuka_h84_w2.npz", 84)])
+def test_forward_backward_vs_reference_fixtures(var_amd, golden_dir, wfile, ffile, h):
+    """Module path exactly as the reference loop uses it: model(...) -> torch TripletMarginLoss -> backward."""
+    sd = load(golden_dir, wfile)
+    fx = load(golden_dir, ffile)
+    m = make_model(var_amd, sd, h)
+    m.train()
+    image = (cuda(fx['image']) / 255.).float()                   # dataset.py:67-68
+    d = m(image, cuda(fx['sound_positive']), cuda(fx['sound_negative']))
+    for k in ('image_feat', 'sound_feat_positive', 'sound_feat_negative', 'image_feat_raw', 'pos_sound_raw'):
+        assert np.max(np.abs(d[k].detach().cpu().numpy() - fx[k])) < 1e-3, k
+        assert np.max(np.abs(d[k].detach().cpu().numpy() - fx[k])) < 5e-5 * max(1.0, np.max(np.abs(fx[k]))), k
+    assert d['image_BCE'] is None and d['sound_BCE'] is None
+    loss = torch.nn.TripletMarginLoss(margin=1.0, p=2)(d['image_feat'], d['sound_feat_positive'],
+                                                       d['sound_feat_negative'])
+    assert abs(loss.item() - float(fx['loss'])) < 1e-5
+    m.zero_grad()
+    loss.backward()
+    for k, p in m.named_parameters():
+        ref = fx['grad.' + k]
+        assert rel_err(p.grad.cpu().numpy(), ref) < 1e-3, (k, rel_err(p.grad.cpu().numpy(), ref))
+    # u8 image input: the /255 is fused into the first conv's load
+    with torch.no_grad():
+        d2 = m(cuda(fx['image']), cuda(fx['sound_positive']), None)
+    assert torch.equal(d2['image_feat'], d['image_feat'].detach())
+    assert d2['sound_feat_negative'] is None
+
+
+def test_fused_loss_grad_and_adam_vs_fixture(var_amd, golden_dir):
+    """Fused trainer (var_arm_loss_grad + var_adam_step) against the reference's 3-step Adam trajectory."""
+    sd = load(golden_dir, "kuka_weights.npz")
+    fx = load(golden_dir, "kuka_adam.npz")
+    m = make_model(var_amd, sd, 84)
+    tr = var_amd.VARTrainer(m, lr=1e-4, weight_decay=1e-6, margin=1.0)
+    p0 = orc.flatten_params(sd)
+    for s in range(3):
+        tr.step(cuda(fx[f'image{s}']), cuda(fx[f'pos{s}']), cuda(fx[f'neg{s}']))
+        assert abs(tr.loss.item() - float(fx['losses'][s])) < 1e-5
+        if s in (0, 2):
+            ref = orc.flatten_params({k: fx[f'step{s + 1}.' + k] for k, _ in orc.PARAM_SPECS})
+            got = m.flat_parameters().cpu().numpy()
+            diff = np.abs(got - ref)
+            # Adam turns rounding-level gradient differences on near-zero gradients into O(lr) moves
+            assert np.mean(diff < 2e-6) > 0.995
+            assert np.max(diff) < 1.05e-4 * (s + 1)
+            assert np.max(np.abs(got - p0)) < 1.05e-4 * (s + 1)
+    # state_dict round trip keeps the reference checkpoint layout
+    sd2 = m.state_dict()
+    assert list(sd2.keys()) == [k for k, _ in orc.PARAM_SPECS]
+    assert all(tuple(sd2[k].shape) == s for k, s in orc.PARAM_SPECS)
+
+
+def test_fused_grads_vs_oracle_random_batch(var_amd, golden_dir):
+    sd = load(golden_dir, "kuka_weights2.npz")
+    rng = np.random.default_rng(5)
+    B = 19                                                       # ragged: not a multiple of any tile
+    img = rng.integers(0, 256, size=(B, 3, 84, 84), dtype=np.uint8)
+    clips = mfcc_np.synth_clips(2 * B, seed=9)
+    feats = np.stack([mfcc_np.process_sound_feat(mfcc_np.mfcc_torchaudio(c).astype(np.float32)) for c in clips])
+    pos, neg = feats[:B].copy(), feats[B:].copy()
+    pos[3] = 0
+    neg[0] = 0
+    m = make_model(var_amd, sd, 84)
+    tr = var_amd.VARTrainer(m)
+    tr.loss_and_grads(cuda(img), cuda(pos), cuda(neg))
+    loss_ref, g_ref, _ = orc.loss_grad(orc.flatten_params(sd), img, pos, neg)
+    assert abs(tr.loss.item() - loss_ref) < 1e-5
+    got = orc.unflatten_params(tr.grads.cpu().numpy())
+    ref = orc.unflatten_params(g_ref)
+    for k, _ in orc.PARAM_SPECS:
+        assert rel_err(got[k], ref[k]) < 1e-3, (k, rel_err(got[k], ref[k]))
+
+
+def test_edge_behaviours(var_amd, golden_dir):
+    sd = load(golden_dir, "kuka_weights.npz")
+    fx = load(golden_dir, "kuka_edge.npz")
+    m = make_model(var_amd, sd, 84)
+    m.eval()
+    image = (cuda(fx['image']) / 255.).float()
+    with torch.no_grad():
+        a = m(image, cuda(fx['sound_positive']), None)
+        assert a['sound_feat_negative'] is None
+        assert np.max(np.abs(a['image_feat'].cpu().numpy() - fx['a.image_feat'])) < 1e-4
+        assert np.max(np.abs(a['sound_feat_positive'].cpu().numpy() - fx['a.sound_feat_positive'])) < 1e-4
+        assert np.max(np.abs(a['pos_sound_raw'].cpu().numpy() - fx['a.pos_sound_raw'])) < 1e-4
+        inf = torch.full_like(cuda(fx['sound_positive']), float('inf'))
+        b = m(image, inf, None)                                  # cached goal sound (pretext_base.py:29-32)
+        assert b['pos_sound_raw'] is None
+        assert np.max(np.abs(b['sound_feat_positive'].cpu().numpy() - fx['b.sound_feat_positive'])) < 1e-4
+        c = m(None, cuda(fx['sound_negative']), None)
+        assert c['image_feat'] is None and c['image_feat_raw'] is None
+        assert np.max(np.abs(c['sound_feat_positive'].cpu().numpy() - fx['c.sound_feat_positive'])) < 1e-4
+        img4 = torch.cat([image, torch.ones(4, 1, 84, 84, device='cuda')], dim=1)
+        d = m(img4, cuda(fx['sound_positive']), cuda(fx['sound_negative']))
+        assert np.max(np.abs(d['image_feat'].cpu().numpy() - fx['d.image_feat'])) < 1e-4
+        assert np.max(np.abs(d['sound_feat_negative'].cpu().numpy() - fx['d.sound_feat_negative'])) < 1e-4
+        reward = (d['image_feat'] * d['sound_feat_positive']).sum(1).cpu().numpy()   # vec_pretext_normalize.py:96-101
+        assert np.max(np.abs(reward - fx['d.reward'])) < 1e-4
+    with pytest.raises(var_amd.VarHipError):
+        m(image.cpu(), None, None)                               # no CPU fallback
+
+
+def test_triplet_op_vs_oracle(var_amd):
+    rng = np.random.default_rng(1)
+    for B in (1, 7, 256, 1000):
+        a, p, n = (rng.standard_normal((B, 3)).astype(np.float32) for _ in range(3))
+        a /= np.linalg.norm(a, axis=1, keepdims=True)
+        loss, ga, gp, gn = var_amd.triplet_margin_loss(cuda(a), cuda(p), cuda(n), margin=1.0)
+        l_ref, ga_r, gp_r, gn_r = orc.triplet(a, p, n)
+        assert abs(loss.item() - l_ref) < 1e-5
+        for g, r in ((ga, ga_r), (gp, gp_r), (gn, gn_r)):
+            assert np.max(np.abs(g.cpu().numpy() - r)) < 1e-6
+
+
+def test_mfcc_vs_oracle(var_amd):
+    clips = mfcc_np.synth_clips(6, seed=21)
+    lens = np.array([16000, 16000, 8000, 12345, 0, 16000], dtype=np.int32)
+    t = np.arange(16000) / 16000.0
+    clips[5] = np.round(20000 * np.sin(2 * np.pi * 440 * t)).astype(np.int16)     # clean tone: silent bins
+    out = var_amd.mfcc(cuda(clips), cuda(lens), 100).cpu().numpy()
+    assert out.shape == (6, 1, 100, 40)
+    for i in range(6):
+        if lens[i] == 0:
+            assert np.all(out[i] == 0)                           # "empty" class
+            continue
+        ref = mfcc_np.process_sound_feat(mfcc_np.mfcc_torchaudio(clips[i, :lens[i]]))
+        err = np.max(np.abs(out[i] - ref))
+        assert err < 2e-3, (i, err)                              # f32 front-end vs f64 oracle; |MFCC| up to ~1e2
+
+
+def test_batch_256_properties(var_amd, golden_dir):
+    """Full bench size: per-sample independence of the forward and linearity of the batch gradient."""
+    sd = load(golden_dir, "kuka_weights2.npz")
+    m = make_model(var_amd, sd, 84)
+    pool = var_amd.SyntheticTripletPool(512, hw=84, seed=3, clips_per_class=8)
+    idx, cp = pool.sample_indices(256)
+    img, pcm, lens = pool.gather(idx, cp)
+    feats = var_amd.mfcc(pcm, lens)
+    pos, neg = feats[:256].contiguous(), feats[256:].contiguous()
+    with torch.no_grad():
+        full = m(img, pos, neg)
+        part = m(img[64:128].contiguous(), pos[64:128].contiguous(), neg[64:128].contiguous())
+    for k in ('image_feat', 'sound_feat_positive', 'sound_feat_negative', 'image_feat_raw'):
+        assert torch.equal(full[k][64:128], part[k]), k
+    tr = var_amd.VARTrainer(m)
+    tr.loss_and_grads(img, pos, neg)
+    g_full, l_full = tr.grads.clone(), tr.loss.item()
+    acc, lacc = torch.zeros_like(g_full), 0.0
+    for s in range(4):
+        sl = slice(64 * s, 64 * s + 64)
+        tr.loss_and_grads(img[sl].contiguous(), pos[sl].contiguous(), neg[sl].contiguous())
+        acc += tr.grads / 4
+        lacc += tr.loss.item() / 4
+    assert abs(l_full - lacc) < 1e-5
+    assert float((g_full - acc).abs().max()) < 1e-3 * float(acc.abs().max())
+    # and against the oracle on a 32-sample slice
+    sl = slice(0, 32)
+    tr.loss_and_grads(img[sl].contiguous(), pos[sl].contiguous(), neg[sl].contiguous())
+    l_ref, g_ref, _ = orc.loss_grad(orc.flatten_params(sd), img[sl].cpu().numpy(), pos[sl].cpu().numpy(),
+                                    neg[sl].cpu().numpy())
+    assert abs(tr.loss.item() - l_ref) < 1e-5
+    assert rel_err(tr.grads.cpu().numpy(), g_ref) < 1e-3

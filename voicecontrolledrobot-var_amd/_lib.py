@@ -1,0 +1,121 @@
+"""ctypes binding of libvar_hip.so (include/var_hip.h).  Fails loudly when the library is
+missing or a call returns an error -- there is no fallback path."""
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libvar_hip.so")
+_lib = None
+_lock = threading.Lock()
+
+
+class VarHipError(RuntimeError):
+    pass
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def build_library(force=False):
+    """Compile csrc/*.hip for gfx950 into libvar_hip.so (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8", "-s"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return _LIB_PATH
+
+
+_vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+
+_SIGNATURES = {
+    "var_init": (_i, [_i, ctypes.POINTER(_vp)]),
+    "var_destroy": (_i, [_vp]),
+    "var_last_error": (ctypes.c_char_p, [_vp]),
+    "var_param_count": (_i, []),
+    "var_plan": (_i, [_vp, _i, _i]),
+    "var_pack_weights": (_i, [_vp, _vp, _vp]),
+    "var_arm_encoder_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i]),
+    "var_arm_encoder_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "var_triplet_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp]),
+    "var_arm_loss_grad": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
+    "var_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i]),
+    "var_mfcc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "var_debug_buffer": (_i, [_vp, ctypes.c_char_p, ctypes.POINTER(_vp), ctypes.POINTER(_l)]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
+
+
+def load_library():
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(_LIB_PATH):
+                raise VarHipError(
+                    f"{_LIB_PATH} is missing: build it with `python __graft_entry__.py` "
+                    "(there is no CPU/eager fallback for the VAR hot path)")
+            lib = ctypes.CDLL(_LIB_PATH)
+            for name, (res, args) in _SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+class Context:
+    """One var_ctx per (process, device)."""
+    _by_device = {}
+
+    def __init__(self, device_index):
+        self.lib = load_library()
+        self.device_index = int(device_index)
+        h = _vp()
+        rc = self.lib.var_init(self.device_index, ctypes.byref(h))
+        if rc != 0:
+            raise VarHipError(f"var_init({device_index}) failed ({rc}): {self.lib.var_last_error(None).decode()}")
+        self.handle = h
+        self.plan = (0, 0)
+
+    @classmethod
+    def get(cls, device_index):
+        ctx = cls._by_device.get(device_index)
+        if ctx is None:
+            ctx = cls._by_device[device_index] = Context(device_index)
+        return ctx
+
+    def check(self, rc, what):
+        if rc != 0:
+            raise VarHipError(f"{what} failed ({rc}): {self.lib.var_last_error(self.handle).decode()}")
+
+    def ensure_plan(self, batch, hw):
+        if self.plan[1] != hw or self.plan[0] < batch:
+            self.check(self.lib.var_plan(self.handle, int(batch), int(hw)), "var_plan")
+            self.plan = (int(batch), int(hw))
+
+    def debug_buffer(self, name):
+        import torch
+        p, n = _vp(), _l()
+        self.check(self.lib.var_debug_buffer(self.handle, name.encode(), ctypes.byref(p), ctypes.byref(n)),
+                   "var_debug_buffer")
+        out = torch.empty(n.value, dtype=torch.float32, device=f"cuda:{self.device_index}")
+        torch.cuda.synchronize()
+        # raw D2D copy through a ctypes-wrapped view is not available; use hipMemcpy via torch's runtime
+        rt = ctypes.CDLL("libamdhip64.so")
+        rt.hipMemcpy.argtypes = [_vp, _vp, ctypes.c_size_t, _i]
+        rc = rt.hipMemcpy(out.data_ptr(), p, n.value * 4, 3)   # hipMemcpyDeviceToDevice
+        if rc != 0:
+            raise VarHipError(f"hipMemcpy failed ({rc})")
+        return out
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def current_stream_handle():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,286 @@
+// C-ABI entry points of libvar_hip.so (see include/var_hip.h).
+#include <new>
+#include <string.h>
+
+#include "var_common.h"
+
+static char g_init_err[256] = "";
+
+#define CHECK_CTX(ctx) do { if (!(ctx)) return VAR_ERR_ARG; } while (0)
+#define SET_DEVICE(ctx) VAR_HIP_CHECK(ctx, hipSetDevice((ctx)->device))
+
+extern "C" {
+
+int var_param_count(void) { return VAR_N_PARAMS; }
+
+const char* var_last_error(var_ctx* ctx) { return ctx ? ctx->err : g_init_err; }
+
+int var_init(int device_id, var_ctx** out) {
+    if (!out) return VAR_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || device_id < 0 || device_id >= n) {
+        snprintf(g_init_err, sizeof(g_init_err), "var_init: device %d not available (%d HIP devices, %s)",
+                 device_id, n, hipGetErrorString(e));
+        return VAR_ERR_HIP;
+    }
+    var_ctx* c = new (std::nothrow) var_ctx();
+    if (!c) return VAR_ERR_HIP;
+    c->device = device_id;
+    c->pl = make_param_layout();
+    c->kl = make_pack_layout();
+    if (c->pl.total != VAR_N_PARAMS) {
+        snprintf(g_init_err, sizeof(g_init_err), "var_init: layout mismatch %d", c->pl.total);
+        delete c;
+        return VAR_ERR_ARG;
+    }
+    e = hipSetDevice(device_id);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->wpack, sizeof(float) * (size_t)c->kl.total);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->loss_buf, sizeof(float) * 64);
+    if (e != hipSuccess) {
+        snprintf(g_init_err, sizeof(g_init_err), "var_init: %s", hipGetErrorString(e));
+        delete c;
+        return VAR_ERR_HIP;
+    }
+    if (mfcc_build_tables(c) != VAR_OK) {
+        snprintf(g_init_err, sizeof(g_init_err), "var_init: %s", c->err);
+        delete c;
+        return VAR_ERR_HIP;
+    }
+    *out = c;
+    return VAR_OK;
+}
+
+int var_destroy(var_ctx* c) {
+    CHECK_CTX(c);
+    (void)hipSetDevice(c->device);
+    if (c->ws) (void)hipFree(c->ws);
+    if (c->wpack) (void)hipFree(c->wpack);
+    if (c->loss_buf) (void)hipFree(c->loss_buf);
+    if (c->mfcc_tab) (void)hipFree(c->mfcc_tab);
+    delete c;
+    return VAR_OK;
+}
+
+int var_plan(var_ctx* c, int max_batch, int img_hw) {
+    CHECK_CTX(c);
+    if (max_batch <= 0 || (img_hw != 84 && img_hw != 96)) {
+        VAR_SET_ERR(c, "var_plan: batch %d / image size %d unsupported (size must be 84 or 96)", max_batch, img_hw);
+        return VAR_ERR_ARG;
+    }
+    SET_DEVICE(c);
+    if (c->ws && c->maxB >= max_batch && c->H == img_hw) return VAR_OK;
+    if (c->ws) { VAR_HIP_CHECK(c, hipFree(c->ws)); c->ws = nullptr; }
+    const size_t B = (size_t)max_batch;
+    int hs[6];
+    hs[0] = img_hw;
+    for (int i = 0; i < 5; i++) hs[i + 1] = conv_out(hs[i]);
+    size_t off = 0;
+    auto carve = [&](size_t nfloats) { size_t o = off; off += (nfloats * 4 + 255) & ~(size_t)255; return o; };
+    size_t o_act[6], o_gact[6], o_sact[5], o_gsact[5];
+    for (int l = 1; l <= 5; l++) {
+        const size_t n = B * kImgCh[l] * hs[l] * hs[l];
+        o_act[l] = carve(n);
+        o_gact[l] = carve(n);
+    }
+    for (int l = 1; l <= 4; l++) {
+        const size_t n = 2 * B * 32 * kSndT[l];
+        o_sact[l] = carve(n);
+        o_gsact[l] = carve(n);
+    }
+    const size_t o_hid_i = carve(B * kHid), o_hid_s = carve(2 * B * kHid);
+    const size_t o_emb = carve(9 * B), o_emb_raw = carve(9 * B), o_gemb = carve(18 * B);
+    const size_t o_ghid = carve(3 * B * kHid);
+    const size_t n_img_slab = img_slab_floats(), n_snd_slab = snd_slab_floats();
+    const size_t o_slab = carve(n_img_slab + n_snd_slab);
+    VAR_HIP_CHECK(c, hipMalloc((void**)&c->ws, off));
+    VAR_HIP_CHECK(c, hipMemset(c->ws, 0, off));
+    c->ws_bytes = off;
+    auto P = [&](size_t o) { return (float*)(c->ws + o); };
+    for (int l = 1; l <= 5; l++) { c->act[l] = P(o_act[l]); c->gact[l] = P(o_gact[l]); }
+    for (int l = 1; l <= 4; l++) { c->sact[l] = P(o_sact[l]); c->gsact[l] = P(o_gsact[l]); }
+    c->hid_i = P(o_hid_i); c->hid_s = P(o_hid_s);
+    c->emb = P(o_emb); c->emb_raw = P(o_emb_raw); c->gemb = P(o_gemb); c->ghid = P(o_ghid);
+    c->slabs = P(o_slab);
+    c->slab_floats = n_img_slab + n_snd_slab;
+    c->snd_slab_off = n_img_slab;
+    c->maxB = max_batch;
+    c->H = img_hw;
+    for (int i = 0; i < 6; i++) c->hs[i] = hs[i];
+    c->saved_B = 0;
+    return VAR_OK;
+}
+
+int var_pack_weights(var_ctx* c, void* stream, const float* params) {
+    CHECK_CTX(c);
+    if (!params) { VAR_SET_ERR(c, "var_pack_weights: null params"); return VAR_ERR_ARG; }
+    SET_DEVICE(c);
+    return launch_pack_weights(c, (hipStream_t)stream, params);
+}
+
+static int check_plan(var_ctx* c, int B, int H, const char* who) {
+    if (!c->ws) { VAR_SET_ERR(c, "%s: var_plan() has not been called", who); return VAR_ERR_PLAN; }
+    if (B <= 0) { VAR_SET_ERR(c, "%s: batch %d", who, B); return VAR_ERR_ARG; }
+    if (B > c->maxB || H != c->H) {
+        VAR_SET_ERR(c, "%s: batch %d / size %d exceeds the plan (%d / %d)", who, B, H, c->maxB, c->H);
+        return VAR_ERR_PLAN;
+    }
+    return VAR_OK;
+}
+
+static int encoder_fwd(var_ctx* c, hipStream_t s, const float* params, const void* image, int is_u8,
+                       long bstride, const float* pos, const float* neg, int B) {
+    int rc;
+    if (image && (rc = launch_img_fwd(c, s, params, image, is_u8, bstride, B)) != VAR_OK) return rc;
+    if ((pos || neg) && (rc = launch_snd_fwd(c, s, params, pos, neg, B)) != VAR_OK) return rc;
+    if ((rc = launch_heads_fwd(c, s, params, B, image != nullptr, pos != nullptr, neg != nullptr)) != VAR_OK) return rc;
+    c->saved_B = B;
+    c->saved_image = image;
+    c->saved_u8 = is_u8;
+    c->saved_bstride = bstride;
+    c->saved_pos = pos;
+    c->saved_neg = neg;
+    return VAR_OK;
+}
+
+int var_arm_encoder_fwd(var_ctx* c, void* stream, const float* params, const void* image, int image_is_u8,
+                        long image_bstride, const float* mfcc_pos, const float* mfcc_neg, int B, int H,
+                        float* image_feat, float* pos_feat, float* neg_feat, float* image_raw, float* pos_raw,
+                        int save_for_bwd) {
+    CHECK_CTX(c);
+    if (!params) { VAR_SET_ERR(c, "var_arm_encoder_fwd: null params"); return VAR_ERR_ARG; }
+    if (image && image_bstride < 3L * H * H) { VAR_SET_ERR(c, "var_arm_encoder_fwd: image stride %ld < 3*H*H", image_bstride); return VAR_ERR_ARG; }
+    int rc = check_plan(c, B, H, "var_arm_encoder_fwd");
+    if (rc != VAR_OK) return rc;
+    SET_DEVICE(c);
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = encoder_fwd(c, s, params, image, image_is_u8, image_bstride, mfcc_pos, mfcc_neg, B)) != VAR_OK) return rc;
+    if (!save_for_bwd) c->saved_B = 0;
+    const size_t e = sizeof(float) * 3 * (size_t)B;
+    if (image && image_feat) VAR_HIP_CHECK(c, hipMemcpyAsync(image_feat, c->emb, e, hipMemcpyDeviceToDevice, s));
+    if (mfcc_pos && pos_feat) VAR_HIP_CHECK(c, hipMemcpyAsync(pos_feat, c->emb + 3 * B, e, hipMemcpyDeviceToDevice, s));
+    if (mfcc_neg && neg_feat) VAR_HIP_CHECK(c, hipMemcpyAsync(neg_feat, c->emb + 6 * B, e, hipMemcpyDeviceToDevice, s));
+    if (image && image_raw)
+        VAR_HIP_CHECK(c, hipMemcpyAsync(image_raw, c->act[5], sizeof(float) * kImgFeat * (size_t)B, hipMemcpyDeviceToDevice, s));
+    if (mfcc_pos && pos_raw)
+        VAR_HIP_CHECK(c, hipMemcpyAsync(pos_raw, c->sact[4], sizeof(float) * kSndFeat * (size_t)B, hipMemcpyDeviceToDevice, s));
+    return VAR_OK;
+}
+
+static int encoder_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads) {
+    const int B = c->saved_B;
+    int rc;
+    if (!c->saved_image || !c->saved_pos || !c->saved_neg) {
+        // a branch that did not run contributes zero gradient
+        VAR_HIP_CHECK(c, hipMemsetAsync(grads, 0, sizeof(float) * VAR_N_PARAMS, s));
+    }
+    const int snd_lo = c->saved_pos ? 0 : B, snd_hi = c->saved_neg ? 2 * B : B;
+    if ((rc = launch_heads_bwd(c, s, params, grads, B, c->saved_image != nullptr, snd_lo, snd_hi)) != VAR_OK) return rc;
+    if (c->saved_image && (rc = launch_img_bwd(c, s, params, grads, B)) != VAR_OK) return rc;
+    if ((rc = launch_snd_bwd(c, s, params, grads, B)) != VAR_OK) return rc;
+    return VAR_OK;
+}
+
+int var_arm_encoder_bwd(var_ctx* c, void* stream, const float* params, const float* g_image_feat,
+                        const float* g_pos_feat, const float* g_neg_feat, float* grads) {
+    CHECK_CTX(c);
+    if (!params || !grads) { VAR_SET_ERR(c, "var_arm_encoder_bwd: null params/grads"); return VAR_ERR_ARG; }
+    if (c->saved_B <= 0) { VAR_SET_ERR(c, "var_arm_encoder_bwd: no forward saved (save_for_bwd=1 required)"); return VAR_ERR_STATE; }
+    SET_DEVICE(c);
+    hipStream_t s = (hipStream_t)stream;
+    const int B = c->saved_B;
+    const size_t e = sizeof(float) * 3 * (size_t)B;
+    const float* g[3] = {g_image_feat, g_pos_feat, g_neg_feat};
+    for (int i = 0; i < 3; i++) {
+        if (g[i]) VAR_HIP_CHECK(c, hipMemcpyAsync(c->gemb + 3 * B * i, g[i], e, hipMemcpyDeviceToDevice, s));
+        else VAR_HIP_CHECK(c, hipMemsetAsync(c->gemb + 3 * B * i, 0, e, s));
+    }
+    return encoder_bwd(c, s, params, grads);
+}
+
+int var_triplet_fwd_bwd(var_ctx* c, void* stream, const float* a, const float* p, const float* n, int B,
+                        float margin, float inv_count, float* loss_out, float* ga, float* gp, float* gn) {
+    CHECK_CTX(c);
+    if (!a || !p || !n || !loss_out || B <= 0) { VAR_SET_ERR(c, "var_triplet_fwd_bwd: bad argument"); return VAR_ERR_ARG; }
+    SET_DEVICE(c);
+    return launch_triplet(c, (hipStream_t)stream, a, p, n, B, margin, inv_count, loss_out, ga, gp, gn);
+}
+
+int var_arm_loss_grad(var_ctx* c, void* stream, const float* params, const void* image, int image_is_u8,
+                      long image_bstride, const float* mfcc_pos, const float* mfcc_neg, int B, int H,
+                      float margin, float inv_count, float* grads, float* loss_out, float* feats_out) {
+    CHECK_CTX(c);
+    if (!params || !image || !mfcc_pos || !mfcc_neg || !grads || !loss_out) {
+        VAR_SET_ERR(c, "var_arm_loss_grad: null argument");
+        return VAR_ERR_ARG;
+    }
+    if (image_bstride < 3L * H * H) { VAR_SET_ERR(c, "var_arm_loss_grad: image stride %ld < 3*H*H", image_bstride); return VAR_ERR_ARG; }
+    int rc = check_plan(c, B, H, "var_arm_loss_grad");
+    if (rc != VAR_OK) return rc;
+    SET_DEVICE(c);
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = encoder_fwd(c, s, params, image, image_is_u8, image_bstride, mfcc_pos, mfcc_neg, B)) != VAR_OK) return rc;
+    if ((rc = launch_triplet(c, s, c->emb, c->emb + 3 * B, c->emb + 6 * B, B, margin, inv_count, loss_out,
+                             c->gemb, c->gemb + 3 * B, c->gemb + 6 * B)) != VAR_OK) return rc;
+    if (feats_out)
+        VAR_HIP_CHECK(c, hipMemcpyAsync(feats_out, c->emb, sizeof(float) * 9 * (size_t)B, hipMemcpyDeviceToDevice, s));
+    return encoder_bwd(c, s, params, grads);
+}
+
+int var_adam_step(var_ctx* c, void* stream, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                  long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step) {
+    CHECK_CTX(c);
+    if (!params || !grads || !exp_avg || !exp_avg_sq || n <= 0 || step < 1) {
+        VAR_SET_ERR(c, "var_adam_step: bad argument");
+        return VAR_ERR_ARG;
+    }
+    SET_DEVICE(c);
+    hipStream_t s = (hipStream_t)stream;
+    int rc = launch_adam(c, s, params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step);
+    if (rc != VAR_OK) return rc;
+    if (n == VAR_N_PARAMS) return launch_pack_weights(c, s, params);
+    return VAR_OK;
+}
+
+int var_mfcc(var_ctx* c, void* stream, const int16_t* pcm, const int* lens, int nclips, int pcm_stride,
+             int out_frames, float* out) {
+    CHECK_CTX(c);
+    if (!pcm || !lens || !out || nclips <= 0 || pcm_stride <= 0 || out_frames <= 0) {
+        VAR_SET_ERR(c, "var_mfcc: bad argument");
+        return VAR_ERR_ARG;
+    }
+    SET_DEVICE(c);
+    return launch_mfcc(c, (hipStream_t)stream, pcm, lens, nclips, pcm_stride, out_frames, out);
+}
+
+/* Testing hook: address and length (floats) of a workspace buffer, by name
+ * ("act1".."act5", "gact1".."gact5", "sact1".."sact4", "gsact1".."gsact4", "emb", "gemb", "wpack"). */
+int var_debug_buffer(var_ctx* c, const char* name, void** ptr, long* nfloats) {
+    CHECK_CTX(c);
+    if (!name || !ptr || !nfloats) return VAR_ERR_ARG;
+    const size_t B = c->maxB;
+    *ptr = nullptr; *nfloats = 0;
+    if (!strcmp(name, "wpack")) { *ptr = c->wpack; *nfloats = c->kl.total; return VAR_OK; }
+    if (!c->ws) { VAR_SET_ERR(c, "var_debug_buffer: no plan"); return VAR_ERR_PLAN; }
+    for (int l = 1; l <= 5; l++) {
+        char a[16], g[16];
+        snprintf(a, sizeof a, "act%d", l); snprintf(g, sizeof g, "gact%d", l);
+        const long n = (long)(B * kImgCh[l] * c->hs[l] * c->hs[l]);
+        if (!strcmp(name, a)) { *ptr = c->act[l]; *nfloats = n; return VAR_OK; }
+        if (!strcmp(name, g)) { *ptr = c->gact[l]; *nfloats = n; return VAR_OK; }
+    }
+    for (int l = 1; l <= 4; l++) {
+        char a[16], g[16];
+        snprintf(a, sizeof a, "sact%d", l); snprintf(g, sizeof g, "gsact%d", l);
+        const long n = (long)(2 * B * 32 * kSndT[l]);
+        if (!strcmp(name, a)) { *ptr = c->sact[l]; *nfloats = n; return VAR_OK; }
+        if (!strcmp(name, g)) { *ptr = c->gsact[l]; *nfloats = n; return VAR_OK; }
+    }
+    if (!strcmp(name, "emb")) { *ptr = c->emb; *nfloats = 9 * (long)B; return VAR_OK; }
+    if (!strcmp(name, "gemb")) { *ptr = c->gemb; *nfloats = 9 * (long)B; return VAR_OK; }
+    VAR_SET_ERR(c, "var_debug_buffer: unknown buffer '%s'", name);
+    return VAR_ERR_ARG;
+}
+
+}  // extern "C"

@@ -1,0 +1,215 @@
+// Image CNN forward: 5 x [Conv2d 3x3 stride 2 pad 1 + bias + ReLU]
+// (models/pretext/arm_pretext_model.py:9-18), hand-written for gfx950.
+//
+// Implicit GEMM on the f32 matrix cores, D[n][pixel] = sum_k W[n][k] * X[k][pixel]:
+//   A operand = filter  (rows = output channel n),  read from the packed image Wf[k][n] (L2-resident)
+//   B operand = input   (cols = output pixel),      read from an LDS-staged band of input rows
+//   k = tap*CIN + c, two k per v_mfma_f32_32x32x2_f32 (lane>>5 selects which).
+// A workgroup owns NU "units"; a unit is R output rows (full width) of one image, whose
+// 2R+1 input rows x CIN planes are staged once into LDS ([c][row][col], left/right/top/bottom
+// zero padding materialised), so every input element is fetched from HBM/L2 once per unit and
+// then reused by up to 9 taps x COUT channels from LDS.  Output pixels of all units are
+// flattened and cut into 32-pixel blocks; (pixel block, 32-channel block) items are dealt
+// round-robin to the NW waves.  The u8 -> f32 "/255" of dataset.py:67-68 is fused into
+// the staging of the first layer.
+#include "var_common.h"
+
+template <int CIN_, int COUT_, int H_, bool U8_, int R_, int NU_, int NW_>
+struct FwdCfg {
+    static constexpr int CIN = CIN_, COUT = COUT_, H = H_, W = H_, R = R_, NU = NU_, NW = NW_;
+    static constexpr bool U8 = U8_;
+    static constexpr int HO = (H - 1) / 2 + 1, WO = HO;
+    static constexpr int IR = 2 * R + 1;            // input rows per unit (iy0 = 2*band*R - 1)
+    static constexpr int PW = 2 * WO + 2;           // LDS row: col = ix + 1, cols 0..2*WO used
+    static constexpr int PLANE = IR * PW;
+    static constexpr int UNIT = CIN * PLANE;
+    static constexpr int NB = (HO + R - 1) / R;     // bands per image
+    static constexpr int PPU = R * WO;              // pixels per unit
+    static constexpr int NPIX = NU * PPU;
+    static constexpr int NPB = (NPIX + 31) / 32;
+    static constexpr int NBLK = COUT / 32;
+    static constexpr int ITEMS = NPB * NBLK;
+    static constexpr int IPW = (ITEMS + NW - 1) / NW;
+    static constexpr int LDS_BYTES = NU * UNIT * 4;
+    static constexpr int KSTEPS = (CIN * 9 + 1) / 2;
+};
+
+template <class C>
+__global__ void __launch_bounds__(C::NW * 64)
+img_conv_fwd_kernel(const void* __restrict__ xin, long bstride, const float* __restrict__ wp,
+                    const float* __restrict__ bias, float* __restrict__ y, int B) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NT = C::NW * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int total_units = B * C::NB;
+    const int unit0 = blockIdx.x * C::NU;
+
+    // ---- stage the input bands (zero padding materialised) ----
+#pragma unroll 1
+    for (int u = 0; u < C::NU; ++u) {
+        const int unit = unit0 + u;
+        const bool uvalid = unit < total_units;
+        const int b = unit / C::NB, band = unit - b * C::NB;
+        const int iy0 = 2 * band * C::R - 1;
+        float* dst = lds + u * C::UNIT;
+        const uint8_t* src8 = (const uint8_t*)xin + (size_t)b * bstride;
+        const float* src32 = (const float*)xin + (size_t)b * bstride;
+        for (int e = tid; e < C::UNIT; e += NT) {
+            const int c = e / C::PLANE;
+            const int rem = e - c * C::PLANE;
+            const int r = rem / C::PW;
+            const int col = rem - r * C::PW;
+            const int iy = iy0 + r, ix = col - 1;
+            float v = 0.f;
+            if (uvalid && iy >= 0 && iy < C::H && ix >= 0 && ix < C::W) {
+                const int off = (c * C::H + iy) * C::W + ix;
+                if constexpr (C::U8) v = (float)src8[off] / 255.f;
+                else v = src32[off];
+            }
+            dst[e] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- per-item lane constants ----
+    int pixoff[C::IPW];
+    const float* wl[C::IPW];
+    f32x16 acc[C::IPW];
+#pragma unroll
+    for (int i = 0; i < C::IPW; ++i) {
+        const int it = wave + C::NW * i;
+        const int pb = it % C::NPB, nb = (it / C::NPB) % C::NBLK;
+        int p = pb * 32 + l31;
+        if (p >= C::NPIX) p = 0;
+        const int u = p / C::PPU, q = p - u * C::PPU;
+        const int oyl = q / C::WO, ox = q - oyl * C::WO;
+        pixoff[i] = u * C::UNIT + (2 * oyl) * C::PW + 2 * ox;
+        wl[i] = wp + nb * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    }
+
+    if constexpr (C::CIN % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < C::IPW; ++i) { pixoff[i] += half * C::PLANE; wl[i] += half * C::COUT; }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int toff = (tap / 3) * C::PW + (tap % 3);
+#pragma unroll 4
+            for (int c2 = 0; c2 < C::CIN / 2; ++c2) {
+                const int k = tap * C::CIN + 2 * c2;
+#pragma unroll
+                for (int i = 0; i < C::IPW; ++i) {
+                    if (wave + C::NW * i < C::ITEMS) {
+                        const float a = wl[i][k * C::COUT];
+                        const float bv = lds[pixoff[i] + 2 * c2 * C::PLANE + toff];
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    } else {
+        // CIN = 3: K = 27 (+1 zero row in the packed filter); k = 2*s + half, tap = k/3, c = k%3
+#pragma unroll
+        for (int s = 0; s < C::KSTEPS; ++s) {
+            constexpr int KMAX = C::CIN * 9 - 1;
+            const int k0 = 2 * s, k1 = (2 * s + 1 > KMAX) ? KMAX : 2 * s + 1;
+            const int o0 = (k0 % 3) * C::PLANE + ((k0 / 3) / 3) * C::PW + ((k0 / 3) % 3);
+            const int o1 = (k1 % 3) * C::PLANE + ((k1 / 3) / 3) * C::PW + ((k1 / 3) % 3);
+            const int o = half ? o1 : o0;
+            const int k = 2 * s + half;
+#pragma unroll
+            for (int i = 0; i < C::IPW; ++i) {
+                if (wave + C::NW * i < C::ITEMS) {
+                    const float a = wl[i][k * C::COUT];
+                    const float bv = lds[pixoff[i] + o];
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: bias + ReLU, NCHW store.  D row = channel, D col (= lane&31) = pixel ----
+#pragma unroll
+    for (int i = 0; i < C::IPW; ++i) {
+        const int it = wave + C::NW * i;
+        if (it >= C::ITEMS) continue;
+        const int pb = it % C::NPB, nb = it / C::NPB;
+        const int p = pb * 32 + l31;
+        if (p >= C::NPIX) continue;
+        const int u = p / C::PPU, q = p - u * C::PPU;
+        const int unit = unit0 + u;
+        if (unit >= total_units) continue;
+        const int b = unit / C::NB, band = unit - b * C::NB;
+        const int oy = band * C::R + q / C::WO;
+        if (oy >= C::HO) continue;
+        float* yp = y + (size_t)b * C::COUT * C::HO * C::WO + band * C::R * C::WO + q;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float v = acc[i][r] + bias[n];
+            yp[(size_t)n * C::HO * C::WO] = v > 0.f ? v : 0.f;
+        }
+    }
+}
+
+template <class C>
+static int launch_one(var_ctx* c, hipStream_t s, const void* x, long bstride, const float* wp,
+                      const float* bias, float* y, int B) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)img_conv_fwd_kernel<C>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        attr_set = true;
+    }
+    const int units = B * C::NB;
+    const int grid = (units + C::NU - 1) / C::NU;
+    hipLaunchKernelGGL(img_conv_fwd_kernel<C>, dim3(grid), dim3(C::NW * 64), C::LDS_BYTES, s,
+                       x, bstride, wp, bias, y, B);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}
+
+//                 CIN COUT  H   U8    R  NU NW
+using F84_1u = FwdCfg<3, 32, 84, true, 6, 1, 4>;
+using F84_1f = FwdCfg<3, 32, 84, false, 6, 1, 4>;
+using F84_2 = FwdCfg<32, 32, 42, false, 3, 2, 4>;
+using F84_3 = FwdCfg<32, 64, 21, false, 11, 1, 4>;
+using F84_4 = FwdCfg<64, 64, 11, false, 6, 2, 3>;
+using F84_5 = FwdCfg<64, 64, 6, false, 3, 7, 4>;
+using F96_1u = FwdCfg<3, 32, 96, true, 4, 1, 3>;
+using F96_1f = FwdCfg<3, 32, 96, false, 4, 1, 3>;
+using F96_2 = FwdCfg<32, 32, 48, false, 4, 1, 3>;
+using F96_3 = FwdCfg<32, 64, 24, false, 4, 2, 3>;
+using F96_4 = FwdCfg<64, 64, 12, false, 6, 2, 3>;
+using F96_5 = FwdCfg<64, 64, 6, false, 3, 7, 4>;
+
+int launch_img_fwd(var_ctx* c, hipStream_t s, const float* params, const void* image, int is_u8,
+                   long bstride, int B) {
+    const ParamLayout& L = c->pl;
+    const PackLayout& K = c->kl;
+    const float* w[5];
+    const float* b[5];
+    for (int i = 0; i < 5; i++) { w[i] = c->wpack + K.img_f[i]; b[i] = params + L.img_b[i]; }
+    int rc;
+#define RUN(CFG, X, BS, I, Y) do { if ((rc = launch_one<CFG>(c, s, X, BS, w[I], b[I], Y, B)) != VAR_OK) return rc; } while (0)
+    if (c->H == 84) {
+        if (is_u8) { RUN(F84_1u, image, bstride, 0, c->act[1]); } else { RUN(F84_1f, image, bstride, 0, c->act[1]); }
+        RUN(F84_2, c->act[1], 32L * 42 * 42, 1, c->act[2]);
+        RUN(F84_3, c->act[2], 32L * 21 * 21, 2, c->act[3]);
+        RUN(F84_4, c->act[3], 64L * 11 * 11, 3, c->act[4]);
+        RUN(F84_5, c->act[4], 64L * 6 * 6, 4, c->act[5]);
+    } else if (c->H == 96) {
+        if (is_u8) { RUN(F96_1u, image, bstride, 0, c->act[1]); } else { RUN(F96_1f, image, bstride, 0, c->act[1]); }
+        RUN(F96_2, c->act[1], 32L * 48 * 48, 1, c->act[2]);
+        RUN(F96_3, c->act[2], 32L * 24 * 24, 2, c->act[3]);
+        RUN(F96_4, c->act[3], 64L * 12 * 12, 3, c->act[4]);
+        RUN(F96_5, c->act[4], 64L * 6 * 6, 4, c->act[5]);
+    } else {
+        VAR_SET_ERR(c, "unsupported image size %d (84 or 96)", c->H);
+        return VAR_ERR_ARG;
+    }
+#undef RUN
+    return VAR_OK;
+}

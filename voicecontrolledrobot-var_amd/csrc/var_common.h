@@ -1,0 +1,149 @@
+// Internal definitions shared by the gfx950 kernels and the C-ABI layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/var_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Kuka VARPretextNet geometry (models/pretext/arm_pretext_model.py:9-56)
+static constexpr int kImgCh[6] = {3, 32, 32, 64, 64, 64};
+static constexpr int kHid = 128;
+static constexpr int kEmb = 3;
+static constexpr int kImgFeat = 576;   // 64*3*3
+static constexpr int kSndFeat = 160;   // 32*5
+static constexpr int kSndT[5] = {100, 48, 23, 11, 5};
+
+// ---- parameter arena offsets (floats), state_dict() registration order ----
+struct ParamLayout {
+    int img_w[5], img_b[5];
+    int snd_w[4], snd_b[4];
+    int ih_w0, ih_b0, ih_w1, ih_b1;
+    int sh_w0, sh_b0, sh_w1, sh_b1;
+    int total;
+};
+
+inline ParamLayout make_param_layout() {
+    ParamLayout L{};
+    int o = 0;
+    for (int i = 0; i < 5; i++) {
+        L.img_w[i] = o; o += kImgCh[i + 1] * kImgCh[i] * 9;
+        L.img_b[i] = o; o += kImgCh[i + 1];
+    }
+    const int snd_k[4] = {200, 96, 96, 96};
+    for (int i = 0; i < 4; i++) {
+        L.snd_w[i] = o; o += 32 * snd_k[i];
+        L.snd_b[i] = o; o += 32;
+    }
+    L.ih_w0 = o; o += kHid * kImgFeat; L.ih_b0 = o; o += kHid;
+    L.ih_w1 = o; o += kEmb * kHid;     L.ih_b1 = o; o += kEmb;
+    L.sh_w0 = o; o += kHid * kSndFeat; L.sh_b0 = o; o += kHid;
+    L.sh_w1 = o; o += kEmb * kHid;     L.sh_b1 = o; o += kEmb;
+    L.total = o;
+    return L;
+}
+
+// ---- packed (kernel-side) weight images, refreshed by var_pack_weights ----
+// fwd image conv l : Wf[k][n], k = tap*CIN + c (conv1: K 27 padded to 28 with a zero row)
+// dX  image conv l : Wd[tap][n][c]             (layers 1..4 = second..fifth conv)
+// sound conv l     : Ws[k][n], k = kt*CINw + c  (conv0: k = kt*40 + f), and WsT[kt][n][c] for dX
+struct PackLayout {
+    int img_f[5];
+    int img_d[5];     // [0] unused
+    int snd_f[4];
+    int snd_d[4];     // [0] unused
+    int ih_w0t;       // image head Linear(576,128) weight transposed: [k][j]
+    int sh_w0t;       // sound head Linear(160,128) weight transposed: [k][j]
+    int total;
+};
+
+inline PackLayout make_pack_layout() {
+    PackLayout P{};
+    int o = 0;
+    for (int i = 0; i < 5; i++) {
+        int K = kImgCh[i] * 9; if (K & 1) K++;
+        P.img_f[i] = o; o += K * kImgCh[i + 1];
+    }
+    P.img_d[0] = -1;
+    for (int i = 1; i < 5; i++) { P.img_d[i] = o; o += 9 * kImgCh[i + 1] * kImgCh[i]; }
+    const int snd_k[4] = {200, 96, 96, 96};
+    for (int i = 0; i < 4; i++) { P.snd_f[i] = o; o += snd_k[i] * 32; }
+    P.snd_d[0] = -1;
+    for (int i = 1; i < 4; i++) { P.snd_d[i] = o; o += 96 * 32; }
+    P.ih_w0t = o; o += kImgFeat * kHid;
+    P.sh_w0t = o; o += kSndFeat * kHid;
+    P.total = o;
+    return P;
+}
+
+struct var_ctx {
+    int device = 0;
+    char err[512] = {0};
+    ParamLayout pl;
+    PackLayout kl;
+    // plan
+    int maxB = 0, H = 0;
+    int hs[6] = {0};
+    char* ws = nullptr;           // one hipMalloc, carved below
+    size_t ws_bytes = 0;
+    float* wpack = nullptr;
+    float* act[6] = {nullptr};    // act[l] = output of image conv l (l = 1..5), post-ReLU, NCHW
+    float* gact[6] = {nullptr};   // d(loss)/d(pre-activation of conv l output)
+    float* sact[5] = {nullptr};   // sound activations for 2B clips: [l] l = 1..4, layout (clip, 32, T_l)
+    float* gsact[5] = {nullptr};
+    float* hid_i = nullptr;       // (B,128) image head hidden, post-ReLU
+    float* hid_s = nullptr;       // (2B,128)
+    float* emb = nullptr;         // (3B,3) normalised [img | pos | neg]
+    float* emb_raw = nullptr;     // (3B,3) pre-normalise
+    float* gemb = nullptr;        // (3B,3) grads wrt normalised embeddings
+    float* ghid = nullptr;        // (3B,128)
+    float* slabs = nullptr;       // split-K partial weight gradients
+    size_t slab_floats = 0;
+    size_t snd_slab_off = 0;      // sound slabs start here inside `slabs`
+    float* loss_buf = nullptr;
+    float* mfcc_tab = nullptr;    // window / twiddles / mel / DCT tables
+    // saved forward
+    int saved_B = 0;
+    const void* saved_image = nullptr;
+    int saved_u8 = 0;
+    long saved_bstride = 0;
+    const float* saved_pos = nullptr;
+    const float* saved_neg = nullptr;
+};
+
+#define VAR_SET_ERR(ctx, ...) do { if (ctx) snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__); } while (0)
+
+#define VAR_HIP_CHECK(ctx, expr)                                                              \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            VAR_SET_ERR(ctx, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return VAR_ERR_HIP;                                                               \
+        }                                                                                     \
+    } while (0)
+
+static inline int conv_out(int h) { return (h - 1) / 2 + 1; }   // 3x3 s2 p1
+
+int mfcc_build_tables(var_ctx* c);
+size_t img_slab_floats();
+size_t snd_slab_floats();
+
+// kernels' host launchers (one per .hip file) ------------------------------------------
+int launch_pack_weights(var_ctx* c, hipStream_t s, const float* params);
+int launch_img_fwd(var_ctx* c, hipStream_t s, const float* params, const void* image, int is_u8,
+                   long bstride, int B);
+int launch_img_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads, int B);
+int launch_snd_fwd(var_ctx* c, hipStream_t s, const float* params, const float* pos, const float* neg, int B);
+int launch_snd_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads, int B);
+int launch_heads_fwd(var_ctx* c, hipStream_t s, const float* params, int B, bool has_img, bool has_pos, bool has_neg);
+int launch_heads_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads, int B, bool has_img,
+                     int snd_lo, int snd_hi);
+int launch_triplet(var_ctx* c, hipStream_t s, const float* a, const float* p, const float* n, int B,
+                   float margin, float inv_count, float* loss_out, float* ga, float* gp, float* gn);
+int launch_adam(var_ctx* c, hipStream_t s, float* p, const float* g, float* m, float* v, long n,
+                float lr, float b1, float b2, float eps, float wd, int step);
+int launch_mfcc(var_ctx* c, hipStream_t s, const int16_t* pcm, const int* lens, int nclips,
+                int pcm_stride, int out_frames, float* out);

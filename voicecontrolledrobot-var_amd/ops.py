@@ -1,0 +1,45 @@
+"""Thin Python fronts of the stand-alone C-ABI operators (no arithmetic here)."""
+import torch
+
+from ._lib import Context, VarHipError, current_stream_handle, ptr
+
+
+def _require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise VarHipError("the VAR hot path runs on the GPU only: got a CPU tensor (no CPU fallback)")
+
+
+def triplet_margin_loss(anchor, positive, negative, margin=1.0, inv_count=None, want_grads=True):
+    """torch.nn.TripletMarginLoss(margin, p=2) forward(+backward) in one HIP launch
+    (VAR/pretext_VAR.py:38,64).  Returns (loss[1], ga, gp, gn)."""
+    _require_cuda(anchor, positive, negative)
+    a, p, n = (t.contiguous().float() for t in (anchor, positive, negative))
+    B = a.shape[0]
+    ctx = Context.get(a.device.index)
+    loss = torch.empty(1, dtype=torch.float32, device=a.device)
+    ga = torch.empty_like(a) if want_grads else None
+    gp = torch.empty_like(a) if want_grads else None
+    gn = torch.empty_like(a) if want_grads else None
+    ctx.check(ctx.lib.var_triplet_fwd_bwd(ctx.handle, current_stream_handle(), ptr(a), ptr(p), ptr(n), B,
+                                          float(margin), float(1.0 / B if inv_count is None else inv_count),
+                                          ptr(loss), ptr(ga), ptr(gp), ptr(gn)), "var_triplet_fwd_bwd")
+    return loss, ga, gp, gn
+
+
+def mfcc(pcm, lens=None, out_frames=100):
+    """int16 PCM (nclips, nsamples) on the GPU -> (nclips, 1, out_frames, 40) f32 MFCC:
+    Envs/audioLoader.py:147-157 (torchaudio branch) + :241-252 (truncate / zero-pad)."""
+    _require_cuda(pcm)
+    if pcm.dtype != torch.int16 or pcm.dim() != 2:
+        raise VarHipError("mfcc expects an int16 (nclips, nsamples) tensor")
+    pcm = pcm.contiguous()
+    n, stride = pcm.shape
+    if lens is None:
+        lens = torch.full((n,), stride, dtype=torch.int32, device=pcm.device)
+    lens = lens.to(device=pcm.device, dtype=torch.int32).contiguous()
+    out = torch.empty((n, 1, out_frames, 40), dtype=torch.float32, device=pcm.device)
+    ctx = Context.get(pcm.device.index)
+    ctx.check(ctx.lib.var_mfcc(ctx.handle, current_stream_handle(), ptr(pcm), ptr(lens), n, stride,
+                               int(out_frames), ptr(out)), "var_mfcc")
+    return out

@@ -1,0 +1,139 @@
+"""Counterpart of VAR_Pretext.trainRepresentation (VAR/pretext_VAR.py:16-95): the step body
+zero_grad -> forward -> TripletMarginLoss -> backward -> Adam.step as fused HIP launches on flat
+arenas, per-epoch MultiStepLR (utils.py:42-46), periodic legacy-format checkpoints and
+progress.csv.  Data parallel: one process per GPU, one RCCL all-reduce of the flat gradient
+arena (+ the loss scalar riding in its last slot) per step."""
+import csv
+import os
+
+import torch
+
+from ._lib import Context, VarHipError, current_stream_handle, ptr
+from .layout import N_PARAMS
+from .ops import mfcc as mfcc_op
+
+
+def multistep_lr(base_lr, milestones, gamma, epoch):
+    """lr in effect during 0-based `epoch` under MultiStepLR(milestones, gamma) stepped once per epoch."""
+    lr = base_lr
+    for ms in sorted(milestones):
+        if epoch >= ms:
+            lr *= gamma
+    return lr
+
+
+class VARTrainer:
+    def __init__(self, model, lr=1e-4, weight_decay=1e-6, betas=(0.9, 0.999), eps=1e-8, margin=1.0,
+                 process_group=None):
+        flat = model.flat_parameters()
+        if not flat.is_cuda:
+            raise VarHipError("VARTrainer needs the model on a GPU (no CPU fallback)")
+        self.model = model
+        self.dev = flat.device
+        self.ctx = Context.get(self.dev.index)
+        self.lr, self.wd, self.betas, self.eps, self.margin = lr, weight_decay, betas, eps, margin
+        self.hw = model.config.img_dim[1]
+        # gradient arena with one extra slot for the loss so that ONE all-reduce carries both
+        self.gbuf = torch.zeros(N_PARAMS + 1, dtype=torch.float32, device=self.dev)
+        self.exp_avg = torch.zeros(N_PARAMS, dtype=torch.float32, device=self.dev)
+        self.exp_avg_sq = torch.zeros(N_PARAMS, dtype=torch.float32, device=self.dev)
+        self.step_count = 0
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+        c = self.ctx
+        c.check(c.lib.var_pack_weights(c.handle, current_stream_handle(), ptr(flat)), "var_pack_weights")
+
+    @property
+    def grads(self):
+        return self.gbuf[:N_PARAMS]
+
+    @property
+    def loss(self):
+        """Device scalar: the (global) mean triplet loss of the last step; reading it syncs."""
+        return self.gbuf[N_PARAMS:]
+
+    def loss_and_grads(self, image, pos, neg, global_batch=None):
+        """fwd + loss + bwd into the gradient arena (no optimiser step, no collective)."""
+        flat = self.model.flat_parameters()
+        B = image.shape[0]
+        gb = B * self.world if global_batch is None else global_batch
+        c = self.ctx
+        c.ensure_plan(B, self.hw)
+        c.check(c.lib.var_arm_loss_grad(c.handle, current_stream_handle(), ptr(flat), ptr(image),
+                                        int(image.dtype == torch.uint8), image.stride(0), ptr(pos), ptr(neg),
+                                        B, self.hw, float(self.margin), 1.0 / gb, ptr(self.gbuf),
+                                        self.gbuf.data_ptr() + 4 * N_PARAMS, None), "var_arm_loss_grad")
+
+    def allreduce(self):
+        if self.world > 1:
+            torch.distributed.all_reduce(self.gbuf, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+
+    def adam(self):
+        self.step_count += 1
+        flat = self.model.flat_parameters()
+        c = self.ctx
+        c.check(c.lib.var_adam_step(c.handle, current_stream_handle(), ptr(flat), ptr(self.gbuf),
+                                    ptr(self.exp_avg), ptr(self.exp_avg_sq), N_PARAMS, float(self.lr),
+                                    float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd),
+                                    int(self.step_count)), "var_adam_step")
+
+    def step(self, image, pos, neg, global_batch=None):
+        """One optimisation step on (image u8|f32 (B,3,H,H), pos, neg f32 (B,1,100,40)).  Asynchronous."""
+        self._check(image, pos, neg)
+        self.loss_and_grads(image, pos, neg, global_batch)
+        self.allreduce()
+        self.adam()
+        return self.loss
+
+    def step_from_pcm(self, image, pcm, lens, mfcc_out=None, global_batch=None):
+        """Same, with the audio front-end in the step: pcm int16 (2B, n) = [pos | neg], lens (2B) (0 = empty)."""
+        B = image.shape[0]
+        feats = mfcc_op(pcm, lens, 100) if mfcc_out is None else self._mfcc_into(pcm, lens, mfcc_out)
+        return self.step(image, feats[:B], feats[B:], global_batch)
+
+    def _mfcc_into(self, pcm, lens, out):
+        c = self.ctx
+        c.check(c.lib.var_mfcc(c.handle, current_stream_handle(), ptr(pcm), ptr(lens), pcm.shape[0], pcm.shape[1],
+                               100, ptr(out)), "var_mfcc")
+        return out
+
+    def _check(self, image, pos, neg):
+        for t in (image, pos, neg):
+            if t is None or not t.is_cuda or not t.is_contiguous():
+                raise VarHipError("VARTrainer.step needs contiguous CUDA tensors (image, pos, neg)")
+        if pos.dtype != torch.float32 or neg.dtype != torch.float32 or image.dtype not in (torch.uint8, torch.float32):
+            raise VarHipError("image must be u8/f32 and MFCC f32")
+
+
+def train_representation(model, batches, epochs, lr=1e-4, weight_decay=1e-6, milestones=(10, 30, 50), gamma=0.2,
+                         margin=1.0, save_dir=None, save_interval=10, start_ep=0, log=print):
+    """The loop of VAR/pretext_VAR.py:44-91.  `batches()` yields (image, sound_positive, sound_negative, gt)
+    CUDA tensors for one epoch.  Returns the per-epoch average losses."""
+    tr = VARTrainer(model, lr=lr, weight_decay=weight_decay, margin=margin)
+    model.train()
+    loss_list = []
+    for ep in range(epochs):
+        tr.lr = multistep_lr(lr, milestones, gamma, ep)
+        losses = []
+        for image, sp, sn, _gt in batches():
+            tr.step(image.contiguous(), sp.float().contiguous(), sn.float().contiguous())
+            losses.append(tr.loss.clone())
+        avg = float(torch.stack(losses).sum().item() / len(losses))      # np.sum(loss_ep)/len(loss_ep), :82
+        loss_list.append(avg)
+        log('average loss', avg)
+        if save_dir and ((ep + 1) % save_interval == 0 or ep + 1 == epochs):
+            os.makedirs(save_dir, exist_ok=True)
+            fname = os.path.join(save_dir, str(start_ep + ep) + '.pt')
+            torch.save(model.state_dict(), fname, _use_new_zipfile_serialization=False)   # legacy format, :79
+            log('Model saved to ' + fname)
+    if save_dir:
+        os.makedirs(save_dir, exist_ok=True)
+        with open(os.path.join(save_dir, 'progress.csv'), 'w', newline='') as f:
+            w = csv.writer(f)
+            w.writerow(['avg_loss'])
+            for v in loss_list:
+                w.writerow([v])
+    model.eval()
+    return loss_list
