@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- pretext triplets/sec of the VAR contrastive-pretext step on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic triplets already resident in HBM:
+  gather (u8 image 84x84x3, 2 x int16 16 kHz/1 s clips) -> MFCC front-end (HIP) -> image CNN + sound CNN
+  + heads forward -> TripletMarginLoss -> backward -> [RCCL all-reduce of the flat gradient arena] -> Adam.
+Workload = BASELINE.json configs[1]: Kuka + GoogleCommand shapes, per-GPU batch 256, fp32, weak scaling.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+Rank 0 prints ONE JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HW = 84
+BATCH = 256
+# 2*MAC per image of layer l's conv (fwd == wgrad == dgrad), H=84: Ho^2 * Cout * Cin * 9 * 2
+_HO = [42, 21, 11, 6, 3]
+_CH = [3, 32, 32, 64, 64, 64]
+LAYER_FLOPS = [2 * _HO[l] ** 2 * _CH[l + 1] * _CH[l] * 9 for l in range(5)]
+FLOPS_PER_TRIPLET = 58.407e6          # fwd+bwd, SURVEY.md section 8(d)
+F32_MFMA_PEAK = 157.3                 # TFLOP/s, MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def host_cores():
+    """CPU threads this process may actually use: affinity mask and cgroup quota, whichever is smaller."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(n, 64)          # torch's intra-op pool does not scale past this on these small convs
+
+
+def cpu_baseline(seconds=10.0):
+    """The reference's step on the host cores: torch.nn CPU restatement (oracle/torch_oracle.py),
+    same shapes, MFCC precomputed (as VARFineTuneDataset does), tensors in RAM."""
+    from oracle.torch_oracle import CPUTrainer
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+    img = torch.randint(0, 256, (BATCH, 3, HW, HW), dtype=torch.uint8, generator=g)
+    pos = torch.randn(BATCH, 1, 100, 40, generator=g) * 5
+    neg = torch.randn(BATCH, 1, 100, 40, generator=g) * 5
+    torch.manual_seed(453)
+    tr = CPUTrainer()
+    for _ in range(2):
+        tr.step(img, pos, neg)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        tr.step(img, pos, neg)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds and n >= 5:
+            break
+    return {"value": round(n * BATCH / dt, 1), "unit": "triplets/s", "cores": cores, "kind": "port",
+            "sample": f"{n} steps of batch {BATCH} (84x84 u8 images, precomputed f32 MFCC in RAM), "
+                      f"torch.nn CPU restatement of the reference step, {cores} threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=dev)
+
+    import var_amd
+    from var_amd._lib import Context
+
+    B = args.batch
+    cfg = types.SimpleNamespace(img_dim=(3, HW, HW), sound_dim=(1, 100, 40), representationDim=3)
+    torch.manual_seed(453)                                     # pretextEnvSeed; identical weights on every rank
+    model = var_amd.VARPretextNet(cfg).to(dev)
+    tr = var_amd.VARTrainer(model, lr=1e-4, weight_decay=1e-6, margin=1.0)
+    pool = var_amd.SyntheticTripletPool(4096, hw=HW, seed=rank, clips_per_class=64, device=dev)
+    img = torch.empty((B, 3, HW, HW), dtype=torch.uint8, device=dev)
+    pcm = torch.empty((2 * B, 16000), dtype=torch.int16, device=dev)
+    lens = torch.empty(2 * B, dtype=torch.int32, device=dev)
+    feats = torch.empty((2 * B, 1, 100, 40), dtype=torch.float32, device=dev)
+    ctx = Context.get(local_rank)
+    ctx.ensure_plan(B, HW)
+
+    def step():
+        idx, cp = pool.sample_indices(B)
+        pool.gather(idx, cp, out_img=img, out_pcm=pcm, out_len=lens)
+        tr.step_from_pcm(img, pcm, lens, mfcc_out=feats, global_batch=B * world)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    # pick the dominant conv kernel family (one profiled step per candidate), rank 0 only matters
+    dom_tag = None
+    if not args.no_roofline:
+        best = -1.0
+        for tag in list(range(0, 10)) + list(range(11, 15)):
+            ctx.profile_select(tag)
+            step()
+            ms, n = ctx.profile_read()
+            if n and ms / n > best:
+                best, dom_tag = ms / n, tag
+        ctx.profile_select(dom_tag)
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t.item())
+    loss = float(tr.loss.item())
+
+    if rank == 0:
+        value = args.steps * B * world / dt
+        out = {
+            "metric": "pretext triplets/sec (84x84 RGB + 16 kHz/1 s audio)",
+            "value": round(value, 1), "unit": "triplets/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Kuka+GoogleCommand pretext step, batch 256 per GPU on MI355X, fp32: "
+                                   "u8 84x84 image + 2 int16 1 s clips per triplet resident in HBM -> MFCC -> "
+                                   "fwd + triplet loss + bwd + Adam (BASELINE.json configs[1])",
+                       "per_gpu_batch": B, "global_batch": B * world, "image": [3, HW, HW], "audio": "16 kHz x 1 s int16 x 2",
+                       "parallelism": f"dp{world}", "final_loss": round(loss, 6)},
+            "mfma_frac_whole_step": round(value / world * FLOPS_PER_TRIPLET / 1e12 / F32_MFMA_PEAK, 4),
+        }
+        if dom_tag is not None:
+            ms, n = ctx.profile_read()
+            names = ctx.tag_names()
+            layer = dom_tag % 5
+            flops = LAYER_FLOPS[layer] * B
+            ach = flops / (ms / n * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": names[dom_tag], "achieved": round(ach, 2),
+                               "peak": F32_MFMA_PEAK, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK, 4),
+                               "traffic": None, "avg_us": round(1e3 * ms / n, 2), "launches": n,
+                               "flops_per_launch": flops}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -118,6 +118,18 @@ int var_adam_step(var_ctx* ctx, void* stream, float* params, const float* grads,
 int var_mfcc(var_ctx* ctx, void* stream, const int16_t* pcm, const int* lens, int nclips,
              int pcm_stride, int out_frames, float* out);
 
+/* Measurement and testing hooks -------------------------------------------------
+ * var_profile_select: record HIP events, on the launch stream, around every launch of one
+ * kernel family (tag in [0, var_profile_tag_count()), -1 = off); var_profile_read returns the
+ * summed durations and the launch count since the select (it synchronises on the events).
+ * var_debug_buffer: address/length of a named workspace buffer ("act1".."act5", "gact1"..,
+ * "sact1".."sact4", "gsact1".., "emb", "gemb", "wpack") for layer-wise parity tests. */
+int var_profile_tag_count(void);
+const char* var_profile_tag_name(int tag);
+int var_profile_select(var_ctx* ctx, int tag);
+int var_profile_read(var_ctx* ctx, float* total_ms, int* count);
+int var_debug_buffer(var_ctx* ctx, const char* name, void** ptr, long* nfloats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,7 +74,7 @@ def test_forward_backward_vs_reference_fixtures(var_amd, golden_dir, wfile, ffil
     fx = load(golden_dir, ffile)
     m = make_model(var_amd, sd, h)
     m.train()
-    image = (cuda(fx['image']) / 255.).float()                   # dataset.py:67-68
+    image = (torch.from_numpy(fx['image']) / 255.).float().cuda()  # dataset.py:67-68 (CPU true division)
     d = m(image, cuda(fx['sound_positive']), cuda(fx['sound_negative']))
     for k in ('image_feat', 'sound_feat_positive', 'sound_feat_negative', 'image_feat_raw', 'pos_sound_raw'):
         assert np.max(np.abs(d[k].detach().cpu().numpy() - fx[k])) < 1e-3, k
@@ -145,7 +145,7 @@ def test_edge_behaviours(var_amd, golden_dir):
     fx = load(golden_dir, "kuka_edge.npz")
     m = make_model(var_amd, sd, 84)
     m.eval()
-    image = (cuda(fx['image']) / 255.).float()
+    image = (torch.from_numpy(fx['image']) / 255.).float().cuda()
     with torch.no_grad():
         a = m(image, cuda(fx['sound_positive']), None)
         assert a['sound_feat_negative'] is None

@@ -43,6 +43,10 @@ _SIGNATURES = {
     "var_arm_loss_grad": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
     "var_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i]),
     "var_mfcc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "var_profile_tag_count": (_i, []),
+    "var_profile_tag_name": (ctypes.c_char_p, [_i]),
+    "var_profile_select": (_i, [_vp, _i]),
+    "var_profile_read": (_i, [_vp, ctypes.POINTER(_f), ctypes.POINTER(_i)]),
     "var_debug_buffer": (_i, [_vp, ctypes.c_char_p, ctypes.POINTER(_vp), ctypes.POINTER(_l)]),
 }
 
@@ -95,6 +99,17 @@ class Context:
         if self.plan[1] != hw or self.plan[0] < batch:
             self.check(self.lib.var_plan(self.handle, int(batch), int(hw)), "var_plan")
             self.plan = (int(batch), int(hw))
+
+    def profile_select(self, tag):
+        self.check(self.lib.var_profile_select(self.handle, int(tag)), "var_profile_select")
+
+    def profile_read(self):
+        ms, n = _f(), _i()
+        self.check(self.lib.var_profile_read(self.handle, ctypes.byref(ms), ctypes.byref(n)), "var_profile_read")
+        return ms.value, n.value
+
+    def tag_names(self):
+        return [self.lib.var_profile_tag_name(t).decode() for t in range(self.lib.var_profile_tag_count())]
 
     def debug_buffer(self, name):
         import torch

@@ -59,6 +59,10 @@ int var_destroy(var_ctx* c) {
     if (c->wpack) (void)hipFree(c->wpack);
     if (c->loss_buf) (void)hipFree(c->loss_buf);
     if (c->mfcc_tab) (void)hipFree(c->mfcc_tab);
+    if (c->prof_ev) {
+        for (int i = 0; i < 2 * kProfMaxPairs; i++) (void)hipEventDestroy(c->prof_ev[i]);
+        delete[] c->prof_ev;
+    }
     delete c;
     return VAR_OK;
 }
@@ -252,6 +256,50 @@ int var_mfcc(var_ctx* c, void* stream, const int16_t* pcm, const int* lens, int 
     }
     SET_DEVICE(c);
     return launch_mfcc(c, (hipStream_t)stream, pcm, lens, nclips, pcm_stride, out_frames, out);
+}
+
+static const char* kTagNames[TAG_COUNT] = {
+    "img_conv_fwd_kernel[0]", "img_conv_fwd_kernel[1]", "img_conv_fwd_kernel[2]", "img_conv_fwd_kernel[3]",
+    "img_conv_fwd_kernel[4]", "img_wgrad_kernel[0]", "img_wgrad_kernel[1]", "img_wgrad_kernel[2]",
+    "img_wgrad_kernel[3]", "img_wgrad_kernel[4]", "img_dgrad_kernel[0]", "img_dgrad_kernel[1]",
+    "img_dgrad_kernel[2]", "img_dgrad_kernel[3]", "img_dgrad_kernel[4]", "img_wgrad_reduce_kernel",
+    "snd_fwd_kernel", "snd_dgrad_kernel", "snd_wgrad_kernel", "snd_reduce_kernel", "heads_fwd_kernel",
+    "heads_bwd_rows_kernel", "heads_bwd_w_kernel", "triplet_kernel", "adam_kernel", "pack_weights_kernel",
+    "mfcc_kernel"};
+
+int var_profile_tag_count(void) { return TAG_COUNT; }
+const char* var_profile_tag_name(int tag) { return (tag >= 0 && tag < TAG_COUNT) ? kTagNames[tag] : ""; }
+
+/* Record HIP events (on the launch stream) around every launch of kernel family `tag`
+ * from now on (-1 = off).  Not for use under graph capture. */
+int var_profile_select(var_ctx* c, int tag) {
+    CHECK_CTX(c);
+    SET_DEVICE(c);
+    if (tag >= TAG_COUNT) { VAR_SET_ERR(c, "var_profile_select: bad tag %d", tag); return VAR_ERR_ARG; }
+    if (tag >= 0 && !c->prof_ev) {
+        c->prof_ev = new hipEvent_t[2 * kProfMaxPairs];
+        for (int i = 0; i < 2 * kProfMaxPairs; i++) VAR_HIP_CHECK(c, hipEventCreate(&c->prof_ev[i]));
+    }
+    c->prof_tag = tag;
+    c->prof_n = 0;
+    return VAR_OK;
+}
+
+/* Sum of the event-pair durations recorded since var_profile_select, and their count. Synchronises. */
+int var_profile_read(var_ctx* c, float* total_ms, int* count) {
+    CHECK_CTX(c);
+    if (!total_ms || !count) return VAR_ERR_ARG;
+    SET_DEVICE(c);
+    float tot = 0.f;
+    for (int i = 0; i < c->prof_n; i++) {
+        float ms = 0.f;
+        VAR_HIP_CHECK(c, hipEventSynchronize(c->prof_ev[2 * i + 1]));
+        VAR_HIP_CHECK(c, hipEventElapsedTime(&ms, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *count = c->prof_n;
+    return VAR_OK;
 }
 
 /* Testing hook: address and length (floats) of a workspace buffer, by name

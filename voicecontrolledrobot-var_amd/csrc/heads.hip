@@ -236,6 +236,7 @@ heads_bwd_w_kernel(const float* __restrict__ x, int row_lo, int row_hi,
 int launch_heads_fwd(var_ctx* c, hipStream_t s, const float* params, int B, bool has_img, bool has_pos, bool has_neg) {
     const ParamLayout& L = c->pl;
     const PackLayout& K = c->kl;
+    ProfScope prof(c, s, TAG_HEADS_FWD);
     if (has_img) {
         hipLaunchKernelGGL(heads_fwd_kernel<kImgFeat>, dim3((B + RB - 1) / RB), dim3(256), 0, s,
                            c->act[5], B, 0, B, c->wpack + K.ih_w0t, params + L.ih_b0, params + L.ih_w1,
@@ -253,6 +254,7 @@ int launch_heads_fwd(var_ctx* c, hipStream_t s, const float* params, int B, bool
 
 int launch_triplet(var_ctx* c, hipStream_t s, const float* a, const float* p, const float* n, int B,
                    float margin, float inv_count, float* loss_out, float* ga, float* gp, float* gn) {
+    ProfScope prof(c, s, TAG_TRIPLET);
     hipLaunchKernelGGL(triplet_kernel, dim3(1), dim3(256), 0, s, a, p, n, B, margin, inv_count, loss_out, ga, gp, gn);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
@@ -264,6 +266,7 @@ int launch_heads_bwd(var_ctx* c, hipStream_t s, const float* params, float* grad
                      int snd_lo, int snd_hi) {
     const ParamLayout& L = c->pl;
     float* graw = c->gemb + 9 * (size_t)c->maxB;          // second half of the gemb buffer
+    ProfScope prof(c, s, TAG_HEADS_BWD_ROWS);
     if (has_img) {
         hipLaunchKernelGGL(heads_bwd_rows_kernel<kImgFeat>, dim3((B + RB - 1) / RB), dim3(256), 0, s,
                            c->act[5], B, 0, B, params + L.ih_w0, params + L.ih_w1, c->hid_i, c->emb_raw, c->emb,

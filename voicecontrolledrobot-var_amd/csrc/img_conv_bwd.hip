@@ -341,7 +341,9 @@ img_wgrad_reduce_kernel(RedTable T, const float* __restrict__ slabs, float* __re
 // host side
 // ------------------------------------------------------------------------------------------
 template <class C>
-static int launch_dgrad(var_ctx* c, hipStream_t s, const float* gy, const float* wd, const float* x, float* gx, int B) {
+static int launch_dgrad(var_ctx* c, hipStream_t s, const float* gy, const float* wd, const float* x, float* gx, int B,
+                        int layer) {
+    ProfScope prof(c, s, TAG_IMG_DGRAD0 + layer);
     static bool attr_set = false;
     if (!attr_set) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)img_dgrad_kernel<C>,
@@ -357,7 +359,8 @@ static int launch_dgrad(var_ctx* c, hipStream_t s, const float* gy, const float*
 
 template <class C>
 static int launch_wgrad(var_ctx* c, hipStream_t s, const void* x, long bstride, const float* gy, float* slabs,
-                        int B, int G) {
+                        int B, int G, int layer) {
+    ProfScope prof(c, s, TAG_IMG_WGRAD0 + layer);
     static bool attr_set = false;
     if (!attr_set) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)img_wgrad_kernel<C>,
@@ -420,8 +423,8 @@ int launch_img_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads,
     int G[5] = {0, 0, 0, 0, 0};
     const long bs[6] = {c->saved_bstride, 32L * c->hs[1] * c->hs[1], 32L * c->hs[2] * c->hs[2],
                         64L * c->hs[3] * c->hs[3], 64L * c->hs[4] * c->hs[4], 0};
-#define DG(CFG, l) do { if ((rc = launch_dgrad<CFG>(c, s, c->gact[l + 1], c->wpack + K.img_d[l], c->act[l], c->gact[l], B)) != VAR_OK) return rc; } while (0)
-#define WG(CFG, l, X) do { G[l] = wg_groups<CFG>(B, kWgG[l]); if ((rc = launch_wgrad<CFG>(c, s, X, bs[l], c->gact[l + 1], c->slabs + so[l], B, G[l])) != VAR_OK) return rc; } while (0)
+#define DG(CFG, l) do { if ((rc = launch_dgrad<CFG>(c, s, c->gact[l + 1], c->wpack + K.img_d[l], c->act[l], c->gact[l], B, l)) != VAR_OK) return rc; } while (0)
+#define WG(CFG, l, X) do { G[l] = wg_groups<CFG>(B, kWgG[l]); if ((rc = launch_wgrad<CFG>(c, s, X, bs[l], c->gact[l + 1], c->slabs + so[l], B, G[l], l)) != VAR_OK) return rc; } while (0)
     if (H == 84) {
         WG(W84_4, 4, c->act[4]); DG(D84_4, 4);
         WG(W84_3, 3, c->act[3]); DG(D84_3, 3);
@@ -449,6 +452,7 @@ int launch_img_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads,
         st += kSlabSz[i];
     }
     T.start[5] = st;
+    ProfScope prof(c, s, TAG_IMG_WREDUCE);
     hipLaunchKernelGGL(img_wgrad_reduce_kernel, dim3((st + 255) / 256), dim3(256), 0, s, T, c->slabs, grads);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;

@@ -156,7 +156,8 @@ img_conv_fwd_kernel(const void* __restrict__ xin, long bstride, const float* __r
 
 template <class C>
 static int launch_one(var_ctx* c, hipStream_t s, const void* x, long bstride, const float* wp,
-                      const float* bias, float* y, int B) {
+                      const float* bias, float* y, int B, int layer) {
+    ProfScope prof(c, s, TAG_IMG_FWD0 + layer);
     static bool attr_set = false;
     if (!attr_set) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)img_conv_fwd_kernel<C>,
@@ -193,7 +194,7 @@ int launch_img_fwd(var_ctx* c, hipStream_t s, const float* params, const void* i
     const float* b[5];
     for (int i = 0; i < 5; i++) { w[i] = c->wpack + K.img_f[i]; b[i] = params + L.img_b[i]; }
     int rc;
-#define RUN(CFG, X, BS, I, Y) do { if ((rc = launch_one<CFG>(c, s, X, BS, w[I], b[I], Y, B)) != VAR_OK) return rc; } while (0)
+#define RUN(CFG, X, BS, I, Y) do { if ((rc = launch_one<CFG>(c, s, X, BS, w[I], b[I], Y, B, I)) != VAR_OK) return rc; } while (0)
     if (c->H == 84) {
         if (is_u8) { RUN(F84_1u, image, bstride, 0, c->act[1]); } else { RUN(F84_1f, image, bstride, 0, c->act[1]); }
         RUN(F84_2, c->act[1], 32L * 42 * 42, 1, c->act[2]);

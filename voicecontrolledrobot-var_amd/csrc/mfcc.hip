@@ -185,6 +185,7 @@ int mfcc_build_tables(var_ctx* c) {
 
 int launch_mfcc(var_ctx* c, hipStream_t s, const int16_t* pcm, const int* lens, int nclips, int pcm_stride,
                 int out_frames, float* out) {
+    ProfScope prof(c, s, TAG_MFCC);
     hipLaunchKernelGGL(mfcc_kernel, dim3(nclips), dim3(256), 0, s, pcm, lens, pcm_stride, out_frames,
                        c->mfcc_tab, out);
     VAR_HIP_CHECK(c, hipGetLastError());

@@ -56,6 +56,7 @@ int launch_pack_weights(var_ctx* c, hipStream_t s, const float* params) {
     add(K.ih_w0t, kImgFeat * kHid, L.ih_w0, kImgFeat, kHid, 1, 0);   // plain transpose
     add(K.sh_w0t, kSndFeat * kHid, L.sh_w0, kSndFeat, kHid, 1, 0);
     T.nseg = n;   // 18
+    ProfScope prof(c, s, TAG_PACK);
     hipLaunchKernelGGL(pack_weights_kernel, dim3(256), dim3(256), 0, s, T, params, c->wpack, K.total);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
@@ -85,6 +86,7 @@ int launch_adam(var_ctx* c, hipStream_t s, float* p, const float* g, float* m, f
     const float bc2_sqrt = (float)sqrt(bc2);
     int grid = (int)((n + 255) / 256);
     if (grid > 2048) grid = 2048;
+    ProfScope prof(c, s, TAG_ADAM);
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, s, p, g, m, v, n, b1, b2, eps, wd, step_size, bc2_sqrt);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;

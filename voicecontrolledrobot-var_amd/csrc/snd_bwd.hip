@@ -158,13 +158,16 @@ int launch_snd_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads,
         VAR_HIP_CHECK(c, hipMemsetAsync(grads + L.snd_w[0], 0, sizeof(float) * SND_SLICE, s));
         return VAR_OK;
     }
+    { ProfScope prof(c, s, TAG_SND_DGRAD);
     hipLaunchKernelGGL(snd_dgrad_kernel, dim3(hi - lo), dim3(256), 0, s, lo,
                        c->wpack + K.snd_d[1], c->wpack + K.snd_d[2], c->wpack + K.snd_d[3],
-                       c->sact[1], c->sact[2], c->sact[3], c->gsact[4], c->gsact[3], c->gsact[2], c->gsact[1]);
+                       c->sact[1], c->sact[2], c->sact[3], c->gsact[4], c->gsact[3], c->gsact[2], c->gsact[1]); }
     int G = hi - lo < kSndG ? hi - lo : kSndG;
     float* slabs = c->slabs + c->snd_slab_off;
+    { ProfScope prof(c, s, TAG_SND_WGRAD);
     hipLaunchKernelGGL(snd_wgrad_kernel, dim3(G), dim3(256), 0, s, lo, hi, B, c->saved_pos, c->saved_neg,
-                       c->sact[1], c->sact[2], c->sact[3], c->gsact[1], c->gsact[2], c->gsact[3], c->gsact[4], slabs);
+                       c->sact[1], c->sact[2], c->sact[3], c->gsact[1], c->gsact[2], c->gsact[3], c->gsact[4], slabs); }
+    ProfScope prof(c, s, TAG_SND_REDUCE);
     hipLaunchKernelGGL(snd_reduce_kernel, dim3((SND_SLICE + 255) / 256), dim3(256), 0, s, slabs, G,
                        grads + L.snd_w[0]);
     VAR_HIP_CHECK(c, hipGetLastError());

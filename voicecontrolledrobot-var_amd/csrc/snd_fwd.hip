@@ -92,6 +92,7 @@ snd_fwd_kernel(const float* __restrict__ pos, const float* __restrict__ neg, int
 int launch_snd_fwd(var_ctx* c, hipStream_t s, const float* params, const float* pos, const float* neg, int B) {
     const ParamLayout& L = c->pl;
     const PackLayout& K = c->kl;
+    ProfScope prof(c, s, TAG_SND_FWD);
     hipLaunchKernelGGL(snd_fwd_kernel, dim3(2 * B), dim3(256), 0, s, pos, neg, B,
                        c->wpack + K.snd_f[0], c->wpack + K.snd_f[1], c->wpack + K.snd_f[2], c->wpack + K.snd_f[3],
                        params + L.snd_b[0], params + L.snd_b[1], params + L.snd_b[2], params + L.snd_b[3],

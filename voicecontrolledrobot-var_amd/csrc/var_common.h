@@ -79,6 +79,18 @@ inline PackLayout make_pack_layout() {
     return P;
 }
 
+// profiling tags: one per kernel family (var_profile_select / var_profile_read)
+enum VarTag {
+    TAG_IMG_FWD0 = 0,    // ..4  img_conv_fwd_kernel, layer l
+    TAG_IMG_WGRAD0 = 5,  // ..9  img_wgrad_kernel, layer l
+    TAG_IMG_DGRAD0 = 10, // 11..14 img_dgrad_kernel, layer l (1..4)
+    TAG_IMG_WREDUCE = 15,
+    TAG_SND_FWD = 16, TAG_SND_DGRAD = 17, TAG_SND_WGRAD = 18, TAG_SND_REDUCE = 19,
+    TAG_HEADS_FWD = 20, TAG_HEADS_BWD_ROWS = 21, TAG_HEADS_BWD_W = 22, TAG_TRIPLET = 23,
+    TAG_ADAM = 24, TAG_PACK = 25, TAG_MFCC = 26, TAG_COUNT = 27
+};
+constexpr int kProfMaxPairs = 4096;
+
 struct var_ctx {
     int device = 0;
     char err[512] = {0};
@@ -105,6 +117,10 @@ struct var_ctx {
     size_t snd_slab_off = 0;      // sound slabs start here inside `slabs`
     float* loss_buf = nullptr;
     float* mfcc_tab = nullptr;    // window / twiddles / mel / DCT tables
+    // profiling: HIP events around the launches of ONE selected kernel family
+    int prof_tag = -1;
+    int prof_n = 0;               // pairs recorded since select
+    hipEvent_t* prof_ev = nullptr;
     // saved forward
     int saved_B = 0;
     const void* saved_image = nullptr;
@@ -124,6 +140,18 @@ struct var_ctx {
             return VAR_ERR_HIP;                                                               \
         }                                                                                     \
     } while (0)
+
+struct ProfScope {
+    var_ctx* c; hipStream_t s; bool on;
+    ProfScope(var_ctx* c_, hipStream_t s_, int tag) : c(c_), s(s_), on(false) {
+        if (c->prof_tag == tag && c->prof_ev && c->prof_n < kProfMaxPairs) {
+            on = hipEventRecord(c->prof_ev[2 * c->prof_n], s) == hipSuccess;
+        }
+    }
+    ~ProfScope() {
+        if (on) { (void)hipEventRecord(c->prof_ev[2 * c->prof_n + 1], s); c->prof_n++; }
+    }
+};
 
 static inline int conv_out(int h) { return (h - 1) / 2 + 1; }   // 3x3 s2 p1
 

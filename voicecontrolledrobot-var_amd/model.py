@@ -22,7 +22,7 @@ class _EncoderFn(torch.autograd.Function):
     """forward/backward of the whole encoder through the C ABI (var_arm_encoder_fwd/_bwd)."""
 
     @staticmethod
-    def forward(ctx, module, image, pos, neg, *params):
+    def forward(ctx, module, need_grad, image, pos, neg, *params):
         flat = module._flat
         dev = flat.device
         c = Context.get(dev.index)
@@ -38,7 +38,6 @@ class _EncoderFn(torch.autograd.Function):
         pos_feat = mk(3) if pos is not None else None
         pos_raw = mk(160) if pos is not None else None
         neg_feat = mk(3) if neg is not None else None
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         is_u8 = image is not None and image.dtype == torch.uint8
         bstride = 0 if image is None else image.stride(0)
         c.check(c.lib.var_arm_encoder_fwd(c.handle, stream, ptr(flat), ptr(image), int(is_u8), bstride,
@@ -67,7 +66,7 @@ class _EncoderFn(torch.autograd.Function):
         c.check(c.lib.var_arm_encoder_bwd(c.handle, current_stream_handle(), ptr(flat), ptr(gs[0]), ptr(gs[1]),
                                           ptr(gs[2]), ptr(gflat)), "var_arm_encoder_bwd")
         grads = [gflat[o:o + int(np.prod(s))].view(s) for o, (_, s) in zip(PARAM_OFFSETS, PARAM_SPECS)]
-        return (None, None, None, None, *grads)
+        return (None, None, None, None, None, *grads)
 
 
 class VARPretextNet(nn.Module):
@@ -185,7 +184,9 @@ class VARPretextNet(nn.Module):
 
         image_feat = image_feat_raw = pos_sound_raw = sound_feat_negative = None
         if image is not None or pos is not None or neg is not None:
-            outs = _EncoderFn.apply(self, image, pos, neg, *self._named_in_order())
+            params = self._named_in_order()
+            need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+            outs = _EncoderFn.apply(self, need_grad, image, pos, neg, *params)
             if image is not None:
                 image_feat, image_feat_raw = outs[0], outs[3]
             if pos is not None:
