@@ -94,8 +94,8 @@ int var_plan(var_ctx* c, int max_batch, int img_hw) {
         o_gsact[l] = carve(n);
     }
     const size_t o_hid_i = carve(B * kHid), o_hid_s = carve(2 * B * kHid);
-    const size_t o_emb = carve(9 * B), o_emb_raw = carve(9 * B), o_gemb = carve(18 * B);
-    const size_t o_ghid = carve(3 * B * kHid);
+    const size_t o_emb = carve(9 * B), o_emb_raw = carve(9 * B), o_gemb = carve(24 * B);
+    const size_t o_ghid = carve(6 * B * kHid);
     const size_t n_img_slab = img_slab_floats(), n_snd_slab = snd_slab_floats();
     const size_t o_slab = carve(n_img_slab + n_snd_slab);
     VAR_HIP_CHECK(c, hipMalloc((void**)&c->ws, off));
@@ -264,7 +264,7 @@ static const char* kTagNames[TAG_COUNT] = {
     "img_wgrad_kernel[3]", "img_wgrad_kernel[4]", "img_dgrad_kernel[0]", "img_dgrad_kernel[1]",
     "img_dgrad_kernel[2]", "img_dgrad_kernel[3]", "img_dgrad_kernel[4]", "img_wgrad_reduce_kernel",
     "snd_fwd_kernel", "snd_dgrad_kernel", "snd_wgrad_kernel", "snd_reduce_kernel", "heads_fwd_kernel",
-    "heads_bwd_rows_kernel", "heads_bwd_w_kernel", "triplet_kernel", "adam_kernel", "pack_weights_kernel",
+    "heads_bwd_rows_kernel", "heads_bwd_gemm_kernel", "triplet_kernel", "adam_kernel", "pack_weights_kernel",
     "mfcc_kernel"};
 
 int var_profile_tag_count(void) { return TAG_COUNT; }

@@ -2,63 +2,116 @@
 //   imgTriplet / soundTriplet = Linear(K,128)+ReLU+Linear(128,3)   (arm_pretext_model.py:46-56)
 //   F.normalize(p=2, dim=1, eps=1e-12)                              (pretext_base.py:18,23)
 //   TripletMarginLoss(margin, p=2, eps=1e-6, mean)                  (VAR/pretext_VAR.py:38,64)
-// Rows are samples; a workgroup owns 8 rows, keeps them in LDS and walks the transposed
-// first-layer weight W0T[k][j] (packed image) with coalesced loads, each value reused for
-// its 4 rows per thread.  All reductions are fixed-order (bitwise reproducible).
+//
+// The 128-wide hidden layer is GEMM-shaped and runs on the f32 matrix cores
+// (v_mfma_f32_32x32x2_f32); the 3-wide output layer, the normalisation and the loss are
+// per-row VALU work.  Every MFMA operand is read either from LDS (padded, conflict-free) or as
+// coalesced 128-byte rows straight from L2, prefetched a block of k-steps ahead in registers.
+// All reductions have a fixed order (bitwise reproducible).
 #include "var_common.h"
 
 namespace {
-constexpr int RB = 8;   // rows per workgroup
+constexpr int U = 8;    // k-steps per register-prefetch block
 
+// ------------------------------------------------------------------------------------------
+// forward: 32 rows x 128 hidden units per workgroup; wave w owns hidden units [32w, 32w+32)
+//   D[row][n] = sum_k X[row][k] * W0T[k][n]
+// ------------------------------------------------------------------------------------------
 template <int K>
 __global__ void __launch_bounds__(256)
-heads_fwd_kernel(const float* __restrict__ x, int nrows, int row_lo, int row_hi,
-                 const float* __restrict__ w0t, const float* __restrict__ b0,
-                 const float* __restrict__ w1, const float* __restrict__ b1,
+heads_fwd_kernel(const float* __restrict__ x, int R, const float* __restrict__ w0t,
+                 const float* __restrict__ b0, const float* __restrict__ w1, const float* __restrict__ b1,
                  float* __restrict__ hid, float* __restrict__ emb_raw, float* __restrict__ emb) {
-    __shared__ float xs[RB * K];
-    __shared__ float hs[RB * kHid];
-    __shared__ float raw[RB * 4];
-    const int tid = threadIdx.x, j = tid & 127, rh = tid >> 7;
-    const int r0 = blockIdx.x * RB;
-    for (int e = tid; e < RB * K; e += 256) {
-        const int r = e / K, k = e - r * K, row = r0 + r;
-        xs[e] = (row >= row_lo && row < row_hi) ? x[(size_t)row * K + k] : 0.f;
+    constexpr int LDX = K + 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* xs = lds;                    // [32][K+1]
+    float* hs = lds;                    // reused after the GEMM: [32][129]
+    float* raw = lds + 32 * 129;        // [32][4], after hs
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int r0 = blockIdx.x * 32;
+    // stage 32 rows (contiguous 32*K floats), 8 float4 loads in flight per lane
+    {
+        constexpr int TOT = 32 * K / 4;
+        const float4* src = (const float4*)(x + (size_t)r0 * K);
+        const int lim = (R - r0) * (K / 4);
+#pragma unroll 1
+        for (int e0 = tid; e0 < TOT; e0 += 256 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + 256 * u;
+                v[u] = (e < TOT && e < lim) ? src[e] : float4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + 256 * u;
+                if (e < TOT) {
+                    const int r = (e * 4) / K, k = (e * 4) - r * K;
+                    float* d = xs + r * LDX + k;
+                    d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+                }
+            }
+        }
     }
     __syncthreads();
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int k = 0; k < K; ++k) {
-        const float wv = w0t[k * kHid + j];
+    f32x16 acc;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] += wv * xs[(rh * 4 + i) * K + k];
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* wl = w0t + half * kHid + wave * 32 + l31;
+    const float* xl = xs + l31 * LDX + half;
+    constexpr int STEPS = K / 2, NBK = STEPS / U;
+    static_assert(STEPS % (2 * U) == 0, "K/2 must be a multiple of two prefetch blocks");
+    float wb[2][U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) wb[0][u] = wl[(2 * u) * kHid];
+#pragma unroll 1
+    for (int blk = 0; blk < NBK; blk += 2) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) wb[1][u] = wl[(2 * ((blk + 1) * U + u)) * kHid];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xl[2 * (blk * U + u)], wb[0][u], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (blk + 2 < NBK) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) wb[0][u] = wl[(2 * ((blk + 2) * U + u)) * kHid];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xl[2 * ((blk + 1) * U + u)], wb[1][u], acc, 0, 0, 0);
     }
-    const float bv = b0[j];
+    __syncthreads();                    // everyone is done reading xs
+    {
+        const int n = wave * 32 + l31;
+        const float bv = b0[n];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = rh * 4 + i, row = r0 + r;
-        float v = acc[i] + bv;
-        v = v > 0.f ? v : 0.f;
-        hs[r * kHid + j] = v;
-        if (row >= row_lo && row < row_hi) hid[(size_t)row * kHid + j] = v;
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            float v = acc[r] + bv;
+            v = v > 0.f ? v : 0.f;
+            hs[row * 129 + n] = v;
+            if (r0 + row < R) hid[(size_t)(r0 + row) * kHid + n] = v;
+        }
     }
     __syncthreads();
-    if (tid < RB * 3) {
+    if (tid < 96) {
         const int r = tid / 3, d = tid - r * 3;
         float s = b1[d];
-        for (int jj = 0; jj < kHid; ++jj) s += hs[r * kHid + jj] * w1[d * kHid + jj];
+#pragma unroll 8
+        for (int j = 0; j < kHid; ++j) s += hs[r * 129 + j] * w1[d * kHid + j];
         raw[r * 4 + d] = s;
     }
     __syncthreads();
-    if (tid < RB) {
+    if (tid < 32 && r0 + tid < R) {
         const int row = r0 + tid;
-        if (row >= row_lo && row < row_hi) {
-            const float a = raw[tid * 4], b = raw[tid * 4 + 1], c = raw[tid * 4 + 2];
-            const float nrm = sqrtf(a * a + b * b + c * c);
-            const float den = nrm > 1e-12f ? nrm : 1e-12f;
-            emb_raw[row * 3 + 0] = a; emb_raw[row * 3 + 1] = b; emb_raw[row * 3 + 2] = c;
-            emb[row * 3 + 0] = a / den; emb[row * 3 + 1] = b / den; emb[row * 3 + 2] = c / den;
-        }
+        const float a = raw[tid * 4], b = raw[tid * 4 + 1], c = raw[tid * 4 + 2];
+        const float nrm = sqrtf(a * a + b * b + c * c);
+        const float den = nrm > 1e-12f ? nrm : 1e-12f;
+        emb_raw[row * 3 + 0] = a; emb_raw[row * 3 + 1] = b; emb_raw[row * 3 + 2] = c;
+        emb[row * 3 + 0] = a / den; emb[row * 3 + 1] = b / den; emb[row * 3 + 2] = c / den;
     }
 }
 
@@ -100,153 +153,174 @@ triplet_kernel(const float* __restrict__ a, const float* __restrict__ p, const f
     if (tid == 0) loss_out[0] = ((part[0] + part[1]) + (part[2] + part[3])) * inv_count;
 }
 
-// Backward, per-row part: normalise-bwd -> graw; ghid = (graw @ W1) * (h>0); gx = (ghid @ W0) * (x>0)
-template <int K>
-__global__ void __launch_bounds__(256)
-heads_bwd_rows_kernel(const float* __restrict__ x, int nrows, int row_lo, int row_hi,
-                      const float* __restrict__ w0 /*(128,K)*/, const float* __restrict__ w1 /*(3,128)*/,
-                      const float* __restrict__ hid, const float* __restrict__ emb_raw,
-                      const float* __restrict__ emb, const float* __restrict__ gemb,
-                      float* __restrict__ graw_out, float* __restrict__ ghid_out, float* __restrict__ gx) {
-    __shared__ float gh[RB * kHid];
-    __shared__ float gr[RB * 4];
-    const int tid = threadIdx.x, j = tid & 127, rh = tid >> 7;
-    const int r0 = blockIdx.x * RB;
-    if (tid < RB) {
-        const int row = r0 + tid;
-        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-        if (row >= row_lo && row < row_hi) {
-            const float a = emb_raw[row * 3], b = emb_raw[row * 3 + 1], c = emb_raw[row * 3 + 2];
-            const float nrm = sqrtf(a * a + b * b + c * c);
-            const float den = nrm > 1e-12f ? nrm : 1e-12f;
-            const float y0 = emb[row * 3], y1 = emb[row * 3 + 1], y2 = emb[row * 3 + 2];
-            const float e0 = gemb[row * 3], e1 = gemb[row * 3 + 1], e2 = gemb[row * 3 + 2];
-            const float dot = y0 * e0 + y1 * e1 + y2 * e2;
-            g0 = (e0 - y0 * dot) / den; g1 = (e1 - y1 * dot) / den; g2 = (e2 - y2 * dot) / den;
-            graw_out[row * 3] = g0; graw_out[row * 3 + 1] = g1; graw_out[row * 3 + 2] = g2;
+// ------------------------------------------------------------------------------------------
+// backward, elementwise part: one thread per (row, hidden unit)
+//   graw = normalise-bwd(gemb);  ghid = (graw @ W1) * (hid > 0)  in both [row][n] and [n][row]
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128)
+heads_bwd_rows_kernel(int R, const float* __restrict__ w1, const float* __restrict__ hid,
+                      const float* __restrict__ emb_raw, const float* __restrict__ emb,
+                      const float* __restrict__ gemb, float* __restrict__ graw_out,
+                      float* __restrict__ ghid, float* __restrict__ ghidT) {
+    const int row = blockIdx.x, n = threadIdx.x;
+    const float a = emb_raw[row * 3], b = emb_raw[row * 3 + 1], c = emb_raw[row * 3 + 2];
+    const float nrm = sqrtf(a * a + b * b + c * c);
+    const float den = nrm > 1e-12f ? nrm : 1e-12f;
+    const float y0 = emb[row * 3], y1 = emb[row * 3 + 1], y2 = emb[row * 3 + 2];
+    const float e0 = gemb[row * 3], e1 = gemb[row * 3 + 1], e2 = gemb[row * 3 + 2];
+    const float dot = y0 * e0 + y1 * e1 + y2 * e2;
+    const float g0 = (e0 - y0 * dot) / den, g1 = (e1 - y1 * dot) / den, g2 = (e2 - y2 * dot) / den;
+    if (n < 4) graw_out[row * 4 + n] = n == 0 ? g0 : (n == 1 ? g1 : (n == 2 ? g2 : 0.f));
+    float v = g0 * w1[n] + g1 * w1[kHid + n] + g2 * w1[2 * kHid + n];
+    if (!(hid[(size_t)row * kHid + n] > 0.f)) v = 0.f;
+    ghid[(size_t)row * kHid + n] = v;
+    ghidT[(size_t)n * R + row] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, GEMM part: one wave per 32x32 output tile, D[i][j] = sum_q A[q][i] * Bm[q][j]
+// with BOTH operands stored [q][free] (free index contiguous => 128-byte coalesced rows):
+//   dW0[n][k]  : A = ghid [row][n],  Bm = x   [row][k],  q = row   (+ db0 = column sums of A)
+//   dW1[d][n]  : A = graw [row][4],  Bm = hid [row][n],  q = row   (+ db1)
+//   gx [row][k]: A = ghidT[n][row],  Bm = W0  [n][k],    q = n,    masked by x > 0
+// ------------------------------------------------------------------------------------------
+struct TileOp {
+    const float* A; int lda; int alim;       // alim: valid extent of A's free index (from its tile origin)
+    const float* Bm; int ldb; int blim;
+    int Q;                                   // reduction length
+};
+
+__device__ __forceinline__ void tile_gemm(const TileOp& t, int lane, f32x16& acc, float& asum) {
+    const int half = lane >> 5, l31 = lane & 31;
+    const bool aok = l31 < t.alim, bok = l31 < t.blim;
+    const float* ap = t.A + (aok ? l31 : 0);
+    const float* bp = t.Bm + (bok ? l31 : 0);
+    const int steps = (t.Q + 1) / 2;
+    float ab[2][U], bb[2][U];
+    auto fetch = [&](int buf, int s0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = 2 * (s0 + u) + half;
+            const bool ok = q < t.Q;
+            const int qc = ok ? q : 0;
+            const float av = ap[(size_t)qc * t.lda];
+            const float bv = bp[(size_t)qc * t.ldb];
+            ab[buf][u] = (ok && aok) ? av : 0.f;
+            bb[buf][u] = (ok && bok) ? bv : 0.f;
         }
-        gr[tid * 4] = g0; gr[tid * 4 + 1] = g1; gr[tid * 4 + 2] = g2;
-    }
-    __syncthreads();
-    {
-        const float wa = w1[j], wb = w1[kHid + j], wc = w1[2 * kHid + j];
+    };
+    fetch(0, 0);
+#pragma unroll 1
+    for (int s0 = 0; s0 < steps; s0 += 2 * U) {
+        fetch(1, s0 + U);
+        __builtin_amdgcn_sched_barrier(0);          // keep the prefetch above the MFMAs it overlaps with
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = rh * 4 + i, row = r0 + r;
-            float v = 0.f;
-            if (row >= row_lo && row < row_hi) {
-                v = gr[r * 4] * wa + gr[r * 4 + 1] * wb + gr[r * 4 + 2] * wc;
-                if (!(hid[(size_t)row * kHid + j] > 0.f)) v = 0.f;
-                ghid_out[(size_t)row * kHid + j] = v;
-            }
-            gh[r * kHid + j] = v;
+        for (int u = 0; u < U; ++u) {
+            asum += ab[0][u];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[0][u], bb[0][u], acc, 0, 0, 0);
         }
-    }
-    __syncthreads();
-    constexpr int KC = (K + 255) / 256;
-    float acc[KC][RB];
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(0, s0 + 2 * U);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int q = 0; q < KC; ++q)
-#pragma unroll
-        for (int r = 0; r < RB; ++r) acc[q][r] = 0.f;
-#pragma unroll 2
-    for (int jj = 0; jj < kHid; ++jj) {
-#pragma unroll
-        for (int q = 0; q < KC; ++q) {
-            const int k = tid + 256 * q;
-            const float wv = (k < K) ? w0[jj * K + k] : 0.f;
-#pragma unroll
-            for (int r = 0; r < RB; ++r) acc[q][r] += wv * gh[r * kHid + jj];
+        for (int u = 0; u < U; ++u) {
+            asum += ab[1][u];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[1][u], bb[1][u], acc, 0, 0, 0);
         }
-    }
-#pragma unroll
-    for (int q = 0; q < KC; ++q) {
-        const int k = tid + 256 * q;
-        if (k >= K) continue;
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const int row = r0 + r;
-            if (row >= row_lo && row < row_hi) {
-                const size_t o = (size_t)row * K + k;
-                gx[o] = x[o] > 0.f ? acc[q][r] : 0.f;
-            }
-        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-// Backward, weight part: dW0 = ghid^T x, db0 = sum ghid, dW1 = graw^T hid, db1 = sum graw
-// over rows [row_lo,row_hi).  Blocks 0..K/32-1 own 32 columns of dW0 each; the last block
-// owns the small tensors.  Fixed row order => deterministic.
 template <int K>
 __global__ void __launch_bounds__(256)
-heads_bwd_w_kernel(const float* __restrict__ x, int row_lo, int row_hi,
-                   const float* __restrict__ hid, const float* __restrict__ graw,
-                   const float* __restrict__ ghid,
-                   float* __restrict__ dw0, float* __restrict__ db0, float* __restrict__ dw1,
-                   float* __restrict__ db1) {
-    __shared__ float ghs[16 * kHid];
-    __shared__ float xs[16 * 32];
-    const int tid = threadIdx.x;
-    if (blockIdx.x == K / 32) {
-        if (tid < kHid) {
-            float s = 0.f;
-            for (int r = row_lo; r < row_hi; ++r) s += ghid[(size_t)r * kHid + tid];
-            db0[tid] = s;
+heads_bwd_gemm_kernel(int R /*rows in this call*/, int RT /*row stride of ghidT*/, const float* __restrict__ x,
+                      const float* __restrict__ w0, const float* __restrict__ hid,
+                      const float* __restrict__ graw, const float* __restrict__ ghid,
+                      const float* __restrict__ ghidT, float* __restrict__ dw0, float* __restrict__ db0,
+                      float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ gx) {
+    constexpr int KB = K / 32;
+    const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int RB = (R + 31) / 32;
+    const int n_dw0 = 4 * KB, n_dw1 = 4, n_gx = RB * KB;
+    if (tile >= n_dw0 + n_dw1 + n_gx) return;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float asum = 0.f;
+    if (tile < n_dw0) {
+        const int nb = tile / KB, kb = tile - nb * KB;
+        TileOp t{ghid + nb * 32, kHid, 32, x + kb * 32, K, 32, R};
+        tile_gemm(t, lane, acc, asum);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            dw0[(size_t)n * K + kb * 32 + l31] = acc[r];
         }
-        for (int o = tid; o < 3 * kHid; o += 256) {
-            const int d = o / kHid, jj = o - d * kHid;
-            float s = 0.f;
-            for (int r = row_lo; r < row_hi; ++r) s += graw[r * 3 + d] * hid[(size_t)r * kHid + jj];
-            dw1[o] = s;
+        if (kb == 0) {
+            asum += __shfl_down(asum, 32, 64);
+            if (half == 0) db0[nb * 32 + l31] = asum;
         }
-        if (tid < 3) {
-            float s = 0.f;
-            for (int r = row_lo; r < row_hi; ++r) s += graw[r * 3 + tid];
-            db1[tid] = s;
+    } else if (tile < n_dw0 + n_dw1) {
+        const int nb = tile - n_dw0;
+        TileOp t{graw, 4, 3, hid + nb * 32, kHid, 32, R};
+        tile_gemm(t, lane, acc, asum);
+        if (half == 0) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) dw1[d * kHid + nb * 32 + l31] = acc[d];
         }
-        return;
+        if (nb == 0) {
+            asum += __shfl_down(asum, 32, 64);
+            if (half == 0 && l31 < 3) db1[l31] = asum;
+        }
+    } else {
+        const int g = tile - n_dw0 - n_dw1;
+        const int rb = g / KB, kb = g - rb * KB;
+        TileOp t{ghidT + rb * 32, RT, R - rb * 32, w0 + kb * 32, K, 32, kHid};
+        tile_gemm(t, lane, acc, asum);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row < R) {
+                const size_t o = (size_t)row * K + kb * 32 + l31;
+                gx[o] = x[o] > 0.f ? acc[r] : 0.f;
+            }
+        }
     }
-    const int k0 = blockIdx.x * 32, kk = tid & 31, jg = tid >> 5;
-    float acc[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    for (int rb = row_lo; rb < row_hi; rb += 16) {
-        __syncthreads();
-        for (int e = tid; e < 16 * kHid; e += 256) {
-            const int r = rb + e / kHid;
-            ghs[e] = r < row_hi ? ghid[(size_t)r * kHid + (e % kHid)] : 0.f;
-        }
-        for (int e = tid; e < 16 * 32; e += 256) {
-            const int r = rb + e / 32;
-            xs[e] = r < row_hi ? x[(size_t)r * K + k0 + (e % 32)] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int rr = 0; rr < 16; ++rr) {
-            const float xv = xs[rr * 32 + kk];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] += ghs[rr * kHid + jg * 16 + i] * xv;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) dw0[(size_t)(jg * 16 + i) * K + k0 + kk] = acc[i];
 }
 }  // namespace
+
+template <int K>
+static int run_heads_fwd(var_ctx* c, hipStream_t s, const float* x, int R, const float* w0t, const float* b0,
+                         const float* w1, const float* b1, float* hid, float* emb_raw, float* emb) {
+    constexpr int A1 = 32 * (K + 1) * 4, A2 = (32 * 129 + 128) * 4;
+    constexpr int LDS_BYTES = A1 > A2 ? A1 : A2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)heads_fwd_kernel<K>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(heads_fwd_kernel<K>, dim3((R + 31) / 32), dim3(256), LDS_BYTES, s, x, R, w0t, b0, w1, b1,
+                       hid, emb_raw, emb);
+    return VAR_OK;
+}
 
 int launch_heads_fwd(var_ctx* c, hipStream_t s, const float* params, int B, bool has_img, bool has_pos, bool has_neg) {
     const ParamLayout& L = c->pl;
     const PackLayout& K = c->kl;
     ProfScope prof(c, s, TAG_HEADS_FWD);
+    int rc;
     if (has_img) {
-        hipLaunchKernelGGL(heads_fwd_kernel<kImgFeat>, dim3((B + RB - 1) / RB), dim3(256), 0, s,
-                           c->act[5], B, 0, B, c->wpack + K.ih_w0t, params + L.ih_b0, params + L.ih_w1,
-                           params + L.ih_b1, c->hid_i, c->emb_raw, c->emb);
+        if ((rc = run_heads_fwd<kImgFeat>(c, s, c->act[5], B, c->wpack + K.ih_w0t, params + L.ih_b0, params + L.ih_w1,
+                                          params + L.ih_b1, c->hid_i, c->emb_raw, c->emb)) != VAR_OK) return rc;
     }
     if (has_pos || has_neg) {
         const int lo = has_pos ? 0 : B, hi = has_neg ? 2 * B : B;
-        hipLaunchKernelGGL(heads_fwd_kernel<kSndFeat>, dim3((2 * B + RB - 1) / RB), dim3(256), 0, s,
-                           c->sact[4], 2 * B, lo, hi, c->wpack + K.sh_w0t, params + L.sh_b0, params + L.sh_w1,
-                           params + L.sh_b1, c->hid_s, c->emb_raw + 3 * B, c->emb + 3 * B);
+        if ((rc = run_heads_fwd<kSndFeat>(c, s, c->sact[4] + (size_t)lo * kSndFeat, hi - lo, c->wpack + K.sh_w0t,
+                                          params + L.sh_b0, params + L.sh_w1, params + L.sh_b1,
+                                          c->hid_s + (size_t)lo * kHid, c->emb_raw + 3 * (B + lo),
+                                          c->emb + 3 * (B + lo))) != VAR_OK) return rc;
     }
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
@@ -265,24 +339,40 @@ int launch_triplet(var_ctx* c, hipStream_t s, const float* a, const float* p, co
 int launch_heads_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads, int B, bool has_img,
                      int snd_lo, int snd_hi) {
     const ParamLayout& L = c->pl;
-    float* graw = c->gemb + 9 * (size_t)c->maxB;          // second half of the gemb buffer
-    ProfScope prof(c, s, TAG_HEADS_BWD_ROWS);
-    if (has_img) {
-        hipLaunchKernelGGL(heads_bwd_rows_kernel<kImgFeat>, dim3((B + RB - 1) / RB), dim3(256), 0, s,
-                           c->act[5], B, 0, B, params + L.ih_w0, params + L.ih_w1, c->hid_i, c->emb_raw, c->emb,
-                           c->gemb, graw, c->ghid, c->gact[5]);
-        hipLaunchKernelGGL(heads_bwd_w_kernel<kImgFeat>, dim3(kImgFeat / 32 + 1), dim3(256), 0, s,
-                           c->act[5], 0, B, c->hid_i, graw, c->ghid,
-                           grads + L.ih_w0, grads + L.ih_b0, grads + L.ih_w1, grads + L.ih_b1);
+    const size_t mB = (size_t)c->maxB;
+    float* graw = c->gemb + 9 * mB;                       // (3B,4)
+    float* ghidT = c->ghid + 3 * mB * kHid;               // second half of the ghid buffer: [128][rows]
+    {
+        ProfScope prof(c, s, TAG_HEADS_BWD_ROWS);
+        if (has_img)
+            hipLaunchKernelGGL(heads_bwd_rows_kernel, dim3(B), dim3(128), 0, s, B, params + L.ih_w1, c->hid_i,
+                               c->emb_raw, c->emb, c->gemb, graw, c->ghid, ghidT);
+        if (snd_hi > snd_lo) {
+            const int R = snd_hi - snd_lo;
+            hipLaunchKernelGGL(heads_bwd_rows_kernel, dim3(R), dim3(128), 0, s, R, params + L.sh_w1,
+                               c->hid_s + (size_t)snd_lo * kHid, c->emb_raw + 3 * (B + snd_lo),
+                               c->emb + 3 * (B + snd_lo), c->gemb + 3 * (B + snd_lo), graw + 4 * (B + snd_lo),
+                               c->ghid + (size_t)(B + snd_lo) * kHid, ghidT + (size_t)B * kHid);
+        }
     }
-    if (snd_hi > snd_lo) {
-        hipLaunchKernelGGL(heads_bwd_rows_kernel<kSndFeat>, dim3((2 * B + RB - 1) / RB), dim3(256), 0, s,
-                           c->sact[4], 2 * B, snd_lo, snd_hi, params + L.sh_w0, params + L.sh_w1, c->hid_s,
-                           c->emb_raw + 3 * B, c->emb + 3 * B, c->gemb + 3 * B, graw + 3 * B,
-                           c->ghid + (size_t)B * kHid, c->gsact[4]);
-        hipLaunchKernelGGL(heads_bwd_w_kernel<kSndFeat>, dim3(kSndFeat / 32 + 1), dim3(256), 0, s,
-                           c->sact[4], snd_lo, snd_hi, c->hid_s, graw + 3 * B, c->ghid + (size_t)B * kHid,
-                           grads + L.sh_w0, grads + L.sh_b0, grads + L.sh_w1, grads + L.sh_b1);
+    {
+        ProfScope prof(c, s, TAG_HEADS_BWD_W);
+        if (has_img) {
+            const int tiles = 4 * (kImgFeat / 32) + 4 + ((B + 31) / 32) * (kImgFeat / 32);
+            hipLaunchKernelGGL(heads_bwd_gemm_kernel<kImgFeat>, dim3((tiles + 3) / 4), dim3(256), 0, s, B, B,
+                               c->act[5], params + L.ih_w0, c->hid_i, graw, c->ghid, ghidT,
+                               grads + L.ih_w0, grads + L.ih_b0, grads + L.ih_w1, grads + L.ih_b1, c->gact[5]);
+        }
+        if (snd_hi > snd_lo) {
+            const int R = snd_hi - snd_lo;
+            const int tiles = 4 * (kSndFeat / 32) + 4 + ((R + 31) / 32) * (kSndFeat / 32);
+            hipLaunchKernelGGL(heads_bwd_gemm_kernel<kSndFeat>, dim3((tiles + 3) / 4), dim3(256), 0, s, R, R,
+                               c->sact[4] + (size_t)snd_lo * kSndFeat, params + L.sh_w0,
+                               c->hid_s + (size_t)snd_lo * kHid, graw + 4 * (B + snd_lo),
+                               c->ghid + (size_t)(B + snd_lo) * kHid, ghidT + (size_t)B * kHid,
+                               grads + L.sh_w0, grads + L.sh_b0, grads + L.sh_w1, grads + L.sh_b1,
+                               c->gsact[4] + (size_t)snd_lo * kSndFeat);
+        }
     }
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;

@@ -13,7 +13,7 @@
 //           accumulators in registers, then writes ONE partial slab; bias sums ride along.
 //   reduce: fixed-order sum of the slabs into the OIHW gradient arena (bitwise reproducible;
 //           no float atomics).
-#include "var_common.h"
+#include "img_stage.h"
 
 // ------------------------------------------------------------------------------------------
 // dgrad
@@ -34,7 +34,8 @@ struct DgCfg {
     static constexpr int CBLK = CIN / 32;
     static constexpr int ITEMS = NPB * CBLK;         // per class
     static constexpr int IPC = (ITEMS + NW - 1) / NW;
-    static constexpr int LDS_BYTES = NU * UNIT * 4;
+    static constexpr int LDS_FLOATS = (NU * UNIT + 3) / 4 * 4;
+    static constexpr int LDS_BYTES = LDS_FLOATS * 4;
     static_assert(RI % 2 == 0, "band must hold whole row pairs");
 };
 
@@ -49,24 +50,15 @@ img_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ wd, con
     const int total_units = B * C::NB;
     const int unit0 = blockIdx.x * C::NU;
 
+    lds_zero<NT>(lds, C::LDS_FLOATS, tid);
+    __syncthreads();
 #pragma unroll 1
     for (int u = 0; u < C::NU; ++u) {
         const int unit = unit0 + u;
         const bool uvalid = unit < total_units;
-        const int b = unit / C::NB, band = unit - b * C::NB;
-        const int oy0 = band * (C::RI / 2);
-        float* dst = lds + u * C::UNIT;
-        const float* src = gy + (size_t)b * C::COUT * C::HO * C::WO;
-        for (int e = tid; e < C::UNIT; e += NT) {
-            const int n = e / C::PLANE;
-            const int rem = e - n * C::PLANE;
-            const int r = rem / C::POW;
-            const int col = rem - r * C::POW;
-            const int oy = oy0 + r;
-            float v = 0.f;
-            if (uvalid && oy < C::HO && col < C::WO) v = src[(n * C::HO + oy) * C::WO + col];
-            dst[e] = v;
-        }
+        const int b = uvalid ? unit / C::NB : 0, band = unit % C::NB;
+        stage_y_band<C::COUT, C::HO, C::WO, C::NR, C::POW, C::PLANE, NT>(
+            lds + u * C::UNIT, gy + (size_t)b * C::COUT * C::HO * C::WO, band * (C::RI / 2), uvalid, tid);
     }
     __syncthreads();
 
@@ -90,26 +82,45 @@ img_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ wd, con
             f32x16 acc0, acc1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-            // row taps: py=0 -> ky=1 (doy 0);  py=1 -> ky=0 (doy 1), ky=2 (doy 0)
+            // row taps: py=0 -> ky=1 (doy 0);  py=1 -> ky=0 (doy 1), ky=2 (doy 0).
+            // Filter values (L2-resident packed image) are prefetched one block of U n-pairs ahead.
+            constexpr int U = 8;
+            constexpr int BPT = (C::COUT / 2) / U;               // blocks per row tap
+            const int NBK = (py ? 2 : 1) * BPT;
+            float wb[2][3][U];
+            {
+                const int ky0 = py ? 0 : 1;
 #pragma unroll
-            for (int t = 0; t < (py ? 2 : 1); ++t) {
-                const int ky = py ? (t ? 2 : 0) : 1;
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        wb[0][kx][u] = wc[(size_t)((ky0 * 3 + kx) * C::COUT + 2 * u) * C::CIN];
+            }
+#pragma unroll
+            for (int blk = 0; blk < (py ? 2 : 1) * BPT; ++blk) {
+                const int t = blk / BPT, nb0 = (blk % BPT) * U;
                 const int doy = (py && !t) ? 1 : 0;
-                const float* w0 = wc + (size_t)((ky * 3 + 0) * C::COUT) * C::CIN;   // kx=0: px=1, dox=1
-                const float* w1 = wc + (size_t)((ky * 3 + 1) * C::COUT) * C::CIN;   // kx=1: px=0, dox=0
-                const float* w2 = wc + (size_t)((ky * 3 + 2) * C::COUT) * C::CIN;   // kx=2: px=1, dox=0
-                const int lb = base + doy * C::POW;
-#pragma unroll 4
-                for (int n2 = 0; n2 < C::COUT / 2; ++n2) {
-                    const float b0 = lds[lb + 2 * n2 * C::PLANE];
-                    const float b1 = lds[lb + 2 * n2 * C::PLANE + 1];
-                    const float a0 = w0[2 * n2 * C::CIN];
-                    const float a1 = w1[2 * n2 * C::CIN];
-                    const float a2 = w2[2 * n2 * C::CIN];
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b0, acc1, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc1, 0, 0, 0);
+                if (blk + 1 < NBK) {
+                    const int t1 = (blk + 1) / BPT, nb1 = ((blk + 1) % BPT) * U;
+                    const int ky1 = py ? (t1 ? 2 : 0) : 1;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                        for (int u = 0; u < U; ++u)
+                            wb[(blk + 1) & 1][kx][u] = wc[(size_t)((ky1 * 3 + kx) * C::COUT + 2 * (nb1 + u)) * C::CIN];
                 }
+                __builtin_amdgcn_sched_barrier(0);      // prefetch loads stay above this block's MFMAs
+                const int lb = base + doy * C::POW;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float b0 = lds[lb + 2 * (nb0 + u) * C::PLANE];
+                    const float b1 = lds[lb + 2 * (nb0 + u) * C::PLANE + 1];
+                    // kx=1 -> px=0 (dox 0); kx=2 -> px=1 (dox 0); kx=0 -> px=1 (dox 1)
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[blk & 1][1][u], b0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[blk & 1][2][u], b0, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[blk & 1][0][u], b1, acc1, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             // epilogue: rows = channel c, col (lane&31) = pixel pair
             const int iy = band * C::RI + 2 * j + py;
@@ -156,8 +167,8 @@ struct WgCfg {
     static constexpr int NBLK = COUT / 32;
     static constexpr int CBLK = SMALLC ? 1 : CIN / 32;
     static constexpr int NW = SMALLC ? 4 : NBLK * CBLK * 3;   // wave -> (nb, cb, ky) | K-split
-    static constexpr int XS = NU * UNIT_X, YS = NU * UNIT_Y;
-    static constexpr int LDS_FLOATS = (XS + YS) > (SMALLC ? 4 * 1024 : 0) ? (XS + YS) : 4 * 1024;
+    static constexpr int XS = (NU * UNIT_X + 3) & ~3, YS = NU * UNIT_Y;
+    static constexpr int LDS_FLOATS = ((XS + YS) > (SMALLC ? 4 * 1024 : 0) ? (XS + YS) : 4 * 1024) + 3 & ~3;
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
     static constexpr int SLAB = SMALLC ? (COUT * 32 + COUT) : (COUT * 9 * CIN + COUT);
     static constexpr int HSTEPS = (WO + 1) / 2;
@@ -195,46 +206,23 @@ img_wgrad_kernel(const void* __restrict__ xin, long bstride, const float* __rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float bsum = 0.f;
+    lds_zero<NT>(lds, C::LDS_FLOATS, tid);
 
 #pragma unroll 1
     for (int unit0 = blockIdx.x * C::NU; unit0 < total_units; unit0 += G * C::NU) {
         __syncthreads();
-        // ---- stage x bands and gy bands ----
+        // ---- stage x bands and gy bands (pads were zeroed once; data cells are always rewritten) ----
 #pragma unroll 1
         for (int u = 0; u < C::NU; ++u) {
             const int unit = unit0 + u;
             const bool uvalid = unit < total_units;
-            const int b = unit / C::NB, band = unit - b * C::NB;
-            const int iy0 = 2 * band * C::R - 1;
-            const uint8_t* src8 = (const uint8_t*)xin + (size_t)b * bstride;
-            const float* src32 = (const float*)xin + (size_t)b * bstride;
-            float* dx = xs + u * C::UNIT_X;
-            for (int e = tid; e < C::UNIT_X; e += NT) {
-                const int c = e / C::PLANE_X;
-                const int rem = e - c * C::PLANE_X;
-                const int r = rem / C::PW;
-                const int col = rem - r * C::PW;
-                const int iy = iy0 + r, ix = col - 1;
-                float v = 0.f;
-                if (uvalid && r < C::IR && iy >= 0 && iy < C::H && ix >= 0 && ix < C::W) {
-                    const int off = (c * C::H + iy) * C::W + ix;
-                    if constexpr (C::U8) v = (float)src8[off] / 255.f;
-                    else v = src32[off];
-                }
-                dx[e] = v;
-            }
-            const float* sy = gy + (size_t)b * C::COUT * C::HO * C::WO;
-            float* dy = ys + u * C::UNIT_Y;
-            for (int e = tid; e < C::UNIT_Y; e += NT) {
-                const int n = e / C::PLANE_Y;
-                const int rem = e - n * C::PLANE_Y;
-                const int r = rem / C::POW;
-                const int col = rem - r * C::POW;
-                const int oy = band * C::R + r;
-                float v = 0.f;
-                if (uvalid && r < C::R && oy < C::HO && col < C::WO) v = sy[(n * C::HO + oy) * C::WO + col];
-                dy[e] = v;
-            }
+            const int b = uvalid ? unit / C::NB : 0, band = unit % C::NB;
+            const void* img = C::U8 ? (const void*)((const uint8_t*)xin + (size_t)b * bstride)
+                                    : (const void*)((const float*)xin + (size_t)b * bstride);
+            stage_x_band<C::CIN, C::H, C::W, C::IR, C::PW, C::PLANE_X, C::U8, NT>(xs + u * C::UNIT_X, img,
+                                                                                  2 * band * C::R - 1, uvalid, tid);
+            stage_y_band<C::COUT, C::HO, C::WO, C::R, C::POW, C::PLANE_Y, NT>(
+                ys + u * C::UNIT_Y, gy + (size_t)b * C::COUT * C::HO * C::WO, band * C::R, uvalid, tid);
         }
         __syncthreads();
         // ---- K loop over the pixels of the staged units ----
@@ -322,6 +310,7 @@ img_wgrad_reduce_kernel(RedTable T, const float* __restrict__ slabs, float* __re
     const int e = j - T.start[l];
     const float* p = slabs + S.slab_off + e;
     float s = 0.f;
+#pragma unroll 8
     for (int g = 0; g < S.G; ++g) s += p[(size_t)g * S.slab_sz];
     const int nw = S.smallc ? S.cout * 32 : S.cout * 9 * S.cin;
     if (e >= nw) { grads[S.gb + (e - nw)] = s; return; }

@@ -12,7 +12,7 @@
 // flattened and cut into 32-pixel blocks; (pixel block, 32-channel block) items are dealt
 // round-robin to the NW waves.  The u8 -> f32 "/255" of dataset.py:67-68 is fused into
 // the staging of the first layer.
-#include "var_common.h"
+#include "img_stage.h"
 
 template <int CIN_, int COUT_, int H_, bool U8_, int R_, int NU_, int NW_>
 struct FwdCfg {
@@ -30,8 +30,10 @@ struct FwdCfg {
     static constexpr int NBLK = COUT / 32;
     static constexpr int ITEMS = NPB * NBLK;
     static constexpr int IPW = (ITEMS + NW - 1) / NW;
-    static constexpr int LDS_BYTES = NU * UNIT * 4;
+    static constexpr int LDS_FLOATS = (NU * UNIT + 3) / 4 * 4;
+    static constexpr int LDS_BYTES = LDS_FLOATS * 4;
     static constexpr int KSTEPS = (CIN * 9 + 1) / 2;
+    static_assert(ITEMS % NW == 0, "every wave must own the same number of (pixel block, channel block) items");
 };
 
 template <class C>
@@ -45,30 +47,18 @@ img_conv_fwd_kernel(const void* __restrict__ xin, long bstride, const float* __r
     const int total_units = B * C::NB;
     const int unit0 = blockIdx.x * C::NU;
 
-    // ---- stage the input bands (zero padding materialised) ----
+    // ---- stage the input bands: zero the pads once, then wide unrolled copies ----
+    lds_zero<NT>(lds, C::LDS_FLOATS, tid);
+    __syncthreads();
 #pragma unroll 1
     for (int u = 0; u < C::NU; ++u) {
         const int unit = unit0 + u;
         const bool uvalid = unit < total_units;
-        const int b = unit / C::NB, band = unit - b * C::NB;
-        const int iy0 = 2 * band * C::R - 1;
-        float* dst = lds + u * C::UNIT;
-        const uint8_t* src8 = (const uint8_t*)xin + (size_t)b * bstride;
-        const float* src32 = (const float*)xin + (size_t)b * bstride;
-        for (int e = tid; e < C::UNIT; e += NT) {
-            const int c = e / C::PLANE;
-            const int rem = e - c * C::PLANE;
-            const int r = rem / C::PW;
-            const int col = rem - r * C::PW;
-            const int iy = iy0 + r, ix = col - 1;
-            float v = 0.f;
-            if (uvalid && iy >= 0 && iy < C::H && ix >= 0 && ix < C::W) {
-                const int off = (c * C::H + iy) * C::W + ix;
-                if constexpr (C::U8) v = (float)src8[off] / 255.f;
-                else v = src32[off];
-            }
-            dst[e] = v;
-        }
+        const int b = uvalid ? unit / C::NB : 0, band = unit % C::NB;
+        const void* img = C::U8 ? (const void*)((const uint8_t*)xin + (size_t)b * bstride)
+                                : (const void*)((const float*)xin + (size_t)b * bstride);
+        stage_x_band<C::CIN, C::H, C::W, C::IR, C::PW, C::PLANE, C::U8, NT>(lds + u * C::UNIT, img,
+                                                                            2 * band * C::R - 1, uvalid, tid);
     }
     __syncthreads();
 
@@ -91,26 +81,53 @@ img_conv_fwd_kernel(const void* __restrict__ xin, long bstride, const float* __r
     }
 
     if constexpr (C::CIN % 2 == 0) {
+        // Filter values come straight from the packed image Wf[k][n] in L2; they are prefetched
+        // one block (U k-steps) ahead into a second register set so that no MFMA waits on L2.
+        constexpr int SPT = C::CIN / 2;                  // k-steps per tap
+        constexpr int U = SPT > 16 ? 16 : SPT;           // k-steps per block
+        constexpr int BPT = SPT / U;                     // blocks per tap
+        constexpr int NBK = 9 * BPT;
+        float wbuf[2][C::IPW][U];
 #pragma unroll
         for (int i = 0; i < C::IPW; ++i) { pixoff[i] += half * C::PLANE; wl[i] += half * C::COUT; }
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        for (int i = 0; i < C::IPW; ++i)
+#pragma unroll
+            for (int u = 0; u < U; ++u) wbuf[0][i][u] = wl[i][(2 * u) * C::COUT];
+#pragma unroll
+        for (int blk = 0; blk < NBK; ++blk) {
+            const int tap = blk / BPT, c2b = (blk % BPT) * U;
             const int toff = (tap / 3) * C::PW + (tap % 3);
-#pragma unroll 4
-            for (int c2 = 0; c2 < C::CIN / 2; ++c2) {
-                const int k = tap * C::CIN + 2 * c2;
+            if (blk + 1 < NBK) {
+                const int ntap = (blk + 1) / BPT, nc2b = ((blk + 1) % BPT) * U;
+#pragma unroll
+                for (int i = 0; i < C::IPW; ++i)
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        wbuf[(blk + 1) & 1][i][u] = wl[i][(ntap * C::CIN + 2 * (nc2b + u)) * C::COUT];
+            }
+            // keep the prefetch loads ABOVE this block's MFMAs: hipcc's scheduler otherwise sinks each
+            // load down to its first use and every MFMA then waits a full L2 round trip
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
 #pragma unroll
                 for (int i = 0; i < C::IPW; ++i) {
-                    if (wave + C::NW * i < C::ITEMS) {
-                        const float a = wl[i][k * C::COUT];
-                        const float bv = lds[pixoff[i] + 2 * c2 * C::PLANE + toff];
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[i], 0, 0, 0);
-                    }
+                    // no per-item predicate here: a conditional MFMA makes hipcc shuttle the whole
+                    // accumulator through v_accvgpr moves around every instruction (ITEMS % NW == 0)
+                    const float bv = lds[pixoff[i] + 2 * (c2b + u) * C::PLANE + toff];
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wbuf[blk & 1][i][u], bv, acc[i], 0, 0, 0);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     } else {
         // CIN = 3: K = 27 (+1 zero row in the packed filter); k = 2*s + half, tap = k/3, c = k%3
+        float wreg[C::IPW][C::KSTEPS];
+#pragma unroll
+        for (int i = 0; i < C::IPW; ++i)
+#pragma unroll
+            for (int s = 0; s < C::KSTEPS; ++s) wreg[i][s] = wl[i][(2 * s + half) * C::COUT];
 #pragma unroll
         for (int s = 0; s < C::KSTEPS; ++s) {
             constexpr int KMAX = C::CIN * 9 - 1;
@@ -118,14 +135,10 @@ img_conv_fwd_kernel(const void* __restrict__ xin, long bstride, const float* __r
             const int o0 = (k0 % 3) * C::PLANE + ((k0 / 3) / 3) * C::PW + ((k0 / 3) % 3);
             const int o1 = (k1 % 3) * C::PLANE + ((k1 / 3) / 3) * C::PW + ((k1 / 3) % 3);
             const int o = half ? o1 : o0;
-            const int k = 2 * s + half;
 #pragma unroll
             for (int i = 0; i < C::IPW; ++i) {
-                if (wave + C::NW * i < C::ITEMS) {
-                    const float a = wl[i][k * C::COUT];
-                    const float bv = lds[pixoff[i] + o];
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[i], 0, 0, 0);
-                }
+                const float bv = lds[pixoff[i] + o];
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[i][s], bv, acc[i], 0, 0, 0);
             }
         }
     }

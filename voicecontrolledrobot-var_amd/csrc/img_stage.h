@@ -1,0 +1,123 @@
+// LDS staging helpers shared by the image-conv kernels.
+//
+// Every conv kernel keeps bands of NCHW rows in LDS as [channel][row][padded col].  Two rules
+// make the copy fast on CDNA4: (1) the widest aligned global load the row width allows
+// (16 B for W % 4 == 0, 8 B for even W, uchar4 for u8 images) and (2) many loads in flight per
+// lane -- the loop is unrolled UF-fold with all loads issued before the first LDS store, so a
+// lane has UF x 16 B outstanding instead of one dependent load per iteration.
+#pragma once
+#include "var_common.h"
+
+template <int NT>
+__device__ __forceinline__ void lds_zero(float* dst, int nfloats, int tid) {
+    // nfloats is a multiple of 4 by construction of the callers (LDS carve rounded up)
+    float4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int e = tid; e < nfloats / 4; e += NT) ((float4*)dst)[e] = z;
+}
+
+// Copy rows [iy0, iy0+IR) x cols [0,W) of CIN planes of one NCHW image into dst[c*PLANE + r*PW + 1 + x].
+// Rows outside [0,H) are written as zeros.  Column 0 and columns > W are NOT touched (pre-zeroed).
+template <int CIN, int H, int W, int IR, int PW, int PLANE, bool U8, int NT>
+__device__ __forceinline__ void stage_x_band(float* __restrict__ dst, const void* __restrict__ img,
+                                             int iy0, bool uvalid, int tid) {
+    constexpr int V = U8 ? 4 : (W % 4 == 0 ? 4 : (W % 2 == 0 ? 2 : 1));
+    constexpr int WV = W / V;
+    constexpr int TOT = CIN * IR * WV;
+    constexpr int UF = 8;
+    static_assert(W % V == 0, "row width must be a multiple of the vector width");
+#pragma unroll 1
+    for (int e0 = tid; e0 < TOT; e0 += NT * UF) {
+        float v[UF][V];
+        int off[UF];
+#pragma unroll
+        for (int u = 0; u < UF; ++u) {
+            const int e = e0 + u * NT;
+            const bool ok = e < TOT;
+            const int ee = ok ? e : 0;
+            const int c = ee / (IR * WV);
+            const int rem = ee - c * (IR * WV);
+            const int r = rem / WV;
+            const int xv = rem - r * WV;
+            const int iy = iy0 + r;
+            const bool valid = ok && uvalid && iy >= 0 && iy < H;
+            const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
+            const int so = (c * H + iyc) * W + xv * V;
+            if constexpr (U8) {
+                const uchar4 q = *(const uchar4*)((const uint8_t*)img + so);
+                v[u][0] = (float)q.x / 255.f; v[u][1] = (float)q.y / 255.f;
+                v[u][2] = (float)q.z / 255.f; v[u][3] = (float)q.w / 255.f;
+            } else if constexpr (V == 4) {
+                const float4 q = *(const float4*)((const float*)img + so);
+                v[u][0] = q.x; v[u][1] = q.y; v[u][2] = q.z; v[u][3] = q.w;
+            } else if constexpr (V == 2) {
+                const float2 q = *(const float2*)((const float*)img + so);
+                v[u][0] = q.x; v[u][1] = q.y;
+            } else {
+                v[u][0] = ((const float*)img)[so];
+            }
+            if (!valid) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) v[u][j] = 0.f;
+            }
+            off[u] = ok ? c * PLANE + r * PW + 1 + xv * V : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < UF; ++u) {
+            if (off[u] >= 0) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) dst[off[u] + j] = v[u][j];
+            }
+        }
+    }
+}
+
+// Copy rows [oy0, oy0+NR) x cols [0,WO) of COUT planes of one (COUT,HO,WO) gradient image into
+// dst[n*PLANE + r*POW + x]; rows >= HO are written as zeros; columns >= WO are NOT touched.
+template <int COUT, int HO, int WO, int NR, int POW, int PLANE, int NT>
+__device__ __forceinline__ void stage_y_band(float* __restrict__ dst, const float* __restrict__ img,
+                                             int oy0, bool uvalid, int tid) {
+    constexpr int V = (WO % 4 == 0) ? 4 : (WO % 2 == 0 ? 2 : 1);
+    constexpr int WV = WO / V;
+    constexpr int TOT = COUT * NR * WV;
+    constexpr int UF = 8;
+#pragma unroll 1
+    for (int e0 = tid; e0 < TOT; e0 += NT * UF) {
+        float v[UF][V];
+        int off[UF];
+#pragma unroll
+        for (int u = 0; u < UF; ++u) {
+            const int e = e0 + u * NT;
+            const bool ok = e < TOT;
+            const int ee = ok ? e : 0;
+            const int n = ee / (NR * WV);
+            const int rem = ee - n * (NR * WV);
+            const int r = rem / WV;
+            const int xv = rem - r * WV;
+            const int oy = oy0 + r;
+            const bool valid = ok && uvalid && oy < HO;
+            const int oyc = oy >= HO ? HO - 1 : oy;
+            const int so = (n * HO + oyc) * WO + xv * V;
+            if constexpr (V == 4) {
+                const float4 q = *(const float4*)(img + so);
+                v[u][0] = q.x; v[u][1] = q.y; v[u][2] = q.z; v[u][3] = q.w;
+            } else if constexpr (V == 2) {
+                const float2 q = *(const float2*)(img + so);
+                v[u][0] = q.x; v[u][1] = q.y;
+            } else {
+                v[u][0] = img[so];
+            }
+            if (!valid) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) v[u][j] = 0.f;
+            }
+            off[u] = ok ? n * PLANE + r * POW + xv * V : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < UF; ++u) {
+            if (off[u] >= 0) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) dst[off[u] + j] = v[u][j];
+            }
+        }
+    }
+}
