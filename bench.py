@@ -104,18 +104,13 @@ def main():
     torch.manual_seed(453)                                     # pretextEnvSeed; identical weights on every rank
     model = var_amd.VARPretextNet(cfg).to(dev)
     tr = var_amd.VARTrainer(model, lr=1e-4, weight_decay=1e-6, margin=1.0)
-    pool = var_amd.SyntheticTripletPool(4096, hw=HW, seed=rank, clips_per_class=64, device=dev)
-    img = torch.empty((B, 3, HW, HW), dtype=torch.uint8, device=dev)
-    pcm = torch.empty((2 * B, 16000), dtype=torch.int16, device=dev)
-    lens = torch.empty(2 * B, dtype=torch.int32, device=dev)
-    feats = torch.empty((2 * B, 1, 100, 40), dtype=torch.float32, device=dev)
+    pool = var_amd.SyntheticTripletPool(4096, hw=HW, seed=rank, clips_per_class=64, device=dev).freeze_pairs()
     ctx = Context.get(local_rank)
     ctx.ensure_plan(B, HW)
 
     def step():
-        idx, cp = pool.sample_indices(B)
-        pool.gather(idx, cp, out_img=img, out_pcm=pcm, out_len=lens)
-        tr.step_from_pcm(img, pcm, lens, mfcc_out=feats, global_batch=B * world)
+        img_idx, clip_idx, lens = pool.next_batch_indices(B)
+        tr.step_from_dataset(pool.images, img_idx, pool.clips, clip_idx, lens, global_batch=B * world)
 
     def barrier():
         if world > 1:

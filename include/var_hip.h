@@ -104,6 +104,19 @@ int var_arm_loss_grad(var_ctx* ctx, void* stream, const float* params,
                       float margin, float inv_count,
                       float* grads, float* loss_out, float* feats_out);
 
+/* The same with the data-loader work of dataset.py:64-89 / Envs/audioLoader.py:147-157 folded in:
+ * the batch is gathered by index from a dataset resident in HBM and the MFCC front-end runs
+ * inside the step (on a side stream, beside the image CNN).
+ *   image        dataset images (N,C>=3,H,H) u8|f32; sample b uses row image_index[b] (NULL: row b)
+ *   pcm          dataset clips, rows of pcm_stride int16 samples; clip_index (2B) = [pos | neg] rows
+ *                (NULL: rows 0..2B-1); lens (2B) valid samples per clip, 0 = the "empty" class whose
+ *                MFCC is all zeros (dataset.py:37-38) */
+int var_arm_loss_grad_pcm(var_ctx* ctx, void* stream, const float* params,
+                          const void* image, int image_is_u8, long image_bstride, const int* image_index,
+                          const int16_t* pcm, int pcm_stride, const int* clip_index, const int* lens,
+                          int B, int H, float margin, float inv_count,
+                          float* grads, float* loss_out, float* feats_out);
+
 /* torch.optim.Adam(lr, betas, eps, weight_decay) .step() (VAR/pretext_VAR.py:33-35,69)
  * on flat arenas; `step` is the 1-based step count.  When n == VAR_N_PARAMS and
  * params is the model arena the packed weight images are refreshed as well. */
@@ -112,11 +125,12 @@ int var_adam_step(var_ctx* ctx, void* stream, float* params, const float* grads,
                   float weight_decay, int step);
 
 /* Audio front-end: Envs/audioLoader.py:147-157 (torchaudio MFCC branch) + :241-252
- * (processSoundFeat).  pcm: nclips rows of `pcm_stride` int16 samples, lens[i] valid
- * samples each (<= pcm_stride); out: (nclips, 1, out_frames, 40) f32, frames beyond
- * 1 + len/160 are zero (MFCC-domain padding), frames beyond out_frames are dropped. */
-int var_mfcc(var_ctx* ctx, void* stream, const int16_t* pcm, const int* lens, int nclips,
-             int pcm_stride, int out_frames, float* out);
+ * (processSoundFeat).  pcm: rows of `pcm_stride` int16 samples; output clip i reads row
+ * clip_index[i] (NULL: row i) and lens[i] valid samples (<= pcm_stride; 0 = "empty" class =>
+ * zeros); out: (nclips, 1, out_frames, 40) f32, frames beyond 1 + len/160 are zero
+ * (MFCC-domain padding), frames beyond out_frames are dropped. */
+int var_mfcc(var_ctx* ctx, void* stream, const int16_t* pcm, const int* lens, const int* clip_index,
+             int nclips, int pcm_stride, int out_frames, float* out);
 
 /* Measurement and testing hooks -------------------------------------------------
  * var_profile_select: record HIP events, on the launch stream, around every launch of one

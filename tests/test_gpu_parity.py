@@ -222,6 +222,20 @@ def test_batch_256_properties(var_amd, golden_dir):
         lacc += tr.loss.item() / 4
     assert abs(l_full - lacc) < 1e-5
     assert float((g_full - acc).abs().max()) < 1e-3 * float(acc.abs().max())
+    # the in-step data path (gather by index + MFCC on the side stream) gives the same step
+    tr.loss_and_grads(img, pos, neg)
+    g_ref2, l_ref2 = tr.grads.clone(), tr.loss.item()
+    tr2 = var_amd.VARTrainer(m)
+    cls = torch.cat([pool.gt[idx], pool.sn[idx]])
+    clip_id = (torch.clamp(cls, max=pool.task_num - 1) * pool.cpc + torch.cat([cp[0], cp[1]])).to(torch.int32)
+    c = tr2.ctx
+    from var_amd._lib import ptr, current_stream_handle
+    c.check(c.lib.var_arm_loss_grad_pcm(c.handle, current_stream_handle(), ptr(m.flat_parameters()), ptr(pool.images), 1,
+                                        pool.images.stride(0), ptr(idx.to(torch.int32)), ptr(pool.clips),
+                                        pool.clips.stride(0), ptr(clip_id), ptr(lens), 256, 84, 1.0, 1.0 / 256,
+                                        ptr(tr2.gbuf), tr2.gbuf.data_ptr() + 4 * var_amd.N_PARAMS, None), "pcm step")
+    assert abs(tr2.loss.item() - l_ref2) < 1e-6
+    assert torch.equal(tr2.grads, g_ref2)
     # and against the oracle on a 32-sample slice
     sl = slice(0, 32)
     tr.loss_and_grads(img[sl].contiguous(), pos[sl].contiguous(), neg[sl].contiguous())

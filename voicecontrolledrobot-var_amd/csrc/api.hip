@@ -43,6 +43,16 @@ int var_init(int device_id, var_ctx** out) {
         delete c;
         return VAR_ERR_HIP;
     }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+        e = hipEventCreateWithFlags(&c->ev_fork[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        snprintf(g_init_err, sizeof(g_init_err), "var_init: %s", hipGetErrorString(e));
+        delete c;
+        return VAR_ERR_HIP;
+    }
     if (mfcc_build_tables(c) != VAR_OK) {
         snprintf(g_init_err, sizeof(g_init_err), "var_init: %s", c->err);
         delete c;
@@ -59,6 +69,11 @@ int var_destroy(var_ctx* c) {
     if (c->wpack) (void)hipFree(c->wpack);
     if (c->loss_buf) (void)hipFree(c->loss_buf);
     if (c->mfcc_tab) (void)hipFree(c->mfcc_tab);
+    for (int i = 0; i < 2; i++) {
+        if (c->ev_fork[i]) (void)hipEventDestroy(c->ev_fork[i]);
+        if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+    }
+    if (c->side) (void)hipStreamDestroy(c->side);
     if (c->prof_ev) {
         for (int i = 0; i < 2 * kProfMaxPairs; i++) (void)hipEventDestroy(c->prof_ev[i]);
         delete[] c->prof_ev;
@@ -98,6 +113,7 @@ int var_plan(var_ctx* c, int max_batch, int img_hw) {
     const size_t o_ghid = carve(6 * B * kHid);
     const size_t n_img_slab = img_slab_floats(), n_snd_slab = snd_slab_floats();
     const size_t o_slab = carve(n_img_slab + n_snd_slab);
+    const size_t o_mfcc = carve(2 * B * VAR_MFCC_FRAMES * VAR_MFCC_COEFFS);
     VAR_HIP_CHECK(c, hipMalloc((void**)&c->ws, off));
     VAR_HIP_CHECK(c, hipMemset(c->ws, 0, off));
     c->ws_bytes = off;
@@ -107,6 +123,7 @@ int var_plan(var_ctx* c, int max_batch, int img_hw) {
     c->hid_i = P(o_hid_i); c->hid_s = P(o_hid_s);
     c->emb = P(o_emb); c->emb_raw = P(o_emb_raw); c->gemb = P(o_gemb); c->ghid = P(o_ghid);
     c->slabs = P(o_slab);
+    c->mfcc_buf = P(o_mfcc);
     c->slab_floats = n_img_slab + n_snd_slab;
     c->snd_slab_off = n_img_slab;
     c->maxB = max_batch;
@@ -133,16 +150,47 @@ static int check_plan(var_ctx* c, int B, int H, const char* who) {
     return VAR_OK;
 }
 
+// Fork the sound branch onto the side stream (it runs beside the image branch: the MFCC front-end
+// is VALU work, the image convolutions are matrix-core work) and join it back before the heads.
+struct AudioIn {            // optional in-step front-end: pcm != NULL => MFCC is computed here
+    const int16_t* pcm = nullptr; const int* lens = nullptr; const int* clip_index = nullptr; int pcm_stride = 0;
+};
+
+static int fork_side(var_ctx* c, hipStream_t s, int i) {
+    VAR_HIP_CHECK(c, hipEventRecord(c->ev_fork[i], s));
+    VAR_HIP_CHECK(c, hipStreamWaitEvent(c->side, c->ev_fork[i], 0));
+    return VAR_OK;
+}
+static int join_side(var_ctx* c, hipStream_t s, int i) {
+    VAR_HIP_CHECK(c, hipEventRecord(c->ev_join[i], c->side));
+    VAR_HIP_CHECK(c, hipStreamWaitEvent(s, c->ev_join[i], 0));
+    return VAR_OK;
+}
+
 static int encoder_fwd(var_ctx* c, hipStream_t s, const float* params, const void* image, int is_u8,
-                       long bstride, const float* pos, const float* neg, int B) {
+                       long bstride, const int* image_index, const float* pos, const float* neg,
+                       const AudioIn* audio, int B) {
     int rc;
-    if (image && (rc = launch_img_fwd(c, s, params, image, is_u8, bstride, B)) != VAR_OK) return rc;
-    if ((pos || neg) && (rc = launch_snd_fwd(c, s, params, pos, neg, B)) != VAR_OK) return rc;
+    if (audio && audio->pcm) {
+        pos = c->mfcc_buf;
+        neg = c->mfcc_buf + (size_t)B * VAR_MFCC_FRAMES * VAR_MFCC_COEFFS;
+    }
+    const bool snd = pos || neg;
+    if (snd) {
+        if ((rc = fork_side(c, s, 0)) != VAR_OK) return rc;
+        if (audio && audio->pcm &&
+            (rc = launch_mfcc(c, c->side, audio->pcm, audio->lens, audio->clip_index, 2 * B, audio->pcm_stride,
+                              VAR_MFCC_FRAMES, c->mfcc_buf)) != VAR_OK) return rc;
+        if ((rc = launch_snd_fwd(c, c->side, params, pos, neg, B)) != VAR_OK) return rc;
+    }
+    if (image && (rc = launch_img_fwd(c, s, params, image, is_u8, bstride, image_index, B)) != VAR_OK) return rc;
+    if (snd && (rc = join_side(c, s, 0)) != VAR_OK) return rc;
     if ((rc = launch_heads_fwd(c, s, params, B, image != nullptr, pos != nullptr, neg != nullptr)) != VAR_OK) return rc;
     c->saved_B = B;
     c->saved_image = image;
     c->saved_u8 = is_u8;
     c->saved_bstride = bstride;
+    c->saved_index = image_index;
     c->saved_pos = pos;
     c->saved_neg = neg;
     return VAR_OK;
@@ -159,7 +207,7 @@ int var_arm_encoder_fwd(var_ctx* c, void* stream, const float* params, const voi
     if (rc != VAR_OK) return rc;
     SET_DEVICE(c);
     hipStream_t s = (hipStream_t)stream;
-    if ((rc = encoder_fwd(c, s, params, image, image_is_u8, image_bstride, mfcc_pos, mfcc_neg, B)) != VAR_OK) return rc;
+    if ((rc = encoder_fwd(c, s, params, image, image_is_u8, image_bstride, nullptr, mfcc_pos, mfcc_neg, nullptr, B)) != VAR_OK) return rc;
     if (!save_for_bwd) c->saved_B = 0;
     const size_t e = sizeof(float) * 3 * (size_t)B;
     if (image && image_feat) VAR_HIP_CHECK(c, hipMemcpyAsync(image_feat, c->emb, e, hipMemcpyDeviceToDevice, s));
@@ -181,9 +229,10 @@ static int encoder_bwd(var_ctx* c, hipStream_t s, const float* params, float* gr
     }
     const int snd_lo = c->saved_pos ? 0 : B, snd_hi = c->saved_neg ? 2 * B : B;
     if ((rc = launch_heads_bwd(c, s, params, grads, B, c->saved_image != nullptr, snd_lo, snd_hi)) != VAR_OK) return rc;
+    if ((rc = fork_side(c, s, 1)) != VAR_OK) return rc;
+    if ((rc = launch_snd_bwd(c, c->side, params, grads, B)) != VAR_OK) return rc;
     if (c->saved_image && (rc = launch_img_bwd(c, s, params, grads, B)) != VAR_OK) return rc;
-    if ((rc = launch_snd_bwd(c, s, params, grads, B)) != VAR_OK) return rc;
-    return VAR_OK;
+    return join_side(c, s, 1);
 }
 
 int var_arm_encoder_bwd(var_ctx* c, void* stream, const float* params, const float* g_image_feat,
@@ -211,6 +260,22 @@ int var_triplet_fwd_bwd(var_ctx* c, void* stream, const float* a, const float* p
     return launch_triplet(c, (hipStream_t)stream, a, p, n, B, margin, inv_count, loss_out, ga, gp, gn);
 }
 
+static int loss_grad_impl(var_ctx* c, hipStream_t s, const float* params, const void* image, int image_is_u8,
+                          long image_bstride, const int* image_index, const float* mfcc_pos, const float* mfcc_neg,
+                          const AudioIn* audio, int B, int H, float margin, float inv_count, float* grads,
+                          float* loss_out, float* feats_out, const char* who) {
+    if (image_bstride < 3L * H * H) { VAR_SET_ERR(c, "%s: image stride %ld < 3*H*H", who, image_bstride); return VAR_ERR_ARG; }
+    int rc = check_plan(c, B, H, who);
+    if (rc != VAR_OK) return rc;
+    SET_DEVICE(c);
+    if ((rc = encoder_fwd(c, s, params, image, image_is_u8, image_bstride, image_index, mfcc_pos, mfcc_neg, audio, B)) != VAR_OK) return rc;
+    if ((rc = launch_triplet(c, s, c->emb, c->emb + 3 * B, c->emb + 6 * B, B, margin, inv_count, loss_out,
+                             c->gemb, c->gemb + 3 * B, c->gemb + 6 * B)) != VAR_OK) return rc;
+    if (feats_out)
+        VAR_HIP_CHECK(c, hipMemcpyAsync(feats_out, c->emb, sizeof(float) * 9 * (size_t)B, hipMemcpyDeviceToDevice, s));
+    return encoder_bwd(c, s, params, grads);
+}
+
 int var_arm_loss_grad(var_ctx* c, void* stream, const float* params, const void* image, int image_is_u8,
                       long image_bstride, const float* mfcc_pos, const float* mfcc_neg, int B, int H,
                       float margin, float inv_count, float* grads, float* loss_out, float* feats_out) {
@@ -219,17 +284,23 @@ int var_arm_loss_grad(var_ctx* c, void* stream, const float* params, const void*
         VAR_SET_ERR(c, "var_arm_loss_grad: null argument");
         return VAR_ERR_ARG;
     }
-    if (image_bstride < 3L * H * H) { VAR_SET_ERR(c, "var_arm_loss_grad: image stride %ld < 3*H*H", image_bstride); return VAR_ERR_ARG; }
-    int rc = check_plan(c, B, H, "var_arm_loss_grad");
-    if (rc != VAR_OK) return rc;
-    SET_DEVICE(c);
-    hipStream_t s = (hipStream_t)stream;
-    if ((rc = encoder_fwd(c, s, params, image, image_is_u8, image_bstride, mfcc_pos, mfcc_neg, B)) != VAR_OK) return rc;
-    if ((rc = launch_triplet(c, s, c->emb, c->emb + 3 * B, c->emb + 6 * B, B, margin, inv_count, loss_out,
-                             c->gemb, c->gemb + 3 * B, c->gemb + 6 * B)) != VAR_OK) return rc;
-    if (feats_out)
-        VAR_HIP_CHECK(c, hipMemcpyAsync(feats_out, c->emb, sizeof(float) * 9 * (size_t)B, hipMemcpyDeviceToDevice, s));
-    return encoder_bwd(c, s, params, grads);
+    return loss_grad_impl(c, (hipStream_t)stream, params, image, image_is_u8, image_bstride, nullptr, mfcc_pos,
+                          mfcc_neg, nullptr, B, H, margin, inv_count, grads, loss_out, feats_out, "var_arm_loss_grad");
+}
+
+int var_arm_loss_grad_pcm(var_ctx* c, void* stream, const float* params, const void* image, int image_is_u8,
+                          long image_bstride, const int* image_index, const int16_t* pcm, int pcm_stride,
+                          const int* clip_index, const int* lens, int B, int H, float margin, float inv_count,
+                          float* grads, float* loss_out, float* feats_out) {
+    CHECK_CTX(c);
+    if (!params || !image || !pcm || !lens || !grads || !loss_out || pcm_stride <= 0) {
+        VAR_SET_ERR(c, "var_arm_loss_grad_pcm: null argument");
+        return VAR_ERR_ARG;
+    }
+    AudioIn a;
+    a.pcm = pcm; a.lens = lens; a.clip_index = clip_index; a.pcm_stride = pcm_stride;
+    return loss_grad_impl(c, (hipStream_t)stream, params, image, image_is_u8, image_bstride, image_index, nullptr,
+                          nullptr, &a, B, H, margin, inv_count, grads, loss_out, feats_out, "var_arm_loss_grad_pcm");
 }
 
 int var_adam_step(var_ctx* c, void* stream, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
@@ -247,15 +318,15 @@ int var_adam_step(var_ctx* c, void* stream, float* params, const float* grads, f
     return VAR_OK;
 }
 
-int var_mfcc(var_ctx* c, void* stream, const int16_t* pcm, const int* lens, int nclips, int pcm_stride,
-             int out_frames, float* out) {
+int var_mfcc(var_ctx* c, void* stream, const int16_t* pcm, const int* lens, const int* clip_index, int nclips,
+             int pcm_stride, int out_frames, float* out) {
     CHECK_CTX(c);
     if (!pcm || !lens || !out || nclips <= 0 || pcm_stride <= 0 || out_frames <= 0) {
         VAR_SET_ERR(c, "var_mfcc: bad argument");
         return VAR_ERR_ARG;
     }
     SET_DEVICE(c);
-    return launch_mfcc(c, (hipStream_t)stream, pcm, lens, nclips, pcm_stride, out_frames, out);
+    return launch_mfcc(c, (hipStream_t)stream, pcm, lens, clip_index, nclips, pcm_stride, out_frames, out);
 }
 
 static const char* kTagNames[TAG_COUNT] = {
@@ -326,6 +397,7 @@ int var_debug_buffer(var_ctx* c, const char* name, void** ptr, long* nfloats) {
         if (!strcmp(name, g)) { *ptr = c->gsact[l]; *nfloats = n; return VAR_OK; }
     }
     if (!strcmp(name, "emb")) { *ptr = c->emb; *nfloats = 9 * (long)B; return VAR_OK; }
+    if (!strcmp(name, "mfcc")) { *ptr = c->mfcc_buf; *nfloats = 2 * (long)B * VAR_MFCC_FRAMES * VAR_MFCC_COEFFS; return VAR_OK; }
     if (!strcmp(name, "gemb")) { *ptr = c->gemb; *nfloats = 9 * (long)B; return VAR_OK; }
     VAR_SET_ERR(c, "var_debug_buffer: unknown buffer '%s'", name);
     return VAR_ERR_ARG;

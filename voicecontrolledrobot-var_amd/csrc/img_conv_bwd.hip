@@ -176,8 +176,8 @@ struct WgCfg {
 
 template <class C>
 __global__ void __launch_bounds__(C::NW * 64)
-img_wgrad_kernel(const void* __restrict__ xin, long bstride, const float* __restrict__ gy,
-                 float* __restrict__ slabs, int B) {
+img_wgrad_kernel(const void* __restrict__ xin, long bstride, const int* __restrict__ bidx,
+                 const float* __restrict__ gy, float* __restrict__ slabs, int B) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;
     float* ys = lds + C::XS;
@@ -217,8 +217,9 @@ img_wgrad_kernel(const void* __restrict__ xin, long bstride, const float* __rest
             const int unit = unit0 + u;
             const bool uvalid = unit < total_units;
             const int b = uvalid ? unit / C::NB : 0, band = unit % C::NB;
-            const void* img = C::U8 ? (const void*)((const uint8_t*)xin + (size_t)b * bstride)
-                                    : (const void*)((const float*)xin + (size_t)b * bstride);
+            const int bx = bidx ? bidx[b] : b;         // optional batch gather for the first layer's input
+            const void* img = C::U8 ? (const void*)((const uint8_t*)xin + (size_t)bx * bstride)
+                                    : (const void*)((const float*)xin + (size_t)bx * bstride);
             stage_x_band<C::CIN, C::H, C::W, C::IR, C::PW, C::PLANE_X, C::U8, NT>(xs + u * C::UNIT_X, img,
                                                                                   2 * band * C::R - 1, uvalid, tid);
             stage_y_band<C::COUT, C::HO, C::WO, C::R, C::POW, C::PLANE_Y, NT>(
@@ -349,6 +350,7 @@ static int launch_dgrad(var_ctx* c, hipStream_t s, const float* gy, const float*
 template <class C>
 static int launch_wgrad(var_ctx* c, hipStream_t s, const void* x, long bstride, const float* gy, float* slabs,
                         int B, int G, int layer) {
+    const int* bidx = layer == 0 ? c->saved_index : nullptr;
     ProfScope prof(c, s, TAG_IMG_WGRAD0 + layer);
     static bool attr_set = false;
     if (!attr_set) {
@@ -356,7 +358,7 @@ static int launch_wgrad(var_ctx* c, hipStream_t s, const void* x, long bstride, 
                                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL(img_wgrad_kernel<C>, dim3(G), dim3(C::NW * 64), C::LDS_BYTES, s, x, bstride, gy, slabs, B);
+    hipLaunchKernelGGL(img_wgrad_kernel<C>, dim3(G), dim3(C::NW * 64), C::LDS_BYTES, s, x, bstride, bidx, gy, slabs, B);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }

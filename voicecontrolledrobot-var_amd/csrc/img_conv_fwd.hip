@@ -38,8 +38,8 @@ struct FwdCfg {
 
 template <class C>
 __global__ void __launch_bounds__(C::NW * 64)
-img_conv_fwd_kernel(const void* __restrict__ xin, long bstride, const float* __restrict__ wp,
-                    const float* __restrict__ bias, float* __restrict__ y, int B) {
+img_conv_fwd_kernel(const void* __restrict__ xin, long bstride, const int* __restrict__ bidx,
+                    const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int B) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NT = C::NW * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -54,7 +54,8 @@ img_conv_fwd_kernel(const void* __restrict__ xin, long bstride, const float* __r
     for (int u = 0; u < C::NU; ++u) {
         const int unit = unit0 + u;
         const bool uvalid = unit < total_units;
-        const int b = uvalid ? unit / C::NB : 0, band = unit % C::NB;
+        const int bo = uvalid ? unit / C::NB : 0, band = unit % C::NB;
+        const int b = bidx ? bidx[bo] : bo;            // optional batch gather (dataset row of sample bo)
         const void* img = C::U8 ? (const void*)((const uint8_t*)xin + (size_t)b * bstride)
                                 : (const void*)((const float*)xin + (size_t)b * bstride);
         stage_x_band<C::CIN, C::H, C::W, C::IR, C::PW, C::PLANE, C::U8, NT>(lds + u * C::UNIT, img,
@@ -168,7 +169,7 @@ img_conv_fwd_kernel(const void* __restrict__ xin, long bstride, const float* __r
 }
 
 template <class C>
-static int launch_one(var_ctx* c, hipStream_t s, const void* x, long bstride, const float* wp,
+static int launch_one(var_ctx* c, hipStream_t s, const void* x, long bstride, const int* bidx, const float* wp,
                       const float* bias, float* y, int B, int layer) {
     ProfScope prof(c, s, TAG_IMG_FWD0 + layer);
     static bool attr_set = false;
@@ -180,7 +181,7 @@ static int launch_one(var_ctx* c, hipStream_t s, const void* x, long bstride, co
     const int units = B * C::NB;
     const int grid = (units + C::NU - 1) / C::NU;
     hipLaunchKernelGGL(img_conv_fwd_kernel<C>, dim3(grid), dim3(C::NW * 64), C::LDS_BYTES, s,
-                       x, bstride, wp, bias, y, B);
+                       x, bstride, bidx, wp, bias, y, B);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }
@@ -200,14 +201,14 @@ using F96_4 = FwdCfg<64, 64, 12, false, 6, 2, 3>;
 using F96_5 = FwdCfg<64, 64, 6, false, 3, 7, 4>;
 
 int launch_img_fwd(var_ctx* c, hipStream_t s, const float* params, const void* image, int is_u8,
-                   long bstride, int B) {
+                   long bstride, const int* image_index, int B) {
     const ParamLayout& L = c->pl;
     const PackLayout& K = c->kl;
     const float* w[5];
     const float* b[5];
     for (int i = 0; i < 5; i++) { w[i] = c->wpack + K.img_f[i]; b[i] = params + L.img_b[i]; }
     int rc;
-#define RUN(CFG, X, BS, I, Y) do { if ((rc = launch_one<CFG>(c, s, X, BS, w[I], b[I], Y, B, I)) != VAR_OK) return rc; } while (0)
+#define RUN(CFG, X, BS, I, Y) do { if ((rc = launch_one<CFG>(c, s, X, BS, (I) == 0 ? image_index : nullptr, w[I], b[I], Y, B, I)) != VAR_OK) return rc; } while (0)
     if (c->H == 84) {
         if (is_u8) { RUN(F84_1u, image, bstride, 0, c->act[1]); } else { RUN(F84_1f, image, bstride, 0, c->act[1]); }
         RUN(F84_2, c->act[1], 32L * 42 * 42, 1, c->act[2]);

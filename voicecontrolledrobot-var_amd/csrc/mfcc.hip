@@ -28,49 +28,63 @@ constexpr int TB_MSTART = TB_DCT + 1600;  // 40 ints
 constexpr int TB_MCOUNT = TB_MSTART + 40;
 constexpr int TB_MOFF = TB_MCOUNT + 40;
 constexpr int TB_MW = TB_MOFF + 40;       // <= 640 weights
-constexpr int TB_TOTAL = TB_MW + 640;
+constexpr int TB_TOTAL = TB_MW + 640;   // 3744 floats, a multiple of 4
 
 struct cplx { float x, y; };
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.x + b.x, a.y + b.y}; }
 __device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.x - b.x, a.y - b.y}; }
 
+// Each wave owns its frames end to end and never synchronises with the other waves: all exchange
+// goes through the wave's private LDS region, where a wave's own DS operations execute in order,
+// so a compiler-level wave barrier is all that separates a butterfly stage from the next.
+#define WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+
 __global__ void __launch_bounds__(256)
-mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, int pcm_stride, int out_frames,
-            const float* __restrict__ tab, float* __restrict__ out) {
+mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const int* __restrict__ clip_index,
+            int pcm_stride, int out_frames, const float* __restrict__ tab, float* __restrict__ out) {
+    __shared__ float tabs[TB_TOTAL];                 // window, twiddles, DCT, mel triangles (15 KB)
     __shared__ cplx bufA[4][256];
     __shared__ cplx bufB[4][256];
     __shared__ float pw[4][264];
     __shared__ float lm[4][NMEL];
     const int clip = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < TB_TOTAL / 4; e += 256) ((float4*)tabs)[e] = ((const float4*)tab)[e];
     const int N = lens[clip];
     const int T = 1 + N / HOP;
-    const int16_t* sig = pcm + (size_t)clip * pcm_stride;
-    const int* itab = (const int*)tab;
-    const cplx* tw256 = (const cplx*)(tab + TB_TW256);
-    const cplx* tw512 = (const cplx*)(tab + TB_TW512);
+    const int16_t* sig = pcm + (size_t)(clip_index ? clip_index[clip] : clip) * pcm_stride;
+    const int* itab = (const int*)tabs;
+    const cplx* tw256 = (const cplx*)(tabs + TB_TW256);
+    const cplx* tw512 = (const cplx*)(tabs + TB_TW512);
     float* xs = (float*)bufA[wave];
+    __syncthreads();
+    // mel filter of this lane (lanes >= 40 idle in that phase)
+    const int ml = lane < NMEL ? lane : 0;
+    const int mst = itab[TB_MSTART + ml], mcnt = lane < NMEL ? itab[TB_MCOUNT + ml] : 0, mwo = itab[TB_MOFF + ml];
 
-    for (int t0 = 0; t0 < out_frames; t0 += 4) {
-        const int t = t0 + wave;
+    for (int t = wave; t < out_frames; t += 4) {
         // frames beyond T are MFCC-domain zero padding; N == 0 is the "empty" class (dataset.py:37-38)
-        const bool live = t < out_frames && t < T && N > 0;
+        const bool live = t < T && N > 0;
+        if (!live) {
+            if (lane < NMFCC) out[((size_t)clip * out_frames + t) * NMFCC + lane] = 0.f;
+            continue;
+        }
         // 1. windowed frame -> LDS
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int idx = lane + 64 * i;
             float v = 0.f;
-            if (live && idx >= WOFF && idx < WOFF + WIN) {
+            if (idx >= WOFF && idx < WOFF + WIN) {
                 int pos = t * HOP + idx - NFFT / 2;
                 if (pos < 0) pos = -pos;
                 if (pos >= N) pos = 2 * (N - 1) - pos;
                 pos = pos < 0 ? 0 : (pos >= N ? N - 1 : pos);
-                v = ((float)sig[pos] / 32768.f) * tab[TB_WIN + idx - WOFF];
+                v = ((float)sig[pos] / 32768.f) * tabs[TB_WIN + idx - WOFF];
             }
             xs[idx] = v;
         }
-        __syncthreads();
+        WAVE_SYNC();
         // 2. 256-point complex FFT of z[n] = x[2n] + i x[2n+1]: Stockham radix-4, natural order out
         cplx* src = bufA[wave];
         cplx* dst = bufB[wave];
@@ -93,7 +107,7 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, int p
             dst[idx + Ns] = cadd(a1, a3);
             dst[idx + 2 * Ns] = csub(a0, a2);
             dst[idx + 3 * Ns] = csub(a1, a3);
-            __syncthreads();
+            WAVE_SYNC();
             cplx* tmp = src; src = dst; dst = tmp;
         }
         // 3. split into the 257 bins of the real FFT, power
@@ -110,25 +124,28 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, int p
             pw[wave][k] = X.x * X.x + X.y * X.y;
         }
         if (lane == 0) { const cplx z0 = src[0]; const float r = z0.x - z0.y; pw[wave][256] = r * r; }
-        __syncthreads();
-        // 4. mel triangles + log
-        if (lane < NMEL) {
-            const int st = itab[TB_MSTART + lane], cnt = itab[TB_MCOUNT + lane], wo = itab[TB_MOFF + lane];
+        WAVE_SYNC();
+        // 4. mel triangles + log: predicated fixed-trip loop so that the LDS reads pipeline
+        {
             float s = 0.f;
-            for (int q = 0; q < cnt; ++q) s += pw[wave][st + q] * tab[TB_MW + wo + q];
-            lm[wave][lane] = logf(s + 1e-6f);
-        }
-        __syncthreads();
-        // 5. DCT-II (ortho) and store; padding frames are zeros
-        if (lane < NMFCC && t < out_frames) {
-            float s = 0.f;
-            if (live) {
 #pragma unroll 8
-                for (int n = 0; n < NMEL; ++n) s += lm[wave][n] * tab[TB_DCT + n * NMFCC + lane];
+            for (int q = 0; q < 40; ++q) {          // widest triangle spans 33 bins
+                const bool ok = q < mcnt;
+                const float p = pw[wave][ok ? mst + q : 0];
+                const float w = tabs[TB_MW + (ok ? mwo + q : 0)];
+                s += ok ? p * w : 0.f;
             }
+            if (lane < NMEL) lm[wave][lane] = logf(s + 1e-6f);
+        }
+        WAVE_SYNC();
+        // 5. DCT-II (ortho) and store
+        if (lane < NMFCC) {
+            float s = 0.f;
+#pragma unroll 8
+            for (int n = 0; n < NMEL; ++n) s += lm[wave][n] * tabs[TB_DCT + n * NMFCC + lane];
             out[((size_t)clip * out_frames + t) * NMFCC + lane] = s;
         }
-        __syncthreads();
+        WAVE_SYNC();
     }
 }
 }  // namespace
@@ -183,10 +200,10 @@ int mfcc_build_tables(var_ctx* c) {
     return VAR_OK;
 }
 
-int launch_mfcc(var_ctx* c, hipStream_t s, const int16_t* pcm, const int* lens, int nclips, int pcm_stride,
-                int out_frames, float* out) {
+int launch_mfcc(var_ctx* c, hipStream_t s, const int16_t* pcm, const int* lens, const int* clip_index, int nclips,
+                int pcm_stride, int out_frames, float* out) {
     ProfScope prof(c, s, TAG_MFCC);
-    hipLaunchKernelGGL(mfcc_kernel, dim3(nclips), dim3(256), 0, s, pcm, lens, pcm_stride, out_frames,
+    hipLaunchKernelGGL(mfcc_kernel, dim3(nclips), dim3(256), 0, s, pcm, lens, clip_index, pcm_stride, out_frames,
                        c->mfcc_tab, out);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;

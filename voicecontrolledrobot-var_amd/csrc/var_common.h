@@ -128,6 +128,11 @@ struct var_ctx {
     long saved_bstride = 0;
     const float* saved_pos = nullptr;
     const float* saved_neg = nullptr;
+    const int* saved_index = nullptr;     // optional image gather index of the saved forward
+    // side stream for the sound branch (runs beside the image branch) and its fork/join events
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
+    float* mfcc_buf = nullptr;            // (2*maxB, 100, 40) when the front-end runs inside the step
 };
 
 #define VAR_SET_ERR(ctx, ...) do { if (ctx) snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__); } while (0)
@@ -162,7 +167,7 @@ size_t snd_slab_floats();
 // kernels' host launchers (one per .hip file) ------------------------------------------
 int launch_pack_weights(var_ctx* c, hipStream_t s, const float* params);
 int launch_img_fwd(var_ctx* c, hipStream_t s, const float* params, const void* image, int is_u8,
-                   long bstride, int B);
+                   long bstride, const int* image_index, int B);
 int launch_img_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads, int B);
 int launch_snd_fwd(var_ctx* c, hipStream_t s, const float* params, const float* pos, const float* neg, int B);
 int launch_snd_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads, int B);
@@ -173,5 +178,5 @@ int launch_triplet(var_ctx* c, hipStream_t s, const float* a, const float* p, co
                    float margin, float inv_count, float* loss_out, float* ga, float* gp, float* gn);
 int launch_adam(var_ctx* c, hipStream_t s, float* p, const float* g, float* m, float* v, long n,
                 float lr, float b1, float b2, float eps, float wd, int step);
-int launch_mfcc(var_ctx* c, hipStream_t s, const int16_t* pcm, const int* lens, int nclips,
+int launch_mfcc(var_ctx* c, hipStream_t s, const int16_t* pcm, const int* lens, const int* clip_index, int nclips,
                 int pcm_stride, int out_frames, float* out);

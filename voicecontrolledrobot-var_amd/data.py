@@ -61,6 +61,31 @@ class SyntheticTripletPool:
         self._gen = torch.Generator(device=self.device)
         self._gen.manual_seed(seed + 2)
 
+    # ---- fixed pairing + epoch permutation (what VARFineTuneDataset + DataLoader(shuffle=True) do,
+    #      dataset.py:94-133,157-162), as index tables so that the step gathers straight from HBM ----
+    def freeze_pairs(self):
+        """Draw each item's positive / negative clip once (dataset.py:101-117) -> (2,N) int32 tables."""
+        n = self.n_items
+        cp = torch.randint(0, self.cpc, (2, n), device=self.device, generator=self._gen)
+        cls = torch.stack([self.gt, self.sn])
+        empty = cls >= self.task_num
+        self.clip_tab = (torch.clamp(cls, max=self.task_num - 1) * self.cpc + cp).to(torch.int32).contiguous()
+        self.len_tab = torch.where(empty, 0, self.clips.shape[1]).to(torch.int32).contiguous()
+        self._perm = None
+        self._cursor = 0
+        return self
+
+    def next_batch_indices(self, batch):
+        """(image_index (B), clip_index (2B), lens (2B)) int32 for the next shuffled batch; 2 small gathers."""
+        if self._perm is None or self._cursor + batch > self.n_items:
+            self._perm = torch.randperm(self.n_items, device=self.device, generator=self._gen)
+            self._perm32 = self._perm.to(torch.int32)
+            self._cursor = 0
+        sl = slice(self._cursor, self._cursor + batch)
+        self._cursor += batch
+        idx = self._perm[sl]
+        return self._perm32[sl], self.clip_tab[:, idx].reshape(-1), self.len_tab[:, idx].reshape(-1)
+
     def sample_indices(self, batch):
         """Random item ids and clip ids (device tensors, no host sync)."""
         idx = torch.randint(0, self.n_items, (batch,), device=self.device, generator=self._gen)

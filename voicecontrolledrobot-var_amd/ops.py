@@ -27,19 +27,22 @@ def triplet_margin_loss(anchor, positive, negative, margin=1.0, inv_count=None, 
     return loss, ga, gp, gn
 
 
-def mfcc(pcm, lens=None, out_frames=100):
+def mfcc(pcm, lens=None, out_frames=100, clip_index=None):
     """int16 PCM (nclips, nsamples) on the GPU -> (nclips, 1, out_frames, 40) f32 MFCC:
     Envs/audioLoader.py:147-157 (torchaudio branch) + :241-252 (truncate / zero-pad)."""
     _require_cuda(pcm)
     if pcm.dtype != torch.int16 or pcm.dim() != 2:
         raise VarHipError("mfcc expects an int16 (nclips, nsamples) tensor")
     pcm = pcm.contiguous()
-    n, stride = pcm.shape
+    stride = pcm.shape[1]
+    n = pcm.shape[0] if clip_index is None else clip_index.numel()
+    if clip_index is not None:
+        clip_index = clip_index.to(device=pcm.device, dtype=torch.int32).contiguous()
     if lens is None:
         lens = torch.full((n,), stride, dtype=torch.int32, device=pcm.device)
     lens = lens.to(device=pcm.device, dtype=torch.int32).contiguous()
     out = torch.empty((n, 1, out_frames, 40), dtype=torch.float32, device=pcm.device)
     ctx = Context.get(pcm.device.index)
-    ctx.check(ctx.lib.var_mfcc(ctx.handle, current_stream_handle(), ptr(pcm), ptr(lens), n, stride,
+    ctx.check(ctx.lib.var_mfcc(ctx.handle, current_stream_handle(), ptr(pcm), ptr(lens), ptr(clip_index), n, stride,
                                int(out_frames), ptr(out)), "var_mfcc")
     return out

@@ -87,17 +87,36 @@ class VARTrainer:
         self.adam()
         return self.loss
 
-    def step_from_pcm(self, image, pcm, lens, mfcc_out=None, global_batch=None):
-        """Same, with the audio front-end in the step: pcm int16 (2B, n) = [pos | neg], lens (2B) (0 = empty)."""
-        B = image.shape[0]
-        feats = mfcc_op(pcm, lens, 100) if mfcc_out is None else self._mfcc_into(pcm, lens, mfcc_out)
-        return self.step(image, feats[:B], feats[B:], global_batch)
-
-    def _mfcc_into(self, pcm, lens, out):
+    def step_from_dataset(self, images, image_index, pcm, clip_index, lens, global_batch=None):
+        """One step with the data-loader work folded in (var_arm_loss_grad_pcm): sample b reads image row
+        image_index[b] of the HBM-resident `images` (N,3,H,H) u8|f32; clips [pos | neg] read rows
+        clip_index (2B) of `pcm` (M, n) int16 with lens (2B) valid samples (0 = "empty" class); the MFCC
+        front-end runs inside the step on a side stream.  Index tensors are int32 CUDA."""
+        flat = self.model.flat_parameters()
+        B = image_index.numel()
+        gb = B * self.world if global_batch is None else global_batch
+        for t in (image_index, clip_index, lens):
+            if t.dtype != torch.int32 or not t.is_cuda or not t.is_contiguous():
+                raise VarHipError("index / length tensors must be contiguous int32 CUDA tensors")
+        if pcm.dtype != torch.int16 or clip_index.numel() != 2 * B or lens.numel() != 2 * B:
+            raise VarHipError("pcm must be int16 and clip_index / lens must hold 2*B entries")
         c = self.ctx
-        c.check(c.lib.var_mfcc(c.handle, current_stream_handle(), ptr(pcm), ptr(lens), pcm.shape[0], pcm.shape[1],
-                               100, ptr(out)), "var_mfcc")
-        return out
+        c.ensure_plan(B, self.hw)
+        c.check(c.lib.var_arm_loss_grad_pcm(c.handle, current_stream_handle(), ptr(flat), ptr(images),
+                                            int(images.dtype == torch.uint8), images.stride(0), ptr(image_index),
+                                            ptr(pcm), pcm.stride(0), ptr(clip_index), ptr(lens), B, self.hw,
+                                            float(self.margin), 1.0 / gb, ptr(self.gbuf),
+                                            self.gbuf.data_ptr() + 4 * N_PARAMS, None), "var_arm_loss_grad_pcm")
+        self.allreduce()
+        self.adam()
+        return self.loss
+
+    def step_from_pcm(self, image, pcm, lens, global_batch=None):
+        """Same without gathering: image (B,3,H,H), pcm int16 (2B, n) = [pos | neg], lens (2B) (0 = empty)."""
+        B = image.shape[0]
+        idx = torch.arange(B, dtype=torch.int32, device=image.device)
+        cidx = torch.arange(2 * B, dtype=torch.int32, device=image.device)
+        return self.step_from_dataset(image, idx, pcm, cidx, lens, global_batch)
 
     def _check(self, image, pos, neg):
         for t in (image, pos, neg):
