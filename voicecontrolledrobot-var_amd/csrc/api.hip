@@ -1,5 +1,6 @@
 // C-ABI entry points of libvar_hip.so (see include/var_hip.h).
 #include <new>
+#include <stdlib.h>
 #include <string.h>
 
 #include "var_common.h"
@@ -28,6 +29,7 @@ int var_init(int device_id, var_ctx** out) {
     var_ctx* c = new (std::nothrow) var_ctx();
     if (!c) return VAR_ERR_HIP;
     c->device = device_id;
+    { const char* e = getenv("VAR_SERIAL"); c->serial = e && e[0] == '1'; }
     c->pl = make_param_layout();
     c->kl = make_pack_layout();
     if (c->pl.total != VAR_N_PARAMS) {
@@ -44,6 +46,9 @@ int var_init(int device_id, var_ctx** out) {
         return VAR_ERR_HIP;
     }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking);
+    for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&c->ev_g[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_wjoin, hipEventDisableTiming);
     for (int i = 0; i < 2 && e == hipSuccess; i++) {
         e = hipEventCreateWithFlags(&c->ev_fork[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming);
@@ -73,7 +78,10 @@ int var_destroy(var_ctx* c) {
         if (c->ev_fork[i]) (void)hipEventDestroy(c->ev_fork[i]);
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
     }
+    for (int i = 0; i < 6; i++) if (c->ev_g[i]) (void)hipEventDestroy(c->ev_g[i]);
+    if (c->ev_wjoin) (void)hipEventDestroy(c->ev_wjoin);
     if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->side2) (void)hipStreamDestroy(c->side2);
     if (c->prof_ev) {
         for (int i = 0; i < 2 * kProfMaxPairs; i++) (void)hipEventDestroy(c->prof_ev[i]);
         delete[] c->prof_ev;
@@ -152,16 +160,20 @@ static int check_plan(var_ctx* c, int B, int H, const char* who) {
 
 // Fork the sound branch onto the side stream (it runs beside the image branch: the MFCC front-end
 // is VALU work, the image convolutions are matrix-core work) and join it back before the heads.
+#define SIDE(c, s) ((c)->serial ? (s) : (c)->side)
+
 struct AudioIn {            // optional in-step front-end: pcm != NULL => MFCC is computed here
     const int16_t* pcm = nullptr; const int* lens = nullptr; const int* clip_index = nullptr; int pcm_stride = 0;
 };
 
 static int fork_side(var_ctx* c, hipStream_t s, int i) {
+    if (c->serial) return VAR_OK;
     VAR_HIP_CHECK(c, hipEventRecord(c->ev_fork[i], s));
     VAR_HIP_CHECK(c, hipStreamWaitEvent(c->side, c->ev_fork[i], 0));
     return VAR_OK;
 }
 static int join_side(var_ctx* c, hipStream_t s, int i) {
+    if (c->serial) return VAR_OK;
     VAR_HIP_CHECK(c, hipEventRecord(c->ev_join[i], c->side));
     VAR_HIP_CHECK(c, hipStreamWaitEvent(s, c->ev_join[i], 0));
     return VAR_OK;
@@ -179,13 +191,13 @@ static int encoder_fwd(var_ctx* c, hipStream_t s, const float* params, const voi
     if (snd) {
         if ((rc = fork_side(c, s, 0)) != VAR_OK) return rc;
         if (audio && audio->pcm &&
-            (rc = launch_mfcc(c, c->side, audio->pcm, audio->lens, audio->clip_index, 2 * B, audio->pcm_stride,
+            (rc = launch_mfcc(c, SIDE(c, s), audio->pcm, audio->lens, audio->clip_index, 2 * B, audio->pcm_stride,
                               VAR_MFCC_FRAMES, c->mfcc_buf)) != VAR_OK) return rc;
-        if ((rc = launch_snd_fwd(c, c->side, params, pos, neg, B)) != VAR_OK) return rc;
+        if ((rc = launch_snd_fwd(c, SIDE(c, s), params, pos, neg, B)) != VAR_OK) return rc;
     }
     if (image && (rc = launch_img_fwd(c, s, params, image, is_u8, bstride, image_index, B)) != VAR_OK) return rc;
+    if ((rc = launch_heads_fwd(c, s, snd ? SIDE(c, s) : s, params, B, image != nullptr, pos != nullptr, neg != nullptr)) != VAR_OK) return rc;
     if (snd && (rc = join_side(c, s, 0)) != VAR_OK) return rc;
-    if ((rc = launch_heads_fwd(c, s, params, B, image != nullptr, pos != nullptr, neg != nullptr)) != VAR_OK) return rc;
     c->saved_B = B;
     c->saved_image = image;
     c->saved_u8 = is_u8;
@@ -228,10 +240,11 @@ static int encoder_bwd(var_ctx* c, hipStream_t s, const float* params, float* gr
         VAR_HIP_CHECK(c, hipMemsetAsync(grads, 0, sizeof(float) * VAR_N_PARAMS, s));
     }
     const int snd_lo = c->saved_pos ? 0 : B, snd_hi = c->saved_neg ? 2 * B : B;
-    if ((rc = launch_heads_bwd(c, s, params, grads, B, c->saved_image != nullptr, snd_lo, snd_hi)) != VAR_OK) return rc;
+    // streams: s = image head + dgrad chain, side = sound head + sound CNN backward, side2 = image wgrads
     if ((rc = fork_side(c, s, 1)) != VAR_OK) return rc;
-    if ((rc = launch_snd_bwd(c, c->side, params, grads, B)) != VAR_OK) return rc;
-    if (c->saved_image && (rc = launch_img_bwd(c, s, params, grads, B)) != VAR_OK) return rc;
+    if ((rc = launch_heads_bwd(c, s, SIDE(c, s), params, grads, B, c->saved_image != nullptr, snd_lo, snd_hi)) != VAR_OK) return rc;
+    if ((rc = launch_snd_bwd(c, SIDE(c, s), params, grads, B)) != VAR_OK) return rc;
+    if (c->saved_image && (rc = launch_img_bwd(c, s, c->serial ? s : c->side2, params, grads, B)) != VAR_OK) return rc;
     return join_side(c, s, 1);
 }
 

@@ -306,18 +306,19 @@ static int run_heads_fwd(var_ctx* c, hipStream_t s, const float* x, int R, const
     return VAR_OK;
 }
 
-int launch_heads_fwd(var_ctx* c, hipStream_t s, const float* params, int B, bool has_img, bool has_pos, bool has_neg) {
+int launch_heads_fwd(var_ctx* c, hipStream_t s, hipStream_t ss, const float* params, int B, bool has_img,
+                     bool has_pos, bool has_neg) {
     const ParamLayout& L = c->pl;
     const PackLayout& K = c->kl;
-    ProfScope prof(c, s, TAG_HEADS_FWD);
     int rc;
     if (has_img) {
+        ProfScope prof(c, s, TAG_HEADS_FWD);
         if ((rc = run_heads_fwd<kImgFeat>(c, s, c->act[5], B, c->wpack + K.ih_w0t, params + L.ih_b0, params + L.ih_w1,
                                           params + L.ih_b1, c->hid_i, c->emb_raw, c->emb)) != VAR_OK) return rc;
     }
     if (has_pos || has_neg) {
         const int lo = has_pos ? 0 : B, hi = has_neg ? 2 * B : B;
-        if ((rc = run_heads_fwd<kSndFeat>(c, s, c->sact[4] + (size_t)lo * kSndFeat, hi - lo, c->wpack + K.sh_w0t,
+        if ((rc = run_heads_fwd<kSndFeat>(c, ss, c->sact[4] + (size_t)lo * kSndFeat, hi - lo, c->wpack + K.sh_w0t,
                                           params + L.sh_b0, params + L.sh_w1, params + L.sh_b1,
                                           c->hid_s + (size_t)lo * kHid, c->emb_raw + 3 * (B + lo),
                                           c->emb + 3 * (B + lo))) != VAR_OK) return rc;
@@ -336,7 +337,7 @@ int launch_triplet(var_ctx* c, hipStream_t s, const float* a, const float* p, co
 
 // gemb (3B,3) must hold the gradients wrt the normalised embeddings [img | pos | neg].
 // Produces gact[5] (B,576), gsact[4] (2B,160) and the 8 head gradient tensors.
-int launch_heads_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads, int B, bool has_img,
+int launch_heads_bwd(var_ctx* c, hipStream_t s, hipStream_t ss, const float* params, float* grads, int B, bool has_img,
                      int snd_lo, int snd_hi) {
     const ParamLayout& L = c->pl;
     const size_t mB = (size_t)c->maxB;
@@ -349,7 +350,7 @@ int launch_heads_bwd(var_ctx* c, hipStream_t s, const float* params, float* grad
                                c->emb_raw, c->emb, c->gemb, graw, c->ghid, ghidT);
         if (snd_hi > snd_lo) {
             const int R = snd_hi - snd_lo;
-            hipLaunchKernelGGL(heads_bwd_rows_kernel, dim3(R), dim3(128), 0, s, R, params + L.sh_w1,
+            hipLaunchKernelGGL(heads_bwd_rows_kernel, dim3(R), dim3(128), 0, ss, R, params + L.sh_w1,
                                c->hid_s + (size_t)snd_lo * kHid, c->emb_raw + 3 * (B + snd_lo),
                                c->emb + 3 * (B + snd_lo), c->gemb + 3 * (B + snd_lo), graw + 4 * (B + snd_lo),
                                c->ghid + (size_t)(B + snd_lo) * kHid, ghidT + (size_t)B * kHid);
@@ -366,7 +367,7 @@ int launch_heads_bwd(var_ctx* c, hipStream_t s, const float* params, float* grad
         if (snd_hi > snd_lo) {
             const int R = snd_hi - snd_lo;
             const int tiles = 4 * (kSndFeat / 32) + 4 + ((R + 31) / 32) * (kSndFeat / 32);
-            hipLaunchKernelGGL(heads_bwd_gemm_kernel<kSndFeat>, dim3((tiles + 3) / 4), dim3(256), 0, s, R, R,
+            hipLaunchKernelGGL(heads_bwd_gemm_kernel<kSndFeat>, dim3((tiles + 3) / 4), dim3(256), 0, ss, R, R,
                                c->sact[4] + (size_t)snd_lo * kSndFeat, params + L.sh_w0,
                                c->hid_s + (size_t)snd_lo * kHid, graw + 4 * (B + snd_lo),
                                c->ghid + (size_t)(B + snd_lo) * kHid, ghidT + (size_t)B * kHid,

@@ -80,7 +80,7 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
                 if (pos < 0) pos = -pos;
                 if (pos >= N) pos = 2 * (N - 1) - pos;
                 pos = pos < 0 ? 0 : (pos >= N ? N - 1 : pos);
-                v = ((float)sig[pos] / 32768.f) * tabs[TB_WIN + idx - WOFF];
+                v = ((float)sig[pos] * (1.f / 32768.f)) * tabs[TB_WIN + idx - WOFF];   // exact: power of two
             }
             xs[idx] = v;
         }

@@ -114,7 +114,8 @@ struct var_ctx {
     float* ghid = nullptr;        // (3B,128)
     float* slabs = nullptr;       // split-K partial weight gradients
     size_t slab_floats = 0;
-    size_t snd_slab_off = 0;      // sound slabs start here inside `slabs`
+    size_t snd_slab_off = 0;
+    int wg_groups[5] = {0};       // split-K workgroups used by the last image wgrad launches      // sound slabs start here inside `slabs`
     float* loss_buf = nullptr;
     float* mfcc_tab = nullptr;    // window / twiddles / mel / DCT tables
     // profiling: HIP events around the launches of ONE selected kernel family
@@ -130,7 +131,11 @@ struct var_ctx {
     const float* saved_neg = nullptr;
     const int* saved_index = nullptr;     // optional image gather index of the saved forward
     // side stream for the sound branch (runs beside the image branch) and its fork/join events
+    bool serial = false;                  // VAR_SERIAL=1: everything on the caller's stream (for per-kernel profiling)
     hipStream_t side = nullptr;
+    hipStream_t side2 = nullptr;          // weight-gradient kernels run here beside the dgrad chain
+    hipEvent_t ev_g[6] = {nullptr};       // gact[l] ready (recorded on the dgrad stream)
+    hipEvent_t ev_wjoin = nullptr;
     hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
     float* mfcc_buf = nullptr;            // (2*maxB, 100, 40) when the front-end runs inside the step
 };
@@ -162,17 +167,20 @@ static inline int conv_out(int h) { return (h - 1) / 2 + 1; }   // 3x3 s2 p1
 
 int mfcc_build_tables(var_ctx* c);
 size_t img_slab_floats();
+int launch_img_wgrad(var_ctx* c, hipStream_t s, int layer, const void* x, long bstride, int is_u8, const float* gy, int B);
+int launch_img_wgrad_reduce(var_ctx* c, hipStream_t s, float* grads);
 size_t snd_slab_floats();
 
 // kernels' host launchers (one per .hip file) ------------------------------------------
 int launch_pack_weights(var_ctx* c, hipStream_t s, const float* params);
 int launch_img_fwd(var_ctx* c, hipStream_t s, const float* params, const void* image, int is_u8,
                    long bstride, const int* image_index, int B);
-int launch_img_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads, int B);
+int launch_img_bwd(var_ctx* c, hipStream_t s, hipStream_t sw, const float* params, float* grads, int B);
 int launch_snd_fwd(var_ctx* c, hipStream_t s, const float* params, const float* pos, const float* neg, int B);
 int launch_snd_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads, int B);
-int launch_heads_fwd(var_ctx* c, hipStream_t s, const float* params, int B, bool has_img, bool has_pos, bool has_neg);
-int launch_heads_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads, int B, bool has_img,
+int launch_heads_fwd(var_ctx* c, hipStream_t s, hipStream_t ss, const float* params, int B, bool has_img, bool has_pos,
+                     bool has_neg);
+int launch_heads_bwd(var_ctx* c, hipStream_t s, hipStream_t ss, const float* params, float* grads, int B, bool has_img,
                      int snd_lo, int snd_hi);
 int launch_triplet(var_ctx* c, hipStream_t s, const float* a, const float* p, const float* n, int B,
                    float margin, float inv_count, float* loss_out, float* ga, float* gp, float* gn);
