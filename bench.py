@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -108,28 +109,47 @@ def main():
     ctx = Context.get(local_rank)
     ctx.ensure_plan(B, HW)
 
-    def step():
-        img_idx, clip_idx, lens = pool.next_batch_indices(B)
-        tr.step_from_dataset(pool.images, img_idx, pool.clips, clip_idx, lens, global_batch=B * world)
+    use_graph = not args.no_graph and not os.environ.get("VAR_SERIAL")
+    state = {"tab": None, "row": 0}
+
+    def next_row():
+        if state["tab"] is None or state["row"] >= state["tab"].shape[0]:
+            state["tab"], state["row"] = pool.epoch_index_table(B), 0
+        r = state["tab"][state["row"]]
+        state["row"] += 1
+        return r
+
+    def eager_step():
+        r = next_row()
+        tr.step_from_dataset(pool.images, r[:B], pool.clips, r[B:3 * B], r[3 * B:], global_batch=B * world)
+
+    step = eager_step
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    # pick the dominant conv kernel family (one profiled step per candidate), rank 0 only matters
+    for _ in range(max(2, args.warmup // 2)):                  # eager warm-up: lazy kernel attributes, workspace plan
+        eager_step()
+    # pick the dominant conv kernel family (one profiled eager step per candidate)
     dom_tag = None
     if not args.no_roofline:
         best = -1.0
         for tag in list(range(0, 10)) + list(range(11, 15)):
             ctx.profile_select(tag)
-            step()
+            eager_step()
             ms, n = ctx.profile_read()
             if n and ms / n > best:
                 best, dom_tag = ms / n, tag
-        ctx.profile_select(dom_tag)
+        ctx.profile_select(-1)
+    if use_graph:
+        replay = tr.capture_dataset_step(pool.images, pool.clips, B, global_batch=B * world)
+
+        def step():
+            replay(next_row())
+    for _ in range(args.warmup):
+        step()
 
     barrier()
     t0 = time.perf_counter()
@@ -137,6 +157,17 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+
+    # roofline leg: HIP events (var_profile_select) around every launch of the dominant kernel, on the
+    # stream it is launched on, over eagerly launched steps of the same workload (events cannot be
+    # read back from inside a replayed graph)
+    roof_ms, roof_n = 0.0, 0
+    if dom_tag is not None:
+        ctx.profile_select(dom_tag)
+        for _ in range(min(args.steps, 100)):
+            eager_step()
+        roof_ms, roof_n = ctx.profile_read()
+        ctx.profile_select(-1)
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -158,8 +189,9 @@ def main():
                        "parallelism": f"dp{world}", "final_loss": round(loss, 6)},
             "mfma_frac_whole_step": round(value / world * FLOPS_PER_TRIPLET / 1e12 / F32_MFMA_PEAK, 4),
         }
-        if dom_tag is not None:
-            ms, n = ctx.profile_read()
+        out["config"]["launch"] = "hip-graph replay" if use_graph else "eager"
+        if dom_tag is not None and roof_n:
+            ms, n = roof_ms, roof_n
             names = ctx.tag_names()
             layer = dom_tag % 5
             flops = LAYER_FLOPS[layer] * B

@@ -124,6 +124,13 @@ int var_adam_step(var_ctx* ctx, void* stream, float* params, const float* grads,
                   float* exp_avg_sq, long n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int step);
 
+/* The same step with the step count (incremented here) and the learning rate read from DEVICE
+ * memory, so that the launch can be captured once into a HIP graph and replayed every step
+ * (MultiStepLR then updates *lr_dev between replays). */
+int var_adam_step_dev(var_ctx* ctx, void* stream, float* params, const float* grads, float* exp_avg,
+                      float* exp_avg_sq, long n, const float* lr_dev, float beta1, float beta2, float eps,
+                      float weight_decay, int* step_dev);
+
 /* Audio front-end: Envs/audioLoader.py:147-157 (torchaudio MFCC branch) + :241-252
  * (processSoundFeat).  pcm: rows of `pcm_stride` int16 samples; output clip i reads row
  * clip_index[i] (NULL: row i) and lens[i] valid samples (<= pcm_stride; 0 = "empty" class =>

@@ -331,6 +331,22 @@ int var_adam_step(var_ctx* c, void* stream, float* params, const float* grads, f
     return VAR_OK;
 }
 
+int var_adam_step_dev(var_ctx* c, void* stream, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                      long n, const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
+                      int* step_dev) {
+    CHECK_CTX(c);
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !lr_dev || !step_dev || n <= 0) {
+        VAR_SET_ERR(c, "var_adam_step_dev: bad argument");
+        return VAR_ERR_ARG;
+    }
+    SET_DEVICE(c);
+    hipStream_t s = (hipStream_t)stream;
+    int rc = launch_adam_dev(c, s, params, grads, exp_avg, exp_avg_sq, n, lr_dev, beta1, beta2, eps, weight_decay, step_dev);
+    if (rc != VAR_OK) return rc;
+    if (n == VAR_N_PARAMS) return launch_pack_weights(c, s, params);
+    return VAR_OK;
+}
+
 int var_mfcc(var_ctx* c, void* stream, const int16_t* pcm, const int* lens, const int* clip_index, int nclips,
              int pcm_stride, int out_frames, float* out) {
     CHECK_CTX(c);

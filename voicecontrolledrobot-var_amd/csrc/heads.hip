@@ -18,39 +18,40 @@ constexpr int U = 8;    // k-steps per register-prefetch block
 //   D[row][n] = sum_k X[row][k] * W0T[k][n]
 // ------------------------------------------------------------------------------------------
 template <int K>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 heads_fwd_kernel(const float* __restrict__ x, int R, const float* __restrict__ w0t,
                  const float* __restrict__ b0, const float* __restrict__ w1, const float* __restrict__ b1,
                  float* __restrict__ hid, float* __restrict__ emb_raw, float* __restrict__ emb) {
-    constexpr int LDX = K + 1;
+    // 16 waves: wave = kslice*4 + nblock; each wave multiplies a quarter of K for its 32 hidden units,
+    // the four partial tiles are folded through LDS in a fixed order.
+    constexpr int LDX = K + 1, NT = 1024, KSL = 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;                    // [32][K+1]
-    float* hs = lds;                    // reused after the GEMM: [32][129]
-    float* raw = lds + 32 * 129;        // [32][4], after hs
+    float* ps = lds;                    // reused after the GEMM: partial tiles [4][32][129]
+    float* hs = lds + 4 * 32 * 129;     // [32][129]
+    float* raw = hs + 32 * 129;         // [32][4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
+    const int nblk = wave & 3, ksl = wave >> 2;
     const int r0 = blockIdx.x * 32;
-    // stage 32 rows (contiguous 32*K floats), 8 float4 loads in flight per lane
     {
         constexpr int TOT = 32 * K / 4;
         const float4* src = (const float4*)(x + (size_t)r0 * K);
         const int lim = (R - r0) * (K / 4);
-#pragma unroll 1
-        for (int e0 = tid; e0 < TOT; e0 += 256 * 8) {
-            float4 v[8];
+        constexpr int IT = (TOT + NT - 1) / NT;
+        float4 v[IT];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = e0 + 256 * u;
-                v[u] = (e < TOT && e < lim) ? src[e] : float4{0.f, 0.f, 0.f, 0.f};
-            }
+        for (int u = 0; u < IT; ++u) {
+            const int e = tid + NT * u;
+            v[u] = (e < TOT && e < lim) ? src[e] : float4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = e0 + 256 * u;
-                if (e < TOT) {
-                    const int r = (e * 4) / K, k = (e * 4) - r * K;
-                    float* d = xs + r * LDX + k;
-                    d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
-                }
+        for (int u = 0; u < IT; ++u) {
+            const int e = tid + NT * u;
+            if (e < TOT) {
+                const int r = (e * 4) / K, k = (e * 4) - r * K;
+                float* d = xs + r * LDX + k;
+                d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
             }
         }
     }
@@ -58,43 +59,41 @@ heads_fwd_kernel(const float* __restrict__ x, int R, const float* __restrict__ w
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const float* wl = w0t + half * kHid + wave * 32 + l31;
-    const float* xl = xs + l31 * LDX + half;
-    constexpr int STEPS = K / 2, NBK = STEPS / U;
-    static_assert(STEPS % (2 * U) == 0, "K/2 must be a multiple of two prefetch blocks");
-    float wb[2][U];
+    constexpr int STEPS = K / 2 / KSL;              // k-steps of this wave's slice
+    constexpr int UF = (STEPS % 8 == 0) ? 8 : 10;   // prefetch block: 72 = 9 x 8 (K = 576), 20 = 2 x 10 (K = 160)
+    static_assert((K / 2) % KSL == 0 && STEPS % UF == 0, "K must split into 4 slices of whole prefetch blocks");
+    constexpr int NBK = STEPS / UF;
+    const int kbase = ksl * STEPS;                  // first k-step of the slice
+    const float* wl = w0t + (size_t)(2 * kbase + half) * kHid + nblk * 32 + l31;
+    const float* xl = xs + l31 * LDX + 2 * kbase + half;
+    float wb[2][UF];
 #pragma unroll
-    for (int u = 0; u < U; ++u) wb[0][u] = wl[(2 * u) * kHid];
-#pragma unroll 1
-    for (int blk = 0; blk < NBK; blk += 2) {
+    for (int u = 0; u < UF; ++u) wb[0][u] = wl[(2 * u) * kHid];
 #pragma unroll
-        for (int u = 0; u < U; ++u) wb[1][u] = wl[(2 * ((blk + 1) * U + u)) * kHid];
-        __builtin_amdgcn_sched_barrier(0);
+    for (int blk = 0; blk < NBK; ++blk) {
+        if (blk + 1 < NBK) {
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xl[2 * (blk * U + u)], wb[0][u], acc, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (blk + 2 < NBK) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) wb[0][u] = wl[(2 * ((blk + 2) * U + u)) * kHid];
+            for (int u = 0; u < UF; ++u) wb[(blk + 1) & 1][u] = wl[(2 * ((blk + 1) * UF + u)) * kHid];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xl[2 * ((blk + 1) * U + u)], wb[1][u], acc, 0, 0, 0);
+        for (int u = 0; u < UF; ++u)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xl[2 * (blk * UF + u)], wb[blk & 1][u], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();                    // everyone is done reading xs
-    {
-        const int n = wave * 32 + l31;
-        const float bv = b0[n];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-            float v = acc[r] + bv;
-            v = v > 0.f ? v : 0.f;
-            hs[row * 129 + n] = v;
-            if (r0 + row < R) hid[(size_t)(r0 + row) * kHid + n] = v;
-        }
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        ps[(ksl * 32 + row) * 129 + nblk * 32 + l31] = acc[r];
+    }
+    __syncthreads();
+    for (int e = tid; e < 32 * kHid; e += NT) {
+        const int row = e >> 7, n = e & 127;
+        float v = ((ps[row * 129 + n] + ps[(32 + row) * 129 + n]) + (ps[(64 + row) * 129 + n] + ps[(96 + row) * 129 + n])) + b0[n];
+        v = v > 0.f ? v : 0.f;
+        hs[row * 129 + n] = v;
+        if (r0 + row < R) hid[(size_t)(r0 + row) * kHid + n] = v;
     }
     __syncthreads();
     if (tid < 96) {
@@ -186,47 +185,49 @@ heads_bwd_rows_kernel(int R, const float* __restrict__ w1, const float* __restri
 // ------------------------------------------------------------------------------------------
 struct TileOp {
     const float* A; int lda; int alim;       // alim: valid extent of A's free index (from its tile origin)
-    const float* Bm; int ldb; int blim;
+    const float* Bm; int ldb;
     int Q;                                   // reduction length
 };
 
-__device__ __forceinline__ void tile_gemm(const TileOp& t, int lane, f32x16& acc, float& asum) {
+// this wave's share of the reduction: steps s = wave, wave+4, ... (two q per step).  Only A is predicated
+// (a zero A kills the product); B rows are merely clamped to stay in bounds.
+__device__ __forceinline__ void tile_gemm(const TileOp& t, int lane, int wave, f32x16& acc, float& asum) {
+    constexpr int UB = 8;
     const int half = lane >> 5, l31 = lane & 31;
-    const bool aok = l31 < t.alim, bok = l31 < t.blim;
+    const bool aok = l31 < t.alim;
     const float* ap = t.A + (aok ? l31 : 0);
-    const float* bp = t.Bm + (bok ? l31 : 0);
+    const float* bp = t.Bm + l31;
     const int steps = (t.Q + 1) / 2;
-    float ab[2][U], bb[2][U];
-    auto fetch = [&](int buf, int s0) {
+    const int mine = (steps - wave + 3) / 4;            // steps of this wave
+    float ab[2][UB], bb[2][UB];
+    auto fetch = [&](int buf, int i0) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int q = 2 * (s0 + u) + half;
-            const bool ok = q < t.Q;
-            const int qc = ok ? q : 0;
-            const float av = ap[(size_t)qc * t.lda];
-            const float bv = bp[(size_t)qc * t.ldb];
-            ab[buf][u] = (ok && aok) ? av : 0.f;
-            bb[buf][u] = (ok && bok) ? bv : 0.f;
+        for (int u = 0; u < UB; ++u) {
+            const int q = 2 * (wave + 4 * (i0 + u)) + half;
+            const int qc = q < t.Q ? q : t.Q - 1;
+            ab[buf][u] = ap[(size_t)qc * t.lda];
+            bb[buf][u] = bp[(size_t)qc * t.ldb];
+        }
+    };
+    auto mul = [&](int buf, int i0) {
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int q = 2 * (wave + 4 * (i0 + u)) + half;
+            const float a = (aok && q < t.Q && i0 + u < mine) ? ab[buf][u] : 0.f;
+            asum += a;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb[buf][u], acc, 0, 0, 0);
         }
     };
     fetch(0, 0);
 #pragma unroll 1
-    for (int s0 = 0; s0 < steps; s0 += 2 * U) {
-        fetch(1, s0 + U);
-        __builtin_amdgcn_sched_barrier(0);          // keep the prefetch above the MFMAs it overlaps with
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            asum += ab[0][u];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[0][u], bb[0][u], acc, 0, 0, 0);
-        }
+    for (int i0 = 0; i0 < mine; i0 += 2 * UB) {
+        fetch(1, i0 + UB);
         __builtin_amdgcn_sched_barrier(0);
-        fetch(0, s0 + 2 * U);
+        mul(0, i0);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            asum += ab[1][u];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[1][u], bb[1][u], acc, 0, 0, 0);
-        }
+        fetch(0, i0 + 2 * UB);
+        __builtin_amdgcn_sched_barrier(0);
+        mul(1, i0 + UB);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -239,53 +240,58 @@ heads_bwd_gemm_kernel(int R /*rows in this call*/, int RT /*row stride of ghidT*
                       const float* __restrict__ ghidT, float* __restrict__ dw0, float* __restrict__ db0,
                       float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ gx) {
     constexpr int KB = K / 32;
-    const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ float red[4][1024];
+    __shared__ float reda[4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int tile = blockIdx.x;                         // one tile per workgroup, 4 waves split its reduction
     const int RB = (R + 31) / 32;
-    const int n_dw0 = 4 * KB, n_dw1 = 4, n_gx = RB * KB;
-    if (tile >= n_dw0 + n_dw1 + n_gx) return;
+    const int n_dw0 = 4 * KB, n_dw1 = 4;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float asum = 0.f;
+    int kind, i0 = 0, i1 = 0;                            // tile coordinates
     if (tile < n_dw0) {
-        const int nb = tile / KB, kb = tile - nb * KB;
-        TileOp t{ghid + nb * 32, kHid, 32, x + kb * 32, K, 32, R};
-        tile_gemm(t, lane, acc, asum);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int n = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            dw0[(size_t)n * K + kb * 32 + l31] = acc[r];
-        }
-        if (kb == 0) {
-            asum += __shfl_down(asum, 32, 64);
-            if (half == 0) db0[nb * 32 + l31] = asum;
-        }
+        kind = 0; i0 = tile / KB; i1 = tile - i0 * KB;   // nb, kb
+        TileOp t{ghid + i0 * 32, kHid, 32, x + i1 * 32, K, R};
+        tile_gemm(t, lane, wave, acc, asum);
     } else if (tile < n_dw0 + n_dw1) {
-        const int nb = tile - n_dw0;
-        TileOp t{graw, 4, 3, hid + nb * 32, kHid, 32, R};
-        tile_gemm(t, lane, acc, asum);
-        if (half == 0) {
-#pragma unroll
-            for (int d = 0; d < 3; ++d) dw1[d * kHid + nb * 32 + l31] = acc[d];
-        }
-        if (nb == 0) {
-            asum += __shfl_down(asum, 32, 64);
-            if (half == 0 && l31 < 3) db1[l31] = asum;
-        }
+        kind = 1; i0 = tile - n_dw0;                     // nb
+        TileOp t{graw, 4, 3, hid + i0 * 32, kHid, R};
+        tile_gemm(t, lane, wave, acc, asum);
     } else {
+        kind = 2;
         const int g = tile - n_dw0 - n_dw1;
-        const int rb = g / KB, kb = g - rb * KB;
-        TileOp t{ghidT + rb * 32, RT, R - rb * 32, w0 + kb * 32, K, 32, kHid};
-        tile_gemm(t, lane, acc, asum);
+        i0 = g / KB; i1 = g - i0 * KB;                   // rb, kb
+        TileOp t{ghidT + i0 * 32, RT, R - i0 * 32, w0 + i1 * 32, K, kHid};
+        tile_gemm(t, lane, wave, acc, asum);
+    }
+    (void)RB;
+    // fold the four K slices (fixed order)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    for (int r = 0; r < 16; ++r) red[wave][((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[r];
+    asum += __shfl_down(asum, 32, 64);
+    if (half == 0) reda[wave][l31] = asum;
+    __syncthreads();
+    for (int e = tid; e < 1024; e += 256) {
+        const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        const int i = e >> 5, j = e & 31;                // D[i][j]
+        if (kind == 0) {
+            dw0[(size_t)(i0 * 32 + i) * K + i1 * 32 + j] = v;
+        } else if (kind == 1) {
+            if (i < 3) dw1[i * kHid + i0 * 32 + j] = v;
+        } else {
+            const int row = i0 * 32 + i;
             if (row < R) {
-                const size_t o = (size_t)row * K + kb * 32 + l31;
-                gx[o] = x[o] > 0.f ? acc[r] : 0.f;
+                const size_t o = (size_t)row * K + i1 * 32 + j;
+                gx[o] = x[o] > 0.f ? v : 0.f;
             }
         }
+    }
+    if (tid < 32) {
+        const float v = (reda[0][tid] + reda[1][tid]) + (reda[2][tid] + reda[3][tid]);
+        if (kind == 0 && i1 == 0) db0[i0 * 32 + tid] = v;
+        if (kind == 1 && i0 == 0 && tid < 3) db1[tid] = v;
     }
 }
 }  // namespace
@@ -293,7 +299,7 @@ heads_bwd_gemm_kernel(int R /*rows in this call*/, int RT /*row stride of ghidT*
 template <int K>
 static int run_heads_fwd(var_ctx* c, hipStream_t s, const float* x, int R, const float* w0t, const float* b0,
                          const float* w1, const float* b1, float* hid, float* emb_raw, float* emb) {
-    constexpr int A1 = 32 * (K + 1) * 4, A2 = (32 * 129 + 128) * 4;
+    constexpr int A1 = 32 * (K + 1) * 4, A2 = (5 * 32 * 129 + 128) * 4;
     constexpr int LDS_BYTES = A1 > A2 ? A1 : A2;
     static bool attr_set = false;
     if (!attr_set) {
@@ -301,7 +307,7 @@ static int run_heads_fwd(var_ctx* c, hipStream_t s, const float* x, int R, const
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL(heads_fwd_kernel<K>, dim3((R + 31) / 32), dim3(256), LDS_BYTES, s, x, R, w0t, b0, w1, b1,
+    hipLaunchKernelGGL(heads_fwd_kernel<K>, dim3((R + 31) / 32), dim3(1024), LDS_BYTES, s, x, R, w0t, b0, w1, b1,
                        hid, emb_raw, emb);
     return VAR_OK;
 }
@@ -360,14 +366,14 @@ int launch_heads_bwd(var_ctx* c, hipStream_t s, hipStream_t ss, const float* par
         ProfScope prof(c, s, TAG_HEADS_BWD_W);
         if (has_img) {
             const int tiles = 4 * (kImgFeat / 32) + 4 + ((B + 31) / 32) * (kImgFeat / 32);
-            hipLaunchKernelGGL(heads_bwd_gemm_kernel<kImgFeat>, dim3((tiles + 3) / 4), dim3(256), 0, s, B, B,
+            hipLaunchKernelGGL(heads_bwd_gemm_kernel<kImgFeat>, dim3(tiles), dim3(256), 0, s, B, B,
                                c->act[5], params + L.ih_w0, c->hid_i, graw, c->ghid, ghidT,
                                grads + L.ih_w0, grads + L.ih_b0, grads + L.ih_w1, grads + L.ih_b1, c->gact[5]);
         }
         if (snd_hi > snd_lo) {
             const int R = snd_hi - snd_lo;
             const int tiles = 4 * (kSndFeat / 32) + 4 + ((R + 31) / 32) * (kSndFeat / 32);
-            hipLaunchKernelGGL(heads_bwd_gemm_kernel<kSndFeat>, dim3((tiles + 3) / 4), dim3(256), 0, ss, R, R,
+            hipLaunchKernelGGL(heads_bwd_gemm_kernel<kSndFeat>, dim3(tiles), dim3(256), 0, ss, R, R,
                                c->sact[4] + (size_t)snd_lo * kSndFeat, params + L.sh_w0,
                                c->hid_s + (size_t)snd_lo * kHid, graw + 4 * (B + snd_lo),
                                c->ghid + (size_t)(B + snd_lo) * kHid, ghidT + (size_t)B * kHid,

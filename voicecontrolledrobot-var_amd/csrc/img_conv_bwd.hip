@@ -191,6 +191,8 @@ int launch_img_bwd(var_ctx* c, hipStream_t s, hipStream_t sw, const float* param
     if ((rc = ready(5)) != VAR_OK) return rc;
     for (int l = 4; l >= 0; --l) {
         if ((rc = launch_img_wgrad(c, sw, l, xin[l], bs[l], l == 0 ? c->saved_u8 : 0, c->gact[l + 1], B)) != VAR_OK) return rc;
+        // slabs are folded right behind their producer so that only the first layer's (small) fold trails the chain
+        if ((rc = launch_img_wgrad_reduce(c, sw, grads, l, l)) != VAR_OK) return rc;
         if (l == 0) break;
         switch (l) {
             case 4: rc = DG(D84_4, D96_4, 4); break;
@@ -202,7 +204,6 @@ int launch_img_bwd(var_ctx* c, hipStream_t s, hipStream_t sw, const float* param
         if ((rc = ready(l)) != VAR_OK) return rc;
     }
 #undef DG
-    if ((rc = launch_img_wgrad_reduce(c, sw, grads)) != VAR_OK) return rc;
     if (sw != s) { VAR_HIP_CHECK(c, hipEventRecord(c->ev_wjoin, sw)); VAR_HIP_CHECK(c, hipStreamWaitEvent(s, c->ev_wjoin, 0)); }
     (void)params;
     return VAR_OK;

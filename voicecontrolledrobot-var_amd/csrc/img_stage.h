@@ -121,3 +121,97 @@ __device__ __forceinline__ void stage_y_band(float* __restrict__ dst, const floa
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// ColStager: column-mapped, register-staged copy of a band of NCHW rows into LDS, in two phases
+// (issue = global loads into registers, store = registers -> LDS) so that the loads of the NEXT
+// tile fly while the CURRENT tile is on the matrix cores.
+//   band  = ROWS rows x W cols of NCH planes of NUNITS images  ->  lds[u*UNIT + ch*PLANE + row*PW + COL0 + col]
+//   lane  = PP (channel, V-wide column) pairs; it walks the ROWS rows of each pair, so global
+//           addresses are base + row*W and LDS offsets base + row*PW (compile-time immediates),
+//           and row validity (rows above/below the image) is wave-uniform.
+// No VALU instruction touches a loaded value in issue(): the compiler therefore waits for the
+// loads only in store().
+// ------------------------------------------------------------------------------------------
+template <int NCH, int H, int W, int ROWS, int PW, int PLANE, int COL0, bool U8, int NT, int NUNITS>
+struct ColStager {
+    static constexpr int V = U8 ? 4 : (W % 4 == 0 ? 4 : (W % 2 == 0 ? 2 : 1));
+    static constexpr int WV = W / V;
+    static constexpr int NP = NCH * WV;                       // pairs per unit
+    static constexpr int PP = (NUNITS * NP + NT - 1) / NT;    // pairs per lane
+    static constexpr int XREG = U8 ? 1 : V;
+    static constexpr int UNIT = NCH * PLANE;
+    int gcol[PP];      // ch*H*W + xv*V (elements from the unit's plane-0 row-0), -1 = no pair
+    int lcol[PP];      // u*UNIT + ch*PLANE + COL0 + xv*V
+    int ucol[PP];      // unit of the pair
+    float data[PP][ROWS][XREG];
+
+    __device__ __forceinline__ void init(int tid) {
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {
+            const int e = tid + p * NT;
+            if (e < NUNITS * NP) {
+                const int u = e / NP, rem = e - u * NP;
+                const int ch = rem / WV, xv = rem - ch * WV;
+                gcol[p] = ch * H * W + xv * V;
+                lcol[p] = u * UNIT + ch * PLANE + COL0 + xv * V;
+                ucol[p] = u;
+            } else {
+                gcol[p] = -1; lcol[p] = 0; ucol[p] = 0;
+            }
+        }
+    }
+    // base: plane 0 / row 0 of the FIRST unit's image; further units (NUNITS > 1) are the following
+    // images, `ustride` elements apart, and share row0.  nvalid = units that exist (>= 1 when called);
+    // pairs of missing units load from unit 0 and are zeroed in store().
+    template <class PT>
+    __device__ __forceinline__ void issue(const PT* base, long ustride, int row0, int nvalid) {
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {
+            const int gc = gcol[p] < 0 ? 0 : gcol[p];
+            const PT* b = base + gc;
+            if constexpr (NUNITS > 1) b += (size_t)(ucol[p] < nvalid ? ucol[p] : 0) * ustride;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                int row = row0 + r;
+                row = row < 0 ? 0 : (row >= H ? H - 1 : row);
+                const PT* src = b + row * W;
+                if constexpr (U8) {
+                    data[p][r][0] = __uint_as_float(*(const uint32_t*)src);
+                } else if constexpr (V == 4) {
+                    const float4 q = *(const float4*)src;
+                    data[p][r][0] = q.x; data[p][r][1] = q.y; data[p][r][2] = q.z; data[p][r][3] = q.w;
+                } else if constexpr (V == 2) {
+                    const float2 q = *(const float2*)src;
+                    data[p][r][0] = q.x; data[p][r][1] = q.y;
+                } else {
+                    data[p][r][0] = *src;
+                }
+            }
+        }
+    }
+    // rows outside [0,H) and units >= nvalid are written as zeros
+    __device__ __forceinline__ void store(float* __restrict__ lds, int row0, int nvalid) const {
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {
+            if (gcol[p] < 0) continue;
+            const bool ok = ucol[p] < nvalid;
+            float* d = lds + lcol[p];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const int row = row0 + r;
+                const bool rok = ok && row >= 0 && row < H;
+                if constexpr (U8) {
+                    const uint32_t q = rok ? __float_as_uint(data[p][r][0]) : 0u;
+                    d[r * PW + 0] = (float)(q & 0xff) / 255.f;
+                    d[r * PW + 1] = (float)((q >> 8) & 0xff) / 255.f;
+                    d[r * PW + 2] = (float)((q >> 16) & 0xff) / 255.f;
+                    d[r * PW + 3] = (float)(q >> 24) / 255.f;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < V; ++j) d[r * PW + j] = rok ? data[p][r][j] : 0.f;
+                }
+            }
+        }
+    }
+};

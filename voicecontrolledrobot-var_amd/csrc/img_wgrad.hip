@@ -3,19 +3,23 @@
 // on the gfx950 f32 matrix cores:  D[n][c] per tap, reduction index = output pixels.
 //
 // Work decomposition
-//   blockIdx.y = (32-channel block of n, 32-channel block of c); a workgroup has 3 waves, wave = ky,
-//   each wave owns the three kx tiles of its ky (A operand shared by the three MFMAs);
-//   blockIdx.x strides over "units" (R output rows of one image): split-K across workgroups.
-//   The first layer (CIN = 3) packs (tap, c) into one 32-wide tile and splits K over 4 waves instead.
+//   blockIdx.y = (32-channel block of n, 32-channel block of c); a workgroup has 12 waves = 3 ky x 4 K slices,
+//   each wave owns the three kx tiles of its ky (A operand shared by the three MFMAs) over its slice of
+//   the staged pixels; blockIdx.x strides over "units" (R output rows of one image): split-K across
+//   workgroups.  The first layer (CIN = 3) packs (tap, c) into one 32-wide tile: 8 waves = 8 K slices.
 // Software pipeline (the point of this kernel)
-//   every lane issues ALL global loads of the NEXT unit into registers right after the barrier
+//   (ColStager, img_stage.h) every lane issues ALL global loads of the NEXT unit into registers right after the barrier
 //   that precedes the MFMAs of the CURRENT unit, and writes them to LDS after those MFMAs:
 //   HBM/L2 latency is overlapped with matrix-core work instead of being paid per batch of loads.
 // Determinism
 //   each workgroup writes one partial slab; img_wgrad_reduce_kernel sums slabs in a fixed order.
-#include "var_common.h"
+#include <stdlib.h>
 
-template <int CIN_, int COUT_, int H_, bool U8_, int R_, int NU_>
+#include <type_traits>
+
+#include "img_stage.h"
+
+template <int CIN_, int COUT_, int H_, bool U8_, int R_, int NU_, int KS_>
 struct WgCfg {
     static constexpr int CIN = CIN_, COUT = COUT_, H = H_, W = H_, R = R_, NU = NU_;
     static constexpr bool U8 = U8_;
@@ -33,23 +37,17 @@ struct WgCfg {
     static constexpr int NBLK = COUT / 32;
     static constexpr int CBLK = SMALLC ? 1 : CIN / 32;
     static constexpr int NCOMBO = NBLK * CBLK;
-    static constexpr int NW = SMALLC ? 4 : 3;
+    static constexpr int KS = KS_;                  // K (pixel) slices inside the workgroup
+    static constexpr int NW = SMALLC ? KS : 3 * KS; // wave = ks*3 + ky
     static constexpr int NT = NW * 64;
     static constexpr int XS = (NU * UNIT_X + 3) & ~3, YS = NU * UNIT_Y;
-    static constexpr int LDS_FLOATS = (((XS + YS) > (SMALLC ? 4096 : 0) ? (XS + YS) : 4096) + 3) & ~3;
+    static constexpr int ZPAD = (XS + YS + 3) & ~3;  // a few always-zero floats: A operand of idle k-steps
+    static constexpr int LDS_FLOATS = ((ZPAD + 4) > NW * 1024 ? (ZPAD + 4) : NW * 1024);
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
     static constexpr int SLAB = SMALLC ? (32 * 32 + 32) : (32 * 9 * 32 + 32);
     static constexpr int HSTEPS = (WO + 1) / 2;
-    // staging vectors
-    static constexpr int VX = U8 ? 4 : (W % 4 == 0 ? 4 : (W % 2 == 0 ? 2 : 1));
-    static constexpr int WVX = W / VX;
-    static constexpr int NXV = XC * IR * WVX;                         // per unit
-    static constexpr int XI = (NU * NXV + NT - 1) / NT;
-    static constexpr int VY = (WO % 4 == 0) ? 4 : (WO % 2 == 0 ? 2 : 1);
-    static constexpr int WVY = WO / VY;
-    static constexpr int NYV = 32 * R * WVY;
-    static constexpr int YI = (NU * NYV + NT - 1) / NT;
-    static constexpr int XREG = U8 ? 1 : VX;                          // registers per staged x vector
+    static constexpr int TS = NU * R * HSTEPS;      // k-steps per stage
+    static constexpr int NSTEP = (TS + KS - 1) / KS; // k-steps per wave and stage
 };
 
 template <class C>
@@ -60,147 +58,37 @@ img_wgrad_kernel(const void* __restrict__ xin, long bstride, const int* __restri
     float* xs = lds;
     float* ys = lds + C::XS;
     constexpr int NT = C::NT;
+    using XT = typename std::conditional<C::U8, uint8_t, float>::type;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int total_units = B * C::NB;
     const int G = gridDim.x;
     const int combo = blockIdx.y;
     const int nb = combo / C::CBLK, cb = combo - nb * C::CBLK;
+    const int ky = C::SMALLC ? 0 : wave % 3, ks = C::SMALLC ? wave : wave / 3;
 
-    // ---- per-thread staging descriptors (fixed for the whole kernel): u | c | r | xv packed ----
-    int xpk[C::XI], ypk[C::YI];
-#pragma unroll
-    for (int i = 0; i < C::XI; ++i) {
-        const int e = tid + i * NT;
-        if (e < C::NU * C::NXV) {
-            const int u = e / C::NXV, rem = e - u * C::NXV;
-            const int c = rem / (C::IR * C::WVX), rem2 = rem - c * (C::IR * C::WVX);
-            const int r = rem2 / C::WVX, xv = rem2 - r * C::WVX;
-            xpk[i] = xv | (r << 8) | (c << 16) | (u << 24);
-        } else {
-            xpk[i] = -1;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < C::YI; ++i) {
-        const int e = tid + i * NT;
-        if (e < C::NU * C::NYV) {
-            const int u = e / C::NYV, rem = e - u * C::NYV;
-            const int n = rem / (C::R * C::WVY), rem2 = rem - n * (C::R * C::WVY);
-            const int r = rem2 / C::WVY, xv = rem2 - r * C::WVY;
-            ypk[i] = xv | (r << 8) | (n << 16) | (u << 24);
-        } else {
-            ypk[i] = -1;
-        }
-    }
-    float xr[C::XI][C::XREG];
-    float yr[C::YI][C::VY];
+    ColStager<C::XC, C::H, C::W, C::IR, C::PW, C::PLANE_X, 1, C::U8, NT, C::NU> sx;
+    ColStager<32, C::HO, C::WO, C::R, C::POW, C::PLANE_Y, 0, false, NT, C::NU> sy;
+    sx.init(tid);
+    sy.init(tid);
 
-    // NOTE: the loaded values are not touched here (no select on them): any VALU use would make the
-    // compiler wait for the loads before the MFMAs they are meant to overlap with.  Rows that fall
-    // outside the image are loaded from a clamped address and zeroed in store_stage.
-    auto issue_loads = [&](int unit0) {
-        // image row of each staged unit, resolved ONCE (an index load inside the element loop would put
-        // a vmcnt(0) wait between every pair of data loads)
-        int ub[C::NU], uband[C::NU];
-#pragma unroll
-        for (int u = 0; u < C::NU; ++u) {
-            const int unit = unit0 + u;
-            const bool uv = unit < total_units;
-            const int bo = uv ? unit / C::NB : 0;
-            uband[u] = uv ? unit - bo * C::NB : 0;
-            ub[u] = bo;
-        }
-        int uimg[C::NU];
-#pragma unroll
-        for (int u = 0; u < C::NU; ++u) uimg[u] = bidx ? bidx[ub[u]] : ub[u];
-#pragma unroll
-        for (int i = 0; i < C::XI; ++i) {
-            const int pk = xpk[i], pkk = pk < 0 ? 0 : pk;      // lanes without an element read element 0
-            const int xv = pkk & 0xff, r = (pkk >> 8) & 0xff, c = (pkk >> 16) & 0xff, u = (pkk >> 24) & 0x7f;
-            const int unit = unit0 + u;
-            const bool uvalid = pk >= 0 && unit < total_units;
-            int b = uimg[0], band = uband[0];
-#pragma unroll
-            for (int q = 1; q < C::NU; ++q) if (u == q) { b = uimg[q]; band = uband[q]; }
-            const int iy = 2 * band * C::R - 1 + r;
-            const bool ok = uvalid && iy >= 0 && iy < C::H;
-            const int iyc = ok ? iy : 0;
-            const size_t so = (size_t)b * bstride + ((cb * C::XC + c) * C::H + iyc) * C::W + xv * C::VX;
-            if constexpr (C::U8) {
-                const uint32_t q = *(const uint32_t*)((const uint8_t*)xin + so);
-                xr[i][0] = __uint_as_float(q);
-            } else if constexpr (C::VX == 4) {
-                const float4 q = *(const float4*)((const float*)xin + so);
-                xr[i][0] = q.x; xr[i][1] = q.y; xr[i][2] = q.z; xr[i][3] = q.w;
-            } else if constexpr (C::VX == 2) {
-                const float2 q = *(const float2*)((const float*)xin + so);
-                xr[i][0] = q.x; xr[i][1] = q.y;
-            } else {
-                xr[i][0] = ((const float*)xin)[so];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < C::YI; ++i) {
-            const int pk = ypk[i], pkk = pk < 0 ? 0 : pk;
-            const int xv = pkk & 0xff, r = (pkk >> 8) & 0xff, n = (pkk >> 16) & 0xff, u = (pkk >> 24) & 0x7f;
-            const int unit = unit0 + u;
-            const bool uvalid = pk >= 0 && unit < total_units;
-            int b = ub[0], band = uband[0];
-#pragma unroll
-            for (int q = 1; q < C::NU; ++q) if (u == q) { b = ub[q]; band = uband[q]; }
-            const int oy = band * C::R + r;
-            const bool ok = uvalid && oy < C::HO;
-            const int oyc = ok ? oy : 0;
-            const float* p = gy + ((size_t)(b * C::COUT + nb * 32 + n) * C::HO + oyc) * C::WO + xv * C::VY;
-            if constexpr (C::VY == 4) {
-                const float4 q = *(const float4*)p;
-                yr[i][0] = q.x; yr[i][1] = q.y; yr[i][2] = q.z; yr[i][3] = q.w;
-            } else if constexpr (C::VY == 2) {
-                const float2 q = *(const float2*)p;
-                yr[i][0] = q.x; yr[i][1] = q.y;
-            } else {
-                yr[i][0] = *p;
-            }
-        }
+    static_assert(C::NU == 1 || C::NB == 1, "multi-unit stages need whole-image units (consecutive images)");
+    // stage bookkeeping (wave-uniform): first unit -> image pointers, band rows, number of live units
+    struct Stage { const XT* bx; const float* by; int row0x, row0y, nvalid; };
+    auto make_stage = [&](int unit0) {
+        Stage st;
+        const int bo = unit0 / C::NB, band = unit0 - bo * C::NB;
+        const int b = bidx ? bidx[bo] : bo;                      // optional batch gather (first layer, NU == 1)
+        st.bx = (const XT*)xin + (size_t)b * bstride + (size_t)(cb * C::XC) * C::H * C::W;
+        st.by = gy + ((size_t)bo * C::COUT + nb * 32) * C::HO * C::WO;
+        st.row0x = 2 * band * C::R - 1;
+        st.row0y = band * C::R;
+        st.nvalid = total_units - unit0 < C::NU ? total_units - unit0 : C::NU;
+        return st;
     };
-    auto store_stage = [&](int unit0) {
-#pragma unroll
-        for (int i = 0; i < C::XI; ++i) {
-            const int pk = xpk[i];
-            if (pk >= 0) {
-                const int xv = pk & 0xff, r = (pk >> 8) & 0xff, c = (pk >> 16) & 0xff, u = (pk >> 24) & 0x7f;
-                const int unit = unit0 + u;
-                const int band = unit % C::NB;
-                const int iy = 2 * band * C::R - 1 + r;
-                const bool ok = unit < total_units && iy >= 0 && iy < C::H;
-                float* d = xs + u * C::UNIT_X + c * C::PLANE_X + r * C::PW + 1 + xv * C::VX;
-                if constexpr (C::U8) {
-                    const uint32_t q = ok ? __float_as_uint(xr[i][0]) : 0u;
-                    d[0] = (float)(q & 0xff) / 255.f; d[1] = (float)((q >> 8) & 0xff) / 255.f;
-                    d[2] = (float)((q >> 16) & 0xff) / 255.f; d[3] = (float)(q >> 24) / 255.f;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < C::VX; ++j) d[j] = ok ? xr[i][j] : 0.f;
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < C::YI; ++i) {
-            const int pk = ypk[i];
-            if (pk >= 0) {
-                const int xv = pk & 0xff, r = (pk >> 8) & 0xff, n = (pk >> 16) & 0xff, u = (pk >> 24) & 0x7f;
-                const int unit = unit0 + u;
-                const bool ok = unit < total_units && (unit % C::NB) * C::R + r < C::HO;
-                float* d = ys + u * C::UNIT_Y + n * C::PLANE_Y + r * C::POW + xv * C::VY;
-#pragma unroll
-                for (int j = 0; j < C::VY; ++j) d[j] = ok ? yr[i][j] : 0.f;
-            }
-        }
-    };
+    constexpr long YSTRIDE = (long)C::COUT * C::HO * C::WO;
 
     // ---- lane offsets for the MFMA operands ----
-    const int ky = C::SMALLC ? 0 : wave;
     const int aoff = l31 * C::PLANE_Y + half;                       // + u*UNIT_Y + oyl*POW + 2s
     int boff;
     if constexpr (C::SMALLC) {
@@ -210,6 +98,21 @@ img_wgrad_kernel(const void* __restrict__ xin, long bstride, const int* __restri
     } else {
         boff = l31 * C::PLANE_X + ky * C::PW + 2 * half;             // + u*UNIT_X + 2*oyl*PW + 4s + kx
     }
+    // This wave's K slice as a fixed list of LDS offsets (computed once): the stage loop below is then
+    // straight-line code and the compiler can hoist the operand reads of later steps above the MFMAs
+    // of earlier ones.  Idle steps (uneven split) read A from an always-zero cell.
+    const int t0 = (ks * C::TS) / C::KS, t1 = ((ks + 1) * C::TS) / C::KS;
+    int aos[C::NSTEP], bos[C::NSTEP];
+#pragma unroll
+    for (int i = 0; i < C::NSTEP; ++i) {
+        const int t = t0 + i;
+        const bool live = t < t1;
+        const int tt = live ? t : t0;
+        const int u = tt / (C::R * C::HSTEPS), rem = tt - u * (C::R * C::HSTEPS);
+        const int oyl = rem / C::HSTEPS, sstep = rem - oyl * C::HSTEPS;
+        aos[i] = live ? C::XS + aoff + u * C::UNIT_Y + oyl * C::POW + 2 * sstep : C::ZPAD;
+        bos[i] = boff + u * C::UNIT_X + 2 * oyl * C::PW + 4 * sstep;
+    }
     f32x16 acc[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t)
@@ -218,86 +121,82 @@ img_wgrad_kernel(const void* __restrict__ xin, long bstride, const int* __restri
     float bsum = 0.f;
 
     // zero the pads once (data cells are rewritten for every unit)
-    {
-        float4 z = {0.f, 0.f, 0.f, 0.f};
-        for (int e = tid; e < C::LDS_FLOATS / 4; e += NT) ((float4*)lds)[e] = z;
-    }
+    lds_zero<NT>(lds, C::LDS_FLOATS, tid);
     const int first = blockIdx.x * C::NU;
-    if (first < total_units) issue_loads(first);
+    if (first < total_units) {
+        const Stage st = make_stage(first);
+        sx.issue(st.bx, bstride, st.row0x, st.nvalid);
+        sy.issue(st.by, YSTRIDE, st.row0y, st.nvalid);
+    }
 #pragma unroll 1
     for (int unit0 = first; unit0 < total_units; unit0 += G * C::NU) {
-        __syncthreads();                              // previous unit's MFMAs are done reading LDS
-        store_stage(unit0);
+        __syncthreads();                              // previous stage's MFMAs are done reading LDS
+        {
+            const Stage st = make_stage(unit0);       // same (cheap, uniform) bookkeeping the loads were issued with
+            sx.store(xs, st.row0x, st.nvalid);
+            sy.store(ys, st.row0y, st.nvalid);
+        }
         __syncthreads();
-        if (unit0 + G * C::NU < total_units) issue_loads(unit0 + G * C::NU);   // in flight during the MFMAs
+        if (unit0 + G * C::NU < total_units) {        // in flight during the MFMAs below
+            const Stage st = make_stage(unit0 + G * C::NU);
+            sx.issue(st.bx, bstride, st.row0x, st.nvalid);
+            sy.issue(st.by, YSTRIDE, st.row0y, st.nvalid);
+        }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll 1
-        for (int u = 0; u < C::NU; ++u) {
-            if constexpr (C::SMALLC) {
-                // K-split over the 4 waves: items = (row, half row)
-#pragma unroll 1
-                for (int it = wave; it < 2 * C::R; it += C::NW) {
-                    const int oyl = it >> 1, s0 = (it & 1) ? (C::HSTEPS + 1) / 2 : 0;
-                    const int s1 = (it & 1) ? C::HSTEPS : (C::HSTEPS + 1) / 2;
-                    const int ao = aoff + u * C::UNIT_Y + oyl * C::POW;
-                    const int bo = boff + u * C::UNIT_X + 2 * oyl * C::PW;
-#pragma unroll 4
-                    for (int s = s0; s < s1; ++s) {
-                        const float a = ys[ao + 2 * s];
-                        const float bv = xs[bo + 4 * s];
-                        bsum += a;
-                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[0], 0, 0, 0);
-                    }
-                }
-            } else {
-#pragma unroll 1
-                for (int oyl = 0; oyl < C::R; ++oyl) {
-                    const int ao = aoff + u * C::UNIT_Y + oyl * C::POW;
-                    const int bo = boff + u * C::UNIT_X + 2 * oyl * C::PW;
 #pragma unroll
-                    for (int s = 0; s < C::HSTEPS; ++s) {
-                        const float a = ys[ao + 2 * s];
-                        const float b0 = xs[bo + 4 * s];
-                        const float b1 = xs[bo + 4 * s + 1];
-                        const float b2 = xs[bo + 4 * s + 2];
-                        bsum += a;
-                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
-                        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
-                    }
-                }
+        for (int i = 0; i < C::NSTEP; ++i) {
+            const float a = lds[aos[i]];
+            bsum += a;
+            if constexpr (C::SMALLC) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xs[bos[i]], acc[0], 0, 0, 0);
+            } else {
+                const float b0 = xs[bos[i]], b1 = xs[bos[i] + 1], b2 = xs[bos[i] + 2];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    // ---- write this workgroup's partial slab ----
+    // ---- fold the K slices through LDS (fixed order) and write this workgroup's partial slab ----
     float* slab = slabs + ((size_t)blockIdx.x * C::NCOMBO + combo) * C::SLAB;
     bsum += __shfl_down(bsum, 32, 64);
-    if constexpr (C::SMALLC) {
+    constexpr int NTILE = C::SMALLC ? 1 : 3;
+#pragma unroll
+    for (int kx = 0; kx < NTILE; ++kx) {
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int n = (r & 3) + 8 * (r >> 2) + 4 * half;
-            lds[wave * 1024 + n * 32 + l31] = acc[0][r];
+            lds[wave * 1024 + n * 32 + l31] = acc[kx][r];
         }
         __syncthreads();
-        for (int e = tid; e < 1024; e += NT)
-            slab[e] = (lds[e] + lds[1024 + e]) + (lds[2048 + e] + lds[3072 + e]);
-        __syncthreads();
-        if (half == 0) lds[wave * 32 + l31] = bsum;
-        __syncthreads();
-        if (tid < 32) slab[1024 + tid] = (lds[tid] + lds[32 + tid]) + (lds[64 + tid] + lds[96 + tid]);
-    } else {
+        if constexpr (C::SMALLC) {
+            for (int e = tid; e < 1024; e += NT) {
+                float sum = 0.f;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
+                for (int q = 0; q < C::KS; ++q) sum += lds[q * 1024 + e];
+                slab[e] = sum;
+            }
+        } else {
+            for (int e = tid; e < 3 * 1024; e += NT) {
+                const int kyy = e >> 10, i = e & 1023;
+                float sum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = (r & 3) + 8 * (r >> 2) + 4 * half;
-                slab[(n * 9 + ky * 3 + kx) * 32 + l31] = acc[kx][r];
+                for (int q = 0; q < C::KS; ++q) sum += lds[(q * 3 + kyy) * 1024 + i];
+                slab[((i >> 5) * 9 + kyy * 3 + kx) * 32 + (i & 31)] = sum;
             }
         }
-        if (ky == 0 && half == 0) slab[32 * 9 * 32 + l31] = bsum;
+    }
+    __syncthreads();
+    if (ky == 0 && half == 0) lds[ks * 32 + l31] = bsum;
+    __syncthreads();
+    if (tid < 32) {
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < C::KS; ++q) sum += lds[q * 32 + tid];
+        slab[(C::SMALLC ? 1024 : 9216) + tid] = sum;
     }
 }
 
@@ -307,20 +206,31 @@ img_wgrad_kernel(const void* __restrict__ xin, long bstride, const int* __restri
 struct RedSeg { int slab_off; int slab_sz; int G; int ncombo; int cblk; int cin; int smallc; int gw; int gb; };
 struct RedTable { RedSeg seg[5]; int start[6]; };
 
+// 32 consecutive slab elements x 8 slices of the workgroup index per block: each lane sums every 8th
+// slab (loads unrolled), the 8 partial sums are folded in a fixed order through LDS.
 __global__ void __launch_bounds__(256)
 img_wgrad_reduce_kernel(RedTable T, const float* __restrict__ slabs, float* __restrict__ grads) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= T.start[5]) return;
+    __shared__ float part[8][33];
+    const int lane32 = threadIdx.x & 31, gs = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + lane32;
+    const bool live = j < T.start[5];
     int l = 0;
 #pragma unroll
-    for (int i = 1; i < 5; ++i) if (j >= T.start[i]) l = i;
+    for (int i = 1; i < 5; ++i) if (j >= T.start[i] && T.start[i + 1] > T.start[i]) l = i;
     const RedSeg S = T.seg[l];
-    const int e = j - T.start[l];                    // element of the (combo, slab) space of this layer
+    const int e = live ? j - T.start[l] : 0;         // element of the (combo, slab) space of this layer
     const float* p = slabs + S.slab_off + e;
     const size_t gstride = (size_t)S.ncombo * S.slab_sz;
     float s = 0.f;
+    if (live) {
 #pragma unroll 8
-    for (int g = 0; g < S.G; ++g) s += p[(size_t)g * gstride];
+        for (int g = gs; g < S.G; g += 8) s += p[(size_t)g * gstride];
+    }
+    part[gs][lane32] = s;
+    __syncthreads();
+    if (gs != 0 || !live) return;
+    s = ((part[0][lane32] + part[1][lane32]) + (part[2][lane32] + part[3][lane32])) +
+        ((part[4][lane32] + part[5][lane32]) + (part[6][lane32] + part[7][lane32]));
     const int combo = e / S.slab_sz, i = e - combo * S.slab_sz;
     if (S.smallc) {
         if (i >= 1024) { grads[S.gb + (i - 1024)] = s; return; }
@@ -343,22 +253,22 @@ img_wgrad_reduce_kernel(RedTable T, const float* __restrict__ slabs, float* __re
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-//                   CIN COUT  H   U8    R  NU
-using W84_0u = WgCfg<3, 32, 84, true, 6, 1>;
-using W84_0f = WgCfg<3, 32, 84, false, 6, 1>;
-using W84_1 = WgCfg<32, 32, 42, false, 3, 1>;
-using W84_2 = WgCfg<32, 64, 21, false, 3, 1>;
-using W84_3 = WgCfg<64, 64, 11, false, 6, 1>;
-using W84_4 = WgCfg<64, 64, 6, false, 3, 4>;
-using W96_0u = WgCfg<3, 32, 96, true, 6, 1>;
-using W96_0f = WgCfg<3, 32, 96, false, 6, 1>;
-using W96_1 = WgCfg<32, 32, 48, false, 3, 1>;
-using W96_2 = WgCfg<32, 64, 24, false, 3, 1>;
-using W96_3 = WgCfg<64, 64, 12, false, 6, 1>;
-using W96_4 = WgCfg<64, 64, 6, false, 3, 4>;
+//                   CIN COUT  H   U8    R  NU KS
+using W84_0u = WgCfg<3, 32, 84, true, 6, 1, 4>;
+using W84_0f = WgCfg<3, 32, 84, false, 6, 1, 4>;
+using W84_1 = WgCfg<32, 32, 42, false, 3, 1, 4>;
+using W84_2 = WgCfg<32, 64, 21, false, 3, 1, 2>;
+using W84_3 = WgCfg<64, 64, 11, false, 6, 1, 2>;
+using W84_4 = WgCfg<64, 64, 6, false, 3, 4, 4>;
+using W96_0u = WgCfg<3, 32, 96, true, 6, 1, 4>;
+using W96_0f = WgCfg<3, 32, 96, false, 6, 1, 4>;
+using W96_1 = WgCfg<32, 32, 48, false, 3, 1, 4>;
+using W96_2 = WgCfg<32, 64, 24, false, 3, 1, 2>;
+using W96_3 = WgCfg<64, 64, 12, false, 6, 1, 2>;
+using W96_4 = WgCfg<64, 64, 6, false, 3, 4, 4>;
 
 // split-K workgroups (grid.x) per layer; grid.y = channel-block combos.  Also sizes the slab workspace.
-static const int kWgG[5] = {256, 256, 128, 64, 64};
+static const int kWgG[5] = {512, 256, 256, 128, 64};
 static const int kCombo[5] = {1, 1, 2, 4, 4};
 static const int kSlabSz[5] = {32 * 32 + 32, 9248, 9248, 9248, 9248};
 
@@ -386,7 +296,14 @@ static int launch_wgrad(var_ctx* c, hipStream_t s, const void* x, long bstride, 
         attr_set = true;
     }
     const int need = (B * C::NB + C::NU - 1) / C::NU;
-    const int G = need < kWgG[layer] ? need : kWgG[layer];
+    int gmax = kWgG[layer];
+    {   // tuning aid: VAR_WG_G<layer>=n (never above the slab workspace)
+        char name[16];
+        snprintf(name, sizeof name, "VAR_WG_G%d", layer);
+        const char* e = getenv(name);
+        if (e && atoi(e) > 0 && atoi(e) <= kWgG[layer]) gmax = atoi(e);
+    }
+    const int G = need < gmax ? need : gmax;
     c->wg_groups[layer] = G;
     hipLaunchKernelGGL(img_wgrad_kernel<C>, dim3(G, C::NCOMBO), dim3(C::NT), C::LDS_BYTES, s, x, bstride, bidx, gy,
                        c->slabs + slab_offset(layer), B);
@@ -408,7 +325,8 @@ int launch_img_wgrad(var_ctx* c, hipStream_t s, int layer, const void* x, long b
 #undef W2
 }
 
-int launch_img_wgrad_reduce(var_ctx* c, hipStream_t s, float* grads) {
+// fixed-order slab sums of layers [lo, hi] into the gradient arena
+int launch_img_wgrad_reduce(var_ctx* c, hipStream_t s, float* grads, int lo, int hi) {
     const ParamLayout& L = c->pl;
     RedTable T{};
     int st = 0;
@@ -416,11 +334,11 @@ int launch_img_wgrad_reduce(var_ctx* c, hipStream_t s, float* grads) {
         T.seg[i] = RedSeg{(int)slab_offset(i), kSlabSz[i], c->wg_groups[i], kCombo[i], i < 3 ? 1 : 2, kImgCh[i],
                           i == 0 ? 1 : 0, L.img_w[i], L.img_b[i]};
         T.start[i] = st;
-        st += kCombo[i] * kSlabSz[i];
+        if (i >= lo && i <= hi) st += kCombo[i] * kSlabSz[i];
     }
     T.start[5] = st;
     ProfScope prof(c, s, TAG_IMG_WREDUCE);
-    hipLaunchKernelGGL(img_wgrad_reduce_kernel, dim3((st + 255) / 256), dim3(256), 0, s, T, c->slabs, grads);
+    hipLaunchKernelGGL(img_wgrad_reduce_kernel, dim3((st + 31) / 32), dim3(256), 0, s, T, c->slabs, grads);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }

@@ -78,6 +78,42 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// Capturable variant (HIP graphs): the step count and the learning rate live in device memory, the
+// bias corrections are formed on the device, so a captured launch stays correct on every replay.
+__global__ void adam_tick_kernel(int* step) { if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1; }
+
+__global__ void __launch_bounds__(256) adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, long n,
+                                                        const float* __restrict__ lr_dev, float b1, float b2,
+                                                        float eps, float wd, const int* __restrict__ step_dev) {
+    const int t = step_dev[0];
+    const double bc1 = 1.0 - pow((double)b1, (double)t);
+    const double bc2 = 1.0 - pow((double)b2, (double)t);
+    const float step_size = (float)((double)lr_dev[0] / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float pi = p[i];
+        const float gi = g[i] + wd * pi;
+        const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - step_size * (mi / denom);
+    }
+}
+
+int launch_adam_dev(var_ctx* c, hipStream_t s, float* p, const float* g, float* m, float* v, long n,
+                    const float* lr_dev, float b1, float b2, float eps, float wd, int* step_dev) {
+    ProfScope prof(c, s, TAG_ADAM);
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, s, step_dev);
+    int grid = (int)((n + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(grid), dim3(256), 0, s, p, g, m, v, n, lr_dev, b1, b2, eps, wd, step_dev);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}
+
 int launch_adam(var_ctx* c, hipStream_t s, float* p, const float* g, float* m, float* v, long n,
                 float lr, float b1, float b2, float eps, float wd, int step) {
     const double bc1 = 1.0 - pow((double)b1, (double)step);

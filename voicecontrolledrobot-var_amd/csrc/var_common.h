@@ -168,7 +168,7 @@ static inline int conv_out(int h) { return (h - 1) / 2 + 1; }   // 3x3 s2 p1
 int mfcc_build_tables(var_ctx* c);
 size_t img_slab_floats();
 int launch_img_wgrad(var_ctx* c, hipStream_t s, int layer, const void* x, long bstride, int is_u8, const float* gy, int B);
-int launch_img_wgrad_reduce(var_ctx* c, hipStream_t s, float* grads);
+int launch_img_wgrad_reduce(var_ctx* c, hipStream_t s, float* grads, int lo, int hi);
 size_t snd_slab_floats();
 
 // kernels' host launchers (one per .hip file) ------------------------------------------
@@ -186,5 +186,7 @@ int launch_triplet(var_ctx* c, hipStream_t s, const float* a, const float* p, co
                    float margin, float inv_count, float* loss_out, float* ga, float* gp, float* gn);
 int launch_adam(var_ctx* c, hipStream_t s, float* p, const float* g, float* m, float* v, long n,
                 float lr, float b1, float b2, float eps, float wd, int step);
+int launch_adam_dev(var_ctx* c, hipStream_t s, float* p, const float* g, float* m, float* v, long n,
+                    const float* lr_dev, float b1, float b2, float eps, float wd, int* step_dev);
 int launch_mfcc(var_ctx* c, hipStream_t s, const int16_t* pcm, const int* lens, const int* clip_index, int nclips,
                 int pcm_stride, int out_frames, float* out);

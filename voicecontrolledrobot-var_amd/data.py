@@ -86,6 +86,16 @@ class SyntheticTripletPool:
         idx = self._perm[sl]
         return self._perm32[sl], self.clip_tab[:, idx].reshape(-1), self.len_tab[:, idx].reshape(-1)
 
+    def epoch_index_table(self, batch):
+        """(steps, 5*batch) int32: rows [image_index | clip_index (2B) | lens (2B)] of one shuffled epoch
+        (drop_last), built with a handful of device ops per EPOCH instead of per step."""
+        steps = self.n_items // batch
+        perm = torch.randperm(self.n_items, device=self.device, generator=self._gen)[:steps * batch]
+        idx = perm.view(steps, batch)
+        clip = self.clip_tab[:, perm].view(2, steps, batch).permute(1, 0, 2).reshape(steps, 2 * batch)
+        lens = self.len_tab[:, perm].view(2, steps, batch).permute(1, 0, 2).reshape(steps, 2 * batch)
+        return torch.cat([idx.to(torch.int32), clip, lens], dim=1).contiguous()
+
     def sample_indices(self, batch):
         """Random item ids and clip ids (device tensors, no host sync)."""
         idx = torch.randint(0, self.n_items, (batch,), device=self.device, generator=self._gen)

@@ -79,6 +79,68 @@ class VARTrainer:
                                     float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd),
                                     int(self.step_count)), "var_adam_step")
 
+    # ---- HIP-graph replay of the whole step (launch-bound otherwise: ~35 kernels + stream fork/joins) ----
+    def capture_dataset_step(self, images, pcm, batch, global_batch=None):
+        """Capture step_from_dataset(images, idx, pcm, clip_idx, lens) once; returns replay(idx_row) where
+        idx_row is an int32 CUDA tensor of 5*batch entries [image_index | clip_index (2B) | lens (2B)].
+        Step count and learning rate live on the device (var_adam_step_dev); set_lr() updates the latter."""
+        dev = self.dev
+        B = batch
+        self._g_idx = torch.zeros(5 * B, dtype=torch.int32, device=dev)
+        self._g_lr = torch.full((1,), float(self.lr), dtype=torch.float32, device=dev)
+        self._g_step = torch.full((1,), int(self.step_count), dtype=torch.int32, device=dev)
+        flat = self.model.flat_parameters()
+        c = self.ctx
+        c.ensure_plan(B, self.hw)
+        gb = B * self.world if global_batch is None else global_batch
+        img_idx, clip_idx, lens = self._g_idx[:B], self._g_idx[B:3 * B], self._g_idx[3 * B:]
+
+        def body_grad():
+            c.check(c.lib.var_arm_loss_grad_pcm(c.handle, current_stream_handle(), ptr(flat), ptr(images),
+                                                int(images.dtype == torch.uint8), images.stride(0), ptr(img_idx),
+                                                ptr(pcm), pcm.stride(0), ptr(clip_idx), ptr(lens), B, self.hw,
+                                                float(self.margin), 1.0 / gb, ptr(self.gbuf),
+                                                self.gbuf.data_ptr() + 4 * N_PARAMS, None), "var_arm_loss_grad_pcm")
+
+        def body_adam():
+            c.check(c.lib.var_adam_step_dev(c.handle, current_stream_handle(), ptr(flat), ptr(self.gbuf),
+                                            ptr(self.exp_avg), ptr(self.exp_avg_sq), N_PARAMS, ptr(self._g_lr),
+                                            float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                            float(self.wd), ptr(self._g_step)), "var_adam_step_dev")
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        graphs = []
+        with torch.cuda.stream(side):
+            if self.world > 1:                      # the RCCL all-reduce stays eager between two graphs
+                for body in (body_grad, body_adam):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=side):
+                        body()
+                    graphs.append(g)
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    body_grad()
+                    body_adam()
+                graphs.append(g)
+        torch.cuda.current_stream().wait_stream(side)
+
+        def replay(idx_row):
+            self._g_idx.copy_(idx_row, non_blocking=True)
+            graphs[0].replay()
+            if self.world > 1:
+                self.allreduce()
+                graphs[1].replay()
+            self.step_count += 1
+            return self.loss
+        return replay
+
+    def set_lr(self, lr):
+        self.lr = lr
+        if getattr(self, "_g_lr", None) is not None:
+            self._g_lr.fill_(float(lr))
+
     def step(self, image, pos, neg, global_batch=None):
         """One optimisation step on (image u8|f32 (B,3,H,H), pos, neg f32 (B,1,100,40)).  Asynchronous."""
         self._check(image, pos, neg)
