@@ -14,9 +14,13 @@
 // ------------------------------------------------------------------------------------------
 // dgrad
 // ------------------------------------------------------------------------------------------
-template <int CIN_, int COUT_, int H_, int RI_, int NU_, int NW_>
+// KC = 0: every wave runs both row-parity classes of its items (NWI waves).
+// KC > 0: 3*KC wave groups split the reduction of ONE item per wave: {py=0 | py=1 row tap 0 | py=1 row tap 1}
+//         (equal work) x KC chunks of the gy channels; partial tiles are folded through LDS in fixed order.
+template <int CIN_, int COUT_, int H_, int RI_, int NU_, int NWI_, int KC_ = 0>
 struct DgCfg {
-    static constexpr int CIN = CIN_, COUT = COUT_, H = H_, W = H_, RI = RI_, NU = NU_, NW = NW_;
+    static constexpr int CIN = CIN_, COUT = COUT_, H = H_, W = H_, RI = RI_, NU = NU_, NWI = NWI_, KC = KC_;
+    static constexpr int KS = KC ? 3 * KC : 1, NW = NWI * KS;
     static constexpr int HO = (H - 1) / 2 + 1, WO = HO;
     static constexpr int NR = RI / 2 + 1;            // gy rows per unit
     static constexpr int POW = WO + 1;               // + zero column at ox = WO
@@ -29,10 +33,14 @@ struct DgCfg {
     static constexpr int NPB = (NPP + 31) / 32;
     static constexpr int CBLK = CIN / 32;
     static constexpr int ITEMS = NPB * CBLK;         // per class
-    static constexpr int IPC = (ITEMS + NW - 1) / NW;
-    static constexpr int LDS_FLOATS = (NU * UNIT + 3) / 4 * 4;
+    static constexpr int IPC = (ITEMS + NWI - 1) / NWI;
+    static constexpr int NSLOT = KC ? 3 * KC - 2 : 0;            // parked partial tile pairs per item
+    static constexpr int RED_FLOATS = NWI * NSLOT * 2048;
+    static constexpr int LDS_FLOATS = ((NU * UNIT > RED_FLOATS ? NU * UNIT : RED_FLOATS) + 3) / 4 * 4;
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
     static_assert(RI % 2 == 0, "band must hold whole row pairs");
+    static_assert(KC == 0 || ITEMS == NWI, "K-split path: exactly one item per wave group");
+    static_assert(KC == 0 || (COUT / 2) % (8 * KC) == 0, "gy channel chunks must be whole prefetch blocks");
 };
 
 template <class C>
@@ -59,6 +67,93 @@ img_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ wd, con
     __syncthreads();
 
     const float* wl = wd + half * C::CIN + l31;        // + (tap*COUT + n)*CIN + cb*32
+    if constexpr (C::KC > 0) {
+        const int wv = wave % C::NWI, ks = wave / C::NWI;
+        const int part = ks % 3, kc = ks / 3;
+        const int py = part ? 1 : 0, ky = part == 0 ? 1 : (part == 1 ? 0 : 2), doy = part == 1 ? 1 : 0;
+        const int pb = wv % C::NPB, cb = wv / C::NPB;
+        int pp = pb * 32 + l31;
+        const bool ppvalid = pp < C::NPP;
+        if (!ppvalid) pp = 0;
+        const int u = pp / C::PPU, q = pp - u * C::PPU;
+        const int j = q / C::WH, i = q - j * C::WH;
+        const int unit = unit0 + u;
+        const int b = unit / C::NB, band = unit - b * C::NB;
+        constexpr int U = 8;
+        constexpr int NC = (C::COUT / 2) / C::KC;                // n-pair steps of a slice
+        constexpr int NBK = NC / U;
+        const int lb = u * C::UNIT + j * C::POW + i + half * C::PLANE + doy * C::POW + (2 * kc * NC) * C::PLANE;
+        const float* wc = wl + cb * 32 + (size_t)((ky * 3) * C::COUT + 2 * kc * NC) * C::CIN;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        float wb[2][3][U];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int uu = 0; uu < U; ++uu) wb[0][kx][uu] = wc[(size_t)(kx * C::COUT + 2 * uu) * C::CIN];
+#pragma unroll
+        for (int blk = 0; blk < NBK; ++blk) {
+            if (blk + 1 < NBK) {
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int uu = 0; uu < U; ++uu)
+                        wb[(blk + 1) & 1][kx][uu] = wc[(size_t)(kx * C::COUT + 2 * ((blk + 1) * U + uu)) * C::CIN];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int uu = 0; uu < U; ++uu) {
+                const float b0 = lds[lb + 2 * (blk * U + uu) * C::PLANE];
+                const float b1 = lds[lb + 2 * (blk * U + uu) * C::PLANE + 1];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[blk & 1][1][uu], b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[blk & 1][2][uu], b0, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[blk & 1][0][uu], b1, acc1, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // fold: leaders are (part 0, kc 0) for py = 0 and (part 1, kc 0) for py = 1
+        const bool leader = kc == 0 && part < 2;
+        // slot of a non-leader among its item's parked tiles; py=0 members first
+        const int slot = part == 0 ? kc - 1 : (C::KC - 1) + (part == 1 ? kc - 1 : C::KC - 1 + kc);
+        __syncthreads();                                    // the staged gy bands are dead now
+        if (!leader) {
+            float* d = lds + (size_t)(wv * C::NSLOT + slot) * 2048;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { d[r * 64 + lane] = acc0[r]; d[1024 + r * 64 + lane] = acc1[r]; }
+        }
+        __syncthreads();
+        if (!leader) return;
+        {
+            const int s0 = part == 0 ? 0 : C::KC - 1, s1 = part == 0 ? C::KC - 1 : C::NSLOT;
+            for (int sl = s0; sl < s1; ++sl) {
+                const float* d = lds + (size_t)(wv * C::NSLOT + sl) * 2048;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[r] += d[r * 64 + lane]; acc1[r] += d[1024 + r * 64 + lane]; }
+            }
+        }
+        const int iy = band * C::RI + 2 * j + py;
+        if (ppvalid && unit < total_units && iy < C::H) {
+            const int ix = 2 * i;
+            const size_t o = (size_t)b * C::CIN * C::H * C::W + (size_t)iy * C::W + ix;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const size_t oc = o + (size_t)c * C::H * C::W;
+                if constexpr (C::W % 2 == 0) {
+                    const float2 xv = *(const float2*)(x + oc);
+                    float2 g;
+                    g.x = xv.x > 0.f ? acc0[r] : 0.f;
+                    g.y = xv.y > 0.f ? acc1[r] : 0.f;
+                    *(float2*)(gx + oc) = g;
+                } else {
+                    gx[oc] = x[oc] > 0.f ? acc0[r] : 0.f;
+                    if (ix + 1 < C::W) gx[oc + 1] = x[oc + 1] > 0.f ? acc1[r] : 0.f;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll 1
     for (int ci = 0; ci < C::IPC; ++ci) {
         const int idx = wave + C::NW * ci;
@@ -165,13 +260,13 @@ static int launch_dgrad(var_ctx* c, hipStream_t s, const float* gy, const float*
 
 //                 CIN COUT  H  RI NU NW
 using D84_1 = DgCfg<32, 32, 42, 6, 2, 4>;
-using D84_2 = DgCfg<32, 64, 21, 22, 1, 4>;
-using D84_3 = DgCfg<64, 64, 11, 12, 2, 6>;
-using D84_4 = DgCfg<64, 64, 6, 6, 7, 4>;
+using D84_2 = DgCfg<32, 64, 21, 22, 1, 4, 1>;     // 4 items x 3 slices          -> 12 waves
+using D84_3 = DgCfg<64, 64, 11, 12, 1, 4, 1>;     // 1 image, 4 items x 3 slices  -> 12 waves
+using D84_4 = DgCfg<64, 64, 6, 6, 3, 2, 2>;       // 3 images, 2 items x 6 slices -> 12 waves
 using D96_1 = DgCfg<32, 32, 48, 8, 1, 3>;
 using D96_2 = DgCfg<32, 64, 24, 8, 2, 3>;
-using D96_3 = DgCfg<64, 64, 12, 12, 2, 6>;
-using D96_4 = DgCfg<64, 64, 6, 6, 7, 4>;
+using D96_3 = DgCfg<64, 64, 12, 12, 1, 4, 1>;
+using D96_4 = DgCfg<64, 64, 6, 6, 3, 2, 2>;
 
 int launch_img_bwd(var_ctx* c, hipStream_t s, hipStream_t sw, const float* params, float* grads, int B) {
     const PackLayout& K = c->kl;

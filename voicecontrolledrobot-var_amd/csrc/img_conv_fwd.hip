@@ -14,9 +14,12 @@
 // the staging of the first layer.
 #include "img_stage.h"
 
-template <int CIN_, int COUT_, int H_, bool U8_, int R_, int NU_, int NW_>
+// NWI waves share the (pixel block, channel block) items; KY x KC wave groups split the reduction
+// (KY = 3: one filter row each, KC: channel chunks) and are folded through LDS in a fixed order.
+template <int CIN_, int COUT_, int H_, bool U8_, int R_, int NU_, int NWI_, int KY_ = 1, int KC_ = 1>
 struct FwdCfg {
-    static constexpr int CIN = CIN_, COUT = COUT_, H = H_, W = H_, R = R_, NU = NU_, NW = NW_;
+    static constexpr int CIN = CIN_, COUT = COUT_, H = H_, W = H_, R = R_, NU = NU_, NWI = NWI_, KY = KY_, KC = KC_;
+    static constexpr int KS = KY * KC, NW = NWI * KS;
     static constexpr bool U8 = U8_;
     static constexpr int HO = (H - 1) / 2 + 1, WO = HO;
     static constexpr int IR = 2 * R + 1;            // input rows per unit (iy0 = 2*band*R - 1)
@@ -29,11 +32,15 @@ struct FwdCfg {
     static constexpr int NPB = (NPIX + 31) / 32;
     static constexpr int NBLK = COUT / 32;
     static constexpr int ITEMS = NPB * NBLK;
-    static constexpr int IPW = (ITEMS + NW - 1) / NW;
-    static constexpr int LDS_FLOATS = (NU * UNIT + 3) / 4 * 4;
+    static constexpr int IPW = (ITEMS + NWI - 1) / NWI;
+    static constexpr int RED_FLOATS = (KS - 1) * NWI * IPW * 1024;     // partial tiles of the K slices 1..KS-1
+    static constexpr int LDS_FLOATS = ((NU * UNIT > RED_FLOATS ? NU * UNIT : RED_FLOATS) + 3) / 4 * 4;
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
     static constexpr int KSTEPS = (CIN * 9 + 1) / 2;
-    static_assert(ITEMS % NW == 0, "every wave must own the same number of (pixel block, channel block) items");
+    static_assert(ITEMS % NWI == 0, "every wave must own the same number of (pixel block, channel block) items");
+    static_assert(KY == 1 || KY == 3, "filter rows split 1 or 3 ways");
+    static_assert(CIN < 32 || (CIN / 2) % KC == 0, "channel chunks must be whole k-steps");
+    static_assert(CIN >= 32 || KS == 1, "the first layer is not K-split");
 };
 
 template <class C>
@@ -64,12 +71,13 @@ img_conv_fwd_kernel(const void* __restrict__ xin, long bstride, const int* __res
     __syncthreads();
 
     // ---- per-item lane constants ----
+    const int wv = wave % C::NWI, ks = wave / C::NWI;     // item group, K slice
     int pixoff[C::IPW];
     const float* wl[C::IPW];
     f32x16 acc[C::IPW];
 #pragma unroll
     for (int i = 0; i < C::IPW; ++i) {
-        const int it = wave + C::NW * i;
+        const int it = wv + C::NWI * i;
         const int pb = it % C::NPB, nb = (it / C::NPB) % C::NBLK;
         int p = pb * 32 + l31;
         if (p >= C::NPIX) p = 0;
@@ -84,20 +92,27 @@ img_conv_fwd_kernel(const void* __restrict__ xin, long bstride, const int* __res
     if constexpr (C::CIN % 2 == 0) {
         // Filter values come straight from the packed image Wf[k][n] in L2; they are prefetched
         // one block (U k-steps) ahead into a second register set so that no MFMA waits on L2.
-        constexpr int SPT = C::CIN / 2;                  // k-steps per tap
+        // This wave's K slice: filter rows ky in [kyi*NKY, +NKY), channels [kci*CC, +CC).
+        constexpr int NKY = 3 / C::KY;                   // filter rows per slice
+        constexpr int CC = C::CIN / C::KC;               // channels per slice
+        constexpr int SPT = CC / 2;                      // k-steps per tap and slice
         constexpr int U = SPT > 16 ? 16 : SPT;           // k-steps per block
         constexpr int BPT = SPT / U;                     // blocks per tap
-        constexpr int NBK = 9 * BPT;
+        constexpr int NBK = NKY * 3 * BPT;
+        const int kyi = ks % C::KY, kci = ks / C::KY;
         float wbuf[2][C::IPW][U];
 #pragma unroll
-        for (int i = 0; i < C::IPW; ++i) { pixoff[i] += half * C::PLANE; wl[i] += half * C::COUT; }
+        for (int i = 0; i < C::IPW; ++i) {
+            pixoff[i] += half * C::PLANE + kyi * NKY * C::PW + kci * CC * C::PLANE;
+            wl[i] += (half + (kyi * NKY * 3) * C::CIN + kci * CC) * C::COUT;
+        }
 #pragma unroll
         for (int i = 0; i < C::IPW; ++i)
 #pragma unroll
             for (int u = 0; u < U; ++u) wbuf[0][i][u] = wl[i][(2 * u) * C::COUT];
 #pragma unroll
         for (int blk = 0; blk < NBK; ++blk) {
-            const int tap = blk / BPT, c2b = (blk % BPT) * U;
+            const int tap = blk / BPT, c2b = (blk % BPT) * U;       // tap relative to the slice: (ky', kx)
             const int toff = (tap / 3) * C::PW + (tap % 3);
             if (blk + 1 < NBK) {
                 const int ntap = (blk + 1) / BPT, nc2b = ((blk + 1) % BPT) * U;
@@ -115,12 +130,33 @@ img_conv_fwd_kernel(const void* __restrict__ xin, long bstride, const int* __res
 #pragma unroll
                 for (int i = 0; i < C::IPW; ++i) {
                     // no per-item predicate here: a conditional MFMA makes hipcc shuttle the whole
-                    // accumulator through v_accvgpr moves around every instruction (ITEMS % NW == 0)
+                    // accumulator through v_accvgpr moves around every instruction (ITEMS % NWI == 0)
                     const float bv = lds[pixoff[i] + 2 * (c2b + u) * C::PLANE + toff];
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wbuf[blk & 1][i][u], bv, acc[i], 0, 0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (C::KS > 1) {
+            // fold the K slices: slices 1.. park their tiles in LDS (the input bands are dead now),
+            // slice 0 adds them in slice order and runs the epilogue
+            __syncthreads();
+            if (ks > 0) {
+#pragma unroll
+                for (int i = 0; i < C::IPW; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        lds[(((ks - 1) * C::NWI + wv) * C::IPW + i) * 1024 + r * 64 + lane] = acc[i][r];
+            }
+            __syncthreads();
+            if (ks > 0) return;
+#pragma unroll
+            for (int q = 1; q < C::KS; ++q)
+#pragma unroll
+                for (int i = 0; i < C::IPW; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[i][r] += lds[(((q - 1) * C::NWI + wv) * C::IPW + i) * 1024 + r * 64 + lane];
         }
     } else {
         // CIN = 3: K = 27 (+1 zero row in the packed filter); k = 2*s + half, tap = k/3, c = k%3
@@ -147,7 +183,7 @@ img_conv_fwd_kernel(const void* __restrict__ xin, long bstride, const int* __res
     // ---- epilogue: bias + ReLU, NCHW store.  D row = channel, D col (= lane&31) = pixel ----
 #pragma unroll
     for (int i = 0; i < C::IPW; ++i) {
-        const int it = wave + C::NW * i;
+        const int it = wv + C::NWI * i;
         if (it >= C::ITEMS) continue;
         const int pb = it % C::NPB, nb = it / C::NPB;
         const int p = pb * 32 + l31;
@@ -191,14 +227,14 @@ using F84_1u = FwdCfg<3, 32, 84, true, 6, 1, 4>;
 using F84_1f = FwdCfg<3, 32, 84, false, 6, 1, 4>;
 using F84_2 = FwdCfg<32, 32, 42, false, 3, 2, 4>;
 using F84_3 = FwdCfg<32, 64, 21, false, 11, 1, 4>;
-using F84_4 = FwdCfg<64, 64, 11, false, 6, 2, 3>;
-using F84_5 = FwdCfg<64, 64, 6, false, 3, 7, 4>;
+using F84_4 = FwdCfg<64, 64, 11, false, 6, 1, 4, 3, 1>;    // 1 image, 4 items, 3 ky slices  -> 12 waves
+using F84_5 = FwdCfg<64, 64, 6, false, 3, 3, 2, 3, 2>;     // 3 images, 2 items, 3 ky x 2 channel halves -> 12 waves
 using F96_1u = FwdCfg<3, 32, 96, true, 4, 1, 3>;
 using F96_1f = FwdCfg<3, 32, 96, false, 4, 1, 3>;
 using F96_2 = FwdCfg<32, 32, 48, false, 4, 1, 3>;
 using F96_3 = FwdCfg<32, 64, 24, false, 4, 2, 3>;
-using F96_4 = FwdCfg<64, 64, 12, false, 6, 2, 3>;
-using F96_5 = FwdCfg<64, 64, 6, false, 3, 7, 4>;
+using F96_4 = FwdCfg<64, 64, 12, false, 6, 1, 4, 3, 1>;
+using F96_5 = FwdCfg<64, 64, 6, false, 3, 3, 2, 3, 2>;
 
 int launch_img_fwd(var_ctx* c, hipStream_t s, const float* params, const void* image, int is_u8,
                    long bstride, const int* image_index, int B) {
