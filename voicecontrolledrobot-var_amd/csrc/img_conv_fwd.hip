@@ -12,6 +12,8 @@
 // flattened and cut into 32-pixel blocks; (pixel block, 32-channel block) items are dealt
 // round-robin to the NW waves.  The u8 -> f32 "/255" of dataset.py:67-68 is fused into
 // the staging of the first layer.
+#include <stdlib.h>
+
 #include "img_stage.h"
 
 // NWI waves share the (pixel block, channel block) items; KY x KC wave groups split the reduction
@@ -46,7 +48,7 @@ struct FwdCfg {
 template <class C>
 __global__ void __launch_bounds__(C::NW * 64)
 img_conv_fwd_kernel(const void* __restrict__ xin, long bstride, const int* __restrict__ bidx,
-                    const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int B) {
+                    const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int B, int dbg) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NT = C::NW * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -65,6 +67,7 @@ img_conv_fwd_kernel(const void* __restrict__ xin, long bstride, const int* __res
         const int b = bidx ? bidx[bo] : bo;            // optional batch gather (dataset row of sample bo)
         const void* img = C::U8 ? (const void*)((const uint8_t*)xin + (size_t)b * bstride)
                                 : (const void*)((const float*)xin + (size_t)b * bstride);
+        if (!(dbg & 2))
         stage_x_band<C::CIN, C::H, C::W, C::IR, C::PW, C::PLANE, C::U8, NT>(lds + u * C::UNIT, img,
                                                                             2 * band * C::R - 1, uvalid, tid);
     }
@@ -110,6 +113,7 @@ img_conv_fwd_kernel(const void* __restrict__ xin, long bstride, const int* __res
         for (int i = 0; i < C::IPW; ++i)
 #pragma unroll
             for (int u = 0; u < U; ++u) wbuf[0][i][u] = wl[i][(2 * u) * C::COUT];
+        if (!(dbg & 1))
 #pragma unroll
         for (int blk = 0; blk < NBK; ++blk) {
             const int tap = blk / BPT, c2b = (blk % BPT) * U;       // tap relative to the slice: (ky', kx)
@@ -193,7 +197,7 @@ img_conv_fwd_kernel(const void* __restrict__ xin, long bstride, const int* __res
         if (unit >= total_units) continue;
         const int b = unit / C::NB, band = unit - b * C::NB;
         const int oy = band * C::R + q / C::WO;
-        if (oy >= C::HO) continue;
+        if (oy >= C::HO || (dbg & 4)) continue;
         float* yp = y + (size_t)b * C::COUT * C::HO * C::WO + band * C::R * C::WO + q;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -217,7 +221,7 @@ static int launch_one(var_ctx* c, hipStream_t s, const void* x, long bstride, co
     const int units = B * C::NB;
     const int grid = (units + C::NU - 1) / C::NU;
     hipLaunchKernelGGL(img_conv_fwd_kernel<C>, dim3(grid), dim3(C::NW * 64), C::LDS_BYTES, s,
-                       x, bstride, bidx, wp, bias, y, B);
+                       x, bstride, bidx, wp, bias, y, B, getenv("VAR_DBG") ? atoi(getenv("VAR_DBG")) : 0);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }

@@ -17,13 +17,15 @@ __device__ __forceinline__ void lds_zero(float* dst, int nfloats, int tid) {
 
 // Copy rows [iy0, iy0+IR) x cols [0,W) of CIN planes of one NCHW image into dst[c*PLANE + r*PW + 1 + x].
 // Rows outside [0,H) are written as zeros.  Column 0 and columns > W are NOT touched (pre-zeroed).
-template <int CIN, int H, int W, int IR, int PW, int PLANE, bool U8, int NT>
+template <int CIN, int H, int W, int IR, int PW, int PLANE, bool U8, int NT, int UFMAX = 64>
 __device__ __forceinline__ void stage_x_band(float* __restrict__ dst, const void* __restrict__ img,
                                              int iy0, bool uvalid, int tid) {
     constexpr int V = U8 ? 4 : (W % 4 == 0 ? 4 : (W % 2 == 0 ? 2 : 1));
     constexpr int WV = W / V;
     constexpr int TOT = CIN * IR * WV;
-    constexpr int UF = 8;
+    // the whole band in ONE batch of loads when it fits the register budget (one memory latency, not several)
+    constexpr int NEED = (TOT + NT - 1) / NT;
+    constexpr int UF = NEED < UFMAX ? NEED : UFMAX;
     static_assert(W % V == 0, "row width must be a multiple of the vector width");
 #pragma unroll 1
     for (int e0 = tid; e0 < TOT; e0 += NT * UF) {
@@ -73,13 +75,14 @@ __device__ __forceinline__ void stage_x_band(float* __restrict__ dst, const void
 
 // Copy rows [oy0, oy0+NR) x cols [0,WO) of COUT planes of one (COUT,HO,WO) gradient image into
 // dst[n*PLANE + r*POW + x]; rows >= HO are written as zeros; columns >= WO are NOT touched.
-template <int COUT, int HO, int WO, int NR, int POW, int PLANE, int NT>
+template <int COUT, int HO, int WO, int NR, int POW, int PLANE, int NT, int UFMAX = 64>
 __device__ __forceinline__ void stage_y_band(float* __restrict__ dst, const float* __restrict__ img,
                                              int oy0, bool uvalid, int tid) {
     constexpr int V = (WO % 4 == 0) ? 4 : (WO % 2 == 0 ? 2 : 1);
     constexpr int WV = WO / V;
     constexpr int TOT = COUT * NR * WV;
-    constexpr int UF = 8;
+    constexpr int NEED = (TOT + NT - 1) / NT;
+    constexpr int UF = NEED < UFMAX ? NEED : UFMAX;
 #pragma unroll 1
     for (int e0 = tid; e0 < TOT; e0 += NT * UF) {
         float v[UF][V];

@@ -40,17 +40,17 @@ __device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.x - b.x, a.y - 
 // so a compiler-level wave barrier is all that separates a butterfly stage from the next.
 #define WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 
-__global__ void __launch_bounds__(256)
+constexpr int MW = 16;     // waves per workgroup (one clip per workgroup, frames dealt to waves)
+
+__global__ void __launch_bounds__(MW * 64)
 mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const int* __restrict__ clip_index,
             int pcm_stride, int out_frames, const float* __restrict__ tab, float* __restrict__ out) {
     __shared__ float tabs[TB_TOTAL];                 // window, twiddles, DCT, mel triangles (15 KB)
-    __shared__ cplx bufA[4][256];
-    __shared__ cplx bufB[4][256];
-    __shared__ float pw[4][264];
-    __shared__ float lm[4][NMEL];
+    __shared__ cplx bufA[MW][256];
+    __shared__ cplx bufB[MW][256];                   // after the FFT: power spectrum (264 floats) + log-mel (40)
     const int clip = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int e = tid; e < TB_TOTAL / 4; e += 256) ((float4*)tabs)[e] = ((const float4*)tab)[e];
+    for (int e = tid; e < TB_TOTAL / 4; e += MW * 64) ((float4*)tabs)[e] = ((const float4*)tab)[e];
     const int N = lens[clip];
     const int T = 1 + N / HOP;
     const int16_t* sig = pcm + (size_t)(clip_index ? clip_index[clip] : clip) * pcm_stride;
@@ -63,7 +63,9 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
     const int ml = lane < NMEL ? lane : 0;
     const int mst = itab[TB_MSTART + ml], mcnt = lane < NMEL ? itab[TB_MCOUNT + ml] : 0, mwo = itab[TB_MOFF + ml];
 
-    for (int t = wave; t < out_frames; t += 4) {
+    float* pw = (float*)bufB[wave];                  // the FFT result ends in bufA (4 stages), bufB is free then
+    float* lm = pw + 264;
+    for (int t = wave; t < out_frames; t += MW) {
         // frames beyond T are MFCC-domain zero padding; N == 0 is the "empty" class (dataset.py:37-38)
         const bool live = t < T && N > 0;
         if (!live) {
@@ -121,9 +123,9 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
             const cplx dd = csub(zk, zm);
             const cplx xo = {0.5f * dd.y, -0.5f * dd.x};    // (zk - zm) / (2i)
             const cplx X = cadd(xe, cmul(tw512[k], xo));
-            pw[wave][k] = X.x * X.x + X.y * X.y;
+            pw[k] = X.x * X.x + X.y * X.y;
         }
-        if (lane == 0) { const cplx z0 = src[0]; const float r = z0.x - z0.y; pw[wave][256] = r * r; }
+        if (lane == 0) { const cplx z0 = src[0]; const float r = z0.x - z0.y; pw[256] = r * r; }
         WAVE_SYNC();
         // 4. mel triangles + log: predicated fixed-trip loop so that the LDS reads pipeline
         {
@@ -131,18 +133,18 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
 #pragma unroll 8
             for (int q = 0; q < 40; ++q) {          // widest triangle spans 33 bins
                 const bool ok = q < mcnt;
-                const float p = pw[wave][ok ? mst + q : 0];
+                const float p = pw[ok ? mst + q : 0];
                 const float w = tabs[TB_MW + (ok ? mwo + q : 0)];
                 s += ok ? p * w : 0.f;
             }
-            if (lane < NMEL) lm[wave][lane] = logf(s + 1e-6f);
+            if (lane < NMEL) lm[lane] = logf(s + 1e-6f);
         }
         WAVE_SYNC();
         // 5. DCT-II (ortho) and store
         if (lane < NMFCC) {
             float s = 0.f;
 #pragma unroll 8
-            for (int n = 0; n < NMEL; ++n) s += lm[wave][n] * tabs[TB_DCT + n * NMFCC + lane];
+            for (int n = 0; n < NMEL; ++n) s += lm[n] * tabs[TB_DCT + n * NMFCC + lane];
             out[((size_t)clip * out_frames + t) * NMFCC + lane] = s;
         }
         WAVE_SYNC();
@@ -203,7 +205,7 @@ int mfcc_build_tables(var_ctx* c) {
 int launch_mfcc(var_ctx* c, hipStream_t s, const int16_t* pcm, const int* lens, const int* clip_index, int nclips,
                 int pcm_stride, int out_frames, float* out) {
     ProfScope prof(c, s, TAG_MFCC);
-    hipLaunchKernelGGL(mfcc_kernel, dim3(nclips), dim3(256), 0, s, pcm, lens, clip_index, pcm_stride, out_frames,
+    hipLaunchKernelGGL(mfcc_kernel, dim3(nclips), dim3(MW * 64), 0, s, pcm, lens, clip_index, pcm_stride, out_frames,
                        c->mfcc_tab, out);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
