@@ -251,13 +251,15 @@ int launch_img_fwd(var_ctx* c, hipStream_t s, const float* params, const void* i
 #define RUN(CFG, X, BS, I, Y) do { if ((rc = launch_one<CFG>(c, s, X, BS, (I) == 0 ? image_index : nullptr, w[I], b[I], Y, B, I)) != VAR_OK) return rc; } while (0)
     if (c->H == 84) {
         if (is_u8) { RUN(F84_1u, image, bstride, 0, c->act[1]); } else { RUN(F84_1f, image, bstride, 0, c->act[1]); }
-        RUN(F84_2, c->act[1], 32L * 42 * 42, 1, c->act[2]);
+        if (!getenv("VAR_NO_PIPE")) { if ((rc = launch_img_fwd_conv2_pipe(c, s, c->act[1], w[1], b[1], c->act[2], B)) != VAR_OK) return rc; }
+        else RUN(F84_2, c->act[1], 32L * 42 * 42, 1, c->act[2]);
         RUN(F84_3, c->act[2], 32L * 21 * 21, 2, c->act[3]);
         RUN(F84_4, c->act[3], 64L * 11 * 11, 3, c->act[4]);
         RUN(F84_5, c->act[4], 64L * 6 * 6, 4, c->act[5]);
     } else if (c->H == 96) {
         if (is_u8) { RUN(F96_1u, image, bstride, 0, c->act[1]); } else { RUN(F96_1f, image, bstride, 0, c->act[1]); }
-        RUN(F96_2, c->act[1], 32L * 48 * 48, 1, c->act[2]);
+        if (!getenv("VAR_NO_PIPE")) { if ((rc = launch_img_fwd_conv2_pipe(c, s, c->act[1], w[1], b[1], c->act[2], B)) != VAR_OK) return rc; }
+        else RUN(F96_2, c->act[1], 32L * 48 * 48, 1, c->act[2]);
         RUN(F96_3, c->act[2], 32L * 24 * 24, 2, c->act[3]);
         RUN(F96_4, c->act[3], 64L * 12 * 12, 3, c->act[4]);
         RUN(F96_5, c->act[4], 64L * 6 * 6, 4, c->act[5]);

@@ -217,4 +217,12 @@ struct ColStager {
             }
         }
     }
+    // One-shot form for loader waves (no state kept between calls): all loads of the band, then the LDS stores.
+    template <class PT>
+    static __device__ __forceinline__ void copy(float* __restrict__ lds, const PT* base, int row0, bool live, int tid) {
+        ColStager st;
+        st.init(tid);
+        st.issue(base, 0, row0, 1);
+        st.store(lds, row0, live ? 1 : 0);
+    }
 };
