@@ -47,6 +47,8 @@ int var_init(int device_id, var_ctx** out) {
     }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side3, hipStreamNonBlocking);
+    for (int i = 0; i < 5 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&c->ev_w[i], hipEventDisableTiming);
     for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&c->ev_g[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_wjoin, hipEventDisableTiming);
     for (int i = 0; i < 2 && e == hipSuccess; i++) {
@@ -82,6 +84,8 @@ int var_destroy(var_ctx* c) {
     if (c->ev_wjoin) (void)hipEventDestroy(c->ev_wjoin);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->side2) (void)hipStreamDestroy(c->side2);
+    if (c->side3) (void)hipStreamDestroy(c->side3);
+    for (int i = 0; i < 5; i++) if (c->ev_w[i]) (void)hipEventDestroy(c->ev_w[i]);
     if (c->prof_ev) {
         for (int i = 0; i < 2 * kProfMaxPairs; i++) (void)hipEventDestroy(c->prof_ev[i]);
         delete[] c->prof_ev;
@@ -244,7 +248,7 @@ static int encoder_bwd(var_ctx* c, hipStream_t s, const float* params, float* gr
     if ((rc = fork_side(c, s, 1)) != VAR_OK) return rc;
     if ((rc = launch_heads_bwd(c, s, SIDE(c, s), params, grads, B, c->saved_image != nullptr, snd_lo, snd_hi)) != VAR_OK) return rc;
     if ((rc = launch_snd_bwd(c, SIDE(c, s), params, grads, B)) != VAR_OK) return rc;
-    if (c->saved_image && (rc = launch_img_bwd(c, s, c->serial ? s : c->side2, params, grads, B)) != VAR_OK) return rc;
+    if (c->saved_image && (rc = launch_img_bwd(c, s, c->serial ? s : c->side2, c->serial ? s : c->side3, params, grads, B)) != VAR_OK) return rc;
     return join_side(c, s, 1);
 }
 

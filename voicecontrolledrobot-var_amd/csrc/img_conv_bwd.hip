@@ -268,7 +268,7 @@ using D96_2 = DgCfg<32, 64, 24, 8, 2, 3>;
 using D96_3 = DgCfg<64, 64, 12, 12, 1, 4, 1>;
 using D96_4 = DgCfg<64, 64, 6, 6, 3, 2, 2>;
 
-int launch_img_bwd(var_ctx* c, hipStream_t s, hipStream_t sw, const float* params, float* grads, int B) {
+int launch_img_bwd(var_ctx* c, hipStream_t s, hipStream_t sw, hipStream_t sr, const float* params, float* grads, int B) {
     const PackLayout& K = c->kl;
     int rc;
     const int H = c->H;
@@ -286,8 +286,9 @@ int launch_img_bwd(var_ctx* c, hipStream_t s, hipStream_t sw, const float* param
     if ((rc = ready(5)) != VAR_OK) return rc;
     for (int l = 4; l >= 0; --l) {
         if ((rc = launch_img_wgrad(c, sw, l, xin[l], bs[l], l == 0 ? c->saved_u8 : 0, c->gact[l + 1], B)) != VAR_OK) return rc;
-        // slabs are folded right behind their producer so that only the first layer's (small) fold trails the chain
-        if ((rc = launch_img_wgrad_reduce(c, sw, grads, l, l)) != VAR_OK) return rc;
+        // slabs are folded on a stream of their own (sr), released by an event, so a fold never delays the next wgrad
+        if (sr != sw) { VAR_HIP_CHECK(c, hipEventRecord(c->ev_w[l], sw)); VAR_HIP_CHECK(c, hipStreamWaitEvent(sr, c->ev_w[l], 0)); }
+        if ((rc = launch_img_wgrad_reduce(c, sr, grads, l, l)) != VAR_OK) return rc;
         if (l == 0) break;
         switch (l) {
             case 4: rc = DG(D84_4, D96_4, 4); break;
@@ -299,7 +300,7 @@ int launch_img_bwd(var_ctx* c, hipStream_t s, hipStream_t sw, const float* param
         if ((rc = ready(l)) != VAR_OK) return rc;
     }
 #undef DG
-    if (sw != s) { VAR_HIP_CHECK(c, hipEventRecord(c->ev_wjoin, sw)); VAR_HIP_CHECK(c, hipStreamWaitEvent(s, c->ev_wjoin, 0)); }
+    if (sr != s) { VAR_HIP_CHECK(c, hipEventRecord(c->ev_wjoin, sr)); VAR_HIP_CHECK(c, hipStreamWaitEvent(s, c->ev_wjoin, 0)); }
     (void)params;
     return VAR_OK;
 }

@@ -136,6 +136,8 @@ struct var_ctx {
     hipStream_t side2 = nullptr;          // weight-gradient kernels run here beside the dgrad chain
     hipEvent_t ev_g[6] = {nullptr};       // gact[l] ready (recorded on the dgrad stream)
     hipEvent_t ev_wjoin = nullptr;
+    hipStream_t side3 = nullptr;          // slab folds run here so that they never delay the next wgrad
+    hipEvent_t ev_w[5] = {nullptr};       // wgrad of layer l done (recorded on side2)
     hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
     float* mfcc_buf = nullptr;            // (2*maxB, 100, 40) when the front-end runs inside the step
 };
@@ -177,7 +179,7 @@ int launch_img_fwd(var_ctx* c, hipStream_t s, const float* params, const void* i
                    long bstride, const int* image_index, int B);
 int launch_img_fwd_conv2_pipe(var_ctx* c, hipStream_t s, const float* x, const float* wp, const float* bias,
                               float* y, int B);
-int launch_img_bwd(var_ctx* c, hipStream_t s, hipStream_t sw, const float* params, float* grads, int B);
+int launch_img_bwd(var_ctx* c, hipStream_t s, hipStream_t sw, hipStream_t sr, const float* params, float* grads, int B);
 int launch_snd_fwd(var_ctx* c, hipStream_t s, const float* params, const float* pos, const float* neg, int B);
 int launch_snd_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads, int B);
 int launch_heads_fwd(var_ctx* c, hipStream_t s, hipStream_t ss, const float* params, int B, bool has_img, bool has_pos,
