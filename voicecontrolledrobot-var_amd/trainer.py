@@ -40,6 +40,9 @@ class VARTrainer:
         self.step_count = 0
         self.pg = process_group
         self.world = 1
+        # VAR_FORCE_ALLREDUCE=1: run the data-parallel code path (RCCL all-reduce between two graphs) even with
+        # one rank, to rehearse the multi-GPU step on a single-GPU box
+        self.force_collective = os.environ.get("VAR_FORCE_ALLREDUCE") == "1"
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
         c = self.ctx
@@ -67,7 +70,7 @@ class VARTrainer:
                                         self.gbuf.data_ptr() + 4 * N_PARAMS, None), "var_arm_loss_grad")
 
     def allreduce(self):
-        if self.world > 1:
+        if self.world > 1 or (self.force_collective and torch.distributed.is_initialized()):
             torch.distributed.all_reduce(self.gbuf, op=torch.distributed.ReduceOp.SUM, group=self.pg)
 
     def adam(self):
@@ -112,7 +115,7 @@ class VARTrainer:
         side.wait_stream(torch.cuda.current_stream())
         graphs = []
         with torch.cuda.stream(side):
-            if self.world > 1:                      # the RCCL all-reduce stays eager between two graphs
+            if self.world > 1 or self.force_collective:   # the RCCL all-reduce stays eager between two graphs
                 for body in (body_grad, body_adam):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=side):
@@ -129,7 +132,7 @@ class VARTrainer:
         def replay(idx_row):
             self._g_idx.copy_(idx_row, non_blocking=True)
             graphs[0].replay()
-            if self.world > 1:
+            if len(graphs) > 1:
                 self.allreduce()
                 graphs[1].replay()
             self.step_count += 1
