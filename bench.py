@@ -74,6 +74,23 @@ def cpu_baseline(seconds=10.0):
                       f"torch.nn CPU restatement of the reference step, {cores} threads, {dt:.1f} s"}
 
 
+def pmc_traffic(tag_name, hw):
+    """HBM bytes per launch of the dominant kernel, from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE
+    WRITE_SIZE in its own run, gfx950 correction: FETCH_SIZE x 2, see profiles/r01_pmc_hbm_traffic.json).
+    PMC counters cannot be collected from inside this process, so this is the figure of that pass
+    (same workload, same kernel); None when the file or the kernel is not in it."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")
+    want = {"img_conv_fwd_kernel[1]": "img_conv_fwd_pipe_kernel<PipeCfg<32, 32, %d," % (hw // 2)}.get(tag_name)
+    if want is None or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        table = json.load(f)
+    for name, row in table.items():
+        if want in name:
+            return int(row["hbm_bytes_fetch_x2_plus_write"])
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -198,7 +215,7 @@ def main():
             ach = flops / (ms / n * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": names[dom_tag], "achieved": round(ach, 2),
                                "peak": F32_MFMA_PEAK, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK, 4),
-                               "traffic": None, "avg_us": round(1e3 * ms / n, 2), "launches": n,
+                               "traffic": pmc_traffic(names[dom_tag], HW), "avg_us": round(1e3 * ms / n, 2), "launches": n,
                                "flops_per_launch": flops}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
