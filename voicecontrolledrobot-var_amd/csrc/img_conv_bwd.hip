@@ -54,8 +54,8 @@ img_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ wd, con
     const int total_units = B * C::NB;
     const int unit0 = blockIdx.x * C::NU;
 
-    lds_zero<NT>(lds, C::LDS_FLOATS, tid);
-    __syncthreads();
+    // only the pad column (ox = WO) needs clearing; all data cells are written by the staging pass
+    lds_zero_cols<NT>(lds, C::NU * C::COUT * C::NR, C::POW, C::WO, 1, tid);
 #pragma unroll 1
     for (int u = 0; u < C::NU; ++u) {
         const int unit = unit0 + u;

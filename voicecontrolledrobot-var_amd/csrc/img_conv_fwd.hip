@@ -57,8 +57,10 @@ img_conv_fwd_kernel(const void* __restrict__ xin, long bstride, const int* __res
     const int unit0 = blockIdx.x * C::NU;
 
     // ---- stage the input bands: zero the pads once, then wide unrolled copies ----
-    lds_zero<NT>(lds, C::LDS_FLOATS, tid);
-    __syncthreads();
+    // (only the pad columns need clearing: col 0 and cols W+1.. ; every data cell, invalid rows and
+    // missing units included, is written by the staging pass)
+    lds_zero_cols<NT>(lds, C::NU * C::CIN * C::IR, C::PW, 0, 1, tid);
+    lds_zero_cols<NT>(lds, C::NU * C::CIN * C::IR, C::PW, C::W + 1, C::PW - C::W - 1, tid);
 #pragma unroll 1
     for (int u = 0; u < C::NU; ++u) {
         const int unit = unit0 + u;

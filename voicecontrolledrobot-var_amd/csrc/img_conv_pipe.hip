@@ -46,8 +46,12 @@ img_conv_fwd_pipe_kernel(const float* __restrict__ x, const float* __restrict__ 
     const bool loader = wave >= C::NMW;
     constexpr long XB = (long)C::CIN * C::H * C::W;
 
-    lds_zero<NT>(lds, C::LDS_FLOATS, tid);                 // pads of both buffers
-    __syncthreads();
+    // pad columns of both buffers (the loaders write every data cell of a tile)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        lds_zero_cols<NT>(lds + b * C::BUF, C::NU * C::CIN * C::IR, C::PW, 0, 1, tid);
+        lds_zero_cols<NT>(lds + b * C::BUF, C::NU * C::CIN * C::IR, C::PW, C::W + 1, C::PW - C::W - 1, tid);
+    }
 
     // ---- loader: register-staged band copies (all loads of the tile in flight, then the LDS stores) ----
     const int ltid = tid - C::NMW * 64;

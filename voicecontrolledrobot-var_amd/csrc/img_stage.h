@@ -15,6 +15,16 @@ __device__ __forceinline__ void lds_zero(float* dst, int nfloats, int tid) {
     for (int e = tid; e < nfloats / 4; e += NT) ((float4*)dst)[e] = z;
 }
 
+// Zero columns [c0, c0+nc) of `nrows` LDS rows of `stride` floats: the padding cells of a band layout whose
+// data cells are all (re)written by the staging pass, so no full clear and no barrier before staging is needed.
+template <int NT>
+__device__ __forceinline__ void lds_zero_cols(float* dst, int nrows, int stride, int c0, int nc, int tid) {
+    for (int e = tid; e < nrows * nc; e += NT) {
+        const int r = e / nc, c = e - r * nc;
+        dst[r * stride + c0 + c] = 0.f;
+    }
+}
+
 // Copy rows [iy0, iy0+IR) x cols [0,W) of CIN planes of one NCHW image into dst[c*PLANE + r*PW + 1 + x].
 // Rows outside [0,H) are written as zeros.  Column 0 and columns > W are NOT touched (pre-zeroed).
 template <int CIN, int H, int W, int IR, int PW, int PLANE, bool U8, int NT, int UFMAX = 64>
