@@ -126,6 +126,7 @@ int var_plan(var_ctx* c, int max_batch, int img_hw) {
     const size_t n_img_slab = img_slab_floats(), n_snd_slab = snd_slab_floats();
     const size_t o_slab = carve(n_img_slab + n_snd_slab);
     const size_t o_mfcc = carve(2 * B * VAR_MFCC_FRAMES * VAR_MFCC_COEFFS);
+    const size_t o_relu1 = carve(B * hs[1] * hs[1]);          // 2 halves x u16 per pixel
     VAR_HIP_CHECK(c, hipMalloc((void**)&c->ws, off));
     VAR_HIP_CHECK(c, hipMemset(c->ws, 0, off));
     c->ws_bytes = off;
@@ -136,6 +137,7 @@ int var_plan(var_ctx* c, int max_batch, int img_hw) {
     c->emb = P(o_emb); c->emb_raw = P(o_emb_raw); c->gemb = P(o_gemb); c->ghid = P(o_ghid);
     c->slabs = P(o_slab);
     c->mfcc_buf = P(o_mfcc);
+    c->relu1 = (uint16_t*)P(o_relu1);
     c->slab_floats = n_img_slab + n_snd_slab;
     c->snd_slab_off = n_img_slab;
     c->maxB = max_batch;

@@ -9,6 +9,8 @@
 //           implicit GEMM  D[c][pixel] = sum_{tap,n} Wd[tap][n][c] * gy[n][pixel shifted].
 //           A lane owns the horizontally adjacent pair (ix=2i, ix=2i+1) -> 8-byte stores.
 //   wgrad / reduce : img_wgrad.hip (weight gradients run on a second stream beside the dgrad chain).
+#include <stdlib.h>
+
 #include "img_stage.h"
 
 // ------------------------------------------------------------------------------------------
@@ -283,8 +285,16 @@ int launch_img_bwd(var_ctx* c, hipStream_t s, hipStream_t sw, hipStream_t sr, co
     };
 #define DG(A, Bc, l) (H == 84 ? launch_dgrad<A>(c, s, c->gact[l + 1], c->wpack + K.img_d[l], c->act[l], c->gact[l], B, l) \
                               : launch_dgrad<Bc>(c, s, c->gact[l + 1], c->wpack + K.img_d[l], c->act[l], c->gact[l], B, l))
+    // VAR_NO_TAIL=1 (tuning aid): separate dgrad of conv 2 and wgrad of conv 1 through gact1 in HBM
+    static const bool fused_tail = !getenv("VAR_NO_TAIL");
     if ((rc = ready(5)) != VAR_OK) return rc;
     for (int l = 4; l >= 0; --l) {
+        if (l == 0 && fused_tail) {
+            // layer 0's slabs were left by the tail kernel on s
+            if (sr != s) { VAR_HIP_CHECK(c, hipEventRecord(c->ev_g[0], s)); VAR_HIP_CHECK(c, hipStreamWaitEvent(sr, c->ev_g[0], 0)); }
+            if ((rc = launch_img_wgrad_reduce(c, sr, grads, 0, 0)) != VAR_OK) return rc;
+            break;
+        }
         if ((rc = launch_img_wgrad(c, sw, l, xin[l], bs[l], l == 0 ? c->saved_u8 : 0, c->gact[l + 1], B)) != VAR_OK) return rc;
         // slabs are folded on a stream of their own (sr), released by an event, so a fold never delays the next wgrad
         if (sr != sw) { VAR_HIP_CHECK(c, hipEventRecord(c->ev_w[l], sw)); VAR_HIP_CHECK(c, hipStreamWaitEvent(sr, c->ev_w[l], 0)); }
@@ -294,10 +304,10 @@ int launch_img_bwd(var_ctx* c, hipStream_t s, hipStream_t sw, hipStream_t sr, co
             case 4: rc = DG(D84_4, D96_4, 4); break;
             case 3: rc = DG(D84_3, D96_3, 3); break;
             case 2: rc = DG(D84_2, D96_2, 2); break;
-            default: rc = DG(D84_1, D96_1, 1); break;
+            default: rc = fused_tail ? launch_img_bwd_tail(c, s, B) : DG(D84_1, D96_1, 1); break;
         }
         if (rc != VAR_OK) return rc;
-        if ((rc = ready(l)) != VAR_OK) return rc;
+        if (l > 1 || !fused_tail) { if ((rc = ready(l)) != VAR_OK) return rc; }
     }
 #undef DG
     if (sr != s) { VAR_HIP_CHECK(c, hipEventRecord(c->ev_wjoin, sr)); VAR_HIP_CHECK(c, hipStreamWaitEvent(s, c->ev_wjoin, 0)); }

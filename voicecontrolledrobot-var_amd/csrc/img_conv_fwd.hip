@@ -48,7 +48,8 @@ struct FwdCfg {
 template <class C>
 __global__ void __launch_bounds__(C::NW * 64)
 img_conv_fwd_kernel(const void* __restrict__ xin, long bstride, const int* __restrict__ bidx,
-                    const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, int B, int dbg) {
+                    const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y,
+                    uint16_t* __restrict__ relu_bits, int B, int dbg) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NT = C::NW * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -201,11 +202,18 @@ img_conv_fwd_kernel(const void* __restrict__ xin, long bstride, const int* __res
         const int oy = band * C::R + q / C::WO;
         if (oy >= C::HO || (dbg & 4)) continue;
         float* yp = y + (size_t)b * C::COUT * C::HO * C::WO + band * C::R * C::WO + q;
+        uint32_t bits = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int n = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             float v = acc[i][r] + bias[n];
             yp[(size_t)n * C::HO * C::WO] = v > 0.f ? v : 0.f;
+            bits |= v > 0.f ? (1u << r) : 0u;
+        }
+        // first layer: the ReLU pattern as one u16 per (pixel, accumulator half), for the fused backward
+        // tail (img_bwd_tail.hip) -- 1/32 of the bytes of re-reading the activation there
+        if constexpr (C::NBLK == 1) {
+            if (relu_bits) relu_bits[((size_t)b * 2 + half) * C::HO * C::WO + band * C::R * C::WO + q] = (uint16_t)bits;
         }
     }
 }
@@ -223,7 +231,7 @@ static int launch_one(var_ctx* c, hipStream_t s, const void* x, long bstride, co
     const int units = B * C::NB;
     const int grid = (units + C::NU - 1) / C::NU;
     hipLaunchKernelGGL(img_conv_fwd_kernel<C>, dim3(grid), dim3(C::NW * 64), C::LDS_BYTES, s,
-                       x, bstride, bidx, wp, bias, y, B, getenv("VAR_DBG") ? atoi(getenv("VAR_DBG")) : 0);
+                       x, bstride, bidx, wp, bias, y, layer == 0 ? c->relu1 : nullptr, B, getenv("VAR_DBG") ? atoi(getenv("VAR_DBG")) : 0);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }

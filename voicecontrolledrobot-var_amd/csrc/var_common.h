@@ -112,6 +112,7 @@ struct var_ctx {
     float* emb_raw = nullptr;     // (3B,3) pre-normalise
     float* gemb = nullptr;        // (3B,3) grads wrt normalised embeddings
     float* ghid = nullptr;        // (3B,128)
+    uint16_t* relu1 = nullptr;    // ReLU bits of the first image activation: [b][half][y][x], bit r <-> channel (r&3)+8(r>>2)+4*half
     float* slabs = nullptr;       // split-K partial weight gradients
     size_t slab_floats = 0;
     size_t snd_slab_off = 0;
@@ -177,8 +178,11 @@ size_t snd_slab_floats();
 int launch_pack_weights(var_ctx* c, hipStream_t s, const float* params);
 int launch_img_fwd(var_ctx* c, hipStream_t s, const float* params, const void* image, int is_u8,
                    long bstride, const int* image_index, int B);
+// (launch_img_fwd also leaves c->relu1)
 int launch_img_fwd_conv2_pipe(var_ctx* c, hipStream_t s, const float* x, const float* wp, const float* bias,
                               float* y, int B);
+static constexpr int kTailG = 256;    // workgroups (= layer-0 slabs) of the fused backward tail
+int launch_img_bwd_tail(var_ctx* c, hipStream_t s, int B);
 int launch_img_bwd(var_ctx* c, hipStream_t s, hipStream_t sw, hipStream_t sr, const float* params, float* grads, int B);
 int launch_snd_fwd(var_ctx* c, hipStream_t s, const float* params, const float* pos, const float* neg, int B);
 int launch_snd_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads, int B);
