@@ -433,6 +433,7 @@ int var_debug_buffer(var_ctx* c, const char* name, void** ptr, long* nfloats) {
     }
     if (!strcmp(name, "emb")) { *ptr = c->emb; *nfloats = 9 * (long)B; return VAR_OK; }
     if (!strcmp(name, "mfcc")) { *ptr = c->mfcc_buf; *nfloats = 2 * (long)B * VAR_MFCC_FRAMES * VAR_MFCC_COEFFS; return VAR_OK; }
+    if (!strcmp(name, "relu1")) { *ptr = (float*)c->relu1; *nfloats = (long)c->maxB * c->hs[1] * c->hs[1]; return VAR_OK; }
     if (!strcmp(name, "slabs")) { *ptr = c->slabs; *nfloats = (long)c->slab_floats; return VAR_OK; }
     if (!strcmp(name, "gemb")) { *ptr = c->gemb; *nfloats = 9 * (long)B; return VAR_OK; }
     VAR_SET_ERR(c, "var_debug_buffer: unknown buffer '%s'", name);

@@ -259,23 +259,31 @@ int launch_img_fwd(var_ctx* c, hipStream_t s, const float* params, const void* i
     for (int i = 0; i < 5; i++) { w[i] = c->wpack + K.img_f[i]; b[i] = params + L.img_b[i]; }
     int rc;
 #define RUN(CFG, X, BS, I, Y) do { if ((rc = launch_one<CFG>(c, s, X, BS, (I) == 0 ? image_index : nullptr, w[I], b[I], Y, B, I)) != VAR_OK) return rc; } while (0)
-    if (c->H == 84) {
+    // VAR_NO_HEAD=1 (tuning aid): conv 1 and conv 2 as separate kernels through act1 in HBM
+    static const bool fused_head = !getenv("VAR_NO_HEAD");
+    if (c->H != 84 && c->H != 96) {
+        VAR_SET_ERR(c, "unsupported image size %d (84 or 96)", c->H);
+        return VAR_ERR_ARG;
+    }
+    if (fused_head) {
+        if ((rc = launch_img_fwd_head(c, s, params, image, is_u8, bstride, image_index, B)) != VAR_OK) return rc;
+    } else if (c->H == 84) {
         if (is_u8) { RUN(F84_1u, image, bstride, 0, c->act[1]); } else { RUN(F84_1f, image, bstride, 0, c->act[1]); }
         if (!getenv("VAR_NO_PIPE")) { if ((rc = launch_img_fwd_conv2_pipe(c, s, c->act[1], w[1], b[1], c->act[2], B)) != VAR_OK) return rc; }
         else RUN(F84_2, c->act[1], 32L * 42 * 42, 1, c->act[2]);
-        RUN(F84_3, c->act[2], 32L * 21 * 21, 2, c->act[3]);
-        RUN(F84_4, c->act[3], 64L * 11 * 11, 3, c->act[4]);
-        RUN(F84_5, c->act[4], 64L * 6 * 6, 4, c->act[5]);
-    } else if (c->H == 96) {
+    } else {
         if (is_u8) { RUN(F96_1u, image, bstride, 0, c->act[1]); } else { RUN(F96_1f, image, bstride, 0, c->act[1]); }
         if (!getenv("VAR_NO_PIPE")) { if ((rc = launch_img_fwd_conv2_pipe(c, s, c->act[1], w[1], b[1], c->act[2], B)) != VAR_OK) return rc; }
         else RUN(F96_2, c->act[1], 32L * 48 * 48, 1, c->act[2]);
+    }
+    if (c->H == 84) {
+        RUN(F84_3, c->act[2], 32L * 21 * 21, 2, c->act[3]);
+        RUN(F84_4, c->act[3], 64L * 11 * 11, 3, c->act[4]);
+        RUN(F84_5, c->act[4], 64L * 6 * 6, 4, c->act[5]);
+    } else {
         RUN(F96_3, c->act[2], 32L * 24 * 24, 2, c->act[3]);
         RUN(F96_4, c->act[3], 64L * 12 * 12, 3, c->act[4]);
         RUN(F96_5, c->act[4], 64L * 6 * 6, 4, c->act[5]);
-    } else {
-        VAR_SET_ERR(c, "unsupported image size %d (84 or 96)", c->H);
-        return VAR_ERR_ARG;
     }
 #undef RUN
     return VAR_OK;

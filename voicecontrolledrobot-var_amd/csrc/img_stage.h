@@ -236,3 +236,91 @@ struct ColStager {
         st.store(lds, row0, live ? 1 : 0);
     }
 };
+
+// ------------------------------------------------------------------------------------------
+// Two-phase copy of NU bands (ROWS rows x W cols of NCH planes each) from global memory to LDS: issue() puts
+// every load of the bands in flight into registers, store() writes them to LDS later -- the matrix work of the
+// current tile runs in between.  NT / (NU*NCH) consecutive lanes walk one plane's band (contiguous in memory),
+// so the index math is one div/mod per phase plus add-and-wrap per element; it is redone in both phases from
+// the caller's opaque copy of tid so that nothing of it lives in registers across the tile loop.
+// u8 sources become f32 through a 256-entry table in LDS (exact x / 255.f without a division per element).
+template <int NCH, int H, int W, int ROWS, bool U8, int NT, int NU>
+struct BandCopy {
+    static constexpr int V = U8 ? 4 : (W % 4 == 0 ? 4 : (W % 2 == 0 ? 2 : 1));
+    static constexpr int WV = W / V, VP = ROWS * WV;          // vectors per plane band
+    static constexpr int PLANES = NU * NCH, TP = NT / PLANES;  // lanes per plane
+    static constexpr int PP = (VP + TP - 1) / TP;
+    static constexpr int XREG = U8 ? 1 : V;
+    static_assert(NT % PLANES == 0, "lanes must split evenly over the planes");
+    float data[PP][XREG];
+
+    struct Lane { int u, ch, r0, x0; };
+    static __device__ __forceinline__ Lane lane_of(int tid) {
+        Lane l;
+        const int plane = tid / TP, tp = tid - plane * TP;
+        l.u = plane / NCH; l.ch = plane - l.u * NCH;
+        l.r0 = tp / WV; l.x0 = tp - l.r0 * WV;
+        return l;
+    }
+    // (row, vector column) of this lane's p-th vector; false when the band has no such vector
+    static __device__ __forceinline__ bool elem(const Lane& l, int p, int& r, int& xv) {
+        constexpr int DMAX = ((PP - 1) * TP) / WV;
+        (void)DMAX;
+        const int dr = (p * TP) / WV, dx = (p * TP) % WV;     // compile-time after unrolling
+        xv = l.x0 + dx; r = l.r0 + dr;
+        if (xv >= WV) { xv -= WV; ++r; }
+        return r < ROWS;
+    }
+    template <class PT>
+    __device__ __forceinline__ void issue(const PT* base0, const PT* base1, int row00, int row01, int tid) {
+        const Lane l = lane_of(tid);
+        const PT* base = (l.u ? base1 : base0) + l.ch * H * W;
+        const int row0 = l.u ? row01 : row00;
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {
+            int r, xv;
+            elem(l, p, r, xv);
+            int row = row0 + r;
+            row = row < 0 ? 0 : (row >= H ? H - 1 : row);
+            const PT* src = base + row * W + xv * V;
+            if constexpr (U8) {
+                data[p][0] = __uint_as_float(*(const uint32_t*)src);
+            } else if constexpr (V == 4) {
+                const float4 q = *(const float4*)src;
+                data[p][0] = q.x; data[p][1] = q.y; data[p][2] = q.z; data[p][3] = q.w;
+            } else if constexpr (V == 2) {
+                const float2 q = *(const float2*)src;
+                data[p][0] = q.x; data[p][1] = q.y;
+            } else {
+                data[p][0] = *src;
+            }
+        }
+    }
+    // dst[u*UNIT + ch*PLANE + r*PW + COL0 + col]; rows outside [0,H) and bands that do not exist become zeros
+    template <int UNIT, int PLANE, int PW, int COL0>
+    __device__ __forceinline__ void store(float* __restrict__ dst, const float* __restrict__ lut, int row00, int row01,
+                                          bool ok0, bool ok1, int tid) const {
+        const Lane l = lane_of(tid);
+        float* d0 = dst + l.u * UNIT + l.ch * PLANE + COL0;
+        const int row0 = l.u ? row01 : row00;
+        const bool uok = l.u ? ok1 : ok0;
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {
+            int r, xv;
+            if (!elem(l, p, r, xv)) continue;
+            const int row = row0 + r;
+            const bool rok = uok && row >= 0 && row < H;
+            float* d = d0 + r * PW + xv * V;
+            if constexpr (U8) {
+                const uint32_t q = rok ? __float_as_uint(data[p][0]) : 0u;      // lut[0] = 0
+                d[0] = lut[q & 0xff];
+                d[1] = lut[(q >> 8) & 0xff];
+                d[2] = lut[(q >> 16) & 0xff];
+                d[3] = lut[q >> 24];
+            } else {
+#pragma unroll
+                for (int j = 0; j < V; ++j) d[j] = rok ? data[p][j] : 0.f;
+            }
+        }
+    }
+};
