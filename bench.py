@@ -74,13 +74,26 @@ def cpu_baseline(seconds=10.0):
                       f"torch.nn CPU restatement of the reference step, {cores} threads, {dt:.1f} s"}
 
 
+def tag_flops(tag):
+    """Algorithmic FLOPs per triplet of a profiled conv kernel family (tags: 0-4 forward, 5-9 weight
+    gradient, 11-14 data gradient of layer tag % 5).  Tag 1 is the fused forward head (conv 1 + conv 2), tag 11
+    the fused backward tail (data gradient of conv 2 + weight gradient of conv 1); halo recomputation inside
+    the fused kernels is not counted."""
+    if tag == 1 and not os.environ.get("VAR_NO_HEAD"):
+        return LAYER_FLOPS[0] + LAYER_FLOPS[1]
+    if tag == 11 and not os.environ.get("VAR_NO_TAIL"):
+        return LAYER_FLOPS[1] + LAYER_FLOPS[0]
+    return LAYER_FLOPS[tag % 5]
+
+
 def pmc_traffic(tag_name, hw):
     """HBM bytes per launch of the dominant kernel, from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE
     WRITE_SIZE in its own run, gfx950 correction: FETCH_SIZE x 2, see profiles/r01_pmc_hbm_traffic.json).
     PMC counters cannot be collected from inside this process, so this is the figure of that pass
     (same workload, same kernel); None when the file or the kernel is not in it."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")
-    want = {"img_conv_fwd_kernel[1]": "img_conv_fwd_pipe_kernel<PipeCfg<32, 32, %d," % (hw // 2)}.get(tag_name)
+    want = {"img_fwd_head_kernel[0+1]": "img_fwd_head_kernel<HeadCfg<%d," % (hw // 2),
+            "img_bwd_tail_kernel[dgrad1+wgrad0]": "img_bwd_tail_kernel<TailCfg<%d," % (hw // 2)}.get(tag_name)
     if want is None or not os.path.exists(path):
         return None
     with open(path) as f:
@@ -210,8 +223,7 @@ def main():
         if dom_tag is not None and roof_n:
             ms, n = roof_ms, roof_n
             names = ctx.tag_names()
-            layer = dom_tag % 5
-            flops = LAYER_FLOPS[layer] * B
+            flops = tag_flops(dom_tag) * B
             ach = flops / (ms / n * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": names[dom_tag], "achieved": round(ach, 2),
                                "peak": F32_MFMA_PEAK, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK, 4),

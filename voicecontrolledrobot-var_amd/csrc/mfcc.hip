@@ -27,8 +27,11 @@ constexpr int TB_DCT = TB_TW512 + 512;    // [n][k] 40 x 40
 constexpr int TB_MSTART = TB_DCT + 1600;  // 40 ints
 constexpr int TB_MCOUNT = TB_MSTART + 40;
 constexpr int TB_MOFF = TB_MCOUNT + 40;
-constexpr int TB_MW = TB_MOFF + 40;       // <= 640 weights
-constexpr int TB_TOTAL = TB_MW + 640;   // 3744 floats, a multiple of 4
+constexpr int TB_MW = TB_MOFF + 40;       // <= 640 weights (triangles back to back; host-side only)
+constexpr int MAXC = 34;                  // trip count of the mel loop (widest triangle: 33 bins)
+constexpr int TB_MWD = TB_MW + 640;       // dense [q][40]: weight of bin mstart[m] + q in filter m, 0 beyond its triangle
+constexpr int TB_WIN512 = TB_MWD + MAXC * 40;   // 512: Hamming(400) / 32768 centred in the frame, 0 outside
+constexpr int TB_TOTAL = TB_WIN512 + 512; // a multiple of 4
 
 struct cplx { float x, y; };
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
@@ -61,7 +64,10 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
     __syncthreads();
     // mel filter of this lane (lanes >= 40 idle in that phase)
     const int ml = lane < NMEL ? lane : 0;
-    const int mst = itab[TB_MSTART + ml], mcnt = lane < NMEL ? itab[TB_MCOUNT + ml] : 0, mwo = itab[TB_MOFF + ml];
+    const int mst = itab[TB_MSTART + ml];
+    float dct[NMEL];
+#pragma unroll
+    for (int n = 0; n < NMEL; ++n) dct[n] = tabs[TB_DCT + n * NMFCC + ml];
 
     float* pw = (float*)bufB[wave];                  // the FFT result ends in bufA (4 stages), bufB is free then
     float* lm = pw + 264;
@@ -72,19 +78,34 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
             if (lane < NMFCC) out[((size_t)clip * out_frames + t) * NMFCC + lane] = 0.f;
             continue;
         }
-        // 1. windowed frame -> LDS
+        // 1. windowed frame -> LDS.  Frames whose 512 samples all lie inside the clip (all but two at either end)
+        //    take two samples per 4-byte load and the zero-extended window table: no index logic per sample.
+        const int p0 = t * HOP - NFFT / 2;
+        if (p0 >= 0 && p0 + NFFT <= N) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = lane + 64 * i;
-            float v = 0.f;
-            if (idx >= WOFF && idx < WOFF + WIN) {
-                int pos = t * HOP + idx - NFFT / 2;
-                if (pos < 0) pos = -pos;
-                if (pos >= N) pos = 2 * (N - 1) - pos;
-                pos = pos < 0 ? 0 : (pos >= N ? N - 1 : pos);
-                v = ((float)sig[pos] * (1.f / 32768.f)) * tabs[TB_WIN + idx - WOFF];   // exact: power of two
+            for (int i = 0; i < 4; ++i) {
+                const int n = lane + 64 * i;
+                const uint32_t two = *(const uint32_t*)(sig + p0 + 2 * n);        // p0 even, clip rows 4-byte aligned
+                const float2 w = *(const float2*)(tabs + TB_WIN512 + 2 * n);
+                float2 z;
+                z.x = (float)(int16_t)(two & 0xffff) * w.x;
+                z.y = (float)((int32_t)two >> 16) * w.y;
+                *(float2*)(xs + 2 * n) = z;
             }
-            xs[idx] = v;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = lane + 64 * i;
+                float v = 0.f;
+                if (idx >= WOFF && idx < WOFF + WIN) {
+                    int pos = p0 + idx;
+                    if (pos < 0) pos = -pos;
+                    if (pos >= N) pos = 2 * (N - 1) - pos;
+                    pos = pos < 0 ? 0 : (pos >= N ? N - 1 : pos);
+                    v = (float)sig[pos] * tabs[TB_WIN512 + idx];
+                }
+                xs[idx] = v;
+            }
         }
         WAVE_SYNC();
         // 2. 256-point complex FFT of z[n] = x[2n] + i x[2n+1]: Stockham radix-4, natural order out
@@ -125,27 +146,24 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
             const cplx X = cadd(xe, cmul(tw512[k], xo));
             pw[k] = X.x * X.x + X.y * X.y;
         }
-        if (lane == 0) { const cplx z0 = src[0]; const float r = z0.x - z0.y; pw[256] = r * r; }
+        // bin 256; bins 257..263 are read (with zero weight) by the mel loop and must be finite
+        if (lane < 8) { const cplx z0 = src[0]; const float r = z0.x - z0.y; pw[256 + lane] = lane ? 0.f : r * r; }
         WAVE_SYNC();
-        // 4. mel triangles + log: predicated fixed-trip loop so that the LDS reads pipeline
+        // 4. mel triangles + log: fixed-trip loop over the dense weight table (zeros beyond a triangle; the
+        //    bins read there are finite: pw[257..263] is kept zero), addresses are base + immediates
         {
             float s = 0.f;
-#pragma unroll 8
-            for (int q = 0; q < 40; ++q) {          // widest triangle spans 33 bins
-                const bool ok = q < mcnt;
-                const float p = pw[ok ? mst + q : 0];
-                const float w = tabs[TB_MW + (ok ? mwo + q : 0)];
-                s += ok ? p * w : 0.f;
-            }
+#pragma unroll
+            for (int q = 0; q < MAXC; ++q) s += pw[mst + q] * tabs[TB_MWD + q * NMEL + ml];
             if (lane < NMEL) lm[lane] = logf(s + 1e-6f);
         }
         WAVE_SYNC();
-        // 5. DCT-II (ortho) and store
-        if (lane < NMFCC) {
+        // 5. DCT-II (ortho) and store: this lane's column of the matrix is in registers
+        {
             float s = 0.f;
-#pragma unroll 8
-            for (int n = 0; n < NMEL; ++n) s += lm[n] * tabs[TB_DCT + n * NMFCC + lane];
-            out[((size_t)clip * out_frames + t) * NMFCC + lane] = s;
+#pragma unroll
+            for (int n = 0; n < NMEL; ++n) s += lm[n] * dct[n];
+            if (lane < NMFCC) out[((size_t)clip * out_frames + t) * NMFCC + lane] = s;
         }
         WAVE_SYNC();
     }
@@ -197,6 +215,12 @@ int mfcc_build_tables(var_ctx* c) {
         it[TB_MOFF + m] = wo;
         wo += count;
     }
+    for (int m = 0; m < NMEL; m++) {
+        if (it[TB_MCOUNT + m] > MAXC || it[TB_MSTART + m] + MAXC - 1 > 263) { VAR_SET_ERR(c, "mfcc tables: triangle too wide"); return VAR_ERR_ARG; }
+        for (int q = 0; q < it[TB_MCOUNT + m]; q++) tb[TB_MWD + q * NMEL + m] = tb[TB_MW + it[TB_MOFF + m] + q];
+    }
+    for (int i = 0; i < WIN; i++) tb[TB_WIN512 + WOFF + i] = tb[TB_WIN + i] * (1.f / 32768.f);   // exact: power of two
+    static_assert(TB_TOTAL % 4 == 0, "table is copied as float4");
     VAR_HIP_CHECK(c, hipMalloc((void**)&c->mfcc_tab, sizeof(float) * TB_TOTAL));
     VAR_HIP_CHECK(c, hipMemcpy(c->mfcc_tab, tb.data(), sizeof(float) * TB_TOTAL, hipMemcpyHostToDevice));
     return VAR_OK;
