@@ -6,7 +6,8 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libvar_hip.so")
+# VAR_HIP_LIB: another build of the same library (A/B timing of two builds in one GPU session)
+_LIB_PATH = os.environ.get("VAR_HIP_LIB") or os.path.join(_HERE, "libvar_hip.so")
 _lib = None
 _lock = threading.Lock()
 

@@ -29,7 +29,13 @@ int var_init(int device_id, var_ctx** out) {
     var_ctx* c = new (std::nothrow) var_ctx();
     if (!c) return VAR_ERR_HIP;
     c->device = device_id;
-    { const char* e = getenv("VAR_SERIAL"); c->serial = e && e[0] == '1'; }
+    // Which parts of a step leave the caller's stream (bit 0: sound branch forward incl. MFCC, bit 1: sound
+    // branch backward, bit 2: image weight gradients, bit 3: slab folds, bit 4: with bit 0, the MFCC kernel stays on the caller's
+    // stream and only the sound CNN forks).  VAR_SERIAL=1 = none; VAR_STREAMS=<mask>.
+    c->streams = kDefaultStreams;
+    { const char* e = getenv("VAR_SERIAL"); if (e && e[0] == '1') c->streams = 0; }
+    { const char* e = getenv("VAR_STREAMS"); if (e && e[0]) c->streams = atoi(e) & 31; }
+    c->serial = c->streams == 0;
     c->pl = make_param_layout();
     c->kl = make_pack_layout();
     if (c->pl.total != VAR_N_PARAMS) {
@@ -166,20 +172,19 @@ static int check_plan(var_ctx* c, int B, int H, const char* who) {
 
 // Fork the sound branch onto the side stream (it runs beside the image branch: the MFCC front-end
 // is VALU work, the image convolutions are matrix-core work) and join it back before the heads.
-#define SIDE(c, s) ((c)->serial ? (s) : (c)->side)
 
 struct AudioIn {            // optional in-step front-end: pcm != NULL => MFCC is computed here
     const int16_t* pcm = nullptr; const int* lens = nullptr; const int* clip_index = nullptr; int pcm_stride = 0;
 };
 
 static int fork_side(var_ctx* c, hipStream_t s, int i) {
-    if (c->serial) return VAR_OK;
+    if (!(c->streams & (1 << i))) return VAR_OK;
     VAR_HIP_CHECK(c, hipEventRecord(c->ev_fork[i], s));
     VAR_HIP_CHECK(c, hipStreamWaitEvent(c->side, c->ev_fork[i], 0));
     return VAR_OK;
 }
 static int join_side(var_ctx* c, hipStream_t s, int i) {
-    if (c->serial) return VAR_OK;
+    if (!(c->streams & (1 << i))) return VAR_OK;
     VAR_HIP_CHECK(c, hipEventRecord(c->ev_join[i], c->side));
     VAR_HIP_CHECK(c, hipStreamWaitEvent(s, c->ev_join[i], 0));
     return VAR_OK;
@@ -194,15 +199,18 @@ static int encoder_fwd(var_ctx* c, hipStream_t s, const float* params, const voi
         neg = c->mfcc_buf + (size_t)B * VAR_MFCC_FRAMES * VAR_MFCC_COEFFS;
     }
     const bool snd = pos || neg;
+    hipStream_t ss = (c->streams & 1) ? c->side : s;
     if (snd) {
-        if ((rc = fork_side(c, s, 0)) != VAR_OK) return rc;
+        const bool mfcc_main = (c->streams & 16) != 0;
+        if (!mfcc_main && (rc = fork_side(c, s, 0)) != VAR_OK) return rc;
         if (audio && audio->pcm &&
-            (rc = launch_mfcc(c, SIDE(c, s), audio->pcm, audio->lens, audio->clip_index, 2 * B, audio->pcm_stride,
+            (rc = launch_mfcc(c, mfcc_main ? s : ss, audio->pcm, audio->lens, audio->clip_index, 2 * B, audio->pcm_stride,
                               VAR_MFCC_FRAMES, c->mfcc_buf)) != VAR_OK) return rc;
-        if ((rc = launch_snd_fwd(c, SIDE(c, s), params, pos, neg, B)) != VAR_OK) return rc;
+        if (mfcc_main && (rc = fork_side(c, s, 0)) != VAR_OK) return rc;
+        if ((rc = launch_snd_fwd(c, ss, params, pos, neg, B)) != VAR_OK) return rc;
     }
     if (image && (rc = launch_img_fwd(c, s, params, image, is_u8, bstride, image_index, B)) != VAR_OK) return rc;
-    if ((rc = launch_heads_fwd(c, s, snd ? SIDE(c, s) : s, params, B, image != nullptr, pos != nullptr, neg != nullptr)) != VAR_OK) return rc;
+    if ((rc = launch_heads_fwd(c, s, snd ? ss : s, params, B, image != nullptr, pos != nullptr, neg != nullptr)) != VAR_OK) return rc;
     if (snd && (rc = join_side(c, s, 0)) != VAR_OK) return rc;
     c->saved_B = B;
     c->saved_image = image;
@@ -247,10 +255,13 @@ static int encoder_bwd(var_ctx* c, hipStream_t s, const float* params, float* gr
     }
     const int snd_lo = c->saved_pos ? 0 : B, snd_hi = c->saved_neg ? 2 * B : B;
     // streams: s = image head + dgrad chain, side = sound head + sound CNN backward, side2 = image wgrads
+    hipStream_t ss = (c->streams & 2) ? c->side : s;
+    hipStream_t sw = (c->streams & 4) ? c->side2 : s;
+    hipStream_t sr = (c->streams & 8) ? c->side3 : sw;
     if ((rc = fork_side(c, s, 1)) != VAR_OK) return rc;
-    if ((rc = launch_heads_bwd(c, s, SIDE(c, s), params, grads, B, c->saved_image != nullptr, snd_lo, snd_hi)) != VAR_OK) return rc;
-    if ((rc = launch_snd_bwd(c, SIDE(c, s), params, grads, B)) != VAR_OK) return rc;
-    if (c->saved_image && (rc = launch_img_bwd(c, s, c->serial ? s : c->side2, c->serial ? s : c->side3, params, grads, B)) != VAR_OK) return rc;
+    if ((rc = launch_heads_bwd(c, s, ss, params, grads, B, c->saved_image != nullptr, snd_lo, snd_hi)) != VAR_OK) return rc;
+    if ((rc = launch_snd_bwd(c, ss, params, grads, B)) != VAR_OK) return rc;
+    if (c->saved_image && (rc = launch_img_bwd(c, s, sw, sr, params, grads, B)) != VAR_OK) return rc;
     return join_side(c, s, 1);
 }
 

@@ -288,17 +288,24 @@ int launch_img_bwd(var_ctx* c, hipStream_t s, hipStream_t sw, hipStream_t sr, co
     // VAR_NO_TAIL=1 (tuning aid): separate dgrad of conv 2 and wgrad of conv 1 through gact1 in HBM
     static const bool fused_tail = !getenv("VAR_NO_TAIL");
     if ((rc = ready(5)) != VAR_OK) return rc;
+    // With the folds on the same stream as the weight gradients (the default) all five layers are folded by ONE
+    // launch after the last weight-gradient kernel; on a stream of their own (sr != sw) each layer's fold is
+    // released by an event as soon as its slabs exist.
+    const bool fold_each = sr != sw;
     for (int l = 4; l >= 0; --l) {
         if (l == 0 && fused_tail) {
             // layer 0's slabs were left by the tail kernel on s
             if (sr != s) { VAR_HIP_CHECK(c, hipEventRecord(c->ev_g[0], s)); VAR_HIP_CHECK(c, hipStreamWaitEvent(sr, c->ev_g[0], 0)); }
-            if ((rc = launch_img_wgrad_reduce(c, sr, grads, 0, 0)) != VAR_OK) return rc;
+            if ((rc = launch_img_wgrad_reduce(c, sr, grads, 0, fold_each ? 0 : 4)) != VAR_OK) return rc;
             break;
         }
         if ((rc = launch_img_wgrad(c, sw, l, xin[l], bs[l], l == 0 ? c->saved_u8 : 0, c->gact[l + 1], B)) != VAR_OK) return rc;
-        // slabs are folded on a stream of their own (sr), released by an event, so a fold never delays the next wgrad
-        if (sr != sw) { VAR_HIP_CHECK(c, hipEventRecord(c->ev_w[l], sw)); VAR_HIP_CHECK(c, hipStreamWaitEvent(sr, c->ev_w[l], 0)); }
-        if ((rc = launch_img_wgrad_reduce(c, sr, grads, l, l)) != VAR_OK) return rc;
+        if (fold_each) {
+            VAR_HIP_CHECK(c, hipEventRecord(c->ev_w[l], sw)); VAR_HIP_CHECK(c, hipStreamWaitEvent(sr, c->ev_w[l], 0));
+            if ((rc = launch_img_wgrad_reduce(c, sr, grads, l, l)) != VAR_OK) return rc;
+        } else if (l == 0) {
+            if ((rc = launch_img_wgrad_reduce(c, sr, grads, 0, 4)) != VAR_OK) return rc;
+        }
         if (l == 0) break;
         switch (l) {
             case 4: rc = DG(D84_4, D96_4, 4); break;

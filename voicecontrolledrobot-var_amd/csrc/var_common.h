@@ -133,6 +133,7 @@ struct var_ctx {
     const int* saved_index = nullptr;     // optional image gather index of the saved forward
     // side stream for the sound branch (runs beside the image branch) and its fork/join events
     bool serial = false;                  // VAR_SERIAL=1: everything on the caller's stream (for per-kernel profiling)
+    int streams = 0;              // bit mask, see var_init
     hipStream_t side = nullptr;
     hipStream_t side2 = nullptr;          // weight-gradient kernels run here beside the dgrad chain
     hipEvent_t ev_g[6] = {nullptr};       // gact[l] ready (recorded on the dgrad stream)
@@ -183,6 +184,11 @@ int launch_img_fwd_head(var_ctx* c, hipStream_t s, const float* params, const vo
 // (launch_img_fwd also leaves c->relu1)
 int launch_img_fwd_conv2_pipe(var_ctx* c, hipStream_t s, const float* x, const float* wp, const float* bias,
                               float* y, int B);
+// default: MFCC on the caller's stream, the sound CNN (forward and backward) beside the image CNN on one side
+// stream; image weight gradients and slab folds stay on the caller's stream.  Measured on MI355X (graph replay):
+// every cross-stream edge costs several us, and two GPU-filling persistent kernels side by side slow each other
+// down more than the overlap gains -- only the small sound kernels are worth forking.
+static constexpr int kDefaultStreams = 19;
 static constexpr int kTailG = 256;    // workgroups (= layer-0 slabs) of the fused backward tail
 int launch_img_bwd_tail(var_ctx* c, hipStream_t s, int B);
 int launch_img_bwd(var_ctx* c, hipStream_t s, hipStream_t sw, hipStream_t sr, const float* params, float* grads, int B);
