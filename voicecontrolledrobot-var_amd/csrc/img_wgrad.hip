@@ -268,7 +268,7 @@ using W96_3 = WgCfg<64, 64, 12, false, 6, 1, 2>;
 using W96_4 = WgCfg<64, 64, 6, false, 3, 4, 4>;
 
 // split-K workgroups (grid.x) per layer; grid.y = channel-block combos.  Also sizes the slab workspace.
-static const int kWgG[5] = {512, 256, 256, 128, 64};
+static const int kWgG[5] = {512, 256, 128, 64, 32};     // layer 0: the fused tail (kTailG <= 512)
 static const int kCombo[5] = {1, 1, 2, 4, 4};
 static const int kSlabSz[5] = {32 * 32 + 32, 9248, 9248, 9248, 9248};
 
