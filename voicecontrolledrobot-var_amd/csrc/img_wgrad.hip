@@ -257,14 +257,14 @@ img_wgrad_reduce_kernel(RedTable T, const float* __restrict__ slabs, float* __re
 using W84_0u = WgCfg<3, 32, 84, true, 6, 1, 4>;
 using W84_0f = WgCfg<3, 32, 84, false, 6, 1, 4>;
 using W84_1 = WgCfg<32, 32, 42, false, 3, 1, 4>;
-using W84_2 = WgCfg<32, 64, 21, false, 3, 1, 2>;
-using W84_3 = WgCfg<64, 64, 11, false, 6, 1, 2>;
+using W84_2 = WgCfg<32, 64, 21, false, 11, 1, 4>;
+using W84_3 = WgCfg<64, 64, 11, false, 6, 1, 4>;
 using W84_4 = WgCfg<64, 64, 6, false, 3, 4, 4>;
 using W96_0u = WgCfg<3, 32, 96, true, 6, 1, 4>;
 using W96_0f = WgCfg<3, 32, 96, false, 6, 1, 4>;
 using W96_1 = WgCfg<32, 32, 48, false, 3, 1, 4>;
-using W96_2 = WgCfg<32, 64, 24, false, 3, 1, 2>;
-using W96_3 = WgCfg<64, 64, 12, false, 6, 1, 2>;
+using W96_2 = WgCfg<32, 64, 24, false, 6, 1, 4>;
+using W96_3 = WgCfg<64, 64, 12, false, 6, 1, 4>;
 using W96_4 = WgCfg<64, 64, 6, false, 3, 4, 4>;
 
 // split-K workgroups (grid.x) per layer; grid.y = channel-block combos.  Also sizes the slab workspace.
