@@ -240,7 +240,7 @@ static int launch_one(var_ctx* c, hipStream_t s, const void* x, long bstride, co
 using F84_1u = FwdCfg<3, 32, 84, true, 6, 1, 4>;
 using F84_1f = FwdCfg<3, 32, 84, false, 6, 1, 4>;
 using F84_2 = FwdCfg<32, 32, 42, false, 3, 2, 4>;
-using F84_3 = FwdCfg<32, 64, 21, false, 11, 1, 4>;
+using F84_3 = FwdCfg<32, 64, 21, false, 11, 1, 4, 3, 1>;     // 1 image, 8 items on 4 waves x 3 ky slices -> 12 waves
 using F84_4 = FwdCfg<64, 64, 11, false, 6, 1, 4, 3, 1>;    // 1 image, 4 items, 3 ky slices  -> 12 waves
 using F84_5 = FwdCfg<64, 64, 6, false, 3, 3, 2, 3, 2>;     // 3 images, 2 items, 3 ky x 2 channel halves -> 12 waves
 using F96_1u = FwdCfg<3, 32, 96, true, 4, 1, 3>;
