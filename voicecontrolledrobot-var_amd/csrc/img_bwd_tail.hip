@@ -65,9 +65,7 @@ template <class C>
 __global__ void __launch_bounds__(C::NT)
 img_bwd_tail_kernel(const float* __restrict__ gy, const float* __restrict__ wd, const uint16_t* __restrict__ relu_bits,
                     const void* __restrict__ image, long bstride, const int* __restrict__ bidx,
-                    float* __restrict__ slabs, int B, int dbg, long long* __restrict__ stamps) {
-    int nstamp = 0;
-#define STAMP() do { if (stamps && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == C::NW - 1) && nstamp < 64) { stamps[(wave ? 64 : 0) + nstamp++] = __builtin_amdgcn_s_memtime(); } } while (0)
+                    float* __restrict__ slabs, int B) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NT = C::NT;
     using XT = typename std::conditional<C::U8, uint8_t, float>::type;
@@ -76,7 +74,6 @@ img_bwd_tail_kernel(const float* __restrict__ gy, const float* __restrict__ wd, 
     const int total_units = B * C::NB;
     const int ntiles = (total_units + C::NU - 1) / C::NU;
     float* gys = lds + C::GYS;
-    float* gxs = lds + C::GXS;
     float* ims = lds + C::IMS;
 
     // ---- dgrad lane constants (K-split path of img_dgrad_kernel, one item per wave) ----
@@ -162,7 +159,6 @@ img_bwd_tail_kernel(const float* __restrict__ gy, const float* __restrict__ wd, 
         return *(const uint32_t*)(relu_bits + ((size_t)b * 2 + half) * C::H * C::W + (band * C::RI) * C::W + gxo);
     };
 
-    STAMP();
     int tile = blockIdx.x;
     uint32_t m = 0;
     int gi0 = 0, gi1 = 0;
@@ -177,7 +173,6 @@ img_bwd_tail_kernel(const float* __restrict__ gy, const float* __restrict__ wd, 
     }
     if (tile + (int)gridDim.x < ntiles) gather_rows(tile + gridDim.x, gi0, gi1);
     __syncthreads();
-    STAMP();
 #pragma unroll 1
     for (; tile < ntiles; tile += gridDim.x) {
         // ---- loads of the NEXT tile: in flight during this tile's matrix work ----
@@ -194,7 +189,6 @@ img_bwd_tail_kernel(const float* __restrict__ gy, const float* __restrict__ wd, 
             m_next = load_mask(next);
         }
 
-        STAMP();   // after issue
         // ---- dgrad: this wave's K part of its pixel block (filter slice already in registers) ----
         f32x16 acc0, acc1;
 #pragma unroll
@@ -214,7 +208,6 @@ img_bwd_tail_kernel(const float* __restrict__ gy, const float* __restrict__ wd, 
                 }
             };
             fetch(0, 0);
-            if (!(dbg & 1))
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 if (ch + 1 < NCH) fetch((ch + 1) & 1, ch + 1);
@@ -229,7 +222,6 @@ img_bwd_tail_kernel(const float* __restrict__ gy, const float* __restrict__ wd, 
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        STAMP();   // after dgrad mfma
         // ---- masked tile -> LDS (parts 0 and 1 write, part 2 adds afterwards: fixed order) ----
         // (bit r of the u16 -> all-ones / zero word by one signed bit-field extract, then AND)
         auto masked = [&](int r) {
@@ -245,9 +237,7 @@ img_bwd_tail_kernel(const float* __restrict__ gy, const float* __restrict__ wd, 
                 *(float2*)(lds + gxl + c * C::PLANE_G) = masked(r);
             }
         }
-        STAMP();   // after gxs write
         __syncthreads();                                   // gys is dead, gxs holds parts 0 and 1
-        STAMP();   // after barrier B
         if (ppvalid && part == 2) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -257,9 +247,7 @@ img_bwd_tail_kernel(const float* __restrict__ gy, const float* __restrict__ wd, 
                 *d = make_float2(o.x + g.x, o.y + g.y);
             }
         }
-        STAMP();   // after add + gy store
         __syncthreads();
-        STAMP();   // after barrier C
 
         // next tile's gy band -> LDS (gys is dead since the barrier before last); these stores overlap the
         // matrix work of the other waves below
@@ -277,7 +265,6 @@ img_bwd_tail_kernel(const float* __restrict__ gy, const float* __restrict__ wd, 
                 }
             };
             fetch(0, 0);
-            if (!(dbg & 8))
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 if (ch + 1 < NCH) fetch((ch + 1) & 1, ch + 1);
@@ -292,12 +279,9 @@ img_bwd_tail_kernel(const float* __restrict__ gy, const float* __restrict__ wd, 
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        STAMP();   // after wgrad mfma
         __syncthreads();                                   // ims and gxs are dead
-        STAMP();   // after barrier D
         if (more) cx.template store<C::UNIT_X, C::PLANE_X, C::PWX, 1>(ims, lut, tn.rx0, tn.rx1, tn.ok0, tn.ok1, tid_t);
         m = m_next;
-        STAMP();   // after img store
     }
 
     // ---- fold the waves through LDS (fixed order) and write this workgroup's partial slab ----
@@ -349,8 +333,7 @@ static int launch_tail(var_ctx* c, hipStream_t s, int B) {
     c->wg_groups[0] = G;
     hipLaunchKernelGGL(img_bwd_tail_kernel<C>, dim3(G), dim3(C::NT), C::LDS_BYTES, s, c->gact[2],
                        c->wpack + c->kl.img_d[1], c->relu1, c->saved_image, c->saved_bstride, c->saved_index,
-                       c->slabs, B, getenv("VAR_DBG") ? atoi(getenv("VAR_DBG")) : 0,
-                       getenv("VAR_STAMPS") ? (long long*)(c->slabs + c->slab_floats - 512) : nullptr);
+                       c->slabs, B);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }
