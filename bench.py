@@ -173,6 +173,27 @@ def main():
             if n and ms / n > best:
                 best, dom_tag = ms / n, tag
         ctx.profile_select(-1)
+    # roofline leg: HIP events (var_profile_select) around every launch of the dominant kernel, on the
+    # stream it is launched on, over eagerly launched steps of the same workload (events cannot be
+    # read back from inside a replayed graph)
+    roof_ms, roof_n, iso_ms, iso_n = 0.0, 0, 0.0, 0
+    if dom_tag is not None:
+        ctx.profile_select(dom_tag)
+        for _ in range(min(args.steps, 100)):
+            eager_step()
+            torch.cuda.synchronize()     # one step in flight at a time, as inside the replayed graph
+        roof_ms, roof_n = ctx.profile_read()
+        # the same kernel alone on the GPU (every launch of the step on one stream): what the kernel itself
+        # achieves, without the sound CNN running beside it
+        old_mask = ctx.set_streams(0)
+        ctx.profile_select(dom_tag)
+        for _ in range(min(args.steps, 100)):
+            eager_step()
+            torch.cuda.synchronize()
+        iso_ms, iso_n = ctx.profile_read()
+        ctx.set_streams(old_mask)
+        ctx.profile_select(-1)
+
     if use_graph:
         replay = tr.capture_dataset_step(pool.images, pool.clips, B, global_batch=B * world)
 
@@ -187,17 +208,6 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-
-    # roofline leg: HIP events (var_profile_select) around every launch of the dominant kernel, on the
-    # stream it is launched on, over eagerly launched steps of the same workload (events cannot be
-    # read back from inside a replayed graph)
-    roof_ms, roof_n = 0.0, 0
-    if dom_tag is not None:
-        ctx.profile_select(dom_tag)
-        for _ in range(min(args.steps, 100)):
-            eager_step()
-        roof_ms, roof_n = ctx.profile_read()
-        ctx.profile_select(-1)
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -228,6 +238,8 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": names[dom_tag], "achieved": round(ach, 2),
                                "peak": F32_MFMA_PEAK, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK, 4),
                                "traffic": pmc_traffic(names[dom_tag], HW), "avg_us": round(1e3 * ms / n, 2), "launches": n,
+                               "alone_us": round(1e3 * iso_ms / iso_n, 2) if iso_n else None,
+                               "alone_frac": round(flops / (iso_ms / iso_n * 1e-3) / 1e12 / F32_MFMA_PEAK, 4) if iso_n else None,
                                "flops_per_launch": flops}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()

@@ -25,7 +25,7 @@ cfg = types.SimpleNamespace(img_dim=(3, 84, 84), sound_dim=(1, 100, 40), represe
 torch.manual_seed(453)
 model = var_amd.VARPretextNet(cfg).to("cuda")
 tr = var_amd.VARTrainer(model)
-pool = var_amd.SyntheticTripletPool(2048, hw=84, seed=0, clips_per_class=32).freeze_pairs()
+pool = var_amd.SyntheticTripletPool(int(os.environ.get("KB_POOL", "2048")), hw=84, seed=0, clips_per_class=int(os.environ.get("KB_CPC", "32"))).freeze_pairs()
 ctx = Context.get(0)
 
 

@@ -49,6 +49,7 @@ _SIGNATURES = {
     "var_profile_tag_count": (_i, []),
     "var_profile_tag_name": (ctypes.c_char_p, [_i]),
     "var_profile_select": (_i, [_vp, _i]),
+    "var_set_streams": (_i, [_vp, _i]),
     "var_profile_read": (_i, [_vp, ctypes.POINTER(_f), ctypes.POINTER(_i)]),
     "var_debug_buffer": (_i, [_vp, ctypes.c_char_p, ctypes.POINTER(_vp), ctypes.POINTER(_l)]),
 }
@@ -105,6 +106,10 @@ class Context:
 
     def profile_select(self, tag):
         self.check(self.lib.var_profile_select(self.handle, int(tag)), "var_profile_select")
+
+    def set_streams(self, mask):
+        """Stream plan of a step (include/var_hip.h); -1 = default.  Returns the previous mask."""
+        return self.lib.var_set_streams(self.handle, int(mask))
 
     def profile_read(self):
         ms, n = _f(), _i()

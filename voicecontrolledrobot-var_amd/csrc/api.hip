@@ -16,6 +16,8 @@ int var_param_count(void) { return VAR_N_PARAMS; }
 
 const char* var_last_error(var_ctx* ctx) { return ctx ? ctx->err : g_init_err; }
 
+static int default_streams();
+
 int var_init(int device_id, var_ctx** out) {
     if (!out) return VAR_ERR_ARG;
     *out = nullptr;
@@ -32,9 +34,7 @@ int var_init(int device_id, var_ctx** out) {
     // Which parts of a step leave the caller's stream (bit 0: sound branch forward incl. MFCC, bit 1: sound
     // branch backward, bit 2: image weight gradients, bit 3: slab folds, bit 4: with bit 0, the MFCC kernel stays on the caller's
     // stream and only the sound CNN forks).  VAR_SERIAL=1 = none; VAR_STREAMS=<mask>.
-    c->streams = kDefaultStreams;
-    { const char* e = getenv("VAR_SERIAL"); if (e && e[0] == '1') c->streams = 0; }
-    { const char* e = getenv("VAR_STREAMS"); if (e && e[0]) c->streams = atoi(e) & 31; }
+    c->streams = default_streams();
     c->serial = c->streams == 0;
     c->pl = make_param_layout();
     c->kl = make_pack_layout();
@@ -389,6 +389,21 @@ const char* var_profile_tag_name(int tag) { return (tag >= 0 && tag < TAG_COUNT)
 
 /* Record HIP events (on the launch stream) around every launch of kernel family `tag`
  * from now on (-1 = off).  Not for use under graph capture. */
+static int default_streams() {
+    int m = kDefaultStreams;
+    { const char* e = getenv("VAR_SERIAL"); if (e && e[0] == '1') m = 0; }
+    { const char* e = getenv("VAR_STREAMS"); if (e && e[0]) m = atoi(e) & 31; }
+    return m;
+}
+
+int var_set_streams(var_ctx* c, int mask) {
+    if (!c) return -1;
+    const int old = c->streams;
+    c->streams = mask < 0 ? default_streams() : (mask & 31);
+    c->serial = c->streams == 0;
+    return old;
+}
+
 int var_profile_select(var_ctx* c, int tag) {
     CHECK_CTX(c);
     SET_DEVICE(c);
