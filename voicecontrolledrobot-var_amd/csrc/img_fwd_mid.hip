@@ -1,0 +1,178 @@
+// Middle and end of the image CNN forward in ONE kernel: conv 3, conv 4 and conv 5 (32 -> 64 -> 64 -> 64
+// channels, each Conv2d 3x3 stride 2 pad 1 + bias + ReLU, models/pretext/arm_pretext_model.py:13-18).
+//
+// From the third conv on an image's activations are small (56 KB -> 31 KB -> 9 KB -> 2 KB): one workgroup owns one
+// image and walks the three layers with the activations resident in LDS.  Per layer: implicit GEMM on the
+// matrix cores exactly as img_conv_fwd.hip (D[n][pixel], filter rows prefetched from the packed image in L2,
+// B operand from the LDS tile), 12 waves = item groups x filter-row / channel slices folded through LDS in a
+// fixed order; the epilogue (bias + ReLU) writes each activation to HBM (backward needs it) AND into the
+// zero-padded LDS tile the next layer reads.  Two kernel launches, two activation round trips through HBM and
+// two pipeline fill/drain phases per step disappear.
+#include "img_stage.h"
+
+namespace {
+constexpr int MID_NW = 12, MID_NT = MID_NW * 64;
+
+// LDS tile of a layer input with HIN x HIN planes: [c][2*HO+1 rows][2*HO+2 cols], cell (r, col) = input (r-1, col-1)
+template <int HIN>
+struct MidTile {
+    static constexpr int HO = (HIN - 1) / 2 + 1;
+    static constexpr int IR = 2 * HO + 1, PW = 2 * HO + 2, PLANE = IR * PW;
+};
+
+// One conv layer of the workgroup's image.  xs: input tile (LDS), red: fold scratch (LDS, may alias xs),
+// xo: next layer's input tile (LDS, pre-zeroed pads) or nullptr, y: this image's output planes in HBM.
+template <int CIN, int COUT, int HIN, int NWI, int KY, int KC, int PLANE_O, int PW_O>
+__device__ __forceinline__ void mid_layer(const float* __restrict__ xs, float* __restrict__ red, float* __restrict__ xo,
+                                          const float* __restrict__ wp, const float* __restrict__ bias,
+                                          float* __restrict__ y, int tid) {
+    using T = MidTile<HIN>;
+    constexpr int HO = T::HO, WO = HO, NPIX = HO * WO;
+    constexpr int NPB = (NPIX + 31) / 32, NBLK = COUT / 32, ITEMS = NPB * NBLK, IPW = ITEMS / NWI;
+    constexpr int KS = KY * KC;
+    static_assert(NWI * KS == MID_NW && ITEMS % NWI == 0, "12 waves = item groups x K slices, whole items per wave");
+    const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int wv = wave % NWI, ks = wave / NWI;
+    const int kyi = ks % KY, kci = ks / KY;
+    constexpr int NKY = 3 / KY, CC = CIN / KC, SPT = CC / 2, U = SPT > 16 ? 16 : SPT, BPT = SPT / U, NBK = NKY * 3 * BPT;
+
+    int pixoff[IPW];
+    const float* wl[IPW];
+    f32x16 acc[IPW];
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+        const int it = wv + NWI * i;
+        const int pb = it % NPB, nb = it / NPB;
+        int p = pb * 32 + l31;
+        if (p >= NPIX) p = 0;
+        const int oy = p / WO, ox = p - oy * WO;
+        pixoff[i] = (2 * oy) * T::PW + 2 * ox + half * T::PLANE + kyi * NKY * T::PW + kci * CC * T::PLANE;
+        wl[i] = wp + nb * 32 + l31 + (half + (kyi * NKY * 3) * CIN + kci * CC) * COUT;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    }
+    float wbuf[2][IPW][U];
+#pragma unroll
+    for (int i = 0; i < IPW; ++i)
+#pragma unroll
+        for (int u = 0; u < U; ++u) wbuf[0][i][u] = wl[i][(2 * u) * COUT];
+#pragma unroll
+    for (int blk = 0; blk < NBK; ++blk) {
+        const int tap = blk / BPT, c2b = (blk % BPT) * U;
+        const int toff = (tap / 3) * T::PW + (tap % 3);
+        if (blk + 1 < NBK) {
+            const int ntap = (blk + 1) / BPT, nc2b = ((blk + 1) % BPT) * U;
+#pragma unroll
+            for (int i = 0; i < IPW; ++i)
+#pragma unroll
+                for (int u = 0; u < U; ++u) wbuf[(blk + 1) & 1][i][u] = wl[i][(ntap * CIN + 2 * (nc2b + u)) * COUT];
+        }
+        __builtin_amdgcn_sched_barrier(0);             // keep the prefetch above this block's MFMAs
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < IPW; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wbuf[blk & 1][i][u], xs[pixoff[i] + 2 * (c2b + u) * T::PLANE + toff],
+                                                              acc[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // fold the K slices (fixed order) through LDS; the input tile is dead after the barrier
+    __syncthreads();
+    if (ks > 0) {
+#pragma unroll
+        for (int i = 0; i < IPW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(((ks - 1) * NWI + wv) * IPW + i) * 1024 + r * 64 + lane] = acc[i][r];
+    }
+    __syncthreads();
+    if (ks == 0) {
+#pragma unroll
+        for (int q = 1; q < KS; ++q)
+#pragma unroll
+            for (int i = 0; i < IPW; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] += red[(((q - 1) * NWI + wv) * IPW + i) * 1024 + r * 64 + lane];
+        // epilogue: bias + ReLU -> HBM and the next layer's LDS tile
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const int it = wv + NWI * i;
+            const int pb = it % NPB, nb = it / NPB;
+            const int p = pb * 32 + l31;
+            if (p >= NPIX) continue;
+            const int oy = p / WO, ox = p - oy * WO;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float v = acc[i][r] + bias[n];
+                v = v > 0.f ? v : 0.f;
+                y[n * NPIX + p] = v;
+                if (xo) xo[n * PLANE_O + (oy + 1) * PW_O + ox + 1] = v;
+            }
+        }
+    }
+}
+
+template <int H2>
+struct MidCfg {
+    using T2 = MidTile<H2>;
+    static constexpr int H3 = T2::HO;
+    using T3 = MidTile<H3>;
+    static constexpr int H4 = T3::HO;
+    using T4 = MidTile<H4>;
+    static constexpr int H5 = T4::HO;
+    // region A: conv-3 input tile, later the conv-3 fold scratch, then the conv-5 input tile (act4)
+    // region B: conv-4 input tile (act3), later the fold scratch of conv 4 and conv 5
+    static constexpr int X2 = 32 * T2::PLANE, X3 = 64 * T3::PLANE, X4 = 64 * T4::PLANE;
+    static constexpr int RED3 = 2 * 4 * 2 * 1024, RED4 = 2 * 4 * 1 * 1024, RED5 = 5 * 2 * 1 * 1024;
+    static constexpr int A = ((X2 > RED3 ? X2 : RED3) + 3) & ~3;
+    static constexpr int Bsz = ((X3 > RED5 ? X3 : RED5) + 3) & ~3;
+    static constexpr int LDS_FLOATS = A + Bsz;
+    static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+    static_assert(X4 <= A && RED4 <= Bsz, "aliasing plan");
+};
+
+template <class C, int H2>
+__global__ void __launch_bounds__(MID_NT)
+img_fwd_mid_kernel(const float* __restrict__ x2, const float* __restrict__ w3, const float* __restrict__ b3,
+                   const float* __restrict__ w4, const float* __restrict__ b4, const float* __restrict__ w5,
+                   const float* __restrict__ b5, float* __restrict__ y3, float* __restrict__ y4, float* __restrict__ y5) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    float* ra = lds;
+    float* rb = lds + C::A;
+    // region B = conv 4's input tile: zero it once (pads stay zero, data cells are written by conv 3's epilogue)
+    lds_zero<MID_NT>(rb, C::Bsz, tid);
+    // conv 3 input: the image's act2 planes, padding materialised
+    lds_zero_cols<MID_NT>(ra, 32 * C::T2::IR, C::T2::PW, 0, 1, tid);
+    lds_zero_cols<MID_NT>(ra, 32 * C::T2::IR, C::T2::PW, H2 + 1, C::T2::PW - H2 - 1, tid);
+    stage_x_band<32, H2, H2, C::T2::IR, C::T2::PW, C::T2::PLANE, false, MID_NT>(ra, x2 + (size_t)b * 32 * H2 * H2, -1, true, tid);
+    __syncthreads();
+    mid_layer<32, 64, H2, 4, 3, 1, C::T3::PLANE, C::T3::PW>(ra, ra, rb, w3, b3, y3 + (size_t)b * 64 * C::H3 * C::H3, tid);
+    // region A is dead (conv 3's fold has been read): it becomes conv 5's input tile
+    __syncthreads();
+    lds_zero<MID_NT>(ra, (C::X4 + 3) & ~3, tid);
+    __syncthreads();
+    mid_layer<64, 64, C::H3, 4, 3, 1, C::T4::PLANE, C::T4::PW>(rb, rb, ra, w4, b4, y4 + (size_t)b * 64 * C::H4 * C::H4, tid);
+    __syncthreads();
+    mid_layer<64, 64, C::H4, 2, 3, 2, 1, 1>(ra, rb, nullptr, w5, b5, y5 + (size_t)b * 64 * C::H5 * C::H5, tid);
+}
+}  // namespace
+
+// conv 3 + conv 4 + conv 5 of the image CNN for 84 x 84 inputs (act2 21 x 21); leaves act[3], act[4], act[5]
+int launch_img_fwd_mid(var_ctx* c, hipStream_t s, const float* params, int B) {
+    using C = MidCfg<21>;
+    ProfScope prof(c, s, TAG_IMG_FWD0 + 2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)img_fwd_mid_kernel<C, 21>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        attr_set = true;
+    }
+    const ParamLayout& L = c->pl;
+    const PackLayout& K = c->kl;
+    hipLaunchKernelGGL((img_fwd_mid_kernel<C, 21>), dim3(B), dim3(MID_NT), C::LDS_BYTES, s, c->act[2],
+                       c->wpack + K.img_f[2], params + L.img_b[2], c->wpack + K.img_f[3], params + L.img_b[3],
+                       c->wpack + K.img_f[4], params + L.img_b[4], c->act[3], c->act[4], c->act[5]);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}

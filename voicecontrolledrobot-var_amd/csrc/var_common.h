@@ -181,6 +181,7 @@ int launch_img_fwd(var_ctx* c, hipStream_t s, const float* params, const void* i
                    long bstride, const int* image_index, int B);
 int launch_img_fwd_head(var_ctx* c, hipStream_t s, const float* params, const void* image, int is_u8, long bstride,
                         const int* image_index, int B);
+int launch_img_fwd_mid(var_ctx* c, hipStream_t s, const float* params, int B);
 // (launch_img_fwd also leaves c->relu1)
 int launch_img_fwd_conv2_pipe(var_ctx* c, hipStream_t s, const float* x, const float* wp, const float* bias,
                               float* y, int B);
