@@ -195,10 +195,19 @@ def main():
         ctx.profile_select(-1)
 
     if use_graph:
-        replay = tr.capture_dataset_step(pool.images, pool.clips, B, global_batch=B * world)
+        # the captured step walks a device-resident table of shuffled epochs by itself (no host copy per step);
+        # the host installs the next epochs' table when this one is used up
+        trows = 256
+        replay, load_table = tr.capture_epoch_steps(pool.images, pool.clips, B, pool.index_table(B, trows)[:trows].contiguous(),
+                                                    global_batch=B * world)
+        gstate = {"left": trows}
 
         def step():
-            replay(next_row())
+            if gstate["left"] == 0:
+                load_table(pool.index_table(B, trows)[:trows].contiguous())
+                gstate["left"] = trows
+            gstate["left"] -= 1
+            replay()
     for _ in range(args.warmup):
         step()
 

@@ -131,6 +131,17 @@ int var_adam_step_dev(var_ctx* ctx, void* stream, float* params, const float* gr
                       float* exp_avg_sq, long n, const float* lr_dev, float beta1, float beta2, float eps,
                       float weight_decay, int* step_dev);
 
+/* var_adam_step_dev plus the data-loader cursor of a graph-replayed epoch: index_table (n_rows x row_ints int32,
+ * e.g. [image_index | clip_index | lens] per step, built once per epoch on the device -- the reference's
+ * DataLoader(shuffle=True), VAR/pretext_VAR.py:26-31,55) is walked on the DEVICE: at the end of the step row
+ * (*cursor_dev + 1) mod n_rows is copied into index_row (the buffer the captured var_arm_loss_grad_pcm reads) and
+ * *cursor_dev is advanced, so a replay needs no host-side copy.  One kernel launch does the Adam update, the
+ * re-pack of the weight images, the step count and the row fetch. */
+int var_adam_step_graph(var_ctx* ctx, void* stream, float* params, const float* grads, float* exp_avg,
+                        float* exp_avg_sq, long n, const float* lr_dev, float beta1, float beta2, float eps,
+                        float weight_decay, int* step_dev, const int* index_table, int row_ints, int n_rows,
+                        int* cursor_dev, int* index_row);
+
 /* Audio front-end: Envs/audioLoader.py:147-157 (torchaudio MFCC branch) + :241-252
  * (processSoundFeat).  pcm: rows of `pcm_stride` int16 samples; output clip i reads row
  * clip_index[i] (NULL: row i) and lens[i] valid samples (<= pcm_stride; 0 = "empty" class =>

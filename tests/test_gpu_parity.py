@@ -253,3 +253,39 @@ def test_batch_256_properties(var_amd, golden_dir):
                                     neg[sl].cpu().numpy())
     assert abs(tr.loss.item() - l_ref) < 1e-5
     assert rel_err(tr.grads.cpu().numpy(), g_ref) < 1e-3
+
+
+def test_graph_replayed_epoch_equals_eager_steps(var_amd, golden_dir):
+    """The captured step (one launch for Adam + weight re-pack + step count + next index row, device-side
+    data-loader cursor) walks the index table exactly like eager step_from_dataset calls on the same rows, and
+    leaves the packed weight images identical to a fresh var_pack_weights of the updated parameters."""
+    sd = load(golden_dir, "kuka_weights.npz")
+    B = 16
+    pool = var_amd.SyntheticTripletPool(64, hw=84, seed=11, clips_per_class=4).freeze_pairs()
+    table = pool.index_table(B, 3)[:3].contiguous()                 # 3 step rows; the 4th replay wraps to row 0
+    # (the packed weight images belong to the device context: one trainer at a time)
+    mb = make_model(var_amd, sd, 84)
+    tb = var_amd.VARTrainer(mb, lr=1e-3, weight_decay=1e-6)
+    replay, load_table = tb.capture_epoch_steps(pool.images, pool.clips, B, table)
+    losses_b = [float(replay().item()) for _ in range(4)]
+    from var_amd._lib import Context
+    ctx = Context.get(0)
+    packed = ctx.debug_buffer("wpack").clone()
+    tb.pack()
+    torch.cuda.synchronize()
+    assert torch.equal(packed, ctx.debug_buffer("wpack"))
+    assert int(tb._g_cursor.item()) == 4 % 3 and int(tb._g_step.item()) == 4
+    load_table(table.flip(0).contiguous())                          # a new table rewinds the cursor
+    pb = mb.flat_parameters().cpu().numpy().copy()
+    replay()
+    assert int(tb._g_cursor.item()) == 1
+    ma = make_model(var_amd, sd, 84)
+    ta = var_amd.VARTrainer(ma, lr=1e-3, weight_decay=1e-6)
+    losses_a = []
+    for s in range(4):
+        r = table[s % 3]
+        losses_a.append(float(ta.step_from_dataset(pool.images, r[:B], pool.clips, r[B:3 * B], r[3 * B:]).item()))
+    torch.cuda.synchronize()
+    assert np.allclose(losses_a, losses_b, rtol=0, atol=1e-6), (losses_a, losses_b)
+    pa = ma.flat_parameters().cpu().numpy()
+    assert np.mean(np.abs(pa - pb) < 2e-6) > 0.995 and np.max(np.abs(pa - pb)) < 5e-3

@@ -44,6 +44,7 @@ _SIGNATURES = {
     "var_arm_loss_grad": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
     "var_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i]),
     "var_adam_step_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _f, _f, _f, _f, _vp]),
+    "var_adam_step_graph": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _f, _f, _f, _f, _vp, _vp, _i, _i, _vp, _vp]),
     "var_mfcc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "var_arm_loss_grad_pcm": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
     "var_profile_tag_count": (_i, []),

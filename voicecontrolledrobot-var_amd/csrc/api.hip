@@ -46,6 +46,8 @@ int var_init(int device_id, var_ctx** out) {
     e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipMalloc((void**)&c->wpack, sizeof(float) * (size_t)c->kl.total);
     if (e == hipSuccess) e = hipMalloc((void**)&c->loss_buf, sizeof(float) * 64);
+    if (e == hipSuccess) e = hipMemset(c->loss_buf, 0, sizeof(float) * 64);
+    c->done_ctr = (unsigned*)(c->loss_buf + 32);
     if (e != hipSuccess) {
         snprintf(g_init_err, sizeof(g_init_err), "var_init: %s", hipGetErrorString(e));
         delete c;
@@ -66,7 +68,7 @@ int var_init(int device_id, var_ctx** out) {
         delete c;
         return VAR_ERR_HIP;
     }
-    if (mfcc_build_tables(c) != VAR_OK) {
+    if (mfcc_build_tables(c) != VAR_OK || pack_table_upload(c) != VAR_OK) {
         snprintf(g_init_err, sizeof(g_init_err), "var_init: %s", c->err);
         delete c;
         return VAR_ERR_HIP;
@@ -82,6 +84,7 @@ int var_destroy(var_ctx* c) {
     if (c->wpack) (void)hipFree(c->wpack);
     if (c->loss_buf) (void)hipFree(c->loss_buf);
     if (c->mfcc_tab) (void)hipFree(c->mfcc_tab);
+    if (c->pack_segs_dev) (void)hipFree(c->pack_segs_dev);
     for (int i = 0; i < 2; i++) {
         if (c->ev_fork[i]) (void)hipEventDestroy(c->ev_fork[i]);
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
@@ -351,17 +354,26 @@ int var_adam_step(var_ctx* c, void* stream, float* params, const float* grads, f
 int var_adam_step_dev(var_ctx* c, void* stream, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                       long n, const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
                       int* step_dev) {
+    return var_adam_step_graph(c, stream, params, grads, exp_avg, exp_avg_sq, n, lr_dev, beta1, beta2, eps,
+                               weight_decay, step_dev, nullptr, 0, 0, nullptr, nullptr);
+}
+
+int var_adam_step_graph(var_ctx* c, void* stream, float* params, const float* grads, float* exp_avg,
+                        float* exp_avg_sq, long n, const float* lr_dev, float beta1, float beta2, float eps,
+                        float weight_decay, int* step_dev, const int* index_table, int row_ints, int n_rows,
+                        int* cursor_dev, int* index_row) {
     CHECK_CTX(c);
     if (!params || !grads || !exp_avg || !exp_avg_sq || !lr_dev || !step_dev || n <= 0) {
         VAR_SET_ERR(c, "var_adam_step_dev: bad argument");
         return VAR_ERR_ARG;
     }
+    if (index_table && (!cursor_dev || !index_row || row_ints <= 0 || n_rows <= 0)) {
+        VAR_SET_ERR(c, "var_adam_step_graph: index table without cursor / row buffer / sizes");
+        return VAR_ERR_ARG;
+    }
     SET_DEVICE(c);
-    hipStream_t s = (hipStream_t)stream;
-    int rc = launch_adam_dev(c, s, params, grads, exp_avg, exp_avg_sq, n, lr_dev, beta1, beta2, eps, weight_decay, step_dev);
-    if (rc != VAR_OK) return rc;
-    if (n == VAR_N_PARAMS) return launch_pack_weights(c, s, params);
-    return VAR_OK;
+    return launch_adam_dev(c, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, lr_dev, beta1, beta2, eps,
+                           weight_decay, step_dev, n == VAR_N_PARAMS, index_table, row_ints, n_rows, cursor_dev, index_row);
 }
 
 int var_mfcc(var_ctx* c, void* stream, const int16_t* pcm, const int* lens, const int* clip_index, int nclips,

@@ -1,6 +1,8 @@
 // Weight re-layout ("pack") and the fused flat-arena Adam step.
 //   pack : OIHW parameters -> the [k][n] / [tap][n][c] images the conv kernels read
 //   adam : torch.optim.Adam(...).step() (VAR/pretext_VAR.py:33-35,69) over one flat arena
+#include <stdlib.h>
+
 #include "var_common.h"
 
 struct PackSeg {
@@ -37,7 +39,7 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(PackTable T, const fl
     }
 }
 
-int launch_pack_weights(var_ctx* c, hipStream_t s, const float* params) {
+static PackTable make_pack_table(var_ctx* c) {
     const ParamLayout& L = c->pl;
     const PackLayout& K = c->kl;
     PackTable T{};
@@ -56,6 +58,12 @@ int launch_pack_weights(var_ctx* c, hipStream_t s, const float* params) {
     add(K.ih_w0t, kImgFeat * kHid, L.ih_w0, kImgFeat, kHid, 1, 0);   // plain transpose
     add(K.sh_w0t, kSndFeat * kHid, L.sh_w0, kSndFeat, kHid, 1, 0);
     T.nseg = n;   // 18
+    return T;
+}
+
+int launch_pack_weights(var_ctx* c, hipStream_t s, const float* params) {
+    const PackLayout& K = c->kl;
+    const PackTable T = make_pack_table(c);
     ProfScope prof(c, s, TAG_PACK);
     hipLaunchKernelGGL(pack_weights_kernel, dim3(256), dim3(256), 0, s, T, params, c->wpack, K.total);
     VAR_HIP_CHECK(c, hipGetLastError());
@@ -80,36 +88,117 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
 
 // Capturable variant (HIP graphs): the step count and the learning rate live in device memory, the
 // bias corrections are formed on the device, so a captured launch stays correct on every replay.
-__global__ void adam_tick_kernel(int* step) { if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1; }
-
-__global__ void __launch_bounds__(256) adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                        float* __restrict__ m, float* __restrict__ v, long n,
-                                                        const float* __restrict__ lr_dev, float b1, float b2,
-                                                        float eps, float wd, const int* __restrict__ step_dev) {
-    const int t = step_dev[0];
-    const double bc1 = 1.0 - pow((double)b1, (double)t);
-    const double bc2 = 1.0 - pow((double)b2, (double)t);
-    const float step_size = (float)((double)lr_dev[0] / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const float pi = p[i];
-        const float gi = g[i] + wd * pi;
-        const float mi = m[i] + (gi - m[i]) * (1.f - b1);
-        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p[i] = pi - step_size * (mi / denom);
+// ---- the graph-replayed step: Adam + weight re-pack + step counter + next index row, ONE launch ----
+// Every parameter element is updated once and SCATTERED to the (up to two) packed images that hold it -- the
+// inverse of pack_weights_kernel's gather, so the separate re-pack launch and its read of the arena go away.
+// The step count is read by every block at its start and advanced by the last block to finish (a device
+// counter tells which one that is), so the launch can be captured into a HIP graph without a "tick" kernel.
+// Block 0 also copies the next row of the epoch's index table into the row buffer the step's kernels read,
+// so a replay needs no host-side copy at all.
+__global__ void __launch_bounds__(256)
+adam_pack_dev_kernel(const PackSeg* __restrict__ segs, int nseg, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                     float* __restrict__ v, long n, const float* __restrict__ lr_dev, float b1, float b2, float eps,
+                     float wd, int* __restrict__ step_dev, unsigned* __restrict__ done_ctr, float* __restrict__ wpack,
+                     const int* __restrict__ idx_table, int row_ints, int n_rows, int* __restrict__ cursor,
+                     int* __restrict__ idx_row) {
+    // bias corrections: double-precision pow once per block, not per thread
+    __shared__ float sh_step[2];
+    const int t = step_dev[0] + 1;
+    if (threadIdx.x == 0) {
+        // beta^t by repeated squaring in double (t is an integer): ~40 multiplies instead of a software pow();
+        // agrees with pow() to a few ulp of double, far below the float the result is rounded to
+        auto ipow = [](double b, int e) { double r = 1.0; while (e > 0) { if (e & 1) r *= b; b *= b; e >>= 1; } return r; };
+        const double bc1 = 1.0 - ipow((double)b1, t);
+        const double bc2 = 1.0 - ipow((double)b2, t);
+        sh_step[0] = (float)((double)lr_dev[0] / bc1);
+        sh_step[1] = (float)sqrt(bc2);
+    }
+    __syncthreads();
+    const float step_size = sh_step[0], bc2_sqrt = sh_step[1];
+    if (blockIdx.x == 0 && idx_table) {
+        int next = cursor[0] + 1;
+        if (next >= n_rows) next = 0;
+        for (int e = threadIdx.x; e < row_ints; e += 256) idx_row[e] = idx_table[(size_t)next * row_ints + e];
+        __syncthreads();
+        if (threadIdx.x == 0) cursor[0] = next;
+    }
+    // segment table -> LDS (one copy per block); each wave then finds the segments that touch its 64 consecutive
+    // elements with ONE ballot (lane q tests segment q) instead of scanning the table per element
+    __shared__ PackSeg ssegs[20];
+    if (wpack) {
+        for (int e = threadIdx.x; e < nseg * (int)(sizeof(PackSeg) / 4); e += 256) ((int*)ssegs)[e] = ((const int*)segs)[e];
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    for (long w0 = (long)blockIdx.x * 256 + (threadIdx.x - lane); w0 < n; w0 += (long)gridDim.x * 256) {   // wave-uniform
+        const long i = w0 + lane;
+        float pn = 0.f;
+        if (i < n) {
+            const float pi = p[i];
+            const float gi = g[i] + wd * pi;
+            const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+            const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+            m[i] = mi;
+            v[i] = vi;
+            const float denom = sqrtf(vi) / bc2_sqrt + eps;
+            pn = pi - step_size * (mi / denom);
+            p[i] = pn;
+        }
+        if (wpack) {
+            bool hit = false;
+            if (lane < nseg) {
+                const int src = ssegs[lane].src, cnt = ssegs[lane].cin * ssegs[lane].cout * ssegs[lane].taps;
+                hit = src < w0 + 64 && src + cnt > w0;
+            }
+            unsigned long long mask = __ballot(hit);
+            while (mask) {
+                const int q = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const PackSeg S = ssegs[q];
+                const int e = (int)i - S.src;
+                if (i >= n || e < 0 || e >= S.cin * S.cout * S.taps) continue;
+                // (e, divisors < 2^18: quotient through a float reciprocal, then one exact correction step)
+                auto divmod = [](int a, int d, int& qq, int& r) {
+                    qq = (int)((float)a * __frcp_rn((float)d));
+                    r = a - qq * d;
+                    if (r < 0) { --qq; r += d; } else if (r >= d) { ++qq; r -= d; }
+                };
+                int c, tap, nn, rest;
+                if (S.type == 2) { divmod(e, S.cin, rest, c); divmod(rest, S.taps, nn, tap); }
+                else { divmod(e, S.taps, rest, tap); divmod(rest, S.cin, nn, c); }
+                const int d = S.type == 1 ? (tap * S.cout + nn) * S.cin + c : (tap * S.cin + c) * S.cout + nn;
+                wpack[S.dst + d] = pn;
+            }
+        }
+    }
+    // The last block to get here has seen every block read step_dev[0]: the increment carries a data dependency
+    // on the value read (t is never INT_MIN), so no fence is needed -- a device-scope fence here would write back
+    // the whole L2 once per block.
+    if (threadIdx.x == 0) {
+        if (atomicAdd(done_ctr, (unsigned)(t != (int)0x80000000)) == gridDim.x - 1) { step_dev[0] = t; done_ctr[0] = 0; }
     }
 }
 
+// the segment table, once (var_init), in device memory
+int pack_table_upload(var_ctx* c) {
+    const PackTable T = make_pack_table(c);
+    VAR_HIP_CHECK(c, hipMalloc((void**)&c->pack_segs_dev, sizeof(T.seg)));
+    VAR_HIP_CHECK(c, hipMemcpy(c->pack_segs_dev, T.seg, sizeof(T.seg), hipMemcpyHostToDevice));
+    c->pack_nseg = T.nseg;
+    return VAR_OK;
+}
+
 int launch_adam_dev(var_ctx* c, hipStream_t s, float* p, const float* g, float* m, float* v, long n,
-                    const float* lr_dev, float b1, float b2, float eps, float wd, int* step_dev) {
+                    const float* lr_dev, float b1, float b2, float eps, float wd, int* step_dev, bool repack,
+                    const int* idx_table, int row_ints, int n_rows, int* cursor, int* idx_row) {
     ProfScope prof(c, s, TAG_ADAM);
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, s, step_dev);
-    int grid = (int)((n + 255) / 256);
-    if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(adam_dev_kernel, dim3(grid), dim3(256), 0, s, p, g, m, v, n, lr_dev, b1, b2, eps, wd, step_dev);
+    // few blocks (4 elements per thread): every block ends with one device-scope atomic on the same word
+    int grid = (int)((n + 1023) / 1024);
+    if (grid > 256) grid = 256;
+    if (const char* e = getenv("VAR_ADAM_GRID")) { if (atoi(e) > 0) grid = atoi(e); }    // tuning aid
+    hipLaunchKernelGGL(adam_pack_dev_kernel, dim3(grid), dim3(256), 0, s, (const PackSeg*)c->pack_segs_dev, c->pack_nseg, p, g, m, v, n, lr_dev,
+                       b1, b2, eps, wd, step_dev, c->done_ctr, repack ? c->wpack : nullptr, idx_table, row_ints, n_rows,
+                       cursor, idx_row);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }

@@ -112,6 +112,8 @@ struct var_ctx {
     float* emb_raw = nullptr;     // (3B,3) pre-normalise
     float* gemb = nullptr;        // (3B,3) grads wrt normalised embeddings
     float* ghid = nullptr;        // (3B,128)
+    void* pack_segs_dev = nullptr; int pack_nseg = 0;   // pack segment table in device memory (pack_adam.hip)
+    unsigned* done_ctr = nullptr; // self-resetting block counter of the graph-replayed Adam kernel
     uint16_t* relu1 = nullptr;    // ReLU bits of the first image activation: [b][half][y][x], bit r <-> channel (r&3)+8(r>>2)+4*half
     float* slabs = nullptr;       // split-K partial weight gradients
     size_t slab_floats = 0;
@@ -170,6 +172,7 @@ struct ProfScope {
 static inline int conv_out(int h) { return (h - 1) / 2 + 1; }   // 3x3 s2 p1
 
 int mfcc_build_tables(var_ctx* c);
+int pack_table_upload(var_ctx* c);
 size_t img_slab_floats();
 int launch_img_wgrad(var_ctx* c, hipStream_t s, int layer, const void* x, long bstride, int is_u8, const float* gy, int B);
 int launch_img_wgrad_reduce(var_ctx* c, hipStream_t s, float* grads, int lo, int hi);
@@ -204,6 +207,7 @@ int launch_triplet(var_ctx* c, hipStream_t s, const float* a, const float* p, co
 int launch_adam(var_ctx* c, hipStream_t s, float* p, const float* g, float* m, float* v, long n,
                 float lr, float b1, float b2, float eps, float wd, int step);
 int launch_adam_dev(var_ctx* c, hipStream_t s, float* p, const float* g, float* m, float* v, long n,
-                    const float* lr_dev, float b1, float b2, float eps, float wd, int* step_dev);
+                    const float* lr_dev, float b1, float b2, float eps, float wd, int* step_dev, bool repack,
+                    const int* idx_table, int row_ints, int n_rows, int* cursor, int* idx_row);
 int launch_mfcc(var_ctx* c, hipStream_t s, const int16_t* pcm, const int* lens, const int* clip_index, int nclips,
                 int pcm_stride, int out_frames, float* out);

@@ -96,6 +96,14 @@ class SyntheticTripletPool:
         lens = self.len_tab[:, perm].view(2, steps, batch).permute(1, 0, 2).reshape(steps, 2 * batch)
         return torch.cat([idx.to(torch.int32), clip, lens], dim=1).contiguous()
 
+    def index_table(self, batch, min_rows):
+        """At least `min_rows` step rows: whole shuffled epochs (epoch_index_table) back to back."""
+        parts, rows = [], 0
+        while rows < min_rows:
+            parts.append(self.epoch_index_table(batch))
+            rows += parts[-1].shape[0]
+        return torch.cat(parts, dim=0).contiguous()
+
     def sample_indices(self, batch):
         """Random item ids and clip ids (device tensors, no host sync)."""
         idx = torch.randint(0, self.n_items, (batch,), device=self.device, generator=self._gen)

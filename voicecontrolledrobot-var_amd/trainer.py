@@ -45,8 +45,14 @@ class VARTrainer:
         self.force_collective = os.environ.get("VAR_FORCE_ALLREDUCE") == "1"
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
+        self.pack()
+
+    def pack(self):
+        """Refresh the packed weight images from the parameter arena (needed after loading a checkpoint or any
+        direct edit of the parameters; every optimiser step does it by itself)."""
         c = self.ctx
-        c.check(c.lib.var_pack_weights(c.handle, current_stream_handle(), ptr(flat)), "var_pack_weights")
+        c.check(c.lib.var_pack_weights(c.handle, current_stream_handle(), ptr(self.model.flat_parameters())),
+                "var_pack_weights")
 
     @property
     def grads(self):
@@ -83,7 +89,7 @@ class VARTrainer:
                                     int(self.step_count)), "var_adam_step")
 
     # ---- HIP-graph replay of the whole step (launch-bound otherwise: ~35 kernels + stream fork/joins) ----
-    def capture_dataset_step(self, images, pcm, batch, global_batch=None):
+    def capture_dataset_step(self, images, pcm, batch, global_batch=None, _table=None):
         """Capture step_from_dataset(images, idx, pcm, clip_idx, lens) once; returns replay(idx_row) where
         idx_row is an int32 CUDA tensor of 5*batch entries [image_index | clip_index (2B) | lens (2B)].
         Step count and learning rate live on the device (var_adam_step_dev); set_lr() updates the latter."""
@@ -106,10 +112,14 @@ class VARTrainer:
                                                 self.gbuf.data_ptr() + 4 * N_PARAMS, None), "var_arm_loss_grad_pcm")
 
         def body_adam():
-            c.check(c.lib.var_adam_step_dev(c.handle, current_stream_handle(), ptr(flat), ptr(self.gbuf),
-                                            ptr(self.exp_avg), ptr(self.exp_avg_sq), N_PARAMS, ptr(self._g_lr),
-                                            float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                                            float(self.wd), ptr(self._g_step)), "var_adam_step_dev")
+            tab, rows, row_ints = _table if _table is not None else (None, 0, 0)
+            c.check(c.lib.var_adam_step_graph(c.handle, current_stream_handle(), ptr(flat), ptr(self.gbuf),
+                                              ptr(self.exp_avg), ptr(self.exp_avg_sq), N_PARAMS, ptr(self._g_lr),
+                                              float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                              float(self.wd), ptr(self._g_step),
+                                              ptr(tab) if tab is not None else None, row_ints, rows,
+                                              ptr(self._g_cursor) if tab is not None else None,
+                                              ptr(self._g_idx) if tab is not None else None), "var_adam_step_graph")
 
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
@@ -130,7 +140,8 @@ class VARTrainer:
         torch.cuda.current_stream().wait_stream(side)
 
         def replay(idx_row):
-            self._g_idx.copy_(idx_row, non_blocking=True)
+            if idx_row is not None:                      # None: the captured step walks its own index table
+                self._g_idx.copy_(idx_row, non_blocking=True)
             graphs[0].replay()
             if len(graphs) > 1:
                 self.allreduce()
@@ -138,6 +149,33 @@ class VARTrainer:
             self.step_count += 1
             return self.loss
         return replay
+
+    def capture_epoch_steps(self, images, pcm, batch, table, global_batch=None):
+        """Like capture_dataset_step, with the data-loader cursor on the device too: `table` is an int32 CUDA
+        tensor (rows, 5*batch) of step rows [image_index | clip_index (2B) | lens (2B)] (one or more shuffled epochs,
+        SyntheticTripletPool.index_table).  Returns (replay, load_table): replay() launches the captured step --
+        no host-side copy, the step itself fetches the next row (var_adam_step_graph); load_table(t) installs a
+        new table of the same shape (next epochs) and rewinds the cursor.  After `rows` replays without a new
+        table the walk starts over."""
+        dev = self.dev
+        B = batch
+        rows, row_ints = int(table.shape[0]), int(table.shape[1])
+        assert row_ints == 5 * B and table.dtype == torch.int32 and table.is_cuda and table.is_contiguous()
+        self._g_table = torch.empty_like(table)
+        self._g_cursor = torch.zeros(1, dtype=torch.int32, device=dev)
+        replay_row = self.capture_dataset_step(images, pcm, B, global_batch, _table=(self._g_table, rows, row_ints))
+
+        def load_table(t):
+            assert t.shape == self._g_table.shape
+            self._g_table.copy_(t, non_blocking=True)
+            self._g_idx.copy_(t[0], non_blocking=True)
+            self._g_cursor.zero_()
+
+        load_table(table)
+
+        def replay():
+            return replay_row(None)
+        return replay, load_table
 
     def set_lr(self, lr):
         self.lr = lr
