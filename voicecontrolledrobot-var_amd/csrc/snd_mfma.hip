@@ -416,14 +416,24 @@ snd_wgrad_kernel(int clip_lo, int clip_hi, int B, const float* __restrict__ pos,
     }
 }
 
+// 32 consecutive elements x 8 slices of the slab index per block: a lane sums every 8th slab with all its loads
+// in flight at once (one memory latency instead of G/8), the 8 partial sums are folded in a fixed order.
 __global__ void __launch_bounds__(256)
 snd_reduce_kernel(const float* __restrict__ slabs, int G, float* __restrict__ out) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= SND_SLICE) return;
+    __shared__ float part[8][33];
+    const int l32 = threadIdx.x & 31, gs = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + l32;
+    const bool live = e < SND_SLICE;
     float s = 0.f;
-#pragma unroll 8
-    for (int g = 0; g < G; ++g) s += slabs[(size_t)g * SND_SLICE + e];
-    out[e] = s;
+    if (live) {
+#pragma unroll 16
+        for (int g = gs; g < G; g += 8) s += slabs[(size_t)g * SND_SLICE + e];
+    }
+    part[gs][l32] = s;
+    __syncthreads();
+    if (gs == 0 && live)
+        out[e] = ((part[0][l32] + part[1][l32]) + (part[2][l32] + part[3][l32])) +
+                 ((part[4][l32] + part[5][l32]) + (part[6][l32] + part[7][l32]));
 }
 }  // namespace
 
@@ -473,7 +483,7 @@ int launch_snd_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads,
                            c->sact[1], c->sact[2], c->sact[3], c->gsact[1], c->gsact[2], c->gsact[3], c->gsact[4], slabs);
     }
     ProfScope prof(c, s, TAG_SND_REDUCE);
-    hipLaunchKernelGGL(snd_reduce_kernel, dim3((SND_SLICE + 255) / 256), dim3(256), 0, s, slabs, G,
+    hipLaunchKernelGGL(snd_reduce_kernel, dim3((SND_SLICE + 31) / 32), dim3(256), 0, s, slabs, G,
                        grads + L.snd_w[0]);
     VAR_HIP_CHECK(c, hipGetLastError());
     (void)params;
