@@ -19,8 +19,9 @@
 
 #include "img_stage.h"
 
-template <int CIN_, int COUT_, int H_, bool U8_, int R_, int NU_, int KS_>
+template <int CIN_, int COUT_, int H_, bool U8_, int R_, int NU_, int KS_, bool DB_ = false>
 struct WgCfg {
+    static constexpr bool DB = DB_;                 // two LDS stages: the next unit is stored while this one is multiplied
     static constexpr int CIN = CIN_, COUT = COUT_, H = H_, W = H_, R = R_, NU = NU_;
     static constexpr bool U8 = U8_;
     static constexpr bool SMALLC = (CIN < 32);      // first layer: columns = (tap, c), 27 of 32 used
@@ -42,7 +43,8 @@ struct WgCfg {
     static constexpr int NT = NW * 64;
     static constexpr int XS = (NU * UNIT_X + 3) & ~3, YS = NU * UNIT_Y;
     static constexpr int ZPAD = (XS + YS + 3) & ~3;  // a few always-zero floats: A operand of idle k-steps
-    static constexpr int LDS_FLOATS = ((ZPAD + 4) > NW * 1024 ? (ZPAD + 4) : NW * 1024);
+    static constexpr int STAGE = ZPAD + 4;
+    static constexpr int LDS_FLOATS = ((DB ? 2 : 1) * STAGE > NW * 1024 ? (DB ? 2 : 1) * STAGE : NW * 1024);
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
     static constexpr int SLAB = SMALLC ? (32 * 32 + 32) : (32 * 9 * 32 + 32);
     static constexpr int HSTEPS = (WO + 1) / 2;
@@ -128,35 +130,70 @@ img_wgrad_kernel(const void* __restrict__ xin, long bstride, const int* __restri
         sx.issue(st.bx, bstride, st.row0x, st.nvalid);
         sy.issue(st.by, YSTRIDE, st.row0y, st.nvalid);
     }
-#pragma unroll 1
-    for (int unit0 = first; unit0 < total_units; unit0 += G * C::NU) {
-        __syncthreads();                              // previous stage's MFMAs are done reading LDS
-        {
-            const Stage st = make_stage(unit0);       // same (cheap, uniform) bookkeeping the loads were issued with
-            sx.store(xs, st.row0x, st.nvalid);
-            sy.store(ys, st.row0y, st.nvalid);
-        }
-        __syncthreads();
-        if (unit0 + G * C::NU < total_units) {        // in flight during the MFMAs below
-            const Stage st = make_stage(unit0 + G * C::NU);
-            sx.issue(st.bx, bstride, st.row0x, st.nvalid);
-            sy.issue(st.by, YSTRIDE, st.row0y, st.nvalid);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+    auto multiply = [&](const float* stage) {
 #pragma unroll
         for (int i = 0; i < C::NSTEP; ++i) {
-            const float a = lds[aos[i]];
+            const float a = stage[aos[i]];
             bsum += a;
             if constexpr (C::SMALLC) {
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xs[bos[i]], acc[0], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, stage[bos[i]], acc[0], 0, 0, 0);
             } else {
-                const float b0 = xs[bos[i]], b1 = xs[bos[i] + 1], b2 = xs[bos[i] + 2];
+                const float b0 = stage[bos[i]], b1 = stage[bos[i] + 1], b2 = stage[bos[i] + 2];
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
                 acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
+    };
+    if constexpr (C::DB) {
+        // Two stages: unit i+1 is written into the other stage right after this wave's MFMAs of unit i, while
+        // slower waves are still multiplying -- one barrier per unit, and the LDS store pass hides behind matrix work.
+        __syncthreads();
+        if (first < total_units) {
+            const Stage st = make_stage(first);
+            sx.store(lds, st.row0x, st.nvalid);
+            sy.store(lds + C::XS, st.row0y, st.nvalid);
+        }
+        __syncthreads();
+        int it = 0;
+#pragma unroll 1
+        for (int unit0 = first; unit0 < total_units; unit0 += G * C::NU, ++it) {
+            const int next = unit0 + G * C::NU;
+            const bool more = next < total_units;
+            const Stage sn = make_stage(more ? next : unit0);
+            if (more) {
+                sx.issue(sn.bx, bstride, sn.row0x, sn.nvalid);
+                sy.issue(sn.by, YSTRIDE, sn.row0y, sn.nvalid);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(lds + (it & 1) * C::STAGE);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+                float* nst = lds + ((it + 1) & 1) * C::STAGE;
+                sx.store(nst, sn.row0x, sn.nvalid);
+                sy.store(nst + C::XS, sn.row0y, sn.nvalid);
+            }
+            __syncthreads();
+        }
+    } else {
+#pragma unroll 1
+        for (int unit0 = first; unit0 < total_units; unit0 += G * C::NU) {
+            __syncthreads();                              // previous stage's MFMAs are done reading LDS
+            {
+                const Stage st = make_stage(unit0);       // same (cheap, uniform) bookkeeping the loads were issued with
+                sx.store(xs, st.row0x, st.nvalid);
+                sy.store(ys, st.row0y, st.nvalid);
+            }
+            __syncthreads();
+            if (unit0 + G * C::NU < total_units) {        // in flight during the MFMAs below
+                const Stage st = make_stage(unit0 + G * C::NU);
+                sx.issue(st.bx, bstride, st.row0x, st.nvalid);
+                sy.issue(st.by, YSTRIDE, st.row0y, st.nvalid);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(lds);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 
     // ---- fold the K slices through LDS (fixed order) and write this workgroup's partial slab ----
@@ -256,7 +293,7 @@ img_wgrad_reduce_kernel(RedTable T, const float* __restrict__ slabs, float* __re
 //                   CIN COUT  H   U8    R  NU KS
 using W84_0u = WgCfg<3, 32, 84, true, 6, 1, 4>;
 using W84_0f = WgCfg<3, 32, 84, false, 6, 1, 4>;
-using W84_1 = WgCfg<32, 32, 42, false, 3, 1, 4>;
+using W84_1 = WgCfg<32, 32, 42, false, 3, 1, 4, true>;
 using W84_2 = WgCfg<32, 64, 21, false, 11, 1, 4>;
 using W84_3 = WgCfg<64, 64, 11, false, 6, 1, 4>;
 using W84_4 = WgCfg<64, 64, 6, false, 3, 4, 4>;
