@@ -203,18 +203,23 @@ static int encoder_fwd(var_ctx* c, hipStream_t s, const float* params, const voi
     }
     const bool snd = pos || neg;
     hipStream_t ss = (c->streams & 1) ? c->side : s;
-    if (snd) {
-        const bool mfcc_main = (c->streams & 16) != 0;
+    // Launch ORDER matters under graph replay: the chain that is enqueued first after a fork keeps the hardware
+    // queue of its predecessor, the other branch pays a cross-queue hand-over (5-10 us).  So the caller's stream
+    // (MFCC -> image CNN -> image head) is enqueued first and the sound branch, which has slack, afterwards.
+    const bool mfcc_main = (c->streams & 16) != 0 || !(c->streams & 1);
+    if (snd && audio && audio->pcm) {
         if (!mfcc_main && (rc = fork_side(c, s, 0)) != VAR_OK) return rc;
-        if (audio && audio->pcm &&
-            (rc = launch_mfcc(c, mfcc_main ? s : ss, audio->pcm, audio->lens, audio->clip_index, 2 * B, audio->pcm_stride,
+        if ((rc = launch_mfcc(c, mfcc_main ? s : ss, audio->pcm, audio->lens, audio->clip_index, 2 * B, audio->pcm_stride,
                               VAR_MFCC_FRAMES, c->mfcc_buf)) != VAR_OK) return rc;
-        if (mfcc_main && (rc = fork_side(c, s, 0)) != VAR_OK) return rc;
-        if ((rc = launch_snd_fwd(c, ss, params, pos, neg, B)) != VAR_OK) return rc;
     }
+    if (snd && mfcc_main && (rc = fork_side(c, s, 0)) != VAR_OK) return rc;
     if (image && (rc = launch_img_fwd(c, s, params, image, is_u8, bstride, image_index, B)) != VAR_OK) return rc;
-    if ((rc = launch_heads_fwd(c, s, snd ? ss : s, params, B, image != nullptr, pos != nullptr, neg != nullptr)) != VAR_OK) return rc;
-    if (snd && (rc = join_side(c, s, 0)) != VAR_OK) return rc;
+    if (image && (rc = launch_heads_fwd(c, s, s, params, B, true, false, false)) != VAR_OK) return rc;
+    if (snd) {
+        if ((rc = launch_snd_fwd(c, ss, params, pos, neg, B)) != VAR_OK) return rc;
+        if ((rc = launch_heads_fwd(c, ss, ss, params, B, false, pos != nullptr, neg != nullptr)) != VAR_OK) return rc;
+        if ((rc = join_side(c, s, 0)) != VAR_OK) return rc;
+    }
     c->saved_B = B;
     c->saved_image = image;
     c->saved_u8 = is_u8;
@@ -261,10 +266,14 @@ static int encoder_bwd(var_ctx* c, hipStream_t s, const float* params, float* gr
     hipStream_t ss = (c->streams & 2) ? c->side : s;
     hipStream_t sw = (c->streams & 4) ? c->side2 : s;
     hipStream_t sr = (c->streams & 8) ? c->side3 : sw;
+    // (same ordering rule as in the forward: the caller's chain first, then the side branch)
     if ((rc = fork_side(c, s, 1)) != VAR_OK) return rc;
-    if ((rc = launch_heads_bwd(c, s, ss, params, grads, B, c->saved_image != nullptr, snd_lo, snd_hi)) != VAR_OK) return rc;
+    if (c->saved_image) {
+        if ((rc = launch_heads_bwd(c, s, s, params, grads, B, true, 0, 0)) != VAR_OK) return rc;
+        if ((rc = launch_img_bwd(c, s, sw, sr, params, grads, B)) != VAR_OK) return rc;
+    }
+    if ((rc = launch_heads_bwd(c, ss, ss, params, grads, B, false, snd_lo, snd_hi)) != VAR_OK) return rc;
     if ((rc = launch_snd_bwd(c, ss, params, grads, B)) != VAR_OK) return rc;
-    if (c->saved_image && (rc = launch_img_bwd(c, s, sw, sr, params, grads, B)) != VAR_OK) return rc;
     return join_side(c, s, 1);
 }
 
