@@ -130,7 +130,7 @@ int var_plan(var_ctx* c, int max_batch, int img_hw) {
         o_gsact[l] = carve(n);
     }
     const size_t o_hid_i = carve(B * kHid), o_hid_s = carve(2 * B * kHid);
-    const size_t o_emb = carve(9 * B), o_emb_raw = carve(9 * B), o_gemb = carve(24 * B);
+    const size_t o_emb = carve(9 * B), o_emb_raw = carve(9 * B), o_gemb = carve(24 * B), o_hpart = carve(48 * B);
     const size_t o_ghid = carve(6 * B * kHid);
     const size_t n_img_slab = img_slab_floats(), n_snd_slab = snd_slab_floats();
     const size_t o_slab = carve(n_img_slab + n_snd_slab);
@@ -143,6 +143,7 @@ int var_plan(var_ctx* c, int max_batch, int img_hw) {
     for (int l = 1; l <= 5; l++) { c->act[l] = P(o_act[l]); c->gact[l] = P(o_gact[l]); }
     for (int l = 1; l <= 4; l++) { c->sact[l] = P(o_sact[l]); c->gsact[l] = P(o_gsact[l]); }
     c->hid_i = P(o_hid_i); c->hid_s = P(o_hid_s);
+    c->head_part = P(o_hpart);
     c->emb = P(o_emb); c->emb_raw = P(o_emb_raw); c->gemb = P(o_gemb); c->ghid = P(o_ghid);
     c->slabs = P(o_slab);
     c->mfcc_buf = P(o_mfcc);

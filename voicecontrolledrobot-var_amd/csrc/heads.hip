@@ -11,108 +11,6 @@
 #include "var_common.h"
 
 namespace {
-constexpr int U = 8;    // k-steps per register-prefetch block
-
-// ------------------------------------------------------------------------------------------
-// forward: 32 rows x 128 hidden units per workgroup; wave w owns hidden units [32w, 32w+32)
-//   D[row][n] = sum_k X[row][k] * W0T[k][n]
-// ------------------------------------------------------------------------------------------
-template <int K>
-__global__ void __launch_bounds__(1024)
-heads_fwd_kernel(const float* __restrict__ x, int R, const float* __restrict__ w0t,
-                 const float* __restrict__ b0, const float* __restrict__ w1, const float* __restrict__ b1,
-                 float* __restrict__ hid, float* __restrict__ emb_raw, float* __restrict__ emb) {
-    // 16 waves: wave = kslice*4 + nblock; each wave multiplies a quarter of K for its 32 hidden units,
-    // the four partial tiles are folded through LDS in a fixed order.
-    constexpr int LDX = K + 1, NT = 1024, KSL = 4;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* xs = lds;                    // [32][K+1]
-    float* ps = lds;                    // reused after the GEMM: partial tiles [4][32][129]
-    float* hs = lds + 4 * 32 * 129;     // [32][129]
-    float* raw = hs + 32 * 129;         // [32][4]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int half = lane >> 5, l31 = lane & 31;
-    const int nblk = wave & 3, ksl = wave >> 2;
-    const int r0 = blockIdx.x * 32;
-    {
-        constexpr int TOT = 32 * K / 4;
-        const float4* src = (const float4*)(x + (size_t)r0 * K);
-        const int lim = (R - r0) * (K / 4);
-        constexpr int IT = (TOT + NT - 1) / NT;
-        float4 v[IT];
-#pragma unroll
-        for (int u = 0; u < IT; ++u) {
-            const int e = tid + NT * u;
-            v[u] = (e < TOT && e < lim) ? src[e] : float4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int u = 0; u < IT; ++u) {
-            const int e = tid + NT * u;
-            if (e < TOT) {
-                const int r = (e * 4) / K, k = (e * 4) - r * K;
-                float* d = xs + r * LDX + k;
-                d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
-            }
-        }
-    }
-    __syncthreads();
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    constexpr int STEPS = K / 2 / KSL;              // k-steps of this wave's slice
-    constexpr int UF = (STEPS % 8 == 0) ? 8 : 10;   // prefetch block: 72 = 9 x 8 (K = 576), 20 = 2 x 10 (K = 160)
-    static_assert((K / 2) % KSL == 0 && STEPS % UF == 0, "K must split into 4 slices of whole prefetch blocks");
-    constexpr int NBK = STEPS / UF;
-    const int kbase = ksl * STEPS;                  // first k-step of the slice
-    const float* wl = w0t + (size_t)(2 * kbase + half) * kHid + nblk * 32 + l31;
-    const float* xl = xs + l31 * LDX + 2 * kbase + half;
-    float wb[2][UF];
-#pragma unroll
-    for (int u = 0; u < UF; ++u) wb[0][u] = wl[(2 * u) * kHid];
-#pragma unroll
-    for (int blk = 0; blk < NBK; ++blk) {
-        if (blk + 1 < NBK) {
-#pragma unroll
-            for (int u = 0; u < UF; ++u) wb[(blk + 1) & 1][u] = wl[(2 * ((blk + 1) * UF + u)) * kHid];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < UF; ++u)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xl[2 * (blk * UF + u)], wb[blk & 1][u], acc, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();                    // everyone is done reading xs
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        ps[(ksl * 32 + row) * 129 + nblk * 32 + l31] = acc[r];
-    }
-    __syncthreads();
-    for (int e = tid; e < 32 * kHid; e += NT) {
-        const int row = e >> 7, n = e & 127;
-        float v = ((ps[row * 129 + n] + ps[(32 + row) * 129 + n]) + (ps[(64 + row) * 129 + n] + ps[(96 + row) * 129 + n])) + b0[n];
-        v = v > 0.f ? v : 0.f;
-        hs[row * 129 + n] = v;
-        if (r0 + row < R) hid[(size_t)(r0 + row) * kHid + n] = v;
-    }
-    __syncthreads();
-    if (tid < 96) {
-        const int r = tid / 3, d = tid - r * 3;
-        float s = b1[d];
-#pragma unroll 8
-        for (int j = 0; j < kHid; ++j) s += hs[r * 129 + j] * w1[d * kHid + j];
-        raw[r * 4 + d] = s;
-    }
-    __syncthreads();
-    if (tid < 32 && r0 + tid < R) {
-        const int row = r0 + tid;
-        const float a = raw[tid * 4], b = raw[tid * 4 + 1], c = raw[tid * 4 + 2];
-        const float nrm = sqrtf(a * a + b * b + c * c);
-        const float den = nrm > 1e-12f ? nrm : 1e-12f;
-        emb_raw[row * 3 + 0] = a; emb_raw[row * 3 + 1] = b; emb_raw[row * 3 + 2] = c;
-        emb[row * 3 + 0] = a / den; emb[row * 3 + 1] = b / den; emb[row * 3 + 2] = c / den;
-    }
-}
 
 // loss_out[0] = inv_count * sum_i max(||a-p+eps|| - ||a-n+eps|| + margin, 0); grads of loss_out.
 __global__ void __launch_bounds__(256)
@@ -296,19 +194,126 @@ heads_bwd_gemm_kernel(int R /*rows in this call*/, int RT /*row stride of ghidT*
 }
 }  // namespace
 
+// ------------------------------------------------------------------------------------------
+// forward, spread over 4x the workgroups: grid = (row blocks of 32, 4 blocks of 32 hidden units); 4 waves split K.
+// Each workgroup leaves its 32 hidden columns (post-ReLU, backward needs them) and its PARTIAL of the 128 -> 3
+// output layer; heads_finish_kernel adds the four partials in a fixed order, the bias, and normalises.
+// (One 16-wave workgroup per 32 rows would keep only 8 / 16 CUs busy for 8 us of matrix work each.)
+// ------------------------------------------------------------------------------------------
+template <int K>
+__global__ void __launch_bounds__(256)
+heads_fwd_split_kernel(const float* __restrict__ x, int R, const float* __restrict__ w0t, const float* __restrict__ b0,
+                       const float* __restrict__ w1, float* __restrict__ hid, float* __restrict__ part) {
+    constexpr int LDX = K + 1, NT = 256, KSL = 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* xs = lds;                    // [32][K+1]
+    float* ps = lds;                    // reused after the GEMM: partial tiles [4][32][33]
+    float* hs = lds + 4 * 32 * 33;      // [32][33]
+    const int tid = threadIdx.x, lane = tid & 63, ksl = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int nblk = blockIdx.y;
+    const int r0 = blockIdx.x * 32;
+    {
+        constexpr int TOT = 32 * K / 4;
+        const float4* src = (const float4*)(x + (size_t)r0 * K);
+        const int lim = (R - r0) * (K / 4);
+        constexpr int IT = (TOT + NT - 1) / NT;
+        float4 v[IT];
+#pragma unroll
+        for (int u = 0; u < IT; ++u) {
+            const int e = tid + NT * u;
+            v[u] = (e < TOT && e < lim) ? src[e] : float4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < IT; ++u) {
+            const int e = tid + NT * u;
+            if (e < TOT) {
+                const int r = (e * 4) / K, k = (e * 4) - r * K;
+                float* d = xs + r * LDX + k;
+                d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+            }
+        }
+    }
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    constexpr int STEPS = K / 2 / KSL;
+    constexpr int UF = (STEPS % 8 == 0) ? 8 : 10;
+    static_assert((K / 2) % KSL == 0 && STEPS % UF == 0, "K must split into 4 slices of whole prefetch blocks");
+    constexpr int NBK = STEPS / UF;
+    const int kbase = ksl * STEPS;
+    const float* wl = w0t + (size_t)(2 * kbase + half) * kHid + nblk * 32 + l31;
+    const float* xl = xs + l31 * LDX + 2 * kbase + half;
+    float wb[2][UF];
+#pragma unroll
+    for (int u = 0; u < UF; ++u) wb[0][u] = wl[(2 * u) * kHid];
+#pragma unroll
+    for (int blk = 0; blk < NBK; ++blk) {
+        if (blk + 1 < NBK) {
+#pragma unroll
+            for (int u = 0; u < UF; ++u) wb[(blk + 1) & 1][u] = wl[(2 * ((blk + 1) * UF + u)) * kHid];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UF; ++u)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xl[2 * (blk * UF + u)], wb[blk & 1][u], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                    // everyone is done reading xs
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        ps[(ksl * 32 + row) * 33 + l31] = acc[r];
+    }
+    __syncthreads();
+    for (int e = tid; e < 32 * 32; e += NT) {
+        const int row = e >> 5, n = e & 31;
+        float v = ((ps[row * 33 + n] + ps[(32 + row) * 33 + n]) + (ps[(64 + row) * 33 + n] + ps[(96 + row) * 33 + n])) + b0[nblk * 32 + n];
+        v = v > 0.f ? v : 0.f;
+        hs[row * 33 + n] = v;
+        if (r0 + row < R) hid[(size_t)(r0 + row) * kHid + nblk * 32 + n] = v;
+    }
+    __syncthreads();
+    if (tid < 96) {
+        const int r = tid / 3, d = tid - r * 3;
+        float s = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < 32; ++j) s += hs[r * 33 + j] * w1[d * kHid + nblk * 32 + j];
+        if (r0 + r < R) part[((size_t)(r0 + r) * 4 + nblk) * 4 + d] = s;
+    }
+}
+
+// emb_raw = b1 + ((part0 + part1) + (part2 + part3)); emb = emb_raw / max(||emb_raw||, 1e-12)
+__global__ void __launch_bounds__(256)
+heads_finish_kernel(const float* __restrict__ part, const float* __restrict__ b1, int R, float* __restrict__ emb_raw,
+                    float* __restrict__ emb) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= R) return;
+    const float4* p = (const float4*)(part + (size_t)row * 16);
+    const float4 p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3];
+    const float a = ((p0.x + p1.x) + (p2.x + p3.x)) + b1[0];
+    const float b = ((p0.y + p1.y) + (p2.y + p3.y)) + b1[1];
+    const float c = ((p0.z + p1.z) + (p2.z + p3.z)) + b1[2];
+    const float nrm = sqrtf(a * a + b * b + c * c);
+    const float den = nrm > 1e-12f ? nrm : 1e-12f;
+    emb_raw[row * 3 + 0] = a; emb_raw[row * 3 + 1] = b; emb_raw[row * 3 + 2] = c;
+    emb[row * 3 + 0] = a / den; emb[row * 3 + 1] = b / den; emb[row * 3 + 2] = c / den;
+}
+
 template <int K>
 static int run_heads_fwd(var_ctx* c, hipStream_t s, const float* x, int R, const float* w0t, const float* b0,
-                         const float* w1, const float* b1, float* hid, float* emb_raw, float* emb) {
-    constexpr int A1 = 32 * (K + 1) * 4, A2 = (5 * 32 * 129 + 128) * 4;
+                         const float* w1, const float* b1, float* hid, float* emb_raw, float* emb, float* part) {
+    constexpr int A1 = 32 * (K + 1) * 4, A2 = 5 * 32 * 33 * 4;
     constexpr int LDS_BYTES = A1 > A2 ? A1 : A2;
     static bool attr_set = false;
     if (!attr_set) {
-        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)heads_fwd_kernel<K>,
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)heads_fwd_split_kernel<K>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL(heads_fwd_kernel<K>, dim3((R + 31) / 32), dim3(1024), LDS_BYTES, s, x, R, w0t, b0, w1, b1,
-                       hid, emb_raw, emb);
+    hipLaunchKernelGGL(heads_fwd_split_kernel<K>, dim3((R + 31) / 32, 4), dim3(256), LDS_BYTES, s, x, R, w0t, b0, w1, hid, part);
+    hipLaunchKernelGGL(heads_finish_kernel, dim3((R + 255) / 256), dim3(256), 0, s, part, b1, R, emb_raw, emb);
     return VAR_OK;
 }
 
@@ -320,14 +325,14 @@ int launch_heads_fwd(var_ctx* c, hipStream_t s, hipStream_t ss, const float* par
     if (has_img) {
         ProfScope prof(c, s, TAG_HEADS_FWD);
         if ((rc = run_heads_fwd<kImgFeat>(c, s, c->act[5], B, c->wpack + K.ih_w0t, params + L.ih_b0, params + L.ih_w1,
-                                          params + L.ih_b1, c->hid_i, c->emb_raw, c->emb)) != VAR_OK) return rc;
+                                          params + L.ih_b1, c->hid_i, c->emb_raw, c->emb, c->head_part)) != VAR_OK) return rc;
     }
     if (has_pos || has_neg) {
         const int lo = has_pos ? 0 : B, hi = has_neg ? 2 * B : B;
         if ((rc = run_heads_fwd<kSndFeat>(c, ss, c->sact[4] + (size_t)lo * kSndFeat, hi - lo, c->wpack + K.sh_w0t,
                                           params + L.sh_b0, params + L.sh_w1, params + L.sh_b1,
                                           c->hid_s + (size_t)lo * kHid, c->emb_raw + 3 * (B + lo),
-                                          c->emb + 3 * (B + lo))) != VAR_OK) return rc;
+                                          c->emb + 3 * (B + lo), c->head_part + 16 * (size_t)(B + lo))) != VAR_OK) return rc;
     }
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;

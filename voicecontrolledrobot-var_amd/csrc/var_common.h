@@ -110,6 +110,7 @@ struct var_ctx {
     float* hid_s = nullptr;       // (2B,128)
     float* emb = nullptr;         // (3B,3) normalised [img | pos | neg]
     float* emb_raw = nullptr;     // (3B,3) pre-normalise
+    float* head_part = nullptr;   // (3B,4,4) partials of the 128 -> 3 layer per block of 32 hidden units
     float* gemb = nullptr;        // (3B,3) grads wrt normalised embeddings
     float* ghid = nullptr;        // (3B,128)
     void* pack_segs_dev = nullptr; int pack_nseg = 0;   // pack segment table in device memory (pack_adam.hip)
