@@ -196,7 +196,7 @@ static int join_side(var_ctx* c, hipStream_t s, int i) {
 
 static int encoder_fwd(var_ctx* c, hipStream_t s, const float* params, const void* image, int is_u8,
                        long bstride, const int* image_index, const float* pos, const float* neg,
-                       const AudioIn* audio, int B) {
+                       const AudioIn* audio, int B, bool finish = true) {
     int rc;
     if (audio && audio->pcm) {
         pos = c->mfcc_buf;
@@ -215,10 +215,10 @@ static int encoder_fwd(var_ctx* c, hipStream_t s, const float* params, const voi
     }
     if (snd && mfcc_main && (rc = fork_side(c, s, 0)) != VAR_OK) return rc;
     if (image && (rc = launch_img_fwd(c, s, params, image, is_u8, bstride, image_index, B)) != VAR_OK) return rc;
-    if (image && (rc = launch_heads_fwd(c, s, s, params, B, true, false, false)) != VAR_OK) return rc;
+    if (image && (rc = launch_heads_fwd(c, s, s, params, B, true, false, false, finish)) != VAR_OK) return rc;
     if (snd) {
         if ((rc = launch_snd_fwd(c, ss, params, pos, neg, B)) != VAR_OK) return rc;
-        if ((rc = launch_heads_fwd(c, ss, ss, params, B, false, pos != nullptr, neg != nullptr)) != VAR_OK) return rc;
+        if ((rc = launch_heads_fwd(c, ss, ss, params, B, false, pos != nullptr, neg != nullptr, finish)) != VAR_OK) return rc;
         if ((rc = join_side(c, s, 0)) != VAR_OK) return rc;
     }
     c->saved_B = B;
@@ -255,7 +255,10 @@ int var_arm_encoder_fwd(var_ctx* c, void* stream, const float* params, const voi
     return VAR_OK;
 }
 
-static int encoder_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads) {
+// fused: the head rows finish the embeddings and form the triplet gradient themselves (heads.hip); the loss value
+// is computed on the side branch
+static int encoder_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads, bool fused = false,
+                       float margin = 0.f, float inv_count = 0.f, float* loss_out = nullptr) {
     const int B = c->saved_B;
     int rc;
     if (!c->saved_image || !c->saved_pos || !c->saved_neg) {
@@ -270,10 +273,11 @@ static int encoder_bwd(var_ctx* c, hipStream_t s, const float* params, float* gr
     // (same ordering rule as in the forward: the caller's chain first, then the side branch)
     if ((rc = fork_side(c, s, 1)) != VAR_OK) return rc;
     if (c->saved_image) {
-        if ((rc = launch_heads_bwd(c, s, s, params, grads, B, true, 0, 0)) != VAR_OK) return rc;
+        if ((rc = launch_heads_bwd(c, s, s, params, grads, B, true, 0, 0, fused, margin, inv_count)) != VAR_OK) return rc;
         if ((rc = launch_img_bwd(c, s, sw, sr, params, grads, B)) != VAR_OK) return rc;
     }
-    if ((rc = launch_heads_bwd(c, ss, ss, params, grads, B, false, snd_lo, snd_hi)) != VAR_OK) return rc;
+    if ((rc = launch_heads_bwd(c, ss, ss, params, grads, B, false, snd_lo, snd_hi, fused, margin, inv_count)) != VAR_OK) return rc;
+    if (fused && (rc = launch_triplet_loss(c, ss, params, B, margin, inv_count, loss_out)) != VAR_OK) return rc;
     if ((rc = launch_snd_bwd(c, ss, params, grads, B)) != VAR_OK) return rc;
     return join_side(c, s, 1);
 }
@@ -311,7 +315,13 @@ static int loss_grad_impl(var_ctx* c, hipStream_t s, const float* params, const 
     int rc = check_plan(c, B, H, who);
     if (rc != VAR_OK) return rc;
     SET_DEVICE(c);
-    if ((rc = encoder_fwd(c, s, params, image, image_is_u8, image_bstride, image_index, mfcc_pos, mfcc_neg, audio, B)) != VAR_OK) return rc;
+    // The training step proper (all three branches, no embedding output requested) takes the fused path: no finish
+    // and no triplet kernel on the caller's chain.  VAR_NO_FUSED_LOSS=1 (tuning aid) keeps the separate kernels.
+    static const bool allow_fused = !getenv("VAR_NO_FUSED_LOSS");
+    const bool fused = allow_fused && !feats_out && image && (mfcc_pos || (audio && audio->pcm)) && (mfcc_neg || (audio && audio->pcm));
+    if ((rc = encoder_fwd(c, s, params, image, image_is_u8, image_bstride, image_index, mfcc_pos, mfcc_neg, audio, B,
+                          !fused)) != VAR_OK) return rc;
+    if (fused) return encoder_bwd(c, s, params, grads, true, margin, inv_count, loss_out);
     if ((rc = launch_triplet(c, s, c->emb, c->emb + 3 * B, c->emb + 6 * B, B, margin, inv_count, loss_out,
                              c->gemb, c->gemb + 3 * B, c->gemb + 6 * B)) != VAR_OK) return rc;
     if (feats_out)

@@ -75,6 +75,102 @@ heads_bwd_rows_kernel(int R, const float* __restrict__ w1, const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------
+// The training step's form of the two kernels above plus heads_finish_kernel and triplet_kernel: a row's triplet
+// gradient depends only on its own sample (a_i, p_i, n_i), so every row block finishes the three embeddings of its
+// sample from the forward partials, forms the loss gradient of its own role (image / positive / negative) and
+// carries on with the row-wise backward.  The critical path loses two launches and a cross-stream hand-over:
+// the loss VALUE (triplet_loss_kernel) is computed beside it on the side stream.
+// ------------------------------------------------------------------------------------------
+struct Emb3 { float raw[3], y[3], den; };
+__device__ __forceinline__ Emb3 finish_emb(const float* __restrict__ part_row, const float* __restrict__ b1) {
+    const float4* p = (const float4*)part_row;
+    const float4 p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3];
+    Emb3 e;
+    e.raw[0] = ((p0.x + p1.x) + (p2.x + p3.x)) + b1[0];
+    e.raw[1] = ((p0.y + p1.y) + (p2.y + p3.y)) + b1[1];
+    e.raw[2] = ((p0.z + p1.z) + (p2.z + p3.z)) + b1[2];
+    const float nrm = sqrtf(e.raw[0] * e.raw[0] + e.raw[1] * e.raw[1] + e.raw[2] * e.raw[2]);
+    e.den = nrm > 1e-12f ? nrm : 1e-12f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) e.y[d] = e.raw[d] / e.den;
+    return e;
+}
+// loss term of one sample and the gradients wrt the three normalised embeddings (triplet_kernel's arithmetic)
+__device__ __forceinline__ float triplet_row(const Emb3& a, const Emb3& p, const Emb3& n, float margin, float inv_count,
+                                             float (&ga)[3], float (&gp)[3], float (&gn)[3]) {
+    float dp[3], dn[3], sp = 0.f, sn = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        dp[d] = (a.y[d] - p.y[d]) + 1e-6f;
+        dn[d] = (a.y[d] - n.y[d]) + 1e-6f;
+        sp += dp[d] * dp[d];
+        sn += dn[d] * dn[d];
+    }
+    const float dap = sqrtf(sp), dan = sqrtf(sn);
+    const float l = dap - dan + margin;
+    const bool active = l > 0.f;
+    const float s = active ? inv_count : 0.f;
+    const float ip = dap > 0.f ? 1.f / dap : 0.f, in_ = dan > 0.f ? 1.f / dan : 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float up = dp[d] * ip, un = dn[d] * in_;
+        ga[d] = s * (up - un);
+        gp[d] = -s * up;
+        gn[d] = s * un;
+    }
+    return active ? l : 0.f;
+}
+
+// rows [g0, g0 + gridDim.x) of the (3B) stack [image | positive | negative]; part = (3B,4,4) forward partials
+__global__ void __launch_bounds__(128)
+heads_bwd_rows_fused_kernel(int R, int B, int g0, const float* __restrict__ w1, const float* __restrict__ hid,
+                            const float* __restrict__ part, const float* __restrict__ b1_img,
+                            const float* __restrict__ b1_snd, float margin, float inv_count,
+                            float* __restrict__ emb_raw, float* __restrict__ emb, float* __restrict__ graw_out,
+                            float* __restrict__ ghid, float* __restrict__ ghidT) {
+    const int row = blockIdx.x, n = threadIdx.x;
+    const int g = g0 + row, role = g / B, i = g - role * B;
+    const Emb3 ea = finish_emb(part + (size_t)i * 16, b1_img);
+    const Emb3 ep = finish_emb(part + (size_t)(B + i) * 16, b1_snd);
+    const Emb3 en = finish_emb(part + (size_t)(2 * B + i) * 16, b1_snd);
+    float ga[3], gp[3], gn[3];
+    (void)triplet_row(ea, ep, en, margin, inv_count, ga, gp, gn);
+    const Emb3& me = role == 0 ? ea : (role == 1 ? ep : en);
+    const float e0 = role == 0 ? ga[0] : (role == 1 ? gp[0] : gn[0]);
+    const float e1 = role == 0 ? ga[1] : (role == 1 ? gp[1] : gn[1]);
+    const float e2 = role == 0 ? ga[2] : (role == 1 ? gp[2] : gn[2]);
+    if (n < 3) { emb_raw[g * 3 + n] = me.raw[n]; emb[g * 3 + n] = me.y[n]; }
+    const float dot = me.y[0] * e0 + me.y[1] * e1 + me.y[2] * e2;
+    const float q0 = (e0 - me.y[0] * dot) / me.den, q1 = (e1 - me.y[1] * dot) / me.den, q2 = (e2 - me.y[2] * dot) / me.den;
+    if (n < 4) graw_out[row * 4 + n] = n == 0 ? q0 : (n == 1 ? q1 : (n == 2 ? q2 : 0.f));
+    float v = q0 * w1[n] + q1 * w1[kHid + n] + q2 * w1[2 * kHid + n];
+    if (!(hid[(size_t)row * kHid + n] > 0.f)) v = 0.f;
+    ghid[(size_t)row * kHid + n] = v;
+    ghidT[(size_t)n * R + row] = v;
+}
+
+// loss_out[0] = inv_count * sum_i max(||a-p+eps|| - ||a-n+eps|| + margin, 0) from the forward partials (fixed order)
+__global__ void __launch_bounds__(256)
+triplet_loss_kernel(const float* __restrict__ part, const float* __restrict__ b1_img, const float* __restrict__ b1_snd,
+                    int B, float margin, float inv_count, float* __restrict__ loss_out) {
+    __shared__ float psum[4];
+    const int tid = threadIdx.x;
+    float local = 0.f;
+    for (int i = tid; i < B; i += 256) {
+        const Emb3 ea = finish_emb(part + (size_t)i * 16, b1_img);
+        const Emb3 ep = finish_emb(part + (size_t)(B + i) * 16, b1_snd);
+        const Emb3 en = finish_emb(part + (size_t)(2 * B + i) * 16, b1_snd);
+        float ga[3], gp[3], gn[3];
+        local += triplet_row(ea, ep, en, margin, inv_count, ga, gp, gn);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if ((tid & 63) == 0) psum[tid >> 6] = local;
+    __syncthreads();
+    if (tid == 0) loss_out[0] = ((psum[0] + psum[1]) + (psum[2] + psum[3])) * inv_count;
+}
+
+// ------------------------------------------------------------------------------------------
 // backward, GEMM part: one wave per 32x32 output tile, D[i][j] = sum_q A[q][i] * Bm[q][j]
 // with BOTH operands stored [q][free] (free index contiguous => 128-byte coalesced rows):
 //   dW0[n][k]  : A = ghid [row][n],  Bm = x   [row][k],  q = row   (+ db0 = column sums of A)
@@ -303,7 +399,8 @@ heads_finish_kernel(const float* __restrict__ part, const float* __restrict__ b1
 
 template <int K>
 static int run_heads_fwd(var_ctx* c, hipStream_t s, const float* x, int R, const float* w0t, const float* b0,
-                         const float* w1, const float* b1, float* hid, float* emb_raw, float* emb, float* part) {
+                         const float* w1, const float* b1, float* hid, float* emb_raw, float* emb, float* part,
+                         bool finish) {
     constexpr int A1 = 32 * (K + 1) * 4, A2 = 5 * 32 * 33 * 4;
     constexpr int LDS_BYTES = A1 > A2 ? A1 : A2;
     static bool attr_set = false;
@@ -313,26 +410,26 @@ static int run_heads_fwd(var_ctx* c, hipStream_t s, const float* x, int R, const
         attr_set = true;
     }
     hipLaunchKernelGGL(heads_fwd_split_kernel<K>, dim3((R + 31) / 32, 4), dim3(256), LDS_BYTES, s, x, R, w0t, b0, w1, hid, part);
-    hipLaunchKernelGGL(heads_finish_kernel, dim3((R + 255) / 256), dim3(256), 0, s, part, b1, R, emb_raw, emb);
+    if (finish) hipLaunchKernelGGL(heads_finish_kernel, dim3((R + 255) / 256), dim3(256), 0, s, part, b1, R, emb_raw, emb);
     return VAR_OK;
 }
 
 int launch_heads_fwd(var_ctx* c, hipStream_t s, hipStream_t ss, const float* params, int B, bool has_img,
-                     bool has_pos, bool has_neg) {
+                     bool has_pos, bool has_neg, bool finish) {
     const ParamLayout& L = c->pl;
     const PackLayout& K = c->kl;
     int rc;
     if (has_img) {
         ProfScope prof(c, s, TAG_HEADS_FWD);
         if ((rc = run_heads_fwd<kImgFeat>(c, s, c->act[5], B, c->wpack + K.ih_w0t, params + L.ih_b0, params + L.ih_w1,
-                                          params + L.ih_b1, c->hid_i, c->emb_raw, c->emb, c->head_part)) != VAR_OK) return rc;
+                                          params + L.ih_b1, c->hid_i, c->emb_raw, c->emb, c->head_part, finish)) != VAR_OK) return rc;
     }
     if (has_pos || has_neg) {
         const int lo = has_pos ? 0 : B, hi = has_neg ? 2 * B : B;
         if ((rc = run_heads_fwd<kSndFeat>(c, ss, c->sact[4] + (size_t)lo * kSndFeat, hi - lo, c->wpack + K.sh_w0t,
                                           params + L.sh_b0, params + L.sh_w1, params + L.sh_b1,
                                           c->hid_s + (size_t)lo * kHid, c->emb_raw + 3 * (B + lo),
-                                          c->emb + 3 * (B + lo), c->head_part + 16 * (size_t)(B + lo))) != VAR_OK) return rc;
+                                          c->emb + 3 * (B + lo), c->head_part + 16 * (size_t)(B + lo), finish)) != VAR_OK) return rc;
     }
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
@@ -346,25 +443,49 @@ int launch_triplet(var_ctx* c, hipStream_t s, const float* a, const float* p, co
     return VAR_OK;
 }
 
+int launch_triplet_loss(var_ctx* c, hipStream_t s, const float* params, int B, float margin, float inv_count,
+                        float* loss_out) {
+    const ParamLayout& L = c->pl;
+    ProfScope prof(c, s, TAG_TRIPLET);
+    hipLaunchKernelGGL(triplet_loss_kernel, dim3(1), dim3(256), 0, s, c->head_part, params + L.ih_b1, params + L.sh_b1, B,
+                       margin, inv_count, loss_out);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}
+
 // gemb (3B,3) must hold the gradients wrt the normalised embeddings [img | pos | neg].
 // Produces gact[5] (B,576), gsact[4] (2B,160) and the 8 head gradient tensors.
 int launch_heads_bwd(var_ctx* c, hipStream_t s, hipStream_t ss, const float* params, float* grads, int B, bool has_img,
-                     int snd_lo, int snd_hi) {
+                     int snd_lo, int snd_hi, bool fused, float margin, float inv_count) {
     const ParamLayout& L = c->pl;
     const size_t mB = (size_t)c->maxB;
     float* graw = c->gemb + 9 * mB;                       // (3B,4)
     float* ghidT = c->ghid + 3 * mB * kHid;               // second half of the ghid buffer: [128][rows]
     {
+        // fused: the rows finish their sample's embeddings and form the triplet gradient themselves (forward
+        // partials in c->head_part); otherwise gemb holds the gradients wrt the normalised embeddings
         ProfScope prof(c, s, TAG_HEADS_BWD_ROWS);
-        if (has_img)
-            hipLaunchKernelGGL(heads_bwd_rows_kernel, dim3(B), dim3(128), 0, s, B, params + L.ih_w1, c->hid_i,
-                               c->emb_raw, c->emb, c->gemb, graw, c->ghid, ghidT);
+        if (has_img) {
+            if (fused)
+                hipLaunchKernelGGL(heads_bwd_rows_fused_kernel, dim3(B), dim3(128), 0, s, B, B, 0, params + L.ih_w1,
+                                   c->hid_i, c->head_part, params + L.ih_b1, params + L.sh_b1, margin, inv_count,
+                                   c->emb_raw, c->emb, graw, c->ghid, ghidT);
+            else
+                hipLaunchKernelGGL(heads_bwd_rows_kernel, dim3(B), dim3(128), 0, s, B, params + L.ih_w1, c->hid_i,
+                                   c->emb_raw, c->emb, c->gemb, graw, c->ghid, ghidT);
+        }
         if (snd_hi > snd_lo) {
             const int R = snd_hi - snd_lo;
-            hipLaunchKernelGGL(heads_bwd_rows_kernel, dim3(R), dim3(128), 0, ss, R, params + L.sh_w1,
-                               c->hid_s + (size_t)snd_lo * kHid, c->emb_raw + 3 * (B + snd_lo),
-                               c->emb + 3 * (B + snd_lo), c->gemb + 3 * (B + snd_lo), graw + 4 * (B + snd_lo),
-                               c->ghid + (size_t)(B + snd_lo) * kHid, ghidT + (size_t)B * kHid);
+            if (fused)
+                hipLaunchKernelGGL(heads_bwd_rows_fused_kernel, dim3(R), dim3(128), 0, ss, R, B, B + snd_lo,
+                                   params + L.sh_w1, c->hid_s + (size_t)snd_lo * kHid, c->head_part, params + L.ih_b1,
+                                   params + L.sh_b1, margin, inv_count, c->emb_raw, c->emb, graw + 4 * (B + snd_lo),
+                                   c->ghid + (size_t)(B + snd_lo) * kHid, ghidT + (size_t)B * kHid);
+            else
+                hipLaunchKernelGGL(heads_bwd_rows_kernel, dim3(R), dim3(128), 0, ss, R, params + L.sh_w1,
+                                   c->hid_s + (size_t)snd_lo * kHid, c->emb_raw + 3 * (B + snd_lo),
+                                   c->emb + 3 * (B + snd_lo), c->gemb + 3 * (B + snd_lo), graw + 4 * (B + snd_lo),
+                                   c->ghid + (size_t)(B + snd_lo) * kHid, ghidT + (size_t)B * kHid);
         }
     }
     {
