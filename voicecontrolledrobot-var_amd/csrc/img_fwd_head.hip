@@ -106,7 +106,13 @@ img_fwd_head_kernel(const void* __restrict__ image, long bstride, const int* __r
     const int pixoff2 = C::A1S + u2 * C::UNIT_1 + (2 * oyl2 + ky) * C::PW1 + 2 * ox2 + half * C::PLANE_1;
     const int wl2 = C::WDS + ((ky * 3) * C::CH + half) * C::CH + l31;      // + (kx*CH + 2*c2)*CH
 
-    BandCopy<3, C::HI, C::HI, C::IRI, C::U8, NT, C::NU> cx;
+    // The next tile's image band is fetched and stored by the waves that idle during the fold (ky > 0): their loads
+    // fly during conv 2, their LDS stores happen while the ky = 0 waves run the epilogue.
+    constexpr int CPW = C::NW >= 12 ? 6 : C::NW - C::NPB2;       // copy waves
+    constexpr int CPT = CPW * 64;
+    const bool copier = wave >= C::NPB2 && wave < C::NPB2 + CPW;
+    const int ctid = tid - C::NPB2 * 64;
+    BandCopy<3, C::HI, C::HI, C::IRI, C::U8, CPT, C::NU> cx;
     struct Tile { const XT* im0; const XT* im1; int rx0, rx1; bool ok0, ok1; };
     auto gather_rows = [&](int tile, int& gi0, int& gi1) {       // dataset rows (optional gather), one tile ahead
         const int u0 = tile * C::NU, u1 = u0 + C::NU - 1;
@@ -130,9 +136,9 @@ img_fwd_head_kernel(const void* __restrict__ image, long bstride, const int* __r
     if (tile < ntiles) {
         gather_rows(tile, gi0, gi1);
         const Tile t = make_tile(tile, gi0, gi1);
-        cx.issue(t.im0, t.im1, t.rx0, t.rx1, tid);
+        if (copier) cx.issue(t.im0, t.im1, t.rx0, t.rx1, ctid);
         __syncthreads();                                   // table is in place
-        cx.template store<C::UNIT_I, C::PLANE_I, C::PWI, 1>(lds + C::IMS, lut, t.rx0, t.rx1, t.ok0, t.ok1, tid);
+        if (copier) cx.template store<C::UNIT_I, C::PLANE_I, C::PWI, 1>(lds + C::IMS, lut, t.rx0, t.rx1, t.ok0, t.ok1, ctid);
     }
     if (tile + (int)gridDim.x < ntiles) gather_rows(tile + gridDim.x, gi0, gi1);
 #pragma unroll 1
@@ -140,11 +146,12 @@ img_fwd_head_kernel(const void* __restrict__ image, long bstride, const int* __r
         __syncthreads();                                   // (1) image band staged; previous fold is done with LDS
         const int next = tile + gridDim.x;
         const bool more = next < ntiles;
-        int tid_t = tid;                                   // opaque copy: see BandCopy
+        int tid_t = tid, ctid_t = ctid;                    // opaque copies: see BandCopy
         asm volatile("" : "+v"(tid_t));
+        asm volatile("" : "+v"(ctid_t));
         const Tile tn = make_tile(more ? next : tile, gi0, gi1);
         if (next + (int)gridDim.x < ntiles) gather_rows(next + gridDim.x, gi0, gi1);
-        if (more) cx.issue(tn.im0, tn.im1, tn.rx0, tn.rx1, tid_t);     // in flight during conv 1
+        if (more && copier) cx.issue(tn.im0, tn.im1, tn.rx0, tn.rx1, ctid_t);     // in flight during conv 1 and conv 2
         // pad columns of the act1 tile (the fold scratch of the previous tile ran over them)
         lds_zero_cols<NT>(lds + C::A1S, C::NU * C::CH * C::IR1, C::PW1, 0, 1, tid_t);
         lds_zero_cols<NT>(lds + C::A1S, C::NU * C::CH * C::IR1, C::PW1, C::W1 + 1, C::PW1 - C::W1 - 1, tid_t);
@@ -189,7 +196,6 @@ img_fwd_head_kernel(const void* __restrict__ image, long bstride, const int* __r
             }
         }
         __syncthreads();                                   // (2) act1 tile complete; image band is dead
-        if (more) cx.template store<C::UNIT_I, C::PLANE_I, C::PWI, 1>(lds + C::IMS, lut, tn.rx0, tn.rx1, tn.ok0, tn.ok1, tid_t);
 
         // ---- conv 2: this wave's filter row of its pixel block ----
         f32x16 acc;
@@ -227,6 +233,7 @@ img_fwd_head_kernel(const void* __restrict__ image, long bstride, const int* __r
             for (int r = 0; r < 16; ++r) lds[C::A1S + ((ky - 1) * C::NPB2 + blk2) * 1024 + r * 64 + lane] = acc[r];
         }
         __syncthreads();                                   // (4)
+        if (more && copier) cx.template store<C::UNIT_I, C::PLANE_I, C::PWI, 1>(lds + C::IMS, lut, tn.rx0, tn.rx1, tn.ok0, tn.ok1, ctid_t);
         if (ky == 0) {
             const int unit = tile * C::NU + u2;
             const bool uok = unit < total_units;

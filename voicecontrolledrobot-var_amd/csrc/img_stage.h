@@ -19,6 +19,10 @@ __device__ __forceinline__ void lds_zero(float* dst, int nfloats, int tid) {
 // data cells are all (re)written by the staging pass, so no full clear and no barrier before staging is needed.
 template <int NT>
 __device__ __forceinline__ void lds_zero_cols(float* dst, int nrows, int stride, int c0, int nc, int tid) {
+    if (nc == 1) {                                       // the common case: no division per element
+        for (int r = tid; r < nrows; r += NT) dst[r * stride + c0] = 0.f;
+        return;
+    }
     for (int e = tid; e < nrows * nc; e += NT) {
         const int r = e / nc, c = e - r * nc;
         dst[r * stride + c0 + c] = 0.f;
