@@ -36,26 +36,25 @@ __device__ __forceinline__ void mid_layer(const float* __restrict__ xs, float* _
     const int kyi = ks % KY, kci = ks / KY;
     constexpr int NKY = 3 / KY, CC = CIN / KC, SPT = CC / 2, U = SPT > 16 ? 16 : SPT, BPT = SPT / U, NBK = NKY * 3 * BPT;
 
+    // a wave's IPW items share the channel block (nb) and differ in the pixel block: ONE filter stream per wave
+    static_assert(NPB % IPW == 0, "a wave's items must share their channel block");
+    constexpr int GPB = NPB / IPW;                           // pixel-block groups
+    const int nb = wv / GPB, pb0 = (wv % GPB) * IPW;
     int pixoff[IPW];
-    const float* wl[IPW];
     f32x16 acc[IPW];
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
-        const int it = wv + NWI * i;
-        const int pb = it % NPB, nb = it / NPB;
-        int p = pb * 32 + l31;
+        int p = (pb0 + i) * 32 + l31;
         if (p >= NPIX) p = 0;
         const int oy = p / WO, ox = p - oy * WO;
         pixoff[i] = (2 * oy) * T::PW + 2 * ox + half * T::PLANE + kyi * NKY * T::PW + kci * CC * T::PLANE;
-        wl[i] = wp + nb * 32 + l31 + (half + (kyi * NKY * 3) * CIN + kci * CC) * COUT;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     }
-    float wbuf[2][IPW][U];
+    const float* wl = wp + nb * 32 + l31 + (half + (kyi * NKY * 3) * CIN + kci * CC) * COUT;
+    float wbuf[2][U];
 #pragma unroll
-    for (int i = 0; i < IPW; ++i)
-#pragma unroll
-        for (int u = 0; u < U; ++u) wbuf[0][i][u] = wl[i][(2 * u) * COUT];
+    for (int u = 0; u < U; ++u) wbuf[0][u] = wl[(2 * u) * COUT];
 #pragma unroll
     for (int blk = 0; blk < NBK; ++blk) {
         const int tap = blk / BPT, c2b = (blk % BPT) * U;
@@ -63,48 +62,55 @@ __device__ __forceinline__ void mid_layer(const float* __restrict__ xs, float* _
         if (blk + 1 < NBK) {
             const int ntap = (blk + 1) / BPT, nc2b = ((blk + 1) % BPT) * U;
 #pragma unroll
-            for (int i = 0; i < IPW; ++i)
-#pragma unroll
-                for (int u = 0; u < U; ++u) wbuf[(blk + 1) & 1][i][u] = wl[i][(ntap * CIN + 2 * (nc2b + u)) * COUT];
+            for (int u = 0; u < U; ++u) wbuf[(blk + 1) & 1][u] = wl[(ntap * CIN + 2 * (nc2b + u)) * COUT];
         }
         __builtin_amdgcn_sched_barrier(0);             // keep the prefetch above this block's MFMAs
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int i = 0; i < IPW; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wbuf[blk & 1][i][u], xs[pixoff[i] + 2 * (c2b + u) * T::PLANE + toff],
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wbuf[blk & 1][u], xs[pixoff[i] + 2 * (c2b + u) * T::PLANE + toff],
                                                               acc[i], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
-    // fold the K slices (fixed order) through LDS; the input tile is dead after the barrier
+    // Fold the K slices through LDS with the work spread over ALL waves: slice k owns accumulator registers
+    // [16k/KS, 16(k+1)/KS) of its item group -- every wave parks the registers it does not own, then sums its own
+    // ones over the other slices (fixed order) and runs the epilogue (bias + ReLU -> HBM and the next layer's LDS
+    // tile) for them.  The input tile is dead after the first barrier (the scratch may alias it).
+    auto own_lo = [](int k) { return (16 * k) / KS; };
+    constexpr int SLOT = (KS - 1) * NWI * IPW * 64;          // floats per owned register index
     __syncthreads();
-    if (ks > 0) {
 #pragma unroll
-        for (int i = 0; i < IPW; ++i)
+    for (int r = 0; r < 16; ++r) {
+        int ko = 0;                                          // owner of register r (compile-time after unrolling)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[(((ks - 1) * NWI + wv) * IPW + i) * 1024 + r * 64 + lane] = acc[i][r];
-    }
-    __syncthreads();
-    if (ks == 0) {
-#pragma unroll
-        for (int q = 1; q < KS; ++q)
+        for (int k = 1; k < KS; ++k) if (r >= (16 * k) / KS) ko = k;
+        if (ko != ks) {
+            const int sp = ks - (ks > ko ? 1 : 0);           // this wave's index among the owner's sources
 #pragma unroll
             for (int i = 0; i < IPW; ++i)
+                red[SLOT * r + ((sp * NWI + wv) * IPW + i) * 64 + lane] = acc[i][r];
+        }
+    }
+    __syncthreads();
+    (void)own_lo;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] += red[(((q - 1) * NWI + wv) * IPW + i) * 1024 + r * 64 + lane];
-        // epilogue: bias + ReLU -> HBM and the next layer's LDS tile
+    for (int i = 0; i < IPW; ++i) {
+        const int p = (pb0 + i) * 32 + l31;
+        const int oy = p / WO, ox = p - oy * WO;
 #pragma unroll
-        for (int i = 0; i < IPW; ++i) {
-            const int it = wv + NWI * i;
-            const int pb = it % NPB, nb = it / NPB;
-            const int p = pb * 32 + l31;
-            if (p >= NPIX) continue;
-            const int oy = p / WO, ox = p - oy * WO;
+        for (int r = 0; r < 16; ++r) {
+            int ko = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                float v = acc[i][r] + bias[n];
-                v = v > 0.f ? v : 0.f;
+            for (int k = 1; k < KS; ++k) if (r >= (16 * k) / KS) ko = k;
+            if (ko != ks) continue;                          // wave-uniform
+            float v = acc[i][r];
+#pragma unroll
+            for (int sp = 0; sp < KS - 1; ++sp) v += red[SLOT * r + ((sp * NWI + wv) * IPW + i) * 64 + lane];
+            const int n = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            v += bias[n];
+            v = v > 0.f ? v : 0.f;
+            if (p < NPIX) {
                 y[n * NPIX + p] = v;
                 if (xo) xo[n * PLANE_O + (oy + 1) * PW_O + ox + 1] = v;
             }
@@ -126,7 +132,8 @@ struct MidCfg {
     static constexpr int RED3 = 2 * 4 * 2 * 1024, RED4 = 2 * 4 * 1 * 1024, RED5 = 5 * 2 * 1 * 1024;
     static constexpr int A = ((X2 > RED3 ? X2 : RED3) + 3) & ~3;
     static constexpr int Bsz = ((X3 > RED5 ? X3 : RED5) + 3) & ~3;
-    static constexpr int LDS_FLOATS = A + Bsz;
+    static constexpr int BIA = A + Bsz;                      // biases of the three layers (3 x 64)
+    static constexpr int LDS_FLOATS = BIA + 192;
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
     static_assert(X4 <= A && RED4 <= Bsz, "aliasing plan");
 };
@@ -140,6 +147,7 @@ img_fwd_mid_kernel(const float* __restrict__ x2, const float* __restrict__ w3, c
     const int tid = threadIdx.x, b = blockIdx.x;
     float* ra = lds;
     float* rb = lds + C::A;
+    if (tid < 64) { lds[C::BIA + tid] = b3[tid]; lds[C::BIA + 64 + tid] = b4[tid]; lds[C::BIA + 128 + tid] = b5[tid]; }
     // region B = conv 4's input tile: zero it once (pads stay zero, data cells are written by conv 3's epilogue)
     lds_zero<MID_NT>(rb, C::Bsz, tid);
     // conv 3 input: the image's act2 planes, padding materialised
@@ -147,14 +155,14 @@ img_fwd_mid_kernel(const float* __restrict__ x2, const float* __restrict__ w3, c
     lds_zero_cols<MID_NT>(ra, 32 * C::T2::IR, C::T2::PW, H2 + 1, C::T2::PW - H2 - 1, tid);
     stage_x_band<32, H2, H2, C::T2::IR, C::T2::PW, C::T2::PLANE, false, MID_NT>(ra, x2 + (size_t)b * 32 * H2 * H2, -1, true, tid);
     __syncthreads();
-    mid_layer<32, 64, H2, 4, 3, 1, C::T3::PLANE, C::T3::PW>(ra, ra, rb, w3, b3, y3 + (size_t)b * 64 * C::H3 * C::H3, tid);
+    mid_layer<32, 64, H2, 4, 3, 1, C::T3::PLANE, C::T3::PW>(ra, ra, rb, w3, lds + C::BIA, y3 + (size_t)b * 64 * C::H3 * C::H3, tid);
     // region A is dead (conv 3's fold has been read): it becomes conv 5's input tile
     __syncthreads();
     lds_zero<MID_NT>(ra, (C::X4 + 3) & ~3, tid);
     __syncthreads();
-    mid_layer<64, 64, C::H3, 4, 3, 1, C::T4::PLANE, C::T4::PW>(rb, rb, ra, w4, b4, y4 + (size_t)b * 64 * C::H4 * C::H4, tid);
+    mid_layer<64, 64, C::H3, 4, 3, 1, C::T4::PLANE, C::T4::PW>(rb, rb, ra, w4, lds + C::BIA + 64, y4 + (size_t)b * 64 * C::H4 * C::H4, tid);
     __syncthreads();
-    mid_layer<64, 64, C::H4, 2, 3, 2, 1, 1>(ra, rb, nullptr, w5, b5, y5 + (size_t)b * 64 * C::H5 * C::H5, tid);
+    mid_layer<64, 64, C::H4, 2, 3, 2, 1, 1>(ra, rb, nullptr, w5, lds + C::BIA + 128, y5 + (size_t)b * 64 * C::H5 * C::H5, tid);
 }
 }  // namespace
 
