@@ -89,6 +89,27 @@ img_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ wd, con
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        // ReLU-mask operand of the epilogue (the previous layer's activation at this lane's pixel pair): loaded
+        // now, by the waves that will run an epilogue, so that its HBM/L2 latency hides behind the matrix work
+        const bool leader = kc == 0 && part < 2;
+        const int iy_pre = band * C::RI + 2 * j + py;
+        const bool st_ok = ppvalid && unit < total_units && iy_pre < C::H;
+        const size_t o_pre = (size_t)b * C::CIN * C::H * C::W + (size_t)(st_ok ? iy_pre : 0) * C::W + 2 * i;
+        float xm0[16], xm1[16];
+        if (leader && st_ok) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const size_t oc = o_pre + (size_t)c * C::H * C::W;
+                if constexpr (C::W % 2 == 0) {
+                    const float2 xv = *(const float2*)(x + oc);
+                    xm0[r] = xv.x; xm1[r] = xv.y;
+                } else {
+                    xm0[r] = x[oc];
+                    xm1[r] = 2 * i + 1 < C::W ? x[oc + 1] : 0.f;
+                }
+            }
+        }
         float wb[2][3][U];
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
@@ -115,7 +136,6 @@ img_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ wd, con
             __builtin_amdgcn_sched_barrier(0);
         }
         // fold: leaders are (part 0, kc 0) for py = 0 and (part 1, kc 0) for py = 1
-        const bool leader = kc == 0 && part < 2;
         // slot of a non-leader among its item's parked tiles; py=0 members first
         const int slot = part == 0 ? kc - 1 : (C::KC - 1) + (part == 1 ? kc - 1 : C::KC - 1 + kc);
         __syncthreads();                                    // the staged gy bands are dead now
@@ -134,23 +154,19 @@ img_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ wd, con
                 for (int r = 0; r < 16; ++r) { acc0[r] += d[r * 64 + lane]; acc1[r] += d[1024 + r * 64 + lane]; }
             }
         }
-        const int iy = band * C::RI + 2 * j + py;
-        if (ppvalid && unit < total_units && iy < C::H) {
-            const int ix = 2 * i;
-            const size_t o = (size_t)b * C::CIN * C::H * C::W + (size_t)iy * C::W + ix;
+        if (st_ok) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const size_t oc = o + (size_t)c * C::H * C::W;
+                const size_t oc = o_pre + (size_t)c * C::H * C::W;
                 if constexpr (C::W % 2 == 0) {
-                    const float2 xv = *(const float2*)(x + oc);
                     float2 g;
-                    g.x = xv.x > 0.f ? acc0[r] : 0.f;
-                    g.y = xv.y > 0.f ? acc1[r] : 0.f;
+                    g.x = xm0[r] > 0.f ? acc0[r] : 0.f;
+                    g.y = xm1[r] > 0.f ? acc1[r] : 0.f;
                     *(float2*)(gx + oc) = g;
                 } else {
-                    gx[oc] = x[oc] > 0.f ? acc0[r] : 0.f;
-                    if (ix + 1 < C::W) gx[oc + 1] = x[oc + 1] > 0.f ? acc1[r] : 0.f;
+                    gx[oc] = xm0[r] > 0.f ? acc0[r] : 0.f;
+                    if (2 * i + 1 < C::W) gx[oc + 1] = xm1[r] > 0.f ? acc1[r] : 0.f;
                 }
             }
         }
