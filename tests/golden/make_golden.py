@@ -18,6 +18,9 @@ What is recorded (SURVEY.md section 8c "How the oracle is taken"):
   kuka_edge.npz         None-input / cached-sound (all-inf) behaviours of
                         models/pretext/pretext_base.py:10-41
   lr_schedule.npz       MultiStepLR([10,30,50], 0.2) sequence (utils.py:42-46)
+  reward_norm.npz       a stream of per-env rewards / episode ends pushed through the reference's RunningMeanStd
+                        (Envs/vec_env/running_mean_std.py, loaded by file path) with the six lines of
+                        VecPretextNormalize.step_wait that normalise the reward (vec_pretext_normalize.py:52-59)
 
 Usage:  python tests/golden/make_golden.py
 """
@@ -185,5 +188,32 @@ def main():
     print("done")
 
 
+def make_reward_norm():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_rms", "/root/reference/Envs/vec_env/running_mean_std.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(77)
+    n_env, steps, gamma, cliprew, eps = 8, 40, 0.99, 10.0, 1e-8
+    rews = rng.normal(0.3, 1.5, size=(steps, n_env))
+    rews[5] *= 40.0                                              # exercises the clip
+    news = rng.random((steps, n_env)) < 0.08
+    outs = {}
+    for cliprew in (10.0, 1.5):                                  # the default, and one that actually clips
+        rms = mod.RunningMeanStd(shape=())
+        ret = np.zeros(n_env)
+        out = np.zeros_like(rews)
+        for t in range(steps):                                   # vec_pretext_normalize.py:52-59
+            ret = ret * gamma + rews[t]
+            rms.update(ret)
+            out[t] = np.clip(rews[t] / np.sqrt(rms.var + eps), -cliprew, cliprew)
+            ret[news[t]] = 0.
+        outs[cliprew] = out
+    np.savez(os.path.join(HERE, "reward_norm.npz"), rews=rews, news=news, out=outs[10.0], out_clip15=outs[1.5],
+             mean=rms.mean, var=rms.var, count=rms.count)
+    print("reward_norm.npz", rews.shape)
+
+
 if __name__ == "__main__":
     main()
+    make_reward_norm()

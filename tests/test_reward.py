@@ -1,0 +1,58 @@
+"""Host logic of the RL-stage helper: streaming return normalisation against the fixture made with
+the reference's RunningMeanStd, and (GPU) the intrinsic reward through the frozen HIP encoder."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def test_return_normalizer_matches_reference_stream(golden_dir):
+    import var_amd
+    fx = dict(np.load(os.path.join(golden_dir, "reward_norm.npz")))
+    norm = var_amd.ReturnNormalizer(num_envs=fx["rews"].shape[1])
+    out = np.stack([norm(fx["rews"][t], fx["news"][t]) for t in range(fx["rews"].shape[0])])
+    assert np.array_equal(out, fx["out"])                         # same float64 arithmetic, same order
+    assert norm.ret_rms.mean == fx["mean"] and norm.ret_rms.var == fx["var"] and norm.ret_rms.count == fx["count"]
+    norm2 = var_amd.ReturnNormalizer(num_envs=fx["rews"].shape[1], cliprew=1.5)
+    out2 = np.stack([norm2(fx["rews"][t], fx["news"][t]) for t in range(fx["rews"].shape[0])])
+    assert np.array_equal(out2, fx["out_clip15"]) and np.max(np.abs(out2)) == 1.5 and np.mean(np.abs(out2) == 1.5) > 0.01
+
+
+def test_running_mean_std_equals_batch_statistics():
+    import var_amd
+    rng = np.random.default_rng(0)
+    x = rng.normal(2.0, 3.0, size=(1000, 4))
+    rms = var_amd.RunningMeanStd(shape=(4,), epsilon=1e-12)
+    for chunk in np.split(x, 10):
+        rms.update(chunk)
+    assert np.allclose(rms.mean, x.mean(0), atol=1e-9) and np.allclose(rms.var, x.var(0), atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_intrinsic_reward_on_hip_encoder(golden_dir):
+    """getEmbeddings + calcReward of the reference wrapper on the HIP forward at the RL batch (8 envs), incl. the
+    cached-goal-sound protocol; expected values are the reference's own forward outputs (kuka_edge.npz)."""
+    import torch
+    import var_amd
+    sd = dict(np.load(os.path.join(golden_dir, "kuka_weights.npz")))
+    fx = dict(np.load(os.path.join(golden_dir, "kuka_edge.npz")))
+    cfg = types.SimpleNamespace(img_dim=(3, 84, 84), sound_dim=(1, 100, 40), representationDim=3)
+    m = var_amd.VARPretextNet(cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.to("cuda")
+    r = var_amd.IntrinsicReward(m)
+    img, goal = fx["image"], fx["sound_positive"]
+    image_feat, goal_feat, _ = r.embeddings(img, goal)
+    env_rew = np.linspace(-1, 1, img.shape[0])
+    total, dot, ss = r.reward(env_rew, image_feat, goal_feat)
+    assert np.max(np.abs(dot - fx["d.reward"])) < 1e-4 and np.all(ss == 0)
+    assert np.max(np.abs(total - (fx["d.reward"] + env_rew))) < 1e-4
+    # later steps of the episode: the goal sound is not embedded again
+    image_feat2, goal_feat2, _ = r.embeddings(img, None)
+    assert np.array_equal(goal_feat2, goal_feat) and np.array_equal(image_feat2, image_feat)

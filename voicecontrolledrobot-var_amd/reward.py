@@ -1,0 +1,89 @@
+"""Frozen-encoder inference for the RL stage: embeddings, intrinsic reward and return-normalised reward
+(BASELINE config 5).
+
+Mirrors what the reference's vectorised-env wrapper does around the pretext model, without the simulator
+plumbing: Envs/vec_env/vec_pretext_normalize.py:82-101 (getEmbeddings / calcReward), :47-59 (discounted-return
+normalisation with clipping) and Envs/vec_env/running_mean_std.py:4-35 (streaming mean / variance).  The encoder
+forward is the HIP path (VARPretextNet.forward); the rest is host arithmetic on (num_envs,) arrays in float64,
+as in the reference.
+"""
+import numpy as np
+import torch
+
+
+class RunningMeanStd:
+    """Streaming mean / variance of batches (parallel-variance update), running_mean_std.py:4-35."""
+
+    def __init__(self, epsilon=1e-4, shape=()):
+        self.mean = np.zeros(shape, np.float64)
+        self.var = np.ones(shape, np.float64)
+        self.count = epsilon
+
+    def update(self, arr):
+        arr = np.asarray(arr)
+        self.update_from_moments(arr.mean(axis=0), arr.var(axis=0), arr.shape[0])
+
+    def update_from_moments(self, batch_mean, batch_var, batch_count):
+        delta = batch_mean - self.mean
+        total = self.count + batch_count
+        m2 = self.var * self.count + batch_var * batch_count + np.square(delta) * self.count * batch_count / total
+        self.mean = self.mean + delta * batch_count / total
+        self.var = m2 / total
+        self.count = total
+
+
+class ReturnNormalizer:
+    """rew / sqrt(var(discounted return) + eps), clipped; returns reset where an episode ended
+    (vec_pretext_normalize.py:47-59: gamma 0.99, cliprew 10, epsilon 1e-8)."""
+
+    def __init__(self, num_envs, gamma=0.99, cliprew=10.0, epsilon=1e-8):
+        self.ret_rms = RunningMeanStd(shape=())
+        self.ret = np.zeros(num_envs)
+        self.gamma, self.cliprew, self.epsilon = gamma, cliprew, epsilon
+
+    def __call__(self, rews, news):
+        rews = np.asarray(rews, dtype=np.float64)
+        self.ret = self.ret * self.gamma + rews
+        self.ret_rms.update(self.ret)
+        out = np.clip(rews / np.sqrt(self.ret_rms.var + self.epsilon), -self.cliprew, self.cliprew)
+        self.ret[np.asarray(news, dtype=bool)] = 0.0
+        return out
+
+    def reset(self):
+        self.ret[:] = 0.0
+
+
+class IntrinsicReward:
+    """reward = env_reward + <image_feat, goal_sound_feat> (+ <current_sound_feat, goal_sound_feat> when
+    sound_sound is on): getEmbeddings + calcReward of the reference wrapper, on the frozen HIP encoder.
+
+    The goal sound of an episode is embedded once: pass goal_sound=None afterwards and the encoder returns the cached
+    embedding (the reference signals this with an all-inf tensor, pretext_base.py:29-32; both are accepted)."""
+
+    def __init__(self, model, representation_dim=3, sound_sound=False):
+        self.model = model.eval()
+        self.rep = representation_dim
+        self.sound_sound = sound_sound
+
+    @torch.no_grad()
+    def embeddings(self, image_u8, goal_sound=None, current_sound=None):
+        dev = next(self.model.parameters()).device
+        to = lambda a: None if a is None else torch.as_tensor(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        img = to(image_u8)
+        if img.dtype != torch.uint8:                  # the wrapper divides by 255 on the host; u8 goes in as is
+            img = img.float().contiguous()
+        goal = to(goal_sound)
+        if goal is None:
+            b = img.shape[0]
+            goal = torch.full((b, 1, 100, 40), float("inf"), device=dev)
+        d = self.model(img, goal.float().contiguous(),
+                       to(current_sound).float().contiguous() if (self.sound_sound and current_sound is not None) else None)
+        image_feat = d["image_feat"].cpu().numpy()
+        goal_feat = d["sound_feat_positive"].cpu().numpy()
+        cur_feat = d["sound_feat_negative"].cpu().numpy() if (self.sound_sound and current_sound is not None) else 0.0
+        return image_feat, goal_feat, cur_feat
+
+    def reward(self, env_reward, image_feat, goal_feat, cur_feat=0.0):
+        img_sound = np.sum(image_feat[:, :self.rep] * goal_feat, axis=1)
+        snd_sound = np.sum(cur_feat * goal_feat, axis=1) if self.sound_sound else np.zeros_like(img_sound)
+        return img_sound + snd_sound * float(self.sound_sound) + np.asarray(env_reward), img_sound, snd_sound
