@@ -31,3 +31,15 @@ with torch.no_grad():
             r = (d["image_feat"] * d["sound_feat_positive"]).sum(1)
         torch.cuda.synchronize()
         print(f"{name:34s} {1e6 * (time.perf_counter() - t0) / n:8.1f} us per step (B={B}, eager, device-side reward)")
+
+r = var_amd.IntrinsicReward(m).capture(B)
+for name, snd in (("graph: image + goal sound", goal), ("graph: image only (goal cached)", None)):
+    for _ in range(20):
+        r.step(img, snd)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 1000
+    for _ in range(n):
+        r.step(img, snd)
+    torch.cuda.synchronize()
+    print(f"{name:34s} {1e6 * (time.perf_counter() - t0) / n:8.1f} us per step (B={B}, replayed graph incl. input copies)")

@@ -83,6 +83,58 @@ class IntrinsicReward:
         cur_feat = d["sound_feat_negative"].cpu().numpy() if (self.sound_sound and current_sound is not None) else 0.0
         return image_feat, goal_feat, cur_feat
 
+    # ---- latency path: the whole frozen-encoder step as a replayed HIP graph --------------------------------
+    def capture(self, batch):
+        """Capture the frozen encoder for a fixed number of envs (BASELINE config 5: 8) into two HIP graphs --
+        image + goal sound (first step of an episode) and image only (later steps: the goal embedding is reused) --
+        over static device buffers.  Weights are packed once here: call again after loading another checkpoint.
+        Returns self; then use step()."""
+        from ._lib import Context, current_stream_handle, ptr
+        m = self.model
+        flat = m.flat_parameters()
+        dev = flat.device
+        c = Context.get(dev.index)
+        hw = m.config.img_dim[1]
+        B = int(batch)
+        c.ensure_plan(B, hw)
+        self._B = B
+        self._img = torch.zeros((B, 3, hw, hw), dtype=torch.uint8, device=dev)
+        self._goal = torch.zeros((B, 1, 100, 40), dtype=torch.float32, device=dev)
+        self._image_feat = torch.zeros((B, 3), device=dev)
+        self._goal_feat = torch.zeros((B, 3), device=dev)
+        self._reward = torch.zeros((B,), device=dev)
+        c.check(c.lib.var_pack_weights(c.handle, current_stream_handle(), ptr(flat)), "var_pack_weights")
+
+        def body(with_goal):
+            c.check(c.lib.var_arm_encoder_fwd(c.handle, current_stream_handle(), ptr(flat), ptr(self._img), 1,
+                                              self._img.stride(0), ptr(self._goal) if with_goal else None, None, B, hw,
+                                              ptr(self._image_feat), ptr(self._goal_feat) if with_goal else None,
+                                              None, None, None, 0), "var_arm_encoder_fwd")
+            torch.sum(self._image_feat * self._goal_feat, dim=1, out=self._reward)    # <image_feat, goal_feat>
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        self._graphs = {}
+        with torch.cuda.stream(side):
+            for with_goal in (True, False):
+                body(with_goal)                                  # warm-up outside capture (lazy kernel attributes)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    body(with_goal)
+                self._graphs[with_goal] = g
+        torch.cuda.current_stream().wait_stream(side)
+        return self
+
+    def step(self, image_u8, goal_sound=None):
+        """One env step of `batch` envs: copies the observations into the static buffers and replays the graph.
+        Returns device tensors (image_feat (B,3), goal_feat (B,3), <image_feat, goal_feat> (B,)); they are
+        overwritten by the next step."""
+        self._img.copy_(torch.as_tensor(image_u8), non_blocking=True)
+        if goal_sound is not None:
+            self._goal.copy_(torch.as_tensor(goal_sound), non_blocking=True)
+        self._graphs[goal_sound is not None].replay()
+        return self._image_feat, self._goal_feat, self._reward
+
     def reward(self, env_reward, image_feat, goal_feat, cur_feat=0.0):
         img_sound = np.sum(image_feat[:, :self.rep] * goal_feat, axis=1)
         snd_sound = np.sum(cur_feat * goal_feat, axis=1) if self.sound_sound else np.zeros_like(img_sound)
