@@ -38,39 +38,96 @@ def synth_clips(n, seed=0, n_samples=16000):
     return out
 
 
-class SyntheticTripletPool:
-    """HBM-resident pool of synthetic triplets: u8 images, int16 1 s clips per class, labels.
+def load_wav_clips(paths_per_class, max_sound_dur=1.0, load_size=None, n_samples=16000):
+    """Wav ingest of Envs/audioLoader.py:101-145 (load2Words): per class, read the files in order with
+    scipy.io.wavfile, skip clips longer than max_sound_dur seconds, stop after load_size clips.  Returns
+    (pcm int16 (M, n_samples) zero-padded, lens int32 (M), class_start, class_count) with the clips class-major."""
+    from scipy.io import wavfile
+    pcm, lens, start, count = [], [], [], []
+    for paths in paths_per_class:
+        start.append(len(pcm))
+        for path in paths:
+            fs, x = wavfile.read(path)
+            if x.size / fs > max_sound_dur:
+                continue
+            if x.dtype != np.int16 or x.ndim != 1:
+                raise ValueError(f"{path}: expected mono int16 PCM (audioLoader.py:154 divides by 32768), got {x.dtype} {x.shape}")
+            row = np.zeros(n_samples, dtype=np.int16)
+            row[:x.size] = x[:n_samples]
+            pcm.append(row)
+            lens.append(min(x.size, n_samples))
+            if load_size is not None and len(pcm) - start[-1] >= load_size:
+                break
+        count.append(len(pcm) - start[-1])
+    return np.stack(pcm), np.asarray(lens, dtype=np.int32), np.asarray(start), np.asarray(count)
 
-    Mirrors what VARDataset.__getitem__ (dataset.py:64-89) hands the loop: image, positive clip of
-    class gt, negative clip of class sn (rule above), class taskNum = all-zero MFCC ("empty",
-    dataset.py:37-38) which is encoded as clip length 0."""
 
-    def __init__(self, n_items, hw=84, task_num=4, clips_per_class=64, seed=0, device="cuda", empty_frac=0.2):
-        g = np.random.default_rng(seed)
-        self.hw, self.task_num, self.device = hw, task_num, torch.device(device)
-        self.images = torch.from_numpy(g.integers(0, 256, size=(n_items, 3, hw, hw), dtype=np.uint8)).to(self.device)
-        gt = g.integers(0, task_num, size=n_items)
-        gt[g.random(n_items) < empty_frac] = task_num          # 20 % "empty" positives
-        sn = np.array([choose_negative_id(a, task_num, rand_int=lambda lo, hi: int(g.integers(lo, hi))) for a in gt])
-        self.gt = torch.from_numpy(gt.astype(np.int64)).to(self.device)
-        self.sn = torch.from_numpy(sn.astype(np.int64)).to(self.device)
-        clips = synth_clips(task_num * clips_per_class, seed=seed + 1)
-        self.clips = torch.from_numpy(clips).to(self.device)    # (task_num*cpc, 16000) int16, class-major
-        self.cpc = clips_per_class
-        self.n_items = n_items
+class TripletPool:
+    """HBM-resident pool of triplets: u8 images, int16 clips per class, labels.
+
+    Mirrors what VARDataset.__getitem__ (dataset.py:64-89) hands the loop: image, positive clip of class gt,
+    negative clip of class sn (rule above), class taskNum = all-zero MFCC ("empty", dataset.py:37-38) which is
+    encoded as clip length 0.  Built from arrays (this constructor), from the reference's collected pickles
+    (from_pickles) or synthetically (SyntheticTripletPool)."""
+
+    def __init__(self, images, gt, sn, clips, clip_len, class_start, class_count, task_num, seed=0, device="cuda"):
+        self.device = torch.device(device)
+        as_t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a).to(dt).to(self.device)  # noqa: E731
+        self.images = as_t(images, torch.uint8)                 # (N,3,H,H)
+        self.hw, self.task_num = int(self.images.shape[2]), int(task_num)
+        self.gt, self.sn = as_t(gt, torch.int64), as_t(sn, torch.int64)
+        self.clips = as_t(clips, torch.int16)                   # (M, n) class-major
+        self.clip_len = as_t(clip_len, torch.int32)             # valid samples per clip
+        self.class_start, self.class_count = as_t(class_start, torch.int64), as_t(class_count, torch.int64)
+        if int(self.class_count.min()) < 1:
+            raise ValueError("every class needs at least one clip")
+        cnt = self.class_count.tolist()
+        self.cpc = cnt[0] if all(c == cnt[0] for c in cnt) and self.class_start.tolist() == [i * cnt[0] for i in range(len(cnt))] else None
+        self.n_items = int(self.images.shape[0])
         self._gen = torch.Generator(device=self.device)
         self._gen.manual_seed(seed + 2)
+
+    @classmethod
+    def from_pickles(cls, paths, clips, clip_len, class_start, class_count, task_num, seed=0, device="cuda"):
+        """The reference's collected data: each pickle is a list of dicts {'image': u8 (3,H,W), 'ground_truth':
+        int (1,), 'sound_negative_id': int (1,) (optional)} (pretext.py:82-92).  A missing negative id is drawn
+        by the rule of dataset.py:73-78 (choose_negative_id)."""
+        import pickle
+        items = []
+        for path in paths:
+            with open(path, "rb") as f:                         # the authors' own format; only load trusted files
+                items.extend(pickle.load(f))
+        rng = np.random.default_rng(seed)
+        images = np.stack([np.asarray(it["image"], dtype=np.uint8) for it in items])
+        gt = np.array([int(np.asarray(it["ground_truth"]).reshape(-1)[0]) for it in items])
+        sn = np.array([choose_negative_id(g, task_num,
+                                          stored=None if it.get("sound_negative_id") is None
+                                          else int(np.asarray(it["sound_negative_id"]).reshape(-1)[0]),
+                                          rand_int=lambda lo, hi: int(rng.integers(lo, hi)))
+                       for g, it in zip(gt, items)])
+        return cls(images, gt, sn, clips, clip_len, class_start, class_count, task_num, seed=seed, device=device)
+
+    def _clip_ids(self, cls_ids, shape):
+        """A random clip of each class id (class taskNum -> any clip, its length is forced to 0)."""
+        c = torch.clamp(cls_ids, max=self.task_num - 1)
+        if self.cpc is not None:                                # uniform classes: the draw the synthetic pool always made
+            cp = torch.randint(0, self.cpc, shape, device=self.device, generator=self._gen)
+        else:
+            u = torch.rand(shape, device=self.device, generator=self._gen)
+            cp = torch.minimum((u * self.class_count[c]).long(), self.class_count[c] - 1)
+        return self.class_start[c] + cp
+
 
     # ---- fixed pairing + epoch permutation (what VARFineTuneDataset + DataLoader(shuffle=True) do,
     #      dataset.py:94-133,157-162), as index tables so that the step gathers straight from HBM ----
     def freeze_pairs(self):
         """Draw each item's positive / negative clip once (dataset.py:101-117) -> (2,N) int32 tables."""
         n = self.n_items
-        cp = torch.randint(0, self.cpc, (2, n), device=self.device, generator=self._gen)
         cls = torch.stack([self.gt, self.sn])
         empty = cls >= self.task_num
-        self.clip_tab = (torch.clamp(cls, max=self.task_num - 1) * self.cpc + cp).to(torch.int32).contiguous()
-        self.len_tab = torch.where(empty, 0, self.clips.shape[1]).to(torch.int32).contiguous()
+        ids = self._clip_ids(cls, (2, n))
+        self.clip_tab = ids.to(torch.int32).contiguous()
+        self.len_tab = torch.where(empty, 0, self.clip_len[ids]).to(torch.int32).contiguous()
         self._perm = None
         self._cursor = 0
         return self
@@ -105,21 +162,44 @@ class SyntheticTripletPool:
         return torch.cat(parts, dim=0).contiguous()
 
     def sample_indices(self, batch):
-        """Random item ids and clip ids (device tensors, no host sync)."""
+        """Random item ids and clip choices (device tensors, no host sync)."""
         idx = torch.randint(0, self.n_items, (batch,), device=self.device, generator=self._gen)
-        cp = torch.randint(0, self.cpc, (2, batch), device=self.device, generator=self._gen)
+        if self.cpc is not None:
+            cp = torch.randint(0, self.cpc, (2, batch), device=self.device, generator=self._gen)
+        else:
+            cp = torch.rand((2, batch), device=self.device, generator=self._gen)
         return idx, cp
 
     def gather(self, idx, cp, out_img=None, out_pcm=None, out_len=None):
-        """image u8 (B,3,H,H), pcm int16 (2B,16000) [pos | neg], lens int32 (2B) (0 = empty class)."""
+        """image u8 (B,3,H,H), pcm int16 (2B,n) [pos | neg], lens int32 (2B) (0 = empty class)."""
         gt, sn = self.gt[idx], self.sn[idx]
         img = torch.index_select(self.images, 0, idx, out=out_img)
         cls = torch.cat([gt, sn])
         empty = cls >= self.task_num
-        clip_id = torch.clamp(cls, max=self.task_num - 1) * self.cpc + torch.cat([cp[0], cp[1]])
+        c = torch.clamp(cls, max=self.task_num - 1)
+        cpf = torch.cat([cp[0], cp[1]])
+        if self.cpc is not None:
+            clip_id = c * self.cpc + cpf
+        else:
+            clip_id = self.class_start[c] + torch.minimum((cpf * self.class_count[c]).long(), self.class_count[c] - 1)
         pcm = torch.index_select(self.clips, 0, clip_id, out=out_pcm)
-        lens = torch.where(empty, 0, self.clips.shape[1]).to(torch.int32)
+        lens = torch.where(empty, 0, self.clip_len[clip_id]).to(torch.int32)
         if out_len is not None:
             out_len.copy_(lens)
             lens = out_len
         return img, pcm, lens
+
+
+class SyntheticTripletPool(TripletPool):
+    """Synthetic pool: U{0..255} images, sine+noise 1 s clips, 20 % "empty" positives."""
+
+    def __init__(self, n_items, hw=84, task_num=4, clips_per_class=64, seed=0, device="cuda", empty_frac=0.2):
+        g = np.random.default_rng(seed)
+        images = g.integers(0, 256, size=(n_items, 3, hw, hw), dtype=np.uint8)
+        gt = g.integers(0, task_num, size=n_items)
+        gt[g.random(n_items) < empty_frac] = task_num          # 20 % "empty" positives
+        sn = np.array([choose_negative_id(a, task_num, rand_int=lambda lo, hi: int(g.integers(lo, hi))) for a in gt])
+        clips = synth_clips(task_num * clips_per_class, seed=seed + 1)   # (task_num*cpc, 16000) int16, class-major
+        super().__init__(images, gt, sn, clips, np.full(clips.shape[0], clips.shape[1], dtype=np.int32),
+                         np.arange(task_num) * clips_per_class, np.full(task_num, clips_per_class), task_num,
+                         seed=seed, device=device)
