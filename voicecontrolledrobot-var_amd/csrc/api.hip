@@ -208,12 +208,13 @@ static int encoder_fwd(var_ctx* c, hipStream_t s, const float* params, const voi
     // queue of its predecessor, the other branch pays a cross-queue hand-over (5-10 us).  So the caller's stream
     // (MFCC -> image CNN -> image head) is enqueued first and the sound branch, which has slack, afterwards.
     const bool mfcc_main = (c->streams & 16) != 0 || !(c->streams & 1);
+    bool forked = false;
     if (snd && audio && audio->pcm) {
-        if (!mfcc_main && (rc = fork_side(c, s, 0)) != VAR_OK) return rc;
+        if (!mfcc_main) { if ((rc = fork_side(c, s, 0)) != VAR_OK) return rc; forked = true; }
         if ((rc = launch_mfcc(c, mfcc_main ? s : ss, audio->pcm, audio->lens, audio->clip_index, 2 * B, audio->pcm_stride,
                               VAR_MFCC_FRAMES, c->mfcc_buf)) != VAR_OK) return rc;
     }
-    if (snd && mfcc_main && (rc = fork_side(c, s, 0)) != VAR_OK) return rc;
+    if (snd && !forked && (rc = fork_side(c, s, 0)) != VAR_OK) return rc;     // the side stream starts after the caller's prior work
     if (image && (rc = launch_img_fwd(c, s, params, image, is_u8, bstride, image_index, B)) != VAR_OK) return rc;
     if (image && (rc = launch_heads_fwd(c, s, s, params, B, true, false, false, finish)) != VAR_OK) return rc;
     if (snd) {
