@@ -118,6 +118,77 @@ __device__ __forceinline__ void mid_layer(const float* __restrict__ xs, float* _
     }
 }
 
+// The same layer on 16 x 16 x 4 matrix tiles (v_mfma_f32_16x16x4_f32: A[i = l & 15][k = l >> 4], B[k][j = l & 15],
+// D col = l & 15, row = 4 (l >> 4) + r): the late layers have 36 and 9 output pixels per image, which fill 56 % and
+// 28 % of 32-pixel tiles but 75 % and 56 % of 16-pixel ones -- the matrix time of these layers drops by 25 % / 50 %.
+// 12 waves = (pixel tile, 16-channel tile) items x KY filter-row slices; with KY = 1 there is no fold at all.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int CIN, int COUT, int HIN, int NWI, int KY, int PLANE_O, int PW_O>
+__device__ __forceinline__ void mid_layer16(const float* __restrict__ xs, float* __restrict__ red, float* __restrict__ xo,
+                                            const float* __restrict__ wp, const float* __restrict__ bias,
+                                            float* __restrict__ y, int tid) {
+    using T = MidTile<HIN>;
+    constexpr int HO = T::HO, WO = HO, NPIX = HO * WO;
+    constexpr int NPT = (NPIX + 15) / 16, NNT = COUT / 16;
+    static_assert(NPT * NNT == NWI && NWI * KY == MID_NW, "12 waves = items x filter-row slices");
+    const int lane = tid & 63, wave = tid >> 6, kq = lane >> 4, l15 = lane & 15;
+    const int wv = wave % NWI, ky0 = (wave / NWI) * (3 / KY);
+    const int pt = wv % NPT, nt = wv / NPT;
+    int p = pt * 16 + l15;
+    const bool pok = p < NPIX;
+    if (!pok) p = 0;
+    const int oy = p / WO, ox = p - oy * WO;
+    const int pixoff = (2 * oy + ky0) * T::PW + 2 * ox + kq * T::PLANE;
+    const float* wl = wp + nt * 16 + l15 + (kq + ky0 * 3 * CIN) * COUT;
+    constexpr int SPT = CIN / 4, U = 16, BPT = SPT / U, NBK = (3 / KY) * 3 * BPT;       // k-steps of 4 channels
+    static_assert(SPT % U == 0, "whole prefetch blocks per tap");
+    f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+    float wbuf[2][U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) wbuf[0][u] = wl[(4 * u) * COUT];
+#pragma unroll
+    for (int blk = 0; blk < NBK; ++blk) {
+        const int tap = blk / BPT, c4b = (blk % BPT) * U;
+        const int toff = (tap / 3) * T::PW + (tap % 3);
+        if (blk + 1 < NBK) {
+            const int ntap = (blk + 1) / BPT, nc4b = ((blk + 1) % BPT) * U;
+#pragma unroll
+            for (int u = 0; u < U; ++u) wbuf[(blk + 1) & 1][u] = wl[(ntap * CIN + 4 * (nc4b + u)) * COUT];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wbuf[blk & 1][u], xs[pixoff + 4 * (c4b + u) * T::PLANE + toff], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const int ks = wave / NWI;
+    if constexpr (KY > 1) {
+        // fold the filter-row slices (fixed order) through LDS: 4 registers per lane, slice 0 finishes
+        __syncthreads();
+        if (ks > 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(((ks - 1) * NWI + wv) * 4 + r) * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (ks == 0) {
+#pragma unroll
+            for (int q = 1; q < KY; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] += red[(((q - 1) * NWI + wv) * 4 + r) * 64 + lane];
+        }
+    }
+    if (pok && ks == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = nt * 16 + 4 * kq + r;
+            float v = acc[r] + bias[n];
+            v = v > 0.f ? v : 0.f;
+            y[n * NPIX + p] = v;
+            if (xo) xo[n * PLANE_O + (oy + 1) * PW_O + ox + 1] = v;
+        }
+    }
+}
+
 template <int H2>
 struct MidCfg {
     using T2 = MidTile<H2>;
@@ -160,9 +231,9 @@ img_fwd_mid_kernel(const float* __restrict__ x2, const float* __restrict__ w3, c
     __syncthreads();
     lds_zero<MID_NT>(ra, (C::X4 + 3) & ~3, tid);
     __syncthreads();
-    mid_layer<64, 64, C::H3, 4, 3, 1, C::T4::PLANE, C::T4::PW>(rb, rb, ra, w4, lds + C::BIA + 64, y4 + (size_t)b * 64 * C::H4 * C::H4, tid);
+    mid_layer16<64, 64, C::H3, 12, 1, C::T4::PLANE, C::T4::PW>(rb, rb, ra, w4, lds + C::BIA + 64, y4 + (size_t)b * 64 * C::H4 * C::H4, tid);
     __syncthreads();
-    mid_layer<64, 64, C::H4, 2, 3, 2, 1, 1>(ra, rb, nullptr, w5, lds + C::BIA + 128, y5 + (size_t)b * 64 * C::H5 * C::H5, tid);
+    mid_layer16<64, 64, C::H4, 4, 3, 1, 1>(ra, rb, nullptr, w5, lds + C::BIA + 128, y5 + (size_t)b * 64 * C::H5 * C::H5, tid);
 }
 }  // namespace
 
