@@ -106,7 +106,7 @@ int var_arm_loss_grad(var_ctx* ctx, void* stream, const float* params,
 
 /* The same with the data-loader work of dataset.py:64-89 / Envs/audioLoader.py:147-157 folded in:
  * the batch is gathered by index from a dataset resident in HBM and the MFCC front-end runs
- * inside the step (on a side stream, beside the image CNN).
+ * inside the step (by default on the caller's stream, in front of the image CNN; see var_set_streams).
  *   image        dataset images (N,C>=3,H,H) u8|f32; sample b uses row image_index[b] (NULL: row b)
  *   pcm          dataset clips, rows of pcm_stride int16 samples; clip_index (2B) = [pos | neg] rows
  *                (NULL: rows 0..2B-1); lens (2B) valid samples per clip, 0 = the "empty" class whose

@@ -267,7 +267,8 @@ static int encoder_bwd(var_ctx* c, hipStream_t s, const float* params, float* gr
         VAR_HIP_CHECK(c, hipMemsetAsync(grads, 0, sizeof(float) * VAR_N_PARAMS, s));
     }
     const int snd_lo = c->saved_pos ? 0 : B, snd_hi = c->saved_neg ? 2 * B : B;
-    // streams: s = image head + dgrad chain, side = sound head + sound CNN backward, side2 = image wgrads
+    // streams: s = image head + dgrad/wgrad chain, side = sound head + sound CNN backward + loss value
+    // (side2 / side3 only with VAR_STREAMS bits 2 / 3)
     hipStream_t ss = (c->streams & 2) ? c->side : s;
     hipStream_t sw = (c->streams & 4) ? c->side2 : s;
     hipStream_t sr = (c->streams & 8) ? c->side3 : sw;

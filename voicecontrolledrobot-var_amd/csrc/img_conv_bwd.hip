@@ -8,7 +8,8 @@
 //           ky in {1} (iy even) or {0,2} (iy odd), same for x, so each class is a dense
 //           implicit GEMM  D[c][pixel] = sum_{tap,n} Wd[tap][n][c] * gy[n][pixel shifted].
 //           A lane owns the horizontally adjacent pair (ix=2i, ix=2i+1) -> 8-byte stores.
-//   wgrad / reduce : img_wgrad.hip (weight gradients run on a second stream beside the dgrad chain).
+//   wgrad / reduce : img_wgrad.hip (by default on the same stream, between the dgrad kernels; VAR_STREAMS bit 2
+//                    moves them to a stream of their own).
 #include <stdlib.h>
 
 #include "img_stage.h"

@@ -138,10 +138,10 @@ struct var_ctx {
     bool serial = false;                  // VAR_SERIAL=1: everything on the caller's stream (for per-kernel profiling)
     int streams = 0;              // bit mask, see var_init
     hipStream_t side = nullptr;
-    hipStream_t side2 = nullptr;          // weight-gradient kernels run here beside the dgrad chain
+    hipStream_t side2 = nullptr;          // VAR_STREAMS bit 2: weight-gradient kernels beside the dgrad chain (off by default)
     hipEvent_t ev_g[6] = {nullptr};       // gact[l] ready (recorded on the dgrad stream)
     hipEvent_t ev_wjoin = nullptr;
-    hipStream_t side3 = nullptr;          // slab folds run here so that they never delay the next wgrad
+    hipStream_t side3 = nullptr;          // VAR_STREAMS bit 3: slab folds on a stream of their own (off by default)
     hipEvent_t ev_w[5] = {nullptr};       // wgrad of layer l done (recorded on side2)
     hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
     float* mfcc_buf = nullptr;            // (2*maxB, 100, 40) when the front-end runs inside the step

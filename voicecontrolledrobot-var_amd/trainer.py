@@ -194,7 +194,7 @@ class VARTrainer:
         """One step with the data-loader work folded in (var_arm_loss_grad_pcm): sample b reads image row
         image_index[b] of the HBM-resident `images` (N,3,H,H) u8|f32; clips [pos | neg] read rows
         clip_index (2B) of `pcm` (M, n) int16 with lens (2B) valid samples (0 = "empty" class); the MFCC
-        front-end runs inside the step on a side stream.  Index tensors are int32 CUDA."""
+        front-end runs inside the step.  Index tensors are int32 CUDA."""
         flat = self.model.flat_parameters()
         B = image_index.numel()
         gb = B * self.world if global_batch is None else global_batch
