@@ -258,6 +258,126 @@ img_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ wd, con
 }
 
 // ------------------------------------------------------------------------------------------
+// dgrad on 16 x 16 x 4 matrix tiles (v_mfma_f32_16x16x4_f32: A[i = l & 15][k = l >> 4], B[k][j = l & 15], D col = l & 15,
+// row = 4 (l >> 4) + r) for the 11 x 11 / 12 x 12 layer: 36 pixel pairs per row-parity class fill 75 % of three
+// 16-pair tiles against 56 % of two 32-pair tiles, and (pair tile, 16-channel tile) gives exactly 12 items -- one per
+// wave, each wave runs both parity classes of its item: no K split, no fold, one barrier in the whole kernel.
+// ------------------------------------------------------------------------------------------
+typedef float f32x4d __attribute__((ext_vector_type(4)));
+template <int CIN_, int COUT_, int H_, int RI_>
+struct Dg16Cfg {
+    static constexpr int CIN = CIN_, COUT = COUT_, H = H_, W = H_, RI = RI_;
+    static constexpr int HO = (H - 1) / 2 + 1, WO = HO;
+    static constexpr int NR = RI / 2 + 1, POW = WO + 1, PLANE = NR * POW, UNIT = COUT * PLANE;
+    static constexpr int NB = (H + RI - 1) / RI;
+    static constexpr int WH = (W + 1) / 2, NPP = (RI / 2) * WH;      // pixel pairs per class
+    static constexpr int NPT = (NPP + 15) / 16, NCT = CIN / 16, NW = NPT * NCT;
+    static constexpr int LDS_BYTES = ((UNIT + 3) & ~3) * 4;
+    static_assert(RI % 2 == 0 && NW == 12 && COUT % 32 == 0, "12 items = 12 waves");
+};
+
+template <class C>
+__global__ void __launch_bounds__(C::NW * 64)
+img_dgrad16_kernel(const float* __restrict__ gy, const float* __restrict__ wd, const float* __restrict__ x,
+                   float* __restrict__ gx, int B) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NT = C::NW * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kq = lane >> 4, l15 = lane & 15;
+    const int unit = blockIdx.x;
+    const int b = unit / C::NB, band = unit - b * C::NB;
+    lds_zero_cols<NT>(lds, C::COUT * C::NR, C::POW, C::WO, 1, tid);
+    stage_y_band<C::COUT, C::HO, C::WO, C::NR, C::POW, C::PLANE, NT>(lds, gy + (size_t)b * C::COUT * C::HO * C::WO,
+                                                                    band * (C::RI / 2), true, tid);
+    const int pt = wave % C::NPT, ct = wave / C::NPT;
+    int pp = pt * 16 + l15;
+    const bool ppvalid = pp < C::NPP;
+    if (!ppvalid) pp = 0;
+    const int j = pp / C::WH, i = pp - j * C::WH;
+    // ReLU-mask operand of both parity classes, in flight during the matrix work
+    float xm[2][4][2];
+    const size_t o0 = (size_t)b * C::CIN * C::H * C::W + (size_t)(ct * 16 + 4 * kq) * C::H * C::W + 2 * i;
+#pragma unroll
+    for (int py = 0; py < 2; ++py) {
+        const int iy = band * C::RI + 2 * j + py;
+        const bool ok = ppvalid && iy < C::H;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const size_t oc = o0 + (size_t)r * C::H * C::W + (size_t)(ok ? iy : 0) * C::W;
+            xm[py][r][0] = ok ? x[oc] : 0.f;
+            xm[py][r][1] = (ok && 2 * i + 1 < C::W) ? x[oc + 1] : 0.f;
+        }
+    }
+    __syncthreads();
+    const float* wl = wd + (size_t)kq * C::CIN + ct * 16 + l15;          // + (tap*COUT + 4 s) * CIN
+    const int lb0 = j * C::POW + i + kq * C::PLANE;                       // + doy*POW + 4 s * PLANE
+    constexpr int U = 8, SPT = C::COUT / 4, BPK = SPT / U;                // blocks per row tap
+#pragma unroll
+    for (int py = 0; py < 2; ++py) {
+        f32x4d acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const int NBK = (py ? 2 : 1) * BPK;
+        float wb[2][3][U];
+        {
+            const int ky0 = py ? 0 : 1;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int u = 0; u < U; ++u) wb[0][kx][u] = wl[(size_t)((ky0 * 3 + kx) * C::COUT + 4 * u) * C::CIN];
+        }
+#pragma unroll
+        for (int blk = 0; blk < (py ? 2 : 1) * BPK; ++blk) {
+            const int t = blk / BPK, s0 = (blk % BPK) * U;
+            const int doy = (py && !t) ? 1 : 0;
+            if (blk + 1 < NBK) {
+                const int t1 = (blk + 1) / BPK, s1 = ((blk + 1) % BPK) * U;
+                const int ky1 = py ? (t1 ? 2 : 0) : 1;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        wb[(blk + 1) & 1][kx][u] = wl[(size_t)((ky1 * 3 + kx) * C::COUT + 4 * (s1 + u)) * C::CIN];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int lb = lb0 + doy * C::POW;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float b0 = lds[lb + 4 * (s0 + u) * C::PLANE];
+                const float b1 = lds[lb + 4 * (s0 + u) * C::PLANE + 1];
+                // kx=1 -> px=0 (dox 0); kx=2 -> px=1 (dox 0); kx=0 -> px=1 (dox 1)
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[blk & 1][1][u], b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[blk & 1][2][u], b0, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[blk & 1][0][u], b1, acc1, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int iy = band * C::RI + 2 * j + py;
+        if (ppvalid && iy < C::H) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const size_t oc = o0 + (size_t)r * C::H * C::W + (size_t)iy * C::W;
+                gx[oc] = xm[py][r][0] > 0.f ? acc0[r] : 0.f;
+                if (2 * i + 1 < C::W) gx[oc + 1] = xm[py][r][1] > 0.f ? acc1[r] : 0.f;
+            }
+        }
+    }
+}
+
+template <class C>
+static int launch_dgrad16(var_ctx* c, hipStream_t s, const float* gy, const float* wd, const float* x, float* gx, int B,
+                          int layer) {
+    ProfScope prof(c, s, TAG_IMG_DGRAD0 + layer);
+    static bool attr_set = false;
+    if (!attr_set) {
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)img_dgrad16_kernel<C>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(img_dgrad16_kernel<C>, dim3(B * C::NB), dim3(C::NW * 64), C::LDS_BYTES, s, gy, wd, x, gx, B);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 template <class C>
@@ -282,6 +402,8 @@ using D84_1 = DgCfg<32, 32, 42, 6, 2, 4>;
 using D84_2 = DgCfg<32, 64, 21, 22, 1, 4, 1>;     // 4 items x 3 slices          -> 12 waves
 using D84_3 = DgCfg<64, 64, 11, 12, 1, 4, 1>;     // 1 image, 4 items x 3 slices  -> 12 waves
 using D84_4 = DgCfg<64, 64, 6, 6, 3, 2, 2>;       // 3 images, 2 items x 6 slices -> 12 waves
+using G84_3 = Dg16Cfg<64, 64, 11, 12>;            // conv 4's data gradient on 16-wide tiles: 3 pair tiles x 4 channel tiles
+using G96_3 = Dg16Cfg<64, 64, 12, 12>;
 using D96_1 = DgCfg<32, 32, 48, 8, 1, 3>;
 using D96_2 = DgCfg<32, 64, 24, 8, 2, 3>;
 using D96_3 = DgCfg<64, 64, 12, 12, 1, 4, 1>;
@@ -326,7 +448,10 @@ int launch_img_bwd(var_ctx* c, hipStream_t s, hipStream_t sw, hipStream_t sr, co
         if (l == 0) break;
         switch (l) {
             case 4: rc = DG(D84_4, D96_4, 4); break;
-            case 3: rc = DG(D84_3, D96_3, 3); break;
+            case 3: rc = getenv("VAR_NO_DG16") ? DG(D84_3, D96_3, 3)
+                       : (H == 84 ? launch_dgrad16<G84_3>(c, s, c->gact[4], c->wpack + K.img_d[3], c->act[3], c->gact[3], B, 3)
+                                  : launch_dgrad16<G96_3>(c, s, c->gact[4], c->wpack + K.img_d[3], c->act[3], c->gact[3], B, 3));
+                    break;
             case 2: rc = DG(D84_2, D96_2, 2); break;
             default: rc = fused_tail ? launch_img_bwd_tail(c, s, B) : DG(D84_1, D96_1, 1); break;
         }
