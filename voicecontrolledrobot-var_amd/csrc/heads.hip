@@ -419,7 +419,11 @@ int launch_heads_fwd(var_ctx* c, hipStream_t s, hipStream_t ss, const float* par
     const ParamLayout& L = c->pl;
     const PackLayout& K = c->kl;
     int rc;
-    if (has_img) {
+    if (has_img && c->head_in_mid) {
+        // the fused conv 3-5 kernel already left hid_i and the 128 -> 3 partials of every image
+        if (finish) hipLaunchKernelGGL(heads_finish_kernel, dim3((B + 255) / 256), dim3(256), 0, s, c->head_part,
+                                       params + L.ih_b1, B, c->emb_raw, c->emb);
+    } else if (has_img) {
         ProfScope prof(c, s, TAG_HEADS_FWD);
         if ((rc = run_heads_fwd<kImgFeat>(c, s, c->act[5], B, c->wpack + K.ih_w0t, params + L.ih_b0, params + L.ih_w1,
                                           params + L.ih_b1, c->hid_i, c->emb_raw, c->emb, c->head_part, finish)) != VAR_OK) return rc;

@@ -276,10 +276,13 @@ int launch_img_fwd(var_ctx* c, hipStream_t s, const float* params, const void* i
         if (!getenv("VAR_NO_PIPE")) { if ((rc = launch_img_fwd_conv2_pipe(c, s, c->act[1], w[1], b[1], c->act[2], B)) != VAR_OK) return rc; }
         else RUN(F96_2, c->act[1], 32L * 48 * 48, 1, c->act[2]);
     }
+    c->head_in_mid = false;
     // VAR_NO_MID=1 (tuning aid): conv 3, 4, 5 as separate kernels
     static const bool fused_mid = !getenv("VAR_NO_MID");
     if (c->H == 84 && fused_mid) {
-        if ((rc = launch_img_fwd_mid(c, s, params, B)) != VAR_OK) return rc;
+        static const bool head_in_mid = !getenv("VAR_NO_MID_HEAD");
+        c->head_in_mid = head_in_mid;
+        if ((rc = launch_img_fwd_mid(c, s, params, B, head_in_mid)) != VAR_OK) return rc;
     } else if (c->H == 84) {
         RUN(F84_3, c->act[2], 32L * 21 * 21, 2, c->act[3]);
         RUN(F84_4, c->act[3], 64L * 11 * 11, 3, c->act[4]);

@@ -126,7 +126,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 template <int CIN, int COUT, int HIN, int NWI, int KY, int PLANE_O, int PW_O>
 __device__ __forceinline__ void mid_layer16(const float* __restrict__ xs, float* __restrict__ red, float* __restrict__ xo,
                                             const float* __restrict__ wp, const float* __restrict__ bias,
-                                            float* __restrict__ y, int tid) {
+                                            float* __restrict__ y, int tid, float* __restrict__ flat = nullptr) {
     using T = MidTile<HIN>;
     constexpr int HO = T::HO, WO = HO, NPIX = HO * WO;
     constexpr int NPT = (NPIX + 15) / 16, NNT = COUT / 16;
@@ -185,6 +185,7 @@ __device__ __forceinline__ void mid_layer16(const float* __restrict__ xs, float*
             v = v > 0.f ? v : 0.f;
             y[n * NPIX + p] = v;
             if (xo) xo[n * PLANE_O + (oy + 1) * PW_O + ox + 1] = v;
+            if (flat) flat[n * NPIX + p] = v;                  // NCHW flatten order (the heads' input)
         }
     }
 }
@@ -204,7 +205,9 @@ struct MidCfg {
     static constexpr int A = ((X2 > RED3 ? X2 : RED3) + 3) & ~3;
     static constexpr int Bsz = ((X3 > RED5 ? X3 : RED5) + 3) & ~3;
     static constexpr int BIA = A + Bsz;                      // biases of the three layers (3 x 64)
-    static constexpr int LDS_FLOATS = BIA + 192;
+    static constexpr int A5S = BIA + 192;                    // act5 of the image, flatten order (576)
+    static constexpr int HPS = A5S + kImgFeat;               // head: 6 K-slice partials of the 128 hidden units, then hidden
+    static constexpr int LDS_FLOATS = HPS + 6 * kHid + kHid;
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
     static_assert(X4 <= A && RED4 <= Bsz, "aliasing plan");
 };
@@ -213,7 +216,9 @@ template <class C, int H2>
 __global__ void __launch_bounds__(MID_NT)
 img_fwd_mid_kernel(const float* __restrict__ x2, const float* __restrict__ w3, const float* __restrict__ b3,
                    const float* __restrict__ w4, const float* __restrict__ b4, const float* __restrict__ w5,
-                   const float* __restrict__ b5, float* __restrict__ y3, float* __restrict__ y4, float* __restrict__ y5) {
+                   const float* __restrict__ b5, float* __restrict__ y3, float* __restrict__ y4, float* __restrict__ y5,
+                   const float* __restrict__ hw0t, const float* __restrict__ hb0, const float* __restrict__ hw1,
+                   float* __restrict__ hid, float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, b = blockIdx.x;
     float* ra = lds;
@@ -233,12 +238,51 @@ img_fwd_mid_kernel(const float* __restrict__ x2, const float* __restrict__ w3, c
     __syncthreads();
     mid_layer16<64, 64, C::H3, 12, 1, C::T4::PLANE, C::T4::PW>(rb, rb, ra, w4, lds + C::BIA + 64, y4 + (size_t)b * 64 * C::H4 * C::H4, tid);
     __syncthreads();
-    mid_layer16<64, 64, C::H4, 4, 3, 1, 1>(ra, rb, nullptr, w5, lds + C::BIA + 128, y5 + (size_t)b * 64 * C::H5 * C::H5, tid);
+    mid_layer16<64, 64, C::H4, 4, 3, 1, 1>(ra, rb, nullptr, w5, lds + C::BIA + 128, y5 + (size_t)b * 64 * C::H5 * C::H5, tid,
+                                          lds + C::A5S);
+    // ---- image head of this image (imgTriplet, arm_pretext_model.py:46-50): hidden = relu(W0 a5 + b0) on the VALU
+    //      (one row: nothing for the matrix cores), 768 threads = 128 hidden units x 6 K slices of 96, folded in
+    //      fixed order; then this image's partial of the 128 -> 3 layer in the (row, 4, 4) layout the finish / rows
+    //      kernels read (block 0 carries the whole dot product, blocks 1..3 are zero).
+    if (hw0t) {
+        static_assert(C::H5 * C::H5 * 64 == kImgFeat && MID_NT == 6 * kHid, "head phase shape");
+        __syncthreads();
+        const float* a5 = lds + C::A5S;
+        float* hp = lds + C::HPS;
+        const int j = tid & (kHid - 1), sl = tid >> 7;
+        const float* wj = hw0t + (size_t)(sl * 96) * kHid + j;
+        float acc = 0.f;
+#pragma unroll 16
+        for (int k = 0; k < 96; ++k) acc += wj[(size_t)k * kHid] * a5[sl * 96 + k];
+        hp[sl * kHid + j] = acc;
+        __syncthreads();
+        float* hh = hp + 6 * kHid;
+        if (tid < kHid) {
+            float v = ((hp[tid] + hp[kHid + tid]) + (hp[2 * kHid + tid] + hp[3 * kHid + tid])) +
+                      (hp[4 * kHid + tid] + hp[5 * kHid + tid]) + hb0[tid];
+            v = v > 0.f ? v : 0.f;
+            hh[tid] = v;
+            hid[(size_t)b * kHid + tid] = v;
+        }
+        __syncthreads();
+        if (tid < 192) {                                       // 3 outputs x 64 lanes, 2 hidden units per lane
+            const int d = tid >> 6, l = tid & 63;
+            float sum = hh[l] * hw1[d * kHid + l] + hh[64 + l] * hw1[d * kHid + 64 + l];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+            if (l == 0) part[(size_t)b * 16 + d] = sum;
+        }
+        if (tid >= 192 && tid < 192 + 13) {                    // the rest of the row: zeros
+            const int e = tid - 192 + 3;
+            part[(size_t)b * 16 + e] = 0.f;
+        }
+    }
 }
 }  // namespace
 
-// conv 3 + conv 4 + conv 5 of the image CNN for 84 x 84 inputs (act2 21 x 21); leaves act[3], act[4], act[5]
-int launch_img_fwd_mid(var_ctx* c, hipStream_t s, const float* params, int B) {
+// conv 3 + conv 4 + conv 5 of the image CNN for 84 x 84 inputs (act2 21 x 21); leaves act[3], act[4], act[5] and,
+// with_head, the image head's hidden layer (hid_i) and 128 -> 3 partials (head_part rows [0, B))
+int launch_img_fwd_mid(var_ctx* c, hipStream_t s, const float* params, int B, bool with_head) {
     using C = MidCfg<21>;
     ProfScope prof(c, s, TAG_IMG_FWD0 + 2);
     static bool attr_set = false;
@@ -251,7 +295,8 @@ int launch_img_fwd_mid(var_ctx* c, hipStream_t s, const float* params, int B) {
     const PackLayout& K = c->kl;
     hipLaunchKernelGGL((img_fwd_mid_kernel<C, 21>), dim3(B), dim3(MID_NT), C::LDS_BYTES, s, c->act[2],
                        c->wpack + K.img_f[2], params + L.img_b[2], c->wpack + K.img_f[3], params + L.img_b[3],
-                       c->wpack + K.img_f[4], params + L.img_b[4], c->act[3], c->act[4], c->act[5]);
+                       c->wpack + K.img_f[4], params + L.img_b[4], c->act[3], c->act[4], c->act[5],
+                       with_head ? c->wpack + K.ih_w0t : nullptr, params + L.ih_b0, params + L.ih_w1, c->hid_i, c->head_part);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }

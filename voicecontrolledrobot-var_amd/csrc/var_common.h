@@ -127,6 +127,7 @@ struct var_ctx {
     int prof_n = 0;               // pairs recorded since select
     hipEvent_t* prof_ev = nullptr;
     // saved forward
+    bool head_in_mid = false;             // the last image forward also ran the image head (img_fwd_mid.hip)
     int saved_B = 0;
     const void* saved_image = nullptr;
     int saved_u8 = 0;
@@ -185,7 +186,7 @@ int launch_img_fwd(var_ctx* c, hipStream_t s, const float* params, const void* i
                    long bstride, const int* image_index, int B);
 int launch_img_fwd_head(var_ctx* c, hipStream_t s, const float* params, const void* image, int is_u8, long bstride,
                         const int* image_index, int B);
-int launch_img_fwd_mid(var_ctx* c, hipStream_t s, const float* params, int B);
+int launch_img_fwd_mid(var_ctx* c, hipStream_t s, const float* params, int B, bool with_head);
 // (launch_img_fwd also leaves c->relu1)
 int launch_img_fwd_conv2_pipe(var_ctx* c, hipStream_t s, const float* x, const float* wp, const float* bias,
                               float* y, int B);
