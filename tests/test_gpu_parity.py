@@ -310,3 +310,18 @@ def test_odd_batches_vs_oracle(var_amd, h, B):
     assert abs(tr.loss.item() - l_ref) < 1e-5
     # L2 bound: a ReLU unit within rounding of zero may flip (see test_fused_grads_vs_oracle_random_batch)
     assert np.linalg.norm(g - g_ref) / np.linalg.norm(g_ref) < 5e-3
+
+
+def test_replayed_training_learns_a_small_pool(var_amd):
+    """End-to-end sanity of the replayed step (gather -> MFCC -> fwd -> loss -> bwd -> Adam -> re-pack -> next row):
+    on a pool small enough to memorise the triplet loss goes down."""
+    torch.manual_seed(453)
+    m = var_amd.VARPretextNet(cfg(84)).to("cuda")
+    tr = var_amd.VARTrainer(m, lr=1e-3, weight_decay=1e-6)
+    pool = var_amd.SyntheticTripletPool(64, hw=84, seed=5, clips_per_class=2, empty_frac=0.1).freeze_pairs()
+    B = 32
+    table = pool.index_table(B, 120)[:120].contiguous()
+    replay, _ = tr.capture_epoch_steps(pool.images, pool.clips, B, table)
+    losses = torch.stack([replay().clone() for _ in range(120)]).cpu().numpy().reshape(-1)
+    assert np.all(np.isfinite(losses))
+    assert losses[-10:].mean() < losses[:10].mean() - 0.15, (losses[:10].mean(), losses[-10:].mean())
