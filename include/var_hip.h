@@ -117,6 +117,16 @@ int var_arm_loss_grad_pcm(var_ctx* ctx, void* stream, const float* params,
                           int B, int H, float margin, float inv_count,
                           float* grads, float* loss_out, float* feats_out);
 
+/* var_arm_loss_grad with the image batch gathered by index (sample b = row image_index[b] of the HBM-resident
+ * dataset, as in var_arm_loss_grad_pcm) and the MFCC features given.  The data-parallel replayed step uses it: the
+ * front-end of step k+1 (var_mfcc) is then enqueued between the gradient all-reduce of step k and its optimiser
+ * step, so that the collective's latency hides behind work that does not depend on the weights. */
+int var_arm_loss_grad_gather(var_ctx* ctx, void* stream, const float* params,
+                             const void* image, int image_is_u8, long image_bstride, const int* image_index,
+                             const float* mfcc_pos, const float* mfcc_neg, int B, int H,
+                             float margin, float inv_count,
+                             float* grads, float* loss_out, float* feats_out);
+
 /* torch.optim.Adam(lr, betas, eps, weight_decay) .step() (VAR/pretext_VAR.py:33-35,69)
  * on flat arenas; `step` is the 1-based step count.  When n == VAR_N_PARAMS and
  * params is the model arena the packed weight images are refreshed as well. */
@@ -136,11 +146,13 @@ int var_adam_step_dev(var_ctx* ctx, void* stream, float* params, const float* gr
  * DataLoader(shuffle=True), VAR/pretext_VAR.py:26-31,55) is walked on the DEVICE: at the end of the step row
  * (*cursor_dev + 1) mod n_rows is copied into index_row (the buffer the captured var_arm_loss_grad_pcm reads) and
  * *cursor_dev is advanced, so a replay needs no host-side copy.  One kernel launch does the Adam update, the
- * re-pack of the weight images, the step count and the row fetch. */
+ * re-pack of the weight images, the step count and the row fetch.  ahead_from > 0: entries [ahead_from, row_ints) of
+ * the row are taken one row further ahead (row cursor + 2) -- the data-parallel pipeline computes the MFCC features of
+ * step k+1 before the optimiser step of step k, so its clip entries run one step ahead of the image entries. */
 int var_adam_step_graph(var_ctx* ctx, void* stream, float* params, const float* grads, float* exp_avg,
                         float* exp_avg_sq, long n, const float* lr_dev, float beta1, float beta2, float eps,
                         float weight_decay, int* step_dev, const int* index_table, int row_ints, int n_rows,
-                        int* cursor_dev, int* index_row);
+                        int* cursor_dev, int* index_row, int ahead_from);
 
 /* Audio front-end: Envs/audioLoader.py:147-157 (torchaudio MFCC branch) + :241-252
  * (processSoundFeat).  pcm: rows of `pcm_stride` int16 samples; output clip i reads row

@@ -325,3 +325,39 @@ def test_replayed_training_learns_a_small_pool(var_amd):
     losses = torch.stack([replay().clone() for _ in range(120)]).cpu().numpy().reshape(-1)
     assert np.all(np.isfinite(losses))
     assert losses[-10:].mean() < losses[:10].mean() - 0.15, (losses[:10].mean(), losses[-10:].mean())
+
+
+def test_data_parallel_replay_path_equals_eager_steps(var_amd, golden_dir):
+    """The data-parallel form of the replayed step (gradient graph -> RCCL all_reduce in flight beside the next
+    step's index row + MFCC -> Adam graph), rehearsed with a one-rank process group: same losses and parameters as
+    eager step_from_dataset calls on the same rows."""
+    import torch.distributed as dist
+    sd = load(golden_dir, "kuka_weights.npz")
+    B = 16
+    pool = var_amd.SyntheticTripletPool(64, hw=84, seed=12, clips_per_class=4).freeze_pairs()
+    table = pool.index_table(B, 3)[:3].contiguous()
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+    try:
+        mb = make_model(var_amd, sd, 84)
+        tb = var_amd.VARTrainer(mb, lr=1e-3, weight_decay=1e-6)
+        tb.force_collective = True
+        replay, load_table = tb.capture_epoch_steps(pool.images, pool.clips, B, table)
+        losses_b = [float(replay().item()) for _ in range(4)]
+        pb = mb.flat_parameters().cpu().numpy().copy()
+        assert int(tb._g_step.item()) == 4
+    finally:
+        if created:
+            dist.destroy_process_group()
+    ma = make_model(var_amd, sd, 84)
+    ta = var_amd.VARTrainer(ma, lr=1e-3, weight_decay=1e-6)
+    assert ta.world == 1
+    losses_a = []
+    for s in range(4):
+        r = table[s % 3]
+        losses_a.append(float(ta.step_from_dataset(pool.images, r[:B], pool.clips, r[B:3 * B], r[3 * B:]).item()))
+    assert np.allclose(losses_a, losses_b, rtol=0, atol=1e-6), (losses_a, losses_b)
+    pa = ma.flat_parameters().cpu().numpy()
+    assert np.mean(np.abs(pa - pb) < 2e-6) > 0.995 and np.max(np.abs(pa - pb)) < 5e-3

@@ -44,9 +44,10 @@ _SIGNATURES = {
     "var_arm_loss_grad": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
     "var_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i]),
     "var_adam_step_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _f, _f, _f, _f, _vp]),
-    "var_adam_step_graph": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _f, _f, _f, _f, _vp, _vp, _i, _i, _vp, _vp]),
+    "var_adam_step_graph": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _f, _f, _f, _f, _vp, _vp, _i, _i, _vp, _vp, _i]),
     "var_mfcc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "var_arm_loss_grad_pcm": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
+    "var_arm_loss_grad_gather": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
     "var_profile_tag_count": (_i, []),
     "var_profile_tag_name": (ctypes.c_char_p, [_i]),
     "var_profile_select": (_i, [_vp, _i]),

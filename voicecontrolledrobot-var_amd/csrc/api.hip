@@ -343,6 +343,20 @@ int var_arm_loss_grad(var_ctx* c, void* stream, const float* params, const void*
                           mfcc_neg, nullptr, B, H, margin, inv_count, grads, loss_out, feats_out, "var_arm_loss_grad");
 }
 
+int var_arm_loss_grad_gather(var_ctx* c, void* stream, const float* params, const void* image, int image_is_u8,
+                             long image_bstride, const int* image_index, const float* mfcc_pos, const float* mfcc_neg,
+                             int B, int H, float margin, float inv_count, float* grads, float* loss_out,
+                             float* feats_out) {
+    CHECK_CTX(c);
+    if (!params || !image || !mfcc_pos || !mfcc_neg || !grads || !loss_out) {
+        VAR_SET_ERR(c, "var_arm_loss_grad_gather: null argument");
+        return VAR_ERR_ARG;
+    }
+    return loss_grad_impl(c, (hipStream_t)stream, params, image, image_is_u8, image_bstride, image_index, mfcc_pos,
+                          mfcc_neg, nullptr, B, H, margin, inv_count, grads, loss_out, feats_out,
+                          "var_arm_loss_grad_gather");
+}
+
 int var_arm_loss_grad_pcm(var_ctx* c, void* stream, const float* params, const void* image, int image_is_u8,
                           long image_bstride, const int* image_index, const int16_t* pcm, int pcm_stride,
                           const int* clip_index, const int* lens, int B, int H, float margin, float inv_count,
@@ -377,13 +391,13 @@ int var_adam_step_dev(var_ctx* c, void* stream, float* params, const float* grad
                       long n, const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
                       int* step_dev) {
     return var_adam_step_graph(c, stream, params, grads, exp_avg, exp_avg_sq, n, lr_dev, beta1, beta2, eps,
-                               weight_decay, step_dev, nullptr, 0, 0, nullptr, nullptr);
+                               weight_decay, step_dev, nullptr, 0, 0, nullptr, nullptr, 0);
 }
 
 int var_adam_step_graph(var_ctx* c, void* stream, float* params, const float* grads, float* exp_avg,
                         float* exp_avg_sq, long n, const float* lr_dev, float beta1, float beta2, float eps,
                         float weight_decay, int* step_dev, const int* index_table, int row_ints, int n_rows,
-                        int* cursor_dev, int* index_row) {
+                        int* cursor_dev, int* index_row, int ahead_from) {
     CHECK_CTX(c);
     if (!params || !grads || !exp_avg || !exp_avg_sq || !lr_dev || !step_dev || n <= 0) {
         VAR_SET_ERR(c, "var_adam_step_dev: bad argument");
@@ -395,7 +409,8 @@ int var_adam_step_graph(var_ctx* c, void* stream, float* params, const float* gr
     }
     SET_DEVICE(c);
     return launch_adam_dev(c, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, lr_dev, beta1, beta2, eps,
-                           weight_decay, step_dev, n == VAR_N_PARAMS, index_table, row_ints, n_rows, cursor_dev, index_row);
+                           weight_decay, step_dev, n == VAR_N_PARAMS, index_table, row_ints, n_rows, cursor_dev, index_row,
+                           ahead_from);
 }
 
 int var_mfcc(var_ctx* c, void* stream, const int16_t* pcm, const int* lens, const int* clip_index, int nclips,

@@ -100,7 +100,7 @@ adam_pack_dev_kernel(const PackSeg* __restrict__ segs, int nseg, float* __restri
                      float* __restrict__ v, long n, const float* __restrict__ lr_dev, float b1, float b2, float eps,
                      float wd, int* __restrict__ step_dev, unsigned* __restrict__ done_ctr, float* __restrict__ wpack,
                      const int* __restrict__ idx_table, int row_ints, int n_rows, int* __restrict__ cursor,
-                     int* __restrict__ idx_row) {
+                     int* __restrict__ idx_row, int ahead_from) {
     // bias corrections: double-precision pow once per block, not per thread
     __shared__ float sh_step[2];
     const int t = step_dev[0] + 1;
@@ -118,7 +118,10 @@ adam_pack_dev_kernel(const PackSeg* __restrict__ segs, int nseg, float* __restri
     if (blockIdx.x == 0 && idx_table) {
         int next = cursor[0] + 1;
         if (next >= n_rows) next = 0;
-        for (int e = threadIdx.x; e < row_ints; e += 256) idx_row[e] = idx_table[(size_t)next * row_ints + e];
+        int next2 = next + 1;                                // entries [ahead_from, row_ints) run one row further ahead
+        if (next2 >= n_rows) next2 = 0;
+        for (int e = threadIdx.x; e < row_ints; e += 256)
+            idx_row[e] = idx_table[(size_t)((ahead_from > 0 && e >= ahead_from) ? next2 : next) * row_ints + e];
         __syncthreads();
         if (threadIdx.x == 0) cursor[0] = next;
     }
@@ -190,7 +193,7 @@ int pack_table_upload(var_ctx* c) {
 
 int launch_adam_dev(var_ctx* c, hipStream_t s, float* p, const float* g, float* m, float* v, long n,
                     const float* lr_dev, float b1, float b2, float eps, float wd, int* step_dev, bool repack,
-                    const int* idx_table, int row_ints, int n_rows, int* cursor, int* idx_row) {
+                    const int* idx_table, int row_ints, int n_rows, int* cursor, int* idx_row, int ahead_from) {
     ProfScope prof(c, s, TAG_ADAM);
     // few blocks (4 elements per thread): every block ends with one device-scope atomic on the same word
     int grid = (int)((n + 1023) / 1024);
@@ -198,7 +201,7 @@ int launch_adam_dev(var_ctx* c, hipStream_t s, float* p, const float* g, float* 
     if (const char* e = getenv("VAR_ADAM_GRID")) { if (atoi(e) > 0) grid = atoi(e); }    // tuning aid
     hipLaunchKernelGGL(adam_pack_dev_kernel, dim3(grid), dim3(256), 0, s, (const PackSeg*)c->pack_segs_dev, c->pack_nseg, p, g, m, v, n, lr_dev,
                        b1, b2, eps, wd, step_dev, c->done_ctr, repack ? c->wpack : nullptr, idx_table, row_ints, n_rows,
-                       cursor, idx_row);
+                       cursor, idx_row, ahead_from);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }

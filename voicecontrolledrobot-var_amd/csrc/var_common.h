@@ -212,6 +212,6 @@ int launch_adam(var_ctx* c, hipStream_t s, float* p, const float* g, float* m, f
                 float lr, float b1, float b2, float eps, float wd, int step);
 int launch_adam_dev(var_ctx* c, hipStream_t s, float* p, const float* g, float* m, float* v, long n,
                     const float* lr_dev, float b1, float b2, float eps, float wd, int* step_dev, bool repack,
-                    const int* idx_table, int row_ints, int n_rows, int* cursor, int* idx_row);
+                    const int* idx_table, int row_ints, int n_rows, int* cursor, int* idx_row, int ahead_from);
 int launch_mfcc(var_ctx* c, hipStream_t s, const int16_t* pcm, const int* lens, const int* clip_index, int nclips,
                 int pcm_stride, int out_frames, float* out);

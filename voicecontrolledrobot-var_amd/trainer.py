@@ -119,7 +119,7 @@ class VARTrainer:
                                               float(self.wd), ptr(self._g_step),
                                               ptr(tab) if tab is not None else None, row_ints, rows,
                                               ptr(self._g_cursor) if tab is not None else None,
-                                              ptr(self._g_idx) if tab is not None else None), "var_adam_step_graph")
+                                              ptr(self._g_idx) if tab is not None else None, 0), "var_adam_step_graph")
 
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
@@ -163,6 +163,8 @@ class VARTrainer:
         assert row_ints == 5 * B and table.dtype == torch.int32 and table.is_cuda and table.is_contiguous()
         self._g_table = torch.empty_like(table)
         self._g_cursor = torch.zeros(1, dtype=torch.int32, device=dev)
+        if self.world > 1 or self.force_collective:
+            return self._capture_epoch_steps_dp(images, pcm, B, table, global_batch)
         replay_row = self.capture_dataset_step(images, pcm, B, global_batch, _table=(self._g_table, rows, row_ints))
 
         def load_table(t):
@@ -175,6 +177,82 @@ class VARTrainer:
 
         def replay():
             return replay_row(None)
+        return replay, load_table
+
+    def _capture_epoch_steps_dp(self, images, pcm, B, table, global_batch):
+        """Data-parallel form of capture_epoch_steps.  The gradient all-reduce (RCCL, eager between graphs) has
+        nothing to overlap with inside the step -- every gradient is complete only at the end of the backward -- but
+        the audio front-end of the NEXT step does not depend on the weights: per step
+            graph [gather + fwd + loss + bwd, MFCC features of this step precomputed]
+            -> all_reduce(async) || MFCC of the next step (graph, on the caller's stream)
+            -> wait -> graph [Adam + re-pack]
+        so up to an MFCC kernel's worth (60 us) of collective latency is hidden."""
+        dev = self.dev
+        c = self.ctx
+        flat = self.model.flat_parameters()
+        c.ensure_plan(B, self.hw)
+        rows = int(table.shape[0])
+        gb = B * self.world if global_batch is None else global_batch
+        self._g_idx = torch.zeros(5 * B, dtype=torch.int32, device=dev)
+        self._g_lr = torch.full((1,), float(self.lr), dtype=torch.float32, device=dev)
+        self._g_step = torch.full((1,), int(self.step_count), dtype=torch.int32, device=dev)
+        self._g_mfcc = torch.zeros(2 * B, 1, 100, 40, dtype=torch.float32, device=dev)
+        img_idx, clip_idx, lens = self._g_idx[:B], self._g_idx[B:3 * B], self._g_idx[3 * B:]
+
+        def body_grad():
+            c.check(c.lib.var_arm_loss_grad_gather(c.handle, current_stream_handle(), ptr(flat), ptr(images),
+                                                   int(images.dtype == torch.uint8), images.stride(0), ptr(img_idx),
+                                                   ptr(self._g_mfcc), ptr(self._g_mfcc[B:]), B, self.hw,
+                                                   float(self.margin), 1.0 / gb, ptr(self.gbuf),
+                                                   self.gbuf.data_ptr() + 4 * N_PARAMS, None), "var_arm_loss_grad_gather")
+
+        def body_front():
+            c.check(c.lib.var_mfcc(c.handle, current_stream_handle(), ptr(pcm), ptr(lens), ptr(clip_idx), 2 * B,
+                                   pcm.stride(0), 100, ptr(self._g_mfcc)), "var_mfcc")
+
+        def body_adam():
+            c.check(c.lib.var_adam_step_graph(c.handle, current_stream_handle(), ptr(flat), ptr(self.gbuf),
+                                              ptr(self.exp_avg), ptr(self.exp_avg_sq), N_PARAMS, ptr(self._g_lr),
+                                              float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                              float(self.wd), ptr(self._g_step), ptr(self._g_table), 5 * B, rows,
+                                              ptr(self._g_cursor), ptr(self._g_idx), B), "var_adam_step_graph")
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        graphs = []
+        with torch.cuda.stream(side):
+            body_front()                                   # warm-up outside capture
+            for body in (body_grad, body_front, body_adam):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    body()
+                graphs.append(g)
+        torch.cuda.current_stream().wait_stream(side)
+        g_grad, g_front, g_adam = graphs
+        collective = self.world > 1 or (self.force_collective and torch.distributed.is_initialized())
+
+        def load_table(t):
+            assert t.shape == self._g_table.shape
+            self._g_table.copy_(t, non_blocking=True)
+            self._g_idx.copy_(t[0], non_blocking=True)
+            g_front.replay()                               # features of row 0
+            self._g_idx[B:].copy_(t[1 % rows][B:], non_blocking=True)   # clip entries run one step ahead
+            self._g_cursor.zero_()
+
+        load_table(table)
+
+        def replay():
+            g_grad.replay()
+            work = None
+            if collective:
+                work = torch.distributed.all_reduce(self.gbuf, op=torch.distributed.ReduceOp.SUM, group=self.pg,
+                                                    async_op=True)
+            g_front.replay()                               # MFCC of the next step while the collective is in flight
+            if work is not None:
+                work.wait()                                # the caller's stream waits for the collective
+            g_adam.replay()                                # ... and fetches the rows of the steps after
+            self.step_count += 1
+            return self.loss
         return replay, load_table
 
     def set_lr(self, lr):
