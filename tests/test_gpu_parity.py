@@ -338,7 +338,11 @@ def test_data_parallel_replay_path_equals_eager_steps(var_amd, golden_dir):
     table = pool.index_table(B, 3)[:3].contiguous()
     created = not dist.is_initialized()
     if created:
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1,
+        import socket
+        with socket.socket() as sock:                           # a free port for the one-rank rendezvous
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
                                 device_id=torch.device("cuda", 0))
     try:
         mb = make_model(var_amd, sd, 84)
