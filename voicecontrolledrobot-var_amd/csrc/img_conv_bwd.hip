@@ -13,6 +13,9 @@
 #include <stdlib.h>
 
 #include "img_stage.h"
+#define VAR_WGRAD_DEVICE_ONLY
+#include "img_wgrad.hip"             // WgCfg, img_wgrad_body, the W84_* / W96_* configurations (device code only)
+#undef VAR_WGRAD_DEVICE_ONLY
 
 // ------------------------------------------------------------------------------------------
 // dgrad
@@ -47,15 +50,14 @@ struct DgCfg {
 };
 
 template <class C>
-__global__ void __launch_bounds__(C::NW * 64)
-img_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ wd, const float* __restrict__ x,
-                 float* __restrict__ gx, int B) {
+__device__ __forceinline__ void img_dgrad_body(const float* __restrict__ gy, const float* __restrict__ wd,
+                                               const float* __restrict__ x, float* __restrict__ gx, int B, int bx) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NT = C::NW * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int total_units = B * C::NB;
-    const int unit0 = blockIdx.x * C::NU;
+    const int unit0 = bx * C::NU;
 
     // only the pad column (ox = WO) needs clearing; all data cells are written by the staging pass
     lds_zero_cols<NT>(lds, C::NU * C::COUT * C::NR, C::POW, C::WO, 1, tid);
@@ -277,14 +279,13 @@ struct Dg16Cfg {
 };
 
 template <class C>
-__global__ void __launch_bounds__(C::NW * 64)
-img_dgrad16_kernel(const float* __restrict__ gy, const float* __restrict__ wd, const float* __restrict__ x,
-                   float* __restrict__ gx, int B) {
+__device__ __forceinline__ void img_dgrad16_body(const float* __restrict__ gy, const float* __restrict__ wd,
+                                                 const float* __restrict__ x, float* __restrict__ gx, int B, int bx) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NT = C::NW * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = lane >> 4, l15 = lane & 15;
-    const int unit = blockIdx.x;
+    const int unit = bx;
     const int b = unit / C::NB, band = unit - b * C::NB;
     lds_zero_cols<NT>(lds, C::COUT * C::NR, C::POW, C::WO, 1, tid);
     stage_y_band<C::COUT, C::HO, C::WO, C::NR, C::POW, C::PLANE, NT>(lds, gy + (size_t)b * C::COUT * C::HO * C::WO,
@@ -363,6 +364,41 @@ img_dgrad16_kernel(const float* __restrict__ gy, const float* __restrict__ wd, c
 }
 
 template <class C>
+__global__ void __launch_bounds__(C::NW * 64)
+img_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ wd, const float* __restrict__ x,
+                 float* __restrict__ gx, int B) {
+    img_dgrad_body<C>(gy, wd, x, gx, B, blockIdx.x);
+}
+
+template <class C>
+__global__ void __launch_bounds__(C::NW * 64)
+img_dgrad16_kernel(const float* __restrict__ gy, const float* __restrict__ wd, const float* __restrict__ x,
+                   float* __restrict__ gx, int B) {
+    img_dgrad16_body<C>(gy, wd, x, gx, B, blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------
+// One launch for the two kernels of a layer that consume the same gy and do not depend on each other: the weight
+// gradient (persistent split-K workgroups, blocks [0, Gw * NCOMBO)) and the data gradient (one tile per workgroup,
+// the blocks after).  A replayed step costs about 5 us per kernel in launch, fill and drain whatever the kernel
+// does; side by side in one grid the drain of the first overlaps the fill of the second as well.
+// ------------------------------------------------------------------------------------------
+template <class WC, class DC, bool D16>
+__global__ void __launch_bounds__(768)
+img_bwd_pair_kernel(const void* __restrict__ wx, long wbstride, const float* __restrict__ gy, float* __restrict__ slabs,
+                    int Gw, const float* __restrict__ wd, const float* __restrict__ x, float* __restrict__ gx, int B) {
+    static_assert(WC::NW * 64 == 768 && DC::NW * 64 == 768, "both halves run 12 waves");
+    const int nw = Gw * WC::NCOMBO;
+    const int id = blockIdx.x;
+    if (id < nw) {
+        img_wgrad_body<WC>(wx, wbstride, nullptr, gy, slabs, B, id % Gw, id / Gw, Gw);
+    } else {
+        if constexpr (D16) img_dgrad16_body<DC>(gy, wd, x, gx, B, id - nw);
+        else img_dgrad_body<DC>(gy, wd, x, gx, B, id - nw);
+    }
+}
+
+template <class C>
 static int launch_dgrad16(var_ctx* c, hipStream_t s, const float* gy, const float* wd, const float* x, float* gx, int B,
                           int layer) {
     ProfScope prof(c, s, TAG_IMG_DGRAD0 + layer);
@@ -409,6 +445,30 @@ using D96_2 = DgCfg<32, 64, 24, 8, 2, 3>;
 using D96_3 = DgCfg<64, 64, 12, 12, 1, 4, 1>;
 using D96_4 = DgCfg<64, 64, 6, 6, 3, 2, 2>;
 
+// weight gradient of layer l and data gradient of layer l in one grid (84 x 84 inputs, layers 2..4)
+template <class WC, class DC, bool D16>
+static int launch_pair(var_ctx* c, hipStream_t s, int layer, const void* wx, long wbstride, const float* gy,
+                       const float* wd, const float* x, float* gx, int B) {
+    ProfScope prof(c, s, TAG_IMG_WGRAD0 + layer);
+    constexpr int LDS_BYTES = WC::LDS_BYTES > DC::LDS_BYTES ? WC::LDS_BYTES : DC::LDS_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)img_bwd_pair_kernel<WC, DC, D16>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_set = true;
+    }
+    const int need = (B * WC::NB + WC::NU - 1) / WC::NU;
+    const int gmax = img_wgrad_groups(layer);
+    const int Gw = need < gmax ? need : gmax;
+    c->wg_groups[layer] = Gw;
+    int nd;
+    if constexpr (D16) nd = B * DC::NB; else nd = (B * DC::NB + DC::NU - 1) / DC::NU;
+    hipLaunchKernelGGL((img_bwd_pair_kernel<WC, DC, D16>), dim3(Gw * WC::NCOMBO + nd), dim3(768), LDS_BYTES, s, wx, wbstride, gy,
+                       c->slabs + img_slab_offset(layer), Gw, wd, x, gx, B);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}
+
 int launch_img_bwd(var_ctx* c, hipStream_t s, hipStream_t sw, hipStream_t sr, const float* params, float* grads, int B) {
     const PackLayout& K = c->kl;
     int rc;
@@ -431,12 +491,24 @@ int launch_img_bwd(var_ctx* c, hipStream_t s, hipStream_t sw, hipStream_t sr, co
     // launch after the last weight-gradient kernel; on a stream of their own (sr != sw) each layer's fold is
     // released by an event as soon as its slabs exist.
     const bool fold_each = sr != sw;
+    // VAR_NO_PAIR=1 (tuning aid): weight and data gradient of a layer as two launches
+    static const bool allow_pair = !getenv("VAR_NO_PAIR");
+    const bool paired = allow_pair && H == 84 && sw == s && !fold_each;
     for (int l = 4; l >= 0; --l) {
         if (l == 0 && fused_tail) {
             // layer 0's slabs were left by the tail kernel on s
             if (sr != s) { VAR_HIP_CHECK(c, hipEventRecord(c->ev_g[0], s)); VAR_HIP_CHECK(c, hipStreamWaitEvent(sr, c->ev_g[0], 0)); }
             if ((rc = launch_img_wgrad_reduce(c, sr, grads, 0, fold_each ? 0 : 4)) != VAR_OK) return rc;
             break;
+        }
+        if (paired && l >= 2) {
+            const float* gyl = c->gact[l + 1];
+            const float* wdl = c->wpack + K.img_d[l];
+            if (l == 4) rc = launch_pair<W84_4, D84_4, false>(c, s, 4, xin[4], bs[4], gyl, wdl, c->act[4], c->gact[4], B);
+            else if (l == 3) rc = launch_pair<W84_3, G84_3, true>(c, s, 3, xin[3], bs[3], gyl, wdl, c->act[3], c->gact[3], B);
+            else rc = launch_pair<W84_2, D84_2, false>(c, s, 2, xin[2], bs[2], gyl, wdl, c->act[2], c->gact[2], B);
+            if (rc != VAR_OK) return rc;
+            continue;
         }
         if ((rc = launch_img_wgrad(c, sw, l, xin[l], bs[l], l == 0 ? c->saved_u8 : 0, c->gact[l + 1], B)) != VAR_OK) return rc;
         if (fold_each) {

@@ -52,10 +52,12 @@ struct WgCfg {
     static constexpr int NSTEP = (TS + KS - 1) / KS; // k-steps per wave and stage
 };
 
+// (a __device__ body so that it can also run as one half of a fused launch, img_conv_bwd.hip: bx / by / G stand for
+// blockIdx.x / blockIdx.y / gridDim.x of a stand-alone launch)
 template <class C>
-__global__ void __launch_bounds__(C::NW * 64)
-img_wgrad_kernel(const void* __restrict__ xin, long bstride, const int* __restrict__ bidx,
-                 const float* __restrict__ gy, float* __restrict__ slabs, int B) {
+__device__ __forceinline__ void img_wgrad_body(const void* __restrict__ xin, long bstride, const int* __restrict__ bidx,
+                                               const float* __restrict__ gy, float* __restrict__ slabs, int B,
+                                               int bx, int by, int G) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;
     float* ys = lds + C::XS;
@@ -64,8 +66,7 @@ img_wgrad_kernel(const void* __restrict__ xin, long bstride, const int* __restri
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int total_units = B * C::NB;
-    const int G = gridDim.x;
-    const int combo = blockIdx.y;
+    const int combo = by;
     const int nb = combo / C::CBLK, cb = combo - nb * C::CBLK;
     const int ky = C::SMALLC ? 0 : wave % 3, ks = C::SMALLC ? wave : wave / 3;
 
@@ -124,7 +125,7 @@ img_wgrad_kernel(const void* __restrict__ xin, long bstride, const int* __restri
 
     // zero the pads once (data cells are rewritten for every unit)
     lds_zero<NT>(lds, C::LDS_FLOATS, tid);
-    const int first = blockIdx.x * C::NU;
+    const int first = bx * C::NU;
     if (first < total_units) {
         const Stage st = make_stage(first);
         sx.issue(st.bx, bstride, st.row0x, st.nvalid);
@@ -197,7 +198,7 @@ img_wgrad_kernel(const void* __restrict__ xin, long bstride, const int* __restri
     }
 
     // ---- fold the K slices through LDS (fixed order) and write this workgroup's partial slab ----
-    float* slab = slabs + ((size_t)blockIdx.x * C::NCOMBO + combo) * C::SLAB;
+    float* slab = slabs + ((size_t)bx * C::NCOMBO + combo) * C::SLAB;
     bsum += __shfl_down(bsum, 32, 64);
     constexpr int NTILE = C::SMALLC ? 1 : 3;
 #pragma unroll
@@ -237,6 +238,28 @@ img_wgrad_kernel(const void* __restrict__ xin, long bstride, const int* __restri
     }
 }
 
+template <class C>
+__global__ void __launch_bounds__(C::NW * 64)
+img_wgrad_kernel(const void* __restrict__ xin, long bstride, const int* __restrict__ bidx,
+                 const float* __restrict__ gy, float* __restrict__ slabs, int B) {
+    img_wgrad_body<C>(xin, bstride, bidx, gy, slabs, B, blockIdx.x, blockIdx.y, gridDim.x);
+}
+
+//                   CIN COUT  H   U8    R  NU KS
+using W84_0u = WgCfg<3, 32, 84, true, 6, 1, 4>;
+using W84_0f = WgCfg<3, 32, 84, false, 6, 1, 4>;
+using W84_1 = WgCfg<32, 32, 42, false, 3, 1, 4, true>;
+using W84_2 = WgCfg<32, 64, 21, false, 11, 1, 4>;
+using W84_3 = WgCfg<64, 64, 11, false, 6, 1, 4>;
+using W84_4 = WgCfg<64, 64, 6, false, 3, 4, 4>;
+using W96_0u = WgCfg<3, 32, 96, true, 6, 1, 4>;
+using W96_0f = WgCfg<3, 32, 96, false, 6, 1, 4>;
+using W96_1 = WgCfg<32, 32, 48, false, 3, 1, 4>;
+using W96_2 = WgCfg<32, 64, 24, false, 6, 1, 4>;
+using W96_3 = WgCfg<64, 64, 12, false, 6, 1, 4>;
+using W96_4 = WgCfg<64, 64, 6, false, 3, 4, 4>;
+
+#ifndef VAR_WGRAD_DEVICE_ONLY      // img_conv_bwd.hip includes this file for the device code above only
 // ------------------------------------------------------------------------------------------
 // slab reduction -> OIHW gradient arena
 // ------------------------------------------------------------------------------------------
@@ -290,20 +313,6 @@ img_wgrad_reduce_kernel(RedTable T, const float* __restrict__ slabs, float* __re
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-//                   CIN COUT  H   U8    R  NU KS
-using W84_0u = WgCfg<3, 32, 84, true, 6, 1, 4>;
-using W84_0f = WgCfg<3, 32, 84, false, 6, 1, 4>;
-using W84_1 = WgCfg<32, 32, 42, false, 3, 1, 4, true>;
-using W84_2 = WgCfg<32, 64, 21, false, 11, 1, 4>;
-using W84_3 = WgCfg<64, 64, 11, false, 6, 1, 4>;
-using W84_4 = WgCfg<64, 64, 6, false, 3, 4, 4>;
-using W96_0u = WgCfg<3, 32, 96, true, 6, 1, 4>;
-using W96_0f = WgCfg<3, 32, 96, false, 6, 1, 4>;
-using W96_1 = WgCfg<32, 32, 48, false, 3, 1, 4>;
-using W96_2 = WgCfg<32, 64, 24, false, 6, 1, 4>;
-using W96_3 = WgCfg<64, 64, 12, false, 6, 1, 4>;
-using W96_4 = WgCfg<64, 64, 6, false, 3, 4, 4>;
-
 // split-K workgroups (grid.x) per layer; grid.y = channel-block combos.  Also sizes the slab workspace.
 static const int kWgG[5] = {512, 256, 128, 64, 32};     // layer 0: the fused tail (kTailG <= 512)
 static const int kCombo[5] = {1, 1, 2, 4, 4};
@@ -379,3 +388,8 @@ int launch_img_wgrad_reduce(var_ctx* c, hipStream_t s, float* grads, int lo, int
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }
+
+// workgroups per layer / slab workspace offsets, for the fused launches of img_conv_bwd.hip
+int img_wgrad_groups(int layer) { return kWgG[layer]; }
+size_t img_slab_offset(int layer) { return slab_offset(layer); }
+#endif  // VAR_WGRAD_DEVICE_ONLY

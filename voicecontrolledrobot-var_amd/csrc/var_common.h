@@ -176,6 +176,8 @@ static inline int conv_out(int h) { return (h - 1) / 2 + 1; }   // 3x3 s2 p1
 int mfcc_build_tables(var_ctx* c);
 int pack_table_upload(var_ctx* c);
 size_t img_slab_floats();
+int img_wgrad_groups(int layer);
+size_t img_slab_offset(int layer);
 int launch_img_wgrad(var_ctx* c, hipStream_t s, int layer, const void* x, long bstride, int is_u8, const float* gy, int B);
 int launch_img_wgrad_reduce(var_ctx* c, hipStream_t s, float* grads, int lo, int hi);
 size_t snd_slab_floats();
