@@ -61,11 +61,13 @@ struct TailCfg {
     static_assert(NU <= 2, "at most two bands per tile");
 };
 
+// (a __device__ body so that it can also run as one half of a fused launch, img_conv_bwd.hip: bx / G stand for
+// blockIdx.x / gridDim.x of a stand-alone launch)
 template <class C>
-__global__ void __launch_bounds__(C::NT)
-img_bwd_tail_kernel(const float* __restrict__ gy, const float* __restrict__ wd, const uint16_t* __restrict__ relu_bits,
-                    const void* __restrict__ image, long bstride, const int* __restrict__ bidx,
-                    float* __restrict__ slabs, int B) {
+__device__ __forceinline__ void img_bwd_tail_body(const float* __restrict__ gy, const float* __restrict__ wd,
+                                                  const uint16_t* __restrict__ relu_bits, const void* __restrict__ image,
+                                                  long bstride, const int* __restrict__ bidx, float* __restrict__ slabs,
+                                                  int B, int bx, int G) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NT = C::NT;
     using XT = typename std::conditional<C::U8, uint8_t, float>::type;
@@ -159,7 +161,7 @@ img_bwd_tail_kernel(const float* __restrict__ gy, const float* __restrict__ wd, 
         return *(const uint32_t*)(relu_bits + ((size_t)b * 2 + half) * C::H * C::W + (band * C::RI) * C::W + gxo);
     };
 
-    int tile = blockIdx.x;
+    int tile = bx;
     uint32_t m = 0;
     int gi0 = 0, gi1 = 0;
     if (tile < ntiles) {
@@ -171,18 +173,18 @@ img_bwd_tail_kernel(const float* __restrict__ gy, const float* __restrict__ wd, 
         cy.template store<C::UNIT_Y, C::PLANE_Y, C::POW, 0>(gys, lut, t.ry0, t.ry1, t.ok0, t.ok1, tid);
         cx.template store<C::UNIT_X, C::PLANE_X, C::PWX, 1>(ims, lut, t.rx0, t.rx1, t.ok0, t.ok1, tid);
     }
-    if (tile + (int)gridDim.x < ntiles) gather_rows(tile + gridDim.x, gi0, gi1);
+    if (tile + G < ntiles) gather_rows(tile + G, gi0, gi1);
     __syncthreads();
 #pragma unroll 1
-    for (; tile < ntiles; tile += gridDim.x) {
+    for (; tile < ntiles; tile += G) {
         // ---- loads of the NEXT tile: in flight during this tile's matrix work ----
-        const int next = tile + gridDim.x;
+        const int next = tile + G;
         const bool more = next < ntiles;
         int tid_t = tid;                                   // opaque copy: see BandCopy
         asm volatile("" : "+v"(tid_t));
         uint32_t m_next = 0;
         const Tile tn = make_tile(more ? next : tile, gi0, gi1);
-        if (next + (int)gridDim.x < ntiles) gather_rows(next + gridDim.x, gi0, gi1);     // for the next iteration
+        if (next + G < ntiles) gather_rows(next + G, gi0, gi1);     // for the next iteration
         if (more) {
             cy.issue(tn.gy0, tn.gy1, tn.ry0, tn.ry1, tid_t);
             cx.issue(tn.im0, tn.im1, tn.rx0, tn.rx1, tid_t);
@@ -285,7 +287,7 @@ img_bwd_tail_kernel(const float* __restrict__ gy, const float* __restrict__ wd, 
     }
 
     // ---- fold the waves through LDS (fixed order) and write this workgroup's partial slab ----
-    float* slab = slabs + (size_t)blockIdx.x * C::SLAB;
+    float* slab = slabs + (size_t)bx * C::SLAB;
     bsum += __shfl_down(bsum, 32, 64);
     __syncthreads();
 #pragma unroll
@@ -311,12 +313,21 @@ img_bwd_tail_kernel(const float* __restrict__ gy, const float* __restrict__ wd, 
     }
 }
 
+template <class C>
+__global__ void __launch_bounds__(C::NT)
+img_bwd_tail_kernel(const float* __restrict__ gy, const float* __restrict__ wd, const uint16_t* __restrict__ relu_bits,
+                    const void* __restrict__ image, long bstride, const int* __restrict__ bidx,
+                    float* __restrict__ slabs, int B) {
+    img_bwd_tail_body<C>(gy, wd, relu_bits, image, bstride, bidx, slabs, B, blockIdx.x, gridDim.x);
+}
+
 //                    H    U8   RI NU
 using T84u = TailCfg<42, true, 6, 2>;      // 2 bands: 4 pixel blocks x 3 K parts = 12 waves, 3 per SIMD
 using T84f = TailCfg<42, false, 6, 2>;
 using T96u = TailCfg<48, true, 8, 1>;      // 1 band: 3 pixel blocks x 3 K parts = 9 waves
 using T96f = TailCfg<48, false, 8, 1>;
 
+#ifndef VAR_TAIL_DEVICE_ONLY       // img_conv_bwd.hip includes this file for the device code above only
 template <class C>
 static int launch_tail(var_ctx* c, hipStream_t s, int B) {
     ProfScope prof(c, s, TAG_IMG_DGRAD0 + 1);
@@ -344,3 +355,4 @@ int launch_img_bwd_tail(var_ctx* c, hipStream_t s, int B) {
     if (c->H == 84) return c->saved_u8 ? launch_tail<T84u>(c, s, B) : launch_tail<T84f>(c, s, B);
     return c->saved_u8 ? launch_tail<T96u>(c, s, B) : launch_tail<T96f>(c, s, B);
 }
+#endif  // VAR_TAIL_DEVICE_ONLY
