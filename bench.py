@@ -76,13 +76,20 @@ def cpu_baseline(seconds=10.0):
 
 def tag_flops(tag):
     """Algorithmic FLOPs per triplet of a profiled conv kernel family (tags: 0-4 forward, 5-9 weight
-    gradient, 11-14 data gradient of layer tag % 5).  Tag 1 is the fused forward head (conv 1 + conv 2), tag 11
-    the fused backward tail (data gradient of conv 2 + weight gradient of conv 1); halo recomputation inside
-    the fused kernels is not counted."""
-    if tag == 1 and not os.environ.get("VAR_NO_HEAD"):
-        return LAYER_FLOPS[0] + LAYER_FLOPS[1]
-    if tag == 11 and not os.environ.get("VAR_NO_TAIL"):
-        return LAYER_FLOPS[1] + LAYER_FLOPS[0]
+    gradient, 11-14 data gradient of layer tag % 5) in the default (fused) configuration: tag 1 = forward head
+    (conv 1 + conv 2), tag 2 = conv 3 + 4 + 5 (+ image head, not counted), tags 7-9 = weight + data gradient of
+    layers 2-4 in one grid, tag 11 = weight gradient of conv 2 + data gradient of conv 2 + weight gradient of conv 1.
+    Halo recomputation inside the fused kernels is not counted."""
+    fused = not any(os.environ.get(k) for k in ("VAR_NO_HEAD", "VAR_NO_TAIL", "VAR_NO_MID", "VAR_NO_PAIR"))
+    if fused:
+        if tag == 1:
+            return LAYER_FLOPS[0] + LAYER_FLOPS[1]
+        if tag == 2:
+            return LAYER_FLOPS[2] + LAYER_FLOPS[3] + LAYER_FLOPS[4]
+        if tag in (7, 8, 9):
+            return 2 * LAYER_FLOPS[tag - 5]
+        if tag == 11:
+            return 2 * LAYER_FLOPS[1] + LAYER_FLOPS[0]
     return LAYER_FLOPS[tag % 5]
 
 
@@ -93,7 +100,9 @@ def pmc_traffic(tag_name, hw):
     (same workload, same kernel); None when the file or the kernel is not in it."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")
     want = {"img_fwd_head_kernel[0+1]": "img_fwd_head_kernel<HeadCfg<%d," % (hw // 2),
-            "img_bwd_tail_kernel[dgrad1+wgrad0]": "img_bwd_tail_kernel<TailCfg<%d," % (hw // 2)}.get(tag_name)
+            "img_bwd_last_kernel[wgrad1+dgrad1+wgrad0]": "img_bwd_last_kernel<",
+            "img_bwd_pair_kernel[wgrad2+dgrad2]": "img_bwd_pair_kernel<WgCfg<32, 64,",
+            "img_bwd_pair_kernel[wgrad3+dgrad3]": "img_bwd_pair_kernel<WgCfg<64, 64, %d," % (11 if hw == 84 else 12)}.get(tag_name)
     if want is None or not os.path.exists(path):
         return None
     with open(path) as f:

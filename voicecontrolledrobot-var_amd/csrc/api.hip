@@ -426,8 +426,8 @@ int var_mfcc(var_ctx* c, void* stream, const int16_t* pcm, const int* lens, cons
 
 static const char* kTagNames[TAG_COUNT] = {
     "img_conv_fwd_kernel[0]", "img_fwd_head_kernel[0+1]", "img_conv_fwd_kernel[2]", "img_conv_fwd_kernel[3]",
-    "img_conv_fwd_kernel[4]", "img_wgrad_kernel[0]", "img_wgrad_kernel[1]", "img_wgrad_kernel[2]",
-    "img_wgrad_kernel[3]", "img_wgrad_kernel[4]", "img_dgrad_kernel[0]", "img_bwd_tail_kernel[dgrad1+wgrad0]",
+    "img_conv_fwd_kernel[4]", "img_wgrad_kernel[0]", "img_wgrad_kernel[1]", "img_bwd_pair_kernel[wgrad2+dgrad2]",
+    "img_bwd_pair_kernel[wgrad3+dgrad3]", "img_bwd_pair_kernel[wgrad4+dgrad4]", "img_dgrad_kernel[0]", "img_bwd_last_kernel[wgrad1+dgrad1+wgrad0]",
     "img_dgrad_kernel[2]", "img_dgrad_kernel[3]", "img_dgrad_kernel[4]", "img_wgrad_reduce_kernel",
     "snd_fwd_kernel", "snd_dgrad_kernel", "snd_wgrad_kernel", "snd_reduce_kernel", "heads_fwd_kernel",
     "heads_bwd_rows_kernel", "heads_bwd_gemm_kernel", "triplet_kernel", "adam_kernel", "pack_weights_kernel",
