@@ -10,6 +10,7 @@
 //           A lane owns the horizontally adjacent pair (ix=2i, ix=2i+1) -> 8-byte stores.
 //   wgrad / reduce : img_wgrad.hip (by default on the same stream, between the dgrad kernels; VAR_STREAMS bit 2
 //                    moves them to a stream of their own).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "img_stage.h"
@@ -473,7 +474,8 @@ static int launch_last(var_ctx* c, hipStream_t s, int B) {
         attr_set = true;
     }
     const int need = (B * WC::NB + WC::NU - 1) / WC::NU;
-    const int gmax = img_wgrad_groups(1);
+    int gmax = img_wgrad_groups(1);
+    if (const char* e = getenv("VAR_WG_G1")) { if (atoi(e) > 0 && atoi(e) <= gmax) gmax = atoi(e); }   // tuning aid
     const int Gw = need < gmax ? need : gmax;
     c->wg_groups[1] = Gw;
     const int ntiles = (B * TC::NB + TC::NU - 1) / TC::NU;
@@ -500,7 +502,13 @@ static int launch_pair(var_ctx* c, hipStream_t s, int layer, const void* wx, lon
         attr_set = true;
     }
     const int need = (B * WC::NB + WC::NU - 1) / WC::NU;
-    const int gmax = img_wgrad_groups(layer);
+    int gmax = img_wgrad_groups(layer);
+    {   // tuning aid: VAR_WG_G<layer>=n (never above the slab workspace)
+        char name[16];
+        snprintf(name, sizeof name, "VAR_WG_G%d", layer);
+        const char* e = getenv(name);
+        if (e && atoi(e) > 0 && atoi(e) <= gmax) gmax = atoi(e);
+    }
     const int Gw = need < gmax ? need : gmax;
     c->wg_groups[layer] = Gw;
     int nd;

@@ -314,7 +314,7 @@ img_wgrad_reduce_kernel(RedTable T, const float* __restrict__ slabs, float* __re
 // host side
 // ------------------------------------------------------------------------------------------
 // split-K workgroups (grid.x) per layer; grid.y = channel-block combos.  Also sizes the slab workspace.
-static const int kWgG[5] = {512, 256, 128, 64, 32};     // layer 0: the fused tail (kTailG <= 512)
+static const int kWgG[5] = {512, 256, 64, 32, 32};     // layer 0: the fused tail (kTailG <= 512)
 static const int kCombo[5] = {1, 1, 2, 4, 4};
 static const int kSlabSz[5] = {32 * 32 + 32, 9248, 9248, 9248, 9248};
 
