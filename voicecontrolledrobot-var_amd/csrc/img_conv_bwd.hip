@@ -479,7 +479,9 @@ static int launch_last(var_ctx* c, hipStream_t s, int B) {
     const int Gw = need < gmax ? need : gmax;
     c->wg_groups[1] = Gw;
     const int ntiles = (B * TC::NB + TC::NU - 1) / TC::NU;
-    const int Gt = ntiles < kTailG ? ntiles : kTailG;
+    int tmax = kTailG;
+    if (const char* e = getenv("VAR_TAIL_G")) { if (atoi(e) > 0 && atoi(e) <= kTailG) tmax = atoi(e); }   // tuning aid
+    const int Gt = ntiles < tmax ? ntiles : tmax;
     c->wg_groups[0] = Gt;
     hipLaunchKernelGGL((img_bwd_last_kernel<WC, TC>), dim3(Gw + Gt), dim3(768), LDS_BYTES, s, c->act[1],
                        32L * c->hs[1] * c->hs[1], c->gact[2], c->slabs + img_slab_offset(1), Gw,
