@@ -162,6 +162,31 @@ int var_adam_step_graph(var_ctx* ctx, void* stream, float* params, const float* 
 int var_mfcc(var_ctx* ctx, void* stream, const int16_t* pcm, const int* lens, const int* clip_index,
              int nclips, int pcm_stride, int out_frames, float* out);
 
+/* iTHOR model ------------------------------------------------------------------------------
+ * The second VARPretextNet of the reference (models/pretext/ai2thor_pretext_model.py:5-58, config 4 of
+ * BASELINE.json): stride-1 3x3 convolutions with 2x2 max pools on the image, three wide stride-2 convolutions
+ * and a bidirectional GRU(448 -> 512) on the (1,600,40) sound features, Linear heads, F.normalize.  Parameters
+ * are its 36 state_dict() tensors back to back in registration order (imgBranch.{0,2,5,8,11,14}, rnn.*_l0,
+ * rnn.*_l0_reverse, cnn.{0,2,4}, imgTriplet.{0,2}, soundTriplet.{0,2,4}), each in its PyTorch layout:
+ * var_ithor_param_count() = 3849126 floats.  The entries mirror the Kuka ones above (same argument meaning);
+ * image_raw is (B,1152), pos_raw (B,1024); img_hw is any side that ends in a 3x3 map (96, 84).
+ * var_adam_step / var_triplet_fwd_bwd are shared with the Kuka model. */
+int var_ithor_param_count(void);
+int var_ithor_plan(var_ctx* ctx, int max_batch, int img_hw);
+int var_ithor_encoder_fwd(var_ctx* ctx, void* stream, const float* params,
+                          const void* image, int image_is_u8, long image_bstride,
+                          const float* snd_pos, const float* snd_neg, int B, int H,
+                          float* image_feat, float* pos_feat, float* neg_feat,
+                          float* image_raw, float* pos_raw, int save_for_bwd);
+int var_ithor_encoder_bwd(var_ctx* ctx, void* stream, const float* params,
+                          const float* g_image_feat, const float* g_pos_feat, const float* g_neg_feat,
+                          float* grads);
+int var_ithor_loss_grad(var_ctx* ctx, void* stream, const float* params,
+                        const void* image, int image_is_u8, long image_bstride,
+                        const float* snd_pos, const float* snd_neg, int B, int H,
+                        float margin, float inv_count,
+                        float* grads, float* loss_out, float* feats_out);
+
 /* Measurement and testing hooks -------------------------------------------------
  * var_profile_select: record HIP events, on the launch stream, around every launch of one
  * kernel family (tag in [0, var_profile_tag_count()), -1 = off); var_profile_read returns the

@@ -1,0 +1,174 @@
+"""GPU parity tests of the iTHOR model: the HIP path through the C
+ABI (var_ithor_*) against (1) the fixture the reference class produced (tests/golden/ithor_h96.npz) and (2) the
+CPU oracle (oracle/torch_oracle.py:IthorNetCPU, itself pinned to that fixture) on seeded inputs.
+Tolerances: north_star's 1e-3 (fp32) on embeddings and loss; gradients by per-tensor L2 error."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle.torch_oracle import ithor_seeded  # noqa: E402  (checker only)
+
+
+def cfg(h):
+    return types.SimpleNamespace(img_dim=(3, h, h), sound_dim=(1, 600, 40), representationDim=3)
+
+
+@pytest.fixture(scope="module")
+def var_amd():
+    import var_amd as m
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return m
+
+
+@pytest.fixture(scope="module")
+def fx(golden_dir):
+    return dict(np.load(os.path.join(golden_dir, "ithor_h96.npz")))
+
+
+def cuda(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def seeded_model(var_amd, seed, h=96):
+    torch.manual_seed(seed)
+    return var_amd.IthorVARPretextNet(cfg(h)).to("cuda")
+
+
+def l2_rel(a, b):
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def test_forward_dict_vs_reference_fixture(var_amd, fx):
+    m = seeded_model(var_amd, int(fx["seed"]))
+    for k, v in m.state_dict().items():                      # the seed reproduces the reference's weights
+        f = v.cpu().numpy().reshape(-1).astype(np.float64)
+        np.testing.assert_array_equal(np.concatenate([[f.sum(), np.abs(f).sum()], f[:8]]), fx["check." + k], err_msg=k)
+    with torch.no_grad():
+        d = m(cuda(fx["image"]), cuda(fx["sound_positive"]), cuda(fx["sound_negative"]))
+    assert d["image_BCE"] is None and d["sound_BCE"] is None
+    for k in ("image_feat", "sound_feat_positive", "sound_feat_negative"):
+        np.testing.assert_allclose(d[k].cpu().numpy(), fx[k], atol=1e-4, rtol=0, err_msg=k)
+    for k in ("image_feat_raw", "pos_sound_raw"):
+        assert l2_rel(d[k].cpu().numpy(), fx[k]) < 1e-4, k
+        np.testing.assert_allclose(d[k].cpu().numpy(), fx[k], atol=1e-4, rtol=1e-3, err_msg=k)
+    # f32 image input (image/255 done by the caller, dataset.py:67-68) gives the same result as u8
+    with torch.no_grad():
+        d2 = m((cuda(fx["image"]) / 255.).float(), None, None)
+    assert d2["sound_feat_negative"] is None and d2["pos_sound_raw"] is None
+    np.testing.assert_allclose(d2["image_feat"].cpu().numpy(), d["image_feat"].cpu().numpy(), atol=2e-6)
+
+
+def test_loss_and_gradients_vs_reference_fixture(var_amd, fx):
+    m = seeded_model(var_amd, int(fx["seed"]))
+    tr = var_amd.IthorTrainer(m)
+    loss, feats = tr.loss_and_grads(cuda(fx["image"]), cuda(fx["sound_positive"]), cuda(fx["sound_negative"]), feats=True)
+    assert abs(loss.item() - float(fx["losses"][0])) < 1e-4
+    np.testing.assert_allclose(feats.cpu().numpy()[:, 0:3], fx["image_feat"], atol=1e-4)
+    np.testing.assert_allclose(feats.cpu().numpy()[:, 6:9], fx["sound_feat_negative"], atol=1e-4)
+    g = tr.grads.cpu().numpy()
+    stride = int(fx["stride"])
+    o = 0
+    for k, p in m.named_parameters():
+        gt = g[o:o + p.numel()]
+        o += p.numel()
+        ref_s, ref_n = fx["gsamp." + k], float(fx["gnorm." + k])
+        assert abs(np.linalg.norm(gt.astype(np.float64)) - ref_n) <= 2e-3 * ref_n + 1e-8, k
+        assert np.linalg.norm(gt[::stride].astype(np.float64) - ref_s) <= 2e-3 * np.linalg.norm(ref_s) + 1e-3 * ref_n / np.sqrt(max(1, p.numel() // stride)) + 1e-9, k
+
+
+def test_autograd_path_equals_fused_path(var_amd, fx):
+    m = seeded_model(var_amd, int(fx["seed"]))
+    tr = var_amd.IthorTrainer(m)
+    tr.loss_and_grads(cuda(fx["image"]), cuda(fx["sound_positive"]), cuda(fx["sound_negative"]))
+    fused = tr.grads.clone()
+    d = m(cuda(fx["image"]), cuda(fx["sound_positive"]), cuda(fx["sound_negative"]))
+    loss = torch.nn.TripletMarginLoss(margin=1.0, p=2)(d["image_feat"], d["sound_feat_positive"], d["sound_feat_negative"])
+    loss.backward()
+    assert abs(loss.item() - float(fx["losses"][0])) < 1e-4
+    auto = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+    assert l2_rel(auto.cpu().numpy(), fused.cpu().numpy()) < 1e-4
+
+
+def test_two_adam_steps_vs_reference_fixture(var_amd, fx):
+    m = seeded_model(var_amd, int(fx["seed"]))
+    tr = var_amd.IthorTrainer(m, lr=1e-4, weight_decay=1e-6)
+    img, pos, neg = cuda(fx["image"]), cuda(fx["sound_positive"]), cuda(fx["sound_negative"])
+    losses = [tr.step(img, pos, neg).item() for _ in range(2)]
+    np.testing.assert_allclose(losses, fx["losses"], atol=2e-4)
+    stride = int(fx["stride"])
+    for k, v in m.state_dict().items():
+        got = v.cpu().numpy().reshape(-1)[::stride]
+        # Adam's first steps move every weight by ~lr whatever the gradient's size: compare the movement
+        np.testing.assert_allclose(got, fx["adam2." + k], atol=4e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("h,b", [(84, 3), (96, 5)])
+def test_full_gradients_vs_oracle(var_amd, h, b):
+    torch.set_num_threads(8)
+    ref = ithor_seeded(123)
+    with torch.no_grad():                                     # spread the embeddings so some hinges are inactive
+        for k, p in ref.named_parameters():
+            if "Triplet" in k and k.endswith("weight"):
+                p.mul_(3.0)
+    m = var_amd.IthorVARPretextNet(cfg(h))
+    m.load_state_dict(ref.state_dict())
+    m = m.to("cuda")
+    rng = np.random.default_rng(5 + h)
+    img = rng.integers(0, 256, size=(b, 3, h, h), dtype=np.uint8)
+    snd = (rng.standard_normal((2 * b, 1, 600, 40)) * 6.0).astype(np.float32)
+    snd[0, :, 350:] = 0.0
+    pos, neg = snd[:b], snd[b:]
+    a, p_, n_ = ref((torch.from_numpy(img) / 255.).float(), torch.from_numpy(pos), torch.from_numpy(neg))
+    loss = torch.nn.TripletMarginLoss(margin=1.0, p=2)(a, p_, n_)
+    loss.backward()
+    tr = var_amd.IthorTrainer(m)
+    l, feats = tr.loss_and_grads(cuda(img), cuda(pos), cuda(neg), feats=True)
+    assert abs(l.item() - loss.item()) < 1e-4
+    np.testing.assert_allclose(feats.cpu().numpy(), torch.cat([a, p_, n_], 1).detach().numpy(), atol=1e-4)
+    g = tr.grads.cpu().numpy()
+    o = 0
+    worst = 0.0
+    for k, q in ref.named_parameters():
+        gt = g[o:o + q.numel()]
+        o += q.numel()
+        e = l2_rel(gt, q.grad.numpy())
+        worst = max(worst, e)
+        assert e < 5e-3, (k, e)
+    print("worst per-tensor L2 error", worst)
+
+
+def test_none_inputs_and_cached_goal_sound(var_amd, fx):
+    m = seeded_model(var_amd, int(fx["seed"]))
+    img, pos, neg = cuda(fx["image"]), cuda(fx["sound_positive"]), cuda(fx["sound_negative"])
+    with torch.no_grad():
+        d = m(img, pos, None)                                 # pretext.py:131,188
+        assert d["sound_feat_negative"] is None
+        np.testing.assert_allclose(d["sound_feat_positive"].cpu().numpy(), fx["sound_feat_positive"], atol=1e-4)
+        d = m(img, torch.full_like(pos, float("inf")), None)  # pretext_base.py:29-32: cached goal embedding
+        assert d["pos_sound_raw"] is None
+        np.testing.assert_allclose(d["sound_feat_positive"].cpu().numpy(), fx["sound_feat_positive"], atol=1e-4)
+        d = m(None, neg, None)
+        assert d["image_feat"] is None and d["image_feat_raw"] is None
+        np.testing.assert_allclose(d["sound_feat_positive"].cpu().numpy(), fx["sound_feat_negative"], atol=1e-4)
+        d = m(None, None, neg)
+        np.testing.assert_allclose(d["sound_feat_negative"].cpu().numpy(), fx["sound_feat_negative"], atol=1e-4)
+        img4 = torch.cat([(img / 255.).float(), torch.ones(2, 1, 96, 96, device="cuda")], dim=1)
+        d = m(img4, None, None)                               # image[:, :3] (pretext_base.py:22)
+        np.testing.assert_allclose(d["image_feat"].cpu().numpy(), fx["image_feat"], atol=1e-4)
+
+
+def test_rejects_cpu_tensors_and_bad_shapes(var_amd):
+    with pytest.raises(var_amd.VarHipError):
+        var_amd.IthorVARPretextNet(types.SimpleNamespace(img_dim=(3, 64, 64), sound_dim=(1, 600, 40), representationDim=3))
+    m = seeded_model(var_amd, 1)
+    with pytest.raises(var_amd.VarHipError):
+        m(torch.zeros(1, 3, 96, 96), None, None)
+    with pytest.raises(var_amd.VarHipError):
+        m(None, torch.zeros(1, 1, 100, 40, device="cuda"), None)

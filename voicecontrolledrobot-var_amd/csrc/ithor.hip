@@ -1,0 +1,678 @@
+// iTHOR VARPretextNet on gfx950 (models/pretext/ai2thor_pretext_model.py:5-58):
+//   image   (B,3,H,H)  -> conv3x3 s1 x2, pool, conv, pool, conv, pool, conv, pool, conv3x3 s2 -> (B,1152)
+//   sound   (B,1,600,40) x {pos,neg} -> conv 11x11 s2, conv 11x5 s2, conv 7x3 s2 -> (B,73,448) -> bidirectional
+//           GRU(448 -> 512), final hidden states of both directions concatenated -> (B,1024)
+//   heads   Linear(1152,128)+ReLU+Linear(128,3); Linear(1024,128)+ReLU+Linear(128,64)+ReLU+Linear(64,3); L2-normalise
+// forward, TripletMarginLoss and the full backward.  Every product (convolutions in all three directions, Linear
+// layers, the GRU's input and recurrent products and their gradients) is an instance of the f32-MFMA
+// gather-GEMM of gg.h; this file adds the element-wise kernels (max pool, GRU gates, ReLU masks, bias sums,
+// normalise) and the host-side schedule.  Parameters are used in place in their state_dict() layouts.
+#include <stdlib.h>
+#include <string.h>
+
+#include "gg.h"
+
+// ---- geometry ------------------------------------------------------------------------------------------------
+static constexpr int kICh[7] = {3, 32, 32, 64, 64, 128, 128};
+static constexpr int kT = 600, kF = 40;             // sound_dim (1,600,40), Envs/ai2thor/config.py
+static constexpr int kSeq = 73, kGin = 448, kGh = 512, kG3 = 1536;
+static constexpr int kIRaw = 1152, kSRaw = 1024;
+
+struct IthorLayout {
+    int iw[6], ib[6];
+    int w_ih[2], w_hh[2], b_ih[2], b_hh[2];
+    int sw[3], sb[3];
+    int ih_w0, ih_b0, ih_w1, ih_b1;
+    int sh_w0, sh_b0, sh_w1, sh_b1, sh_w2, sh_b2;
+    int total;
+};
+static constexpr int kSK[3] = {121, 64 * 55, 64 * 21};
+
+static IthorLayout make_ithor_layout() {
+    IthorLayout L{};
+    int o = 0;
+    for (int i = 0; i < 6; i++) { L.iw[i] = o; o += kICh[i + 1] * kICh[i] * 9; L.ib[i] = o; o += kICh[i + 1]; }
+    for (int d = 0; d < 2; d++) {
+        L.w_ih[d] = o; o += kG3 * kGin; L.w_hh[d] = o; o += kG3 * kGh;
+        L.b_ih[d] = o; o += kG3;        L.b_hh[d] = o; o += kG3;
+    }
+    for (int i = 0; i < 3; i++) { L.sw[i] = o; o += 64 * kSK[i]; L.sb[i] = o; o += 64; }
+    L.ih_w0 = o; o += 128 * kIRaw; L.ih_b0 = o; o += 128; L.ih_w1 = o; o += 3 * 128; L.ih_b1 = o; o += 3;
+    L.sh_w0 = o; o += 128 * kSRaw; L.sh_b0 = o; o += 128; L.sh_w1 = o; o += 64 * 128; L.sh_b1 = o; o += 64;
+    L.sh_w2 = o; o += 3 * 64;      L.sh_b2 = o; o += 3;
+    L.total = o;
+    return L;
+}
+
+struct ithor_state {
+    IthorLayout L;
+    int maxB = 0, H = 0;
+    int hs[6] = {0};                // image side lengths: input, after pool 1..4, after the last conv
+    char* ws = nullptr;
+    // image activations (post-ReLU) and pooled maps, and the gradients wrt them
+    float *a[7] = {nullptr}, *p[6] = {nullptr}, *ga[7] = {nullptr}, *gp[6] = {nullptr};
+    float *s[4] = {nullptr}, *gs[4] = {nullptr};          // sound conv outputs 1..3 (3 in sequence layout)
+    float *GI = nullptr, *GH = nullptr, *Hb = nullptr, *R = nullptr, *Z = nullptr, *Nn = nullptr, *GHN = nullptr;
+    float *DGI = nullptr, *DGH = nullptr, *DH = nullptr;
+    float *sraw = nullptr, *gsraw = nullptr;              // (clips,1024)
+    float *hid_i = nullptr, *ghid_i = nullptr, *hid_s1 = nullptr, *ghid_s1 = nullptr, *hid_s2 = nullptr, *ghid_s2 = nullptr;
+    float *raw = nullptr, *graw = nullptr, *emb = nullptr, *gemb = nullptr;   // (3B,3) [img | pos | neg]
+    float* loss = nullptr;
+    // saved forward
+    int B = 0, nclips = 0; bool has_img = false, has_pos = false, has_neg = false;
+    const void* image = nullptr; int is_u8 = 0; long bstride = 0;
+    const float *pos = nullptr, *neg = nullptr;
+};
+
+static inline ithor_state* ith(var_ctx* c) { return (ithor_state*)c->ith; }
+
+void ithor_free(var_ctx* c) {
+    ithor_state* st = ith(c);
+    if (!st) return;
+    if (st->ws) (void)hipFree(st->ws);
+    delete st;
+    c->ith = nullptr;
+}
+
+// ---- element-wise kernels ---------------------------------------------------------------------------------------
+// nn.MaxPool2d(2, stride=2): the last row/column of an odd map is dropped
+__global__ void pool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n, int H, int HP) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int px = (int)(i % HP), py = (int)((i / HP) % HP);
+    const long plane = i / ((long)HP * HP);
+    const float* q = x + plane * H * H + (long)(2 * py) * H + 2 * px;
+    y[i] = fmaxf(fmaxf(q[0], q[1]), fmaxf(q[H], q[H + 1]));
+}
+
+// backward of ReLU followed by the max pool: the gradient of a pooled cell goes to the first maximum of its
+// window in scan order (PyTorch's choice) and is dropped where that activation is not positive.
+__global__ void pool_relu_bwd_kernel(const float* __restrict__ act, const float* __restrict__ gpool,
+                                     float* __restrict__ gact, long n, int H, int HP) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int x = (int)(i % H), y = (int)((i / H) % H);
+    const long plane = i / ((long)H * H);
+    const int px = x >> 1, py = y >> 1;
+    float g = 0.f;
+    if (px < HP && py < HP) {
+        const float* q = act + plane * H * H + (long)(2 * py) * H + 2 * px;
+        const float v0 = q[0], v1 = q[1], v2 = q[H], v3 = q[H + 1];
+        int best = 0; float bv = v0;
+        if (v1 > bv) { bv = v1; best = 1; }
+        if (v2 > bv) { bv = v2; best = 2; }
+        if (v3 > bv) { bv = v3; best = 3; }
+        const int mine = (y & 1) * 2 + (x & 1);
+        if (mine == best && bv > 0.f) g = gpool[plane * HP * HP + (long)py * HP + px];
+    }
+    gact[i] = g;
+}
+
+__global__ void relu_mask_kernel(float* __restrict__ g, const float* __restrict__ act, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !(act[i] > 0.f)) g[i] = 0.f;
+}
+
+// out[c] += sum_{o < outer} sum_{i < inner} g[(o*C + c)*inner + i]   (bias gradients of every layer kind)
+__global__ void __launch_bounds__(256) chan_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int outer,
+                                                      int C, int inner) {
+    const int c = blockIdx.x;
+    const long per = ((long)outer * inner + gridDim.y - 1) / gridDim.y;
+    const long lo = blockIdx.y * per, hi = min((long)outer * inner, lo + per);
+    float acc = 0.f;
+    for (long e = lo + threadIdx.x; e < hi; e += 256) {
+        const long o = e / inner; const int i = (int)(e - o * inner);
+        acc += g[(o * C + c) * inner + i];
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(out + c, red[0]);
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// one GRU time step, both directions (torch.nn.GRU gate order r, z, n):
+//   r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h' = (1 - z) * n + z * h
+// GI (dir, clip*T + t, 1536) holds x W_ih^T + b_ih, GH (dir, clip, 1536) holds h W_hh^T + b_hh.
+__global__ void gru_gate_fwd_kernel(const float* __restrict__ GI, const float* __restrict__ GH, const float* __restrict__ hprev,
+                                    float* __restrict__ hnext, float* __restrict__ R, float* __restrict__ Z,
+                                    float* __restrict__ Nn, float* __restrict__ GHN, int nclips, int step, long dirGI,
+                                    long dirH, long dirS, int save) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nclips * kGh) return;
+    const int dir = blockIdx.y;
+    const int clip = i / kGh, j = i - clip * kGh;
+    const int t = dir ? kSeq - 1 - step : step;
+    const float* gi = GI + dir * dirGI + ((long)clip * kSeq + t) * kG3;
+    const float* gh = GH + (long)dir * nclips * kG3 + (long)clip * kG3;
+    const float r = sigmoidf_(gi[j] + gh[j]);
+    const float z = sigmoidf_(gi[kGh + j] + gh[kGh + j]);
+    const float ghn = gh[2 * kGh + j];
+    const float n = tanhf(gi[2 * kGh + j] + r * ghn);
+    const float hp = hprev[dir * dirH + i];
+    hnext[dir * dirH + i] = (1.f - z) * n + z * hp;
+    if (save) {
+        const long o = dir * dirS + (long)step * nclips * kGh + i;
+        R[o] = r; Z[o] = z; Nn[o] = n; GHN[o] = ghn;
+    }
+}
+
+// backward of that step: from dh (in place -> dh * z, the direct path to h_prev) to the gate pre-activation
+// gradients, DGI in (dir, clip*T + t, 1536) and DGH in (dir, step, clip, 1536).
+__global__ void gru_gate_bwd_kernel(float* __restrict__ DH, const float* __restrict__ hprev, const float* __restrict__ R,
+                                    const float* __restrict__ Z, const float* __restrict__ Nn, const float* __restrict__ GHN,
+                                    float* __restrict__ DGI, float* __restrict__ DGH, int nclips, int step, long dirGI,
+                                    long dirH, long dirS, long dirDGH) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nclips * kGh) return;
+    const int dir = blockIdx.y;
+    const int clip = i / kGh, j = i - clip * kGh;
+    const int t = dir ? kSeq - 1 - step : step;
+    const long o = dir * dirS + (long)step * nclips * kGh + i;
+    const float r = R[o], z = Z[o], n = Nn[o], ghn = GHN[o];
+    const float dh = DH[(long)dir * nclips * kGh + i];
+    const float hp = hprev[dir * dirH + i];
+    const float dn_pre = dh * (1.f - z) * (1.f - n * n);
+    const float dz_pre = dh * (hp - n) * z * (1.f - z);
+    const float dr_pre = dn_pre * ghn * r * (1.f - r);
+    float* gi = DGI + dir * dirGI + ((long)clip * kSeq + t) * kG3;
+    float* gh = DGH + dir * dirDGH + ((long)step * nclips + clip) * kG3;
+    gi[j] = dr_pre; gi[kGh + j] = dz_pre; gi[2 * kGh + j] = dn_pre;
+    gh[j] = dr_pre; gh[kGh + j] = dz_pre; gh[2 * kGh + j] = dn_pre * r;
+    DH[(long)dir * nclips * kGh + i] = dh * z;
+}
+
+// sraw[clip] = [h_T forward | h_T reverse]; and its inverse for the gradient
+__global__ void gru_concat_kernel(const float* __restrict__ hfin, float* __restrict__ sraw, int nclips, long dirH, int inverse) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nclips * kSRaw) return;
+    const int clip = i / kSRaw, q = i - clip * kSRaw, dir = q / kGh, j = q - dir * kGh;
+    if (inverse) ((float*)hfin)[dir * dirH + (long)clip * kGh + j] = sraw[i];
+    else sraw[i] = hfin[dir * dirH + (long)clip * kGh + j];
+}
+
+// F.normalize(x, p=2, dim=1) on rows of 3 (pretext_base.py:18,23) and its backward
+__global__ void l2norm_fwd_kernel(const float* __restrict__ raw, float* __restrict__ emb, int rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const float x = raw[3 * i], y = raw[3 * i + 1], z = raw[3 * i + 2];
+    const float nrm = fmaxf(sqrtf(x * x + y * y + z * z), 1e-12f);
+    emb[3 * i] = x / nrm; emb[3 * i + 1] = y / nrm; emb[3 * i + 2] = z / nrm;
+}
+__global__ void l2norm_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ gemb, float* __restrict__ graw, int rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const float x = raw[3 * i], y = raw[3 * i + 1], z = raw[3 * i + 2];
+    const float gx = gemb[3 * i], gy = gemb[3 * i + 1], gz = gemb[3 * i + 2];
+    const float n2 = sqrtf(x * x + y * y + z * z);
+    if (n2 < 1e-12f) { graw[3 * i] = gx / 1e-12f; graw[3 * i + 1] = gy / 1e-12f; graw[3 * i + 2] = gz / 1e-12f; return; }
+    const float ex = x / n2, ey = y / n2, ez = z / n2;
+    const float dot = gx * ex + gy * ey + gz * ez;
+    graw[3 * i] = (gx - ex * dot) / n2; graw[3 * i + 1] = (gy - ey * dot) / n2; graw[3 * i + 2] = (gz - ez * dot) / n2;
+}
+
+__global__ void copy_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+// ---- launch helpers ---------------------------------------------------------------------------------------------
+static inline dim3 g1(long n) { return dim3((unsigned)((n + 255) / 256)); }
+
+#define IT_CHECK(c) VAR_HIP_CHECK(c, hipGetLastError())
+
+template <class G, bool U8, bool SEQ>
+static int conv_fwd(var_ctx* c, hipStream_t s, const ConvDims& d, const void* x, const float* w, const float* bias, float* y) {
+    ConvFwdP<G, U8, SEQ> p{};
+    p.M = d.B * d.HO * d.WO; p.N = d.COUT; p.K = d.CIN * G::KHW; p.nsplit = 1;
+    p.d = d; p.x = x; p.w = w; p.bias = bias; p.y = y;
+    return gg_launch(c, s, p);
+}
+template <class G, bool SEQ>
+static int conv_dgrad(var_ctx* c, hipStream_t s, const ConvDims& d, const float* gy, const float* w, float* dx) {
+    ConvDgradP<G, SEQ> p{};
+    p.M = d.B * d.H * d.W; p.N = d.CIN; p.K = d.COUT * G::KHW; p.nsplit = 1;
+    p.d = d; p.gy = gy; p.w = w; p.dx = dx;
+    return gg_launch(c, s, p);
+}
+template <class G, bool U8, bool SEQ>
+static int conv_wgrad(var_ctx* c, hipStream_t s, const ConvDims& d, const void* x, const float* gy, float* dw) {
+    ConvWgradP<G, U8, SEQ> p{};
+    p.M = d.CIN * G::KHW; p.N = d.COUT; p.K = d.B * d.HO * d.WO;
+    const int tiles = ((p.M + GG_MT - 1) / GG_MT) * ((p.N + 63) / 64);
+    int ns = (1024 + tiles - 1) / tiles;                    // about 4 workgroups per CU
+    const int kchunks = (p.K + GG_KC - 1) / GG_KC;
+    if (ns > kchunks / 8) ns = kchunks / 8 > 0 ? kchunks / 8 : 1;
+    p.nsplit = ns;
+    p.d = d; p.x = x; p.gy = gy; p.dw = dw;
+    return gg_launch(c, s, p);
+}
+static int chan_sum(var_ctx* c, hipStream_t s, const float* g, float* out, int outer, int C, int inner) {
+    long tot = (long)outer * inner;
+    int chunks = (int)((tot + 8191) / 8192);
+    if (chunks > 64) chunks = 64;
+    if (chunks < 1) chunks = 1;
+    hipLaunchKernelGGL(chan_sum_kernel, dim3(C, chunks), dim3(256), 0, s, g, out, outer, C, inner);
+    IT_CHECK(c);
+    return VAR_OK;
+}
+
+// Y (rows, O) = X (rows, K) W^T + b, optional ReLU
+static int linear_fwd(var_ctx* c, hipStream_t s, const float* X, const float* W, const float* b, float* Y, int rows, int K,
+                      int O, int relu) {
+    DenseP<true, true, 0> p{};
+    p.M = O; p.N = rows; p.K = K; p.nsplit = 1;
+    p.A = W; p.sam = K; p.sak = 1; p.Bm = X; p.sbk = 1; p.sbn = K; p.C = Y; p.scm = 1; p.scn = O; p.bias = b; p.relu = relu;
+    return gg_launch(c, s, p);
+}
+// backward of that layer from dY (already masked by the layer's own ReLU): dW += dY^T X, db += colsum(dY), dX = dY W
+static int linear_bwd(var_ctx* c, hipStream_t s, const float* X, const float* W, const float* dY, float* dW, float* db,
+                      float* dX, int rows, int K, int O) {
+    {
+        DenseP<false, false, 2> p{};
+        p.M = K; p.N = O; p.K = rows; p.nsplit = 1;
+        p.A = X; p.sam = 1; p.sak = K; p.Bm = dY; p.sbk = O; p.sbn = 1; p.C = dW; p.scm = 1; p.scn = K;
+        int r = gg_launch(c, s, p); if (r) return r;
+    }
+    int r = chan_sum(c, s, dY, db, rows, O, 1); if (r) return r;
+    if (dX) {
+        DenseP<false, true, 0> p{};
+        p.M = K; p.N = rows; p.K = O; p.nsplit = 1;
+        p.A = W; p.sam = 1; p.sak = K; p.Bm = dY; p.sbk = 1; p.sbn = O; p.C = dX; p.scm = 1; p.scn = K;
+        r = gg_launch(c, s, p); if (r) return r;
+    }
+    return VAR_OK;
+}
+static int relu_mask(var_ctx* c, hipStream_t s, float* g, const float* act, long n) {
+    hipLaunchKernelGGL(relu_mask_kernel, g1(n), dim3(256), 0, s, g, act, n);
+    IT_CHECK(c);
+    return VAR_OK;
+}
+
+using G3s1 = Geo<3, 3, 1, 1, 1, 1>;
+using G3s2 = Geo<3, 3, 2, 2, 1, 1>;
+using GS1 = Geo<11, 11, 2, 2, 5, 5>;
+using GS2 = Geo<11, 5, 2, 2, 5, 5>;
+using GS3 = Geo<7, 3, 2, 2, 1, 1>;
+
+static ConvDims img_dims(const ithor_state* st, int l, int B) {      // l = 1..6
+    const int hin = l == 1 ? st->hs[0] : (l == 2 ? st->hs[0] : st->hs[l - 2]);
+    return conv_dims(B, kICh[l - 1], hin, hin, kICh[l], 3, 3, l == 6 ? 2 : 1, l == 6 ? 2 : 1, 1, 1);
+}
+static ConvDims snd_dims(int l, int n) {                              // l = 1..3
+    if (l == 1) return conv_dims(n, 1, kT, kF, 64, 11, 11, 2, 2, 5, 5);
+    if (l == 2) return conv_dims(n, 64, 300, 20, 64, 11, 5, 2, 2, 5, 5);
+    return conv_dims(n, 64, 150, 13, 64, 7, 3, 2, 2, 1, 1);
+}
+
+#define RUN(x) do { int r_ = (x); if (r_ != VAR_OK) return r_; } while (0)
+
+// ---- forward ----------------------------------------------------------------------------------------------------
+static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* image, int is_u8, long bstride, const float* pos,
+                     const float* neg, int B, bool save) {
+    ithor_state* st = ith(c);
+    const IthorLayout& L = st->L;
+    const int* hs = st->hs;
+    st->B = B; st->has_img = image != nullptr; st->has_pos = pos != nullptr; st->has_neg = neg != nullptr;
+    st->image = image; st->is_u8 = is_u8; st->bstride = bstride; st->pos = pos; st->neg = neg;
+    const int nclips = (pos ? B : 0) + (neg ? B : 0);
+    st->nclips = nclips;
+    if (image) {
+        ConvDims d = img_dims(st, 1, B);
+        d.xb = bstride;
+        if (is_u8) RUN((conv_fwd<G3s1, true, false>(c, s, d, image, P + L.iw[0], P + L.ib[0], st->a[1])));
+        else RUN((conv_fwd<G3s1, false, false>(c, s, d, image, P + L.iw[0], P + L.ib[0], st->a[1])));
+        RUN((conv_fwd<G3s1, false, false>(c, s, img_dims(st, 2, B), st->a[1], P + L.iw[1], P + L.ib[1], st->a[2])));
+        for (int l = 2; l <= 5; ++l) {
+            // pool the output of conv l into p[l], then conv l+1
+            const long n = (long)B * kICh[l] * hs[l - 1] * hs[l - 1];
+            const int hin = l == 2 ? hs[0] : hs[l - 2];
+            hipLaunchKernelGGL(pool_fwd_kernel, g1(n), dim3(256), 0, s, st->a[l], st->p[l], n, hin, hs[l - 1]);
+            IT_CHECK(c);
+            if (l < 5) RUN((conv_fwd<G3s1, false, false>(c, s, img_dims(st, l + 1, B), st->p[l], P + L.iw[l], P + L.ib[l], st->a[l + 1])));
+            else RUN((conv_fwd<G3s2, false, false>(c, s, img_dims(st, 6, B), st->p[5], P + L.iw[5], P + L.ib[5], st->a[6])));
+        }
+        RUN(linear_fwd(c, s, st->a[6], P + L.ih_w0, P + L.ih_b0, st->hid_i, B, kIRaw, 128, 1));
+        RUN(linear_fwd(c, s, st->hid_i, P + L.ih_w1, P + L.ih_b1, st->raw, B, 128, 3, 0));
+    }
+    if (nclips) {
+        // clips: [pos | neg] (whichever are given), local index 0..nclips-1
+        int off = 0;
+        for (int q = 0; q < 2; ++q) {
+            const float* src = q == 0 ? pos : neg;
+            if (!src) continue;
+            RUN((conv_fwd<GS1, false, false>(c, s, snd_dims(1, B), src, P + L.sw[0], P + L.sb[0],
+                                             st->s[1] + (long)off * 64 * 300 * 20)));
+            off += B;
+        }
+        RUN((conv_fwd<GS2, false, false>(c, s, snd_dims(2, nclips), st->s[1], P + L.sw[1], P + L.sb[1], st->s[2])));
+        RUN((conv_fwd<GS3, false, true>(c, s, snd_dims(3, nclips), st->s[2], P + L.sw[2], P + L.sb[2], st->s[3])));
+        const int rows = nclips * kSeq;
+        const long dirP = L.w_ih[1] - L.w_ih[0];
+        const long dirGI = (long)rows * kG3, dirH = (long)(kSeq + 1) * nclips * kGh, dirS = (long)kSeq * nclips * kGh;
+        {
+            DenseP<true, true, 0> p{};
+            p.M = kG3; p.N = rows; p.K = kGin; p.nsplit = 1;
+            p.A = P + L.w_ih[0]; p.sam = kGin; p.sak = 1; p.zA = dirP;
+            p.Bm = st->s[3]; p.sbk = 1; p.sbn = kGin; p.zB = 0;
+            p.C = st->GI; p.scm = 1; p.scn = kG3; p.zC = dirGI; p.bias = P + L.b_ih[0]; p.zbias = dirP;
+            RUN(gg_launch(c, s, p, 2));
+        }
+        for (int d = 0; d < 2; ++d) VAR_HIP_CHECK(c, hipMemsetAsync(st->Hb + d * dirH, 0, sizeof(float) * nclips * kGh, s));
+        for (int step = 0; step < kSeq; ++step) {
+            DenseP<true, true, 0> p{};
+            p.M = kG3; p.N = nclips; p.K = kGh; p.nsplit = 1;
+            p.A = P + L.w_hh[0]; p.sam = kGh; p.sak = 1; p.zA = dirP;
+            p.Bm = st->Hb + (long)step * nclips * kGh; p.sbk = 1; p.sbn = kGh; p.zB = dirH;
+            p.C = st->GH; p.scm = 1; p.scn = kG3; p.zC = (long)nclips * kG3; p.bias = P + L.b_hh[0]; p.zbias = dirP;
+            RUN(gg_launch(c, s, p, 2));
+            hipLaunchKernelGGL(gru_gate_fwd_kernel, dim3((nclips * kGh + 255) / 256, 2), dim3(256), 0, s, st->GI, st->GH,
+                               st->Hb + (long)step * nclips * kGh, st->Hb + (long)(step + 1) * nclips * kGh, st->R, st->Z,
+                               st->Nn, st->GHN, nclips, step, dirGI, dirH, dirS, save ? 1 : 0);
+            IT_CHECK(c);
+        }
+        hipLaunchKernelGGL(gru_concat_kernel, g1((long)nclips * kSRaw), dim3(256), 0, s,
+                           st->Hb + (long)kSeq * nclips * kGh, st->sraw, nclips, dirH, 0);
+        IT_CHECK(c);
+        RUN(linear_fwd(c, s, st->sraw, P + L.sh_w0, P + L.sh_b0, st->hid_s1, nclips, kSRaw, 128, 1));
+        RUN(linear_fwd(c, s, st->hid_s1, P + L.sh_w1, P + L.sh_b1, st->hid_s2, nclips, 128, 64, 1));
+        RUN(linear_fwd(c, s, st->hid_s2, P + L.sh_w2, P + L.sh_b2, st->raw + 3 * (long)st->maxB, nclips, 64, 3, 0));
+    }
+    if (image) { hipLaunchKernelGGL(l2norm_fwd_kernel, g1(B), dim3(256), 0, s, st->raw, st->emb, B); IT_CHECK(c); }
+    if (nclips) {
+        hipLaunchKernelGGL(l2norm_fwd_kernel, g1(nclips), dim3(256), 0, s, st->raw + 3 * (long)st->maxB,
+                           st->emb + 3 * (long)st->maxB, nclips);
+        IT_CHECK(c);
+    }
+    return VAR_OK;
+}
+
+// ---- backward from gemb (gradients wrt the normalised embeddings, rows [img | clips]) ---------------------------
+static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
+    ithor_state* st = ith(c);
+    const IthorLayout& L = st->L;
+    const int* hs = st->hs;
+    const int B = st->B, nclips = st->nclips;
+    const long mB = st->maxB;
+    VAR_HIP_CHECK(c, hipMemsetAsync(G, 0, sizeof(float) * L.total, s));
+    if (st->has_img) {
+        hipLaunchKernelGGL(l2norm_bwd_kernel, g1(B), dim3(256), 0, s, st->raw, st->gemb, st->graw, B);
+        IT_CHECK(c);
+        RUN(linear_bwd(c, s, st->hid_i, P + L.ih_w1, st->graw, G + L.ih_w1, G + L.ih_b1, st->ghid_i, B, 128, 3));
+        RUN(relu_mask(c, s, st->ghid_i, st->hid_i, (long)B * 128));
+        RUN(linear_bwd(c, s, st->a[6], P + L.ih_w0, st->ghid_i, G + L.ih_w0, G + L.ih_b0, st->ga[6], B, kIRaw, 128));
+        RUN(relu_mask(c, s, st->ga[6], st->a[6], (long)B * kIRaw));
+        // conv 6 (stride 2) on p[5]
+        {
+            const ConvDims d = img_dims(st, 6, B);
+            RUN((conv_wgrad<G3s2, false, false>(c, s, d, st->p[5], st->ga[6], G + L.iw[5])));
+            RUN(chan_sum(c, s, st->ga[6], G + L.ib[5], B, 128, 9));
+            RUN((conv_dgrad<G3s2, false>(c, s, d, st->ga[6], P + L.iw[5], st->gp[5])));
+        }
+        for (int l = 5; l >= 2; --l) {
+            const int hin = l == 2 ? hs[0] : hs[l - 2];       // side of conv l's output (= its input, stride 1)
+            const long n = (long)B * kICh[l] * hin * hin;
+            hipLaunchKernelGGL(pool_relu_bwd_kernel, g1(n), dim3(256), 0, s, st->a[l], st->gp[l], st->ga[l], n, hin, hs[l - 1]);
+            IT_CHECK(c);
+            const ConvDims d = img_dims(st, l, B);
+            const float* xin = l == 2 ? st->a[1] : st->p[l - 1];
+            RUN((conv_wgrad<G3s1, false, false>(c, s, d, xin, st->ga[l], G + L.iw[l - 1])));
+            RUN(chan_sum(c, s, st->ga[l], G + L.ib[l - 1], B, kICh[l], hin * hin));
+            float* dx = l == 2 ? st->ga[1] : st->gp[l - 1];
+            RUN((conv_dgrad<G3s1, false>(c, s, d, st->ga[l], P + L.iw[l - 1], dx)));
+        }
+        RUN(relu_mask(c, s, st->ga[1], st->a[1], (long)B * 32 * hs[0] * hs[0]));
+        {
+            ConvDims d = img_dims(st, 1, B);
+            d.xb = st->bstride;
+            if (st->is_u8) RUN((conv_wgrad<G3s1, true, false>(c, s, d, st->image, st->ga[1], G + L.iw[0])));
+            else RUN((conv_wgrad<G3s1, false, false>(c, s, d, st->image, st->ga[1], G + L.iw[0])));
+            RUN(chan_sum(c, s, st->ga[1], G + L.ib[0], B, 32, hs[0] * hs[0]));
+        }
+    }
+    if (nclips) {
+        const float* raw = st->raw + 3 * mB;
+        float* graw = st->graw + 3 * mB;
+        hipLaunchKernelGGL(l2norm_bwd_kernel, g1(nclips), dim3(256), 0, s, raw, st->gemb + 3 * mB, graw, nclips);
+        IT_CHECK(c);
+        RUN(linear_bwd(c, s, st->hid_s2, P + L.sh_w2, graw, G + L.sh_w2, G + L.sh_b2, st->ghid_s2, nclips, 64, 3));
+        RUN(relu_mask(c, s, st->ghid_s2, st->hid_s2, (long)nclips * 64));
+        RUN(linear_bwd(c, s, st->hid_s1, P + L.sh_w1, st->ghid_s2, G + L.sh_w1, G + L.sh_b1, st->ghid_s1, nclips, 128, 64));
+        RUN(relu_mask(c, s, st->ghid_s1, st->hid_s1, (long)nclips * 128));
+        RUN(linear_bwd(c, s, st->sraw, P + L.sh_w0, st->ghid_s1, G + L.sh_w0, G + L.sh_b0, st->gsraw, nclips, kSRaw, 128));
+        // GRU, backward through time
+        const int rows = nclips * kSeq;
+        const long dirP = L.w_ih[1] - L.w_ih[0];
+        const long dirGI = (long)rows * kG3, dirH = (long)(kSeq + 1) * nclips * kGh, dirS = (long)kSeq * nclips * kGh;
+        const long dirDGH = (long)kSeq * nclips * kG3;
+        hipLaunchKernelGGL(gru_concat_kernel, g1((long)nclips * kSRaw), dim3(256), 0, s, st->DH, st->gsraw, nclips,
+                           (long)nclips * kGh, 1);
+        IT_CHECK(c);
+        for (int step = kSeq - 1; step >= 0; --step) {
+            hipLaunchKernelGGL(gru_gate_bwd_kernel, dim3((nclips * kGh + 255) / 256, 2), dim3(256), 0, s, st->DH,
+                               st->Hb + (long)step * nclips * kGh, st->R, st->Z, st->Nn, st->GHN, st->DGI, st->DGH, nclips, step,
+                               dirGI, dirH, dirS, dirDGH);
+            IT_CHECK(c);
+            if (step == 0) break;                               // h_0 = 0 has no consumer
+            DenseP<false, true, 1> p{};
+            p.M = kGh; p.N = nclips; p.K = kG3; p.nsplit = 1;
+            p.A = P + L.w_hh[0]; p.sam = 1; p.sak = kGh; p.zA = dirP;
+            p.Bm = st->DGH + (long)step * nclips * kG3; p.sbk = 1; p.sbn = kG3; p.zB = dirDGH;
+            p.C = st->DH; p.scm = 1; p.scn = kGh; p.zC = (long)nclips * kGh;
+            RUN(gg_launch(c, s, p, 2));
+        }
+        {   // dW_hh[dir][g][j] = sum_{step,clip} DGH[dir][step,clip][g] * h_prev[dir][step,clip][j]
+            DenseP<false, false, 2> p{};
+            p.M = kGh; p.N = kG3; p.K = kSeq * nclips;
+            p.nsplit = p.K >= 2048 ? 8 : (p.K >= 512 ? 4 : 1);
+            p.A = st->Hb; p.sam = 1; p.sak = kGh; p.zA = dirH;
+            p.Bm = st->DGH; p.sbk = kG3; p.sbn = 1; p.zB = dirDGH;
+            p.C = G + L.w_hh[0]; p.scm = 1; p.scn = kGh; p.zC = dirP;
+            RUN(gg_launch(c, s, p, 2));
+            // dW_ih[dir][g][i] = sum_{clip,t} DGI[dir][clip,t][g] * X[clip,t][i]
+            p.M = kGin; p.N = kG3; p.K = rows;
+            p.A = st->s[3]; p.sam = 1; p.sak = kGin; p.zA = 0;
+            p.Bm = st->DGI; p.sbk = kG3; p.sbn = 1; p.zB = dirGI;
+            p.C = G + L.w_ih[0]; p.scm = 1; p.scn = kGin; p.zC = dirP;
+            RUN(gg_launch(c, s, p, 2));
+        }
+        for (int d = 0; d < 2; ++d) {
+            RUN(chan_sum(c, s, st->DGI + d * dirGI, G + L.b_ih[d], rows, kG3, 1));
+            RUN(chan_sum(c, s, st->DGH + d * dirDGH, G + L.b_hh[d], rows, kG3, 1));
+        }
+        {   // dX[clip,t][i] = sum_dir sum_g DGI[dir][clip,t][g] * W_ih[dir][g][i]
+            DenseP<false, true, 0> p{};
+            p.M = kGin; p.N = rows; p.K = kG3; p.nsplit = 1;
+            p.A = P + L.w_ih[0]; p.sam = 1; p.sak = kGin; p.Bm = st->DGI; p.sbk = 1; p.sbn = kG3;
+            p.C = st->gs[3]; p.scm = 1; p.scn = kGin;
+            RUN(gg_launch(c, s, p));
+            DenseP<false, true, 1> q{};
+            q.M = kGin; q.N = rows; q.K = kG3; q.nsplit = 1;
+            q.A = P + L.w_ih[1]; q.sam = 1; q.sak = kGin; q.Bm = st->DGI + dirGI; q.sbk = 1; q.sbn = kG3;
+            q.C = st->gs[3]; q.scm = 1; q.scn = kGin;
+            RUN(gg_launch(c, s, q));
+        }
+        RUN(relu_mask(c, s, st->gs[3], st->s[3], (long)rows * kGin));
+        {
+            const ConvDims d = snd_dims(3, nclips);
+            RUN((conv_wgrad<GS3, false, true>(c, s, d, st->s[2], st->gs[3], G + L.sw[2])));
+            RUN(chan_sum(c, s, st->gs[3], G + L.sb[2], nclips * kSeq, 64, 7));
+            RUN((conv_dgrad<GS3, true>(c, s, d, st->gs[3], P + L.sw[2], st->gs[2])));
+            RUN(relu_mask(c, s, st->gs[2], st->s[2], (long)nclips * 64 * 150 * 13));
+        }
+        {
+            const ConvDims d = snd_dims(2, nclips);
+            RUN((conv_wgrad<GS2, false, false>(c, s, d, st->s[1], st->gs[2], G + L.sw[1])));
+            RUN(chan_sum(c, s, st->gs[2], G + L.sb[1], nclips, 64, 150 * 13));
+            RUN((conv_dgrad<GS2, false>(c, s, d, st->gs[2], P + L.sw[1], st->gs[1])));
+            RUN(relu_mask(c, s, st->gs[1], st->s[1], (long)nclips * 64 * 300 * 20));
+        }
+        {
+            int off = 0;
+            for (int q = 0; q < 2; ++q) {
+                const float* src = q == 0 ? st->pos : st->neg;
+                if (!src) continue;
+                RUN((conv_wgrad<GS1, false, false>(c, s, snd_dims(1, B), src, st->gs[1] + (long)off * 64 * 300 * 20, G + L.sw[0])));
+                off += B;
+            }
+            RUN(chan_sum(c, s, st->gs[1], G + L.sb[0], nclips, 64, 300 * 20));
+        }
+    }
+    return VAR_OK;
+}
+
+// ---- C ABI ------------------------------------------------------------------------------------------------------
+#define CHECK_CTX(c) do { if (!(c)) return VAR_ERR_ARG; } while (0)
+
+extern "C" {
+
+int var_ithor_param_count(void) { return make_ithor_layout().total; }
+
+int var_ithor_plan(var_ctx* c, int max_batch, int img_hw) {
+    CHECK_CTX(c);
+    if (max_batch < 1 || max_batch > 1024) { VAR_SET_ERR(c, "var_ithor_plan: batch %d outside 1..1024", max_batch); return VAR_ERR_ARG; }
+    int hs[6];
+    hs[0] = img_hw;
+    for (int i = 1; i <= 4; ++i) hs[i] = hs[i - 1] / 2;
+    hs[5] = (hs[4] - 1) / 2 + 1;
+    if (img_hw < 16 || hs[5] != 3) {
+        VAR_SET_ERR(c, "var_ithor_plan: img side %d does not end in a 3x3 map (Linear(1152, .))", img_hw);
+        return VAR_ERR_ARG;
+    }
+    VAR_HIP_CHECK(c, hipSetDevice(c->device));
+    ithor_state* st = ith(c);
+    if (st && st->maxB >= max_batch && st->H == img_hw) return VAR_OK;
+    ithor_free(c);
+    st = new ithor_state();
+    c->ith = st;
+    st->L = make_ithor_layout();
+    st->maxB = max_batch; st->H = img_hw;
+    memcpy(st->hs, hs, sizeof(hs));
+    const long B = max_batch, C2 = 2 * B;
+    // sizes (floats)
+    long asz[7] = {0}, psz[6] = {0};
+    asz[1] = B * 32 * hs[0] * hs[0]; asz[2] = asz[1];
+    for (int l = 3; l <= 5; ++l) asz[l] = B * kICh[l] * hs[l - 2] * hs[l - 2];
+    asz[6] = B * kIRaw;
+    for (int l = 2; l <= 5; ++l) psz[l] = B * kICh[l] * hs[l - 1] * hs[l - 1];
+    const long ssz[4] = {0, C2 * 64 * 300 * 20, C2 * 64 * 150 * 13, C2 * kSeq * kGin};
+    const long rows = C2 * kSeq;
+    long total = 0;
+    auto take = [&](long n) { long o = total; total += (n + 63) & ~63L; return o; };
+    long oa[7], oga[7], op[6], ogp[6], os[4], ogs[4];
+    for (int l = 1; l <= 6; ++l) { oa[l] = take(asz[l]); oga[l] = take(asz[l]); }
+    for (int l = 2; l <= 5; ++l) { op[l] = take(psz[l]); ogp[l] = take(psz[l]); }
+    for (int l = 1; l <= 3; ++l) { os[l] = take(ssz[l]); ogs[l] = take(ssz[l]); }
+    const long oGI = take(2 * rows * kG3), oDGI = take(2 * rows * kG3), oDGH = take(2 * rows * kG3);
+    const long oGH = take(2 * C2 * kG3), oHb = take(2 * (kSeq + 1) * C2 * kGh);
+    const long oR = take(2 * rows * kGh), oZ = take(2 * rows * kGh), oN = take(2 * rows * kGh), oGHN = take(2 * rows * kGh);
+    const long oDH = take(2 * C2 * kGh), osraw = take(C2 * kSRaw), ogsraw = take(C2 * kSRaw);
+    const long ohi = take(B * 128), oghi = take(B * 128), ohs1 = take(C2 * 128), oghs1 = take(C2 * 128);
+    const long ohs2 = take(C2 * 64), oghs2 = take(C2 * 64);
+    const long oraw = take(9 * B), ograw = take(9 * B), oemb = take(9 * B), ogemb = take(9 * B), oloss = take(64);
+    VAR_HIP_CHECK(c, hipMalloc((void**)&st->ws, (size_t)total * sizeof(float)));
+    float* w = (float*)st->ws;
+    for (int l = 1; l <= 6; ++l) { st->a[l] = w + oa[l]; st->ga[l] = w + oga[l]; }
+    for (int l = 2; l <= 5; ++l) { st->p[l] = w + op[l]; st->gp[l] = w + ogp[l]; }
+    for (int l = 1; l <= 3; ++l) { st->s[l] = w + os[l]; st->gs[l] = w + ogs[l]; }
+    st->GI = w + oGI; st->DGI = w + oDGI; st->DGH = w + oDGH; st->GH = w + oGH; st->Hb = w + oHb;
+    st->R = w + oR; st->Z = w + oZ; st->Nn = w + oN; st->GHN = w + oGHN; st->DH = w + oDH;
+    st->sraw = w + osraw; st->gsraw = w + ogsraw;
+    st->hid_i = w + ohi; st->ghid_i = w + oghi; st->hid_s1 = w + ohs1; st->ghid_s1 = w + oghs1;
+    st->hid_s2 = w + ohs2; st->ghid_s2 = w + oghs2;
+    st->raw = w + oraw; st->graw = w + ograw; st->emb = w + oemb; st->gemb = w + ogemb; st->loss = w + oloss;
+    return VAR_OK;
+}
+
+static int ithor_check(var_ctx* c, int B, int H, const char* who) {
+    ithor_state* st = ith(c);
+    if (!st || B > st->maxB || H != st->H) { VAR_SET_ERR(c, "%s: var_ithor_plan(%d, %d) first", who, B, H); return VAR_ERR_PLAN; }
+    if (B < 1) { VAR_SET_ERR(c, "%s: empty batch", who); return VAR_ERR_ARG; }
+    return VAR_OK;
+}
+
+static int copy_out(var_ctx* c, hipStream_t s, const float* src, float* dst, long n) {
+    if (!dst || n <= 0) return VAR_OK;
+    hipLaunchKernelGGL(copy_rows_kernel, g1(n), dim3(256), 0, s, src, dst, n);
+    IT_CHECK(c);
+    return VAR_OK;
+}
+
+int var_ithor_encoder_fwd(var_ctx* c, void* stream, const float* params, const void* image, int image_is_u8,
+                          long image_bstride, const float* snd_pos, const float* snd_neg, int B, int H,
+                          float* image_feat, float* pos_feat, float* neg_feat, float* image_raw, float* pos_raw,
+                          int save_for_bwd) {
+    CHECK_CTX(c);
+    VAR_HIP_CHECK(c, hipSetDevice(c->device));
+    if (!params) { VAR_SET_ERR(c, "var_ithor_encoder_fwd: params is NULL"); return VAR_ERR_ARG; }
+    RUN(ithor_check(c, B, H, "var_ithor_encoder_fwd"));
+    hipStream_t s = (hipStream_t)stream;
+    ithor_state* st = ith(c);
+    RUN(ithor_fwd(c, s, params, image, image_is_u8, image_bstride, snd_pos, snd_neg, B, save_for_bwd != 0));
+    const long mB = st->maxB;
+    if (image) {
+        RUN(copy_out(c, s, st->emb, image_feat, 3L * B));
+        RUN(copy_out(c, s, st->a[6], image_raw, (long)kIRaw * B));
+    }
+    int off = 0;
+    if (snd_pos) {
+        RUN(copy_out(c, s, st->emb + 3 * mB, pos_feat, 3L * B));
+        RUN(copy_out(c, s, st->sraw, pos_raw, (long)kSRaw * B));
+        off = B;
+    }
+    if (snd_neg) RUN(copy_out(c, s, st->emb + 3 * mB + 3L * off, neg_feat, 3L * B));
+    return VAR_OK;
+}
+
+int var_ithor_encoder_bwd(var_ctx* c, void* stream, const float* params, const float* g_image_feat,
+                          const float* g_pos_feat, const float* g_neg_feat, float* grads) {
+    CHECK_CTX(c);
+    VAR_HIP_CHECK(c, hipSetDevice(c->device));
+    ithor_state* st = ith(c);
+    if (!st || st->B == 0) { VAR_SET_ERR(c, "var_ithor_encoder_bwd: no saved forward"); return VAR_ERR_STATE; }
+    if (!params || !grads) { VAR_SET_ERR(c, "var_ithor_encoder_bwd: NULL argument"); return VAR_ERR_ARG; }
+    hipStream_t s = (hipStream_t)stream;
+    const long mB = st->maxB; const int B = st->B;
+    VAR_HIP_CHECK(c, hipMemsetAsync(st->gemb, 0, sizeof(float) * 9 * mB, s));
+    if (st->has_img && g_image_feat) RUN(copy_out(c, s, g_image_feat, st->gemb, 3L * B));
+    int off = 0;
+    if (st->has_pos) { if (g_pos_feat) RUN(copy_out(c, s, g_pos_feat, st->gemb + 3 * mB, 3L * B)); off = B; }
+    if (st->has_neg && g_neg_feat) RUN(copy_out(c, s, g_neg_feat, st->gemb + 3 * mB + 3L * off, 3L * B));
+    return ithor_bwd(c, s, params, grads);
+}
+
+int var_ithor_loss_grad(var_ctx* c, void* stream, const float* params, const void* image, int image_is_u8,
+                        long image_bstride, const float* snd_pos, const float* snd_neg, int B, int H, float margin,
+                        float inv_count, float* grads, float* loss_out, float* feats_out) {
+    CHECK_CTX(c);
+    VAR_HIP_CHECK(c, hipSetDevice(c->device));
+    if (!params || !image || !snd_pos || !snd_neg || !grads) {
+        VAR_SET_ERR(c, "var_ithor_loss_grad: params, image, both sounds and grads are required");
+        return VAR_ERR_ARG;
+    }
+    RUN(ithor_check(c, B, H, "var_ithor_loss_grad"));
+    hipStream_t s = (hipStream_t)stream;
+    ithor_state* st = ith(c);
+    const long mB = st->maxB;
+    RUN(ithor_fwd(c, s, params, image, image_is_u8, image_bstride, snd_pos, snd_neg, B, true));
+    float* lo = loss_out ? loss_out : st->loss;
+    RUN(launch_triplet(c, s, st->emb, st->emb + 3 * mB, st->emb + 3 * mB + 3L * B, B, margin, inv_count, lo, st->gemb,
+                       st->gemb + 3 * mB, st->gemb + 3 * mB + 3L * B));
+    if (feats_out) {
+        // (B,9) = [a | p | n]
+        VAR_HIP_CHECK(c, hipMemcpy2DAsync(feats_out, 9 * sizeof(float), st->emb, 3 * sizeof(float), 3 * sizeof(float), B,
+                                          hipMemcpyDeviceToDevice, s));
+        VAR_HIP_CHECK(c, hipMemcpy2DAsync(feats_out + 3, 9 * sizeof(float), st->emb + 3 * mB, 3 * sizeof(float),
+                                          3 * sizeof(float), B, hipMemcpyDeviceToDevice, s));
+        VAR_HIP_CHECK(c, hipMemcpy2DAsync(feats_out + 6, 9 * sizeof(float), st->emb + 3 * mB + 3L * B, 3 * sizeof(float),
+                                          3 * sizeof(float), B, hipMemcpyDeviceToDevice, s));
+    }
+    return ithor_bwd(c, s, params, grads);
+}
+
+}  // extern "C"

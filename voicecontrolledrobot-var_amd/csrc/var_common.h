@@ -146,6 +146,7 @@ struct var_ctx {
     hipEvent_t ev_w[5] = {nullptr};       // wgrad of layer l done (recorded on side2)
     hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
     float* mfcc_buf = nullptr;            // (2*maxB, 100, 40) when the front-end runs inside the step
+    void* ith = nullptr;                  // iTHOR model state (ithor.hip), created by var_ithor_plan
 };
 
 #define VAR_SET_ERR(ctx, ...) do { if (ctx) snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__); } while (0)
@@ -174,6 +175,7 @@ struct ProfScope {
 static inline int conv_out(int h) { return (h - 1) / 2 + 1; }   // 3x3 s2 p1
 
 int mfcc_build_tables(var_ctx* c);
+void ithor_free(var_ctx* c);
 int pack_table_upload(var_ctx* c);
 size_t img_slab_floats();
 int img_wgrad_groups(int layer);

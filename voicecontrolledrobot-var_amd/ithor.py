@@ -1,0 +1,229 @@
+"""Drop-in for the reference's iTHOR `config.pretextModel` (Envs/ai2thor/config.py:33):
+models/pretext/ai2thor_pretext_model.py:VARPretextNet with the same constructor, module names, state_dict
+layout (36 tensors) and forward() contract (pretext_base.py:10-41); the arithmetic is libvar_hip.so
+(csrc/ithor.hip, var_ithor_* of include/var_hip.h).  GPU only -- no CPU fallback."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ._lib import Context, VarHipError, current_stream_handle, ptr
+
+
+class _IthorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, need_grad, image, pos, neg, *params):
+        flat = module._flat
+        dev = flat.device
+        c = Context.get(dev.index)
+        ref = image if image is not None else (pos if pos is not None else neg)
+        B = ref.shape[0]
+        H = module.config.img_dim[1]
+        module._ensure_plan(c, B)
+        mk = lambda n: torch.empty((B, n), dtype=torch.float32, device=dev)
+        image_feat = mk(3) if image is not None else None
+        image_raw = mk(1152) if image is not None else None
+        pos_feat = mk(3) if pos is not None else None
+        pos_raw = mk(1024) if pos is not None else None
+        neg_feat = mk(3) if neg is not None else None
+        is_u8 = image is not None and image.dtype == torch.uint8
+        bstride = 0 if image is None else image.stride(0)
+        c.check(c.lib.var_ithor_encoder_fwd(c.handle, current_stream_handle(), ptr(flat), ptr(image), int(is_u8),
+                                            bstride, ptr(pos), ptr(neg), B, H, ptr(image_feat), ptr(pos_feat),
+                                            ptr(neg_feat), ptr(image_raw), ptr(pos_raw), int(need_grad)),
+                "var_ithor_encoder_fwd")
+        ctx.module = module
+        ctx.keep = (image, pos, neg)
+        outs = (image_feat, pos_feat, neg_feat, image_raw, pos_raw)
+        ctx.present = [o is not None for o in outs]
+        dummy = torch.zeros(0, device=dev)
+        res = tuple(o if o is not None else dummy for o in outs)
+        ctx.mark_non_differentiable(*res[3:])
+        return res
+
+    @staticmethod
+    def backward(ctx, g_if, g_pf, g_nf, g_ir, g_pr):
+        module = ctx.module
+        flat = module._flat
+        c = Context.get(flat.device.index)
+        gflat = module._grad_arena()
+        gs = [g.contiguous().float() if (present and g is not None) else None
+              for g, present in zip((g_if, g_pf, g_nf), ctx.present[:3])]
+        c.check(c.lib.var_ithor_encoder_bwd(c.handle, current_stream_handle(), ptr(flat), ptr(gs[0]), ptr(gs[1]),
+                                            ptr(gs[2]), ptr(gflat)), "var_ithor_encoder_bwd")
+        grads, o = [], 0
+        for p in module._params_in_order():
+            grads.append(gflat[o:o + p.numel()].view(p.shape))
+            o += p.numel()
+        return (None, None, None, None, None, *grads)
+
+
+class IthorVARPretextNet(nn.Module):
+    """iTHOR VAR encoder.  ctor(config) reads config.img_dim / sound_dim / representationDim
+    (ai2thor_pretext_model.py:42-58); modules are created in the reference's order (imgBranch, rnn, cnn,
+    imgTriplet, soundTriplet) so that a given torch.manual_seed draws the reference's initial weights."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        if tuple(config.sound_dim) != (1, 600, 40) or config.representationDim != 3 or config.img_dim[0] != 3 \
+                or config.img_dim[1] != config.img_dim[2] or self._final_side(config.img_dim[1]) != 3:
+            raise VarHipError("HIP iTHOR VARPretextNet supports square 3-channel images ending in a 3x3 map "
+                              f"(96, 84), sound_dim (1,600,40), representationDim 3; got {config.img_dim} "
+                              f"{config.sound_dim} {config.representationDim}")
+        self.cached_sound = None
+        self.imgBranch = nn.Sequential(
+            nn.Conv2d(3, 32, 3, stride=1, padding=1), nn.ReLU(), nn.Conv2d(32, 32, 3, stride=1, padding=1), nn.ReLU(),
+            nn.MaxPool2d(2, stride=2), nn.Conv2d(32, 64, 3, stride=1, padding=1), nn.ReLU(), nn.MaxPool2d(2, stride=2),
+            nn.Conv2d(64, 64, 3, stride=1, padding=1), nn.ReLU(), nn.MaxPool2d(2, stride=2),
+            nn.Conv2d(64, 128, 3, stride=1, padding=1), nn.ReLU(), nn.MaxPool2d(2, stride=2),
+            nn.Conv2d(128, 128, 3, stride=2, padding=1), nn.ReLU(), nn.Flatten())
+        self.rnn = nn.GRU(input_size=64 * 7, hidden_size=512, batch_first=True, bidirectional=True)
+        self.cnn = nn.Sequential(
+            nn.Conv2d(1, 64, (11, 11), stride=(2, 2), padding=(5, 5)), nn.ReLU(),
+            nn.Conv2d(64, 64, (11, 5), stride=(2, 2), padding=(5, 5)), nn.ReLU(),
+            nn.Conv2d(64, 64, (7, 3), stride=(2, 2), padding=(1, 1)), nn.ReLU())
+        self.imgTriplet = nn.Sequential(nn.Linear(128 * 9, 128), nn.ReLU(), nn.Linear(128, config.representationDim))
+        self.soundTriplet = nn.Sequential(nn.Linear(2 * 512, 128), nn.ReLU(), nn.Linear(128, 64), nn.ReLU(),
+                                          nn.Linear(64, config.representationDim))
+        self._flat = None
+        self._gflat = None
+        self._plan = 0
+        self._flatten_params()
+
+    @staticmethod
+    def _final_side(h):
+        for _ in range(4):
+            h //= 2
+        return (h - 1) // 2 + 1
+
+    # ---- flat parameter arena in state_dict order (what the C ABI reads) ----
+    def _params_in_order(self):
+        return [p for _, p in self.named_parameters()]
+
+    def _flatten_params(self):
+        params = self._params_in_order()
+        n = sum(p.numel() for p in params)
+        flat = torch.empty(n, dtype=torch.float32, device=params[0].device)
+        o = 0
+        for p in params:
+            flat[o:o + p.numel()].copy_(p.data.reshape(-1).float())
+            p.data = flat[o:o + p.numel()].view(p.shape)
+            o += p.numel()
+        self._flat = flat
+        self._gflat = None
+
+    def _arena_intact(self):
+        o = self._flat.data_ptr()
+        for p in self._params_in_order():
+            if p.data_ptr() != o or p.dtype != torch.float32:
+                return False
+            o += 4 * p.numel()
+        return True
+
+    def _grad_arena(self):
+        if self._gflat is None or self._gflat.device != self._flat.device:
+            self._gflat = torch.empty_like(self._flat)
+        return self._gflat
+
+    def flat_parameters(self):
+        if not self._arena_intact():
+            self._flatten_params()
+        return self._flat
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        # nn.GRU keeps a list of flattened weights; our arena replaces its storage, which is all it needs
+        self._flatten_params()
+        return r
+
+    def _ensure_plan(self, c, batch):
+        key = (batch, self.config.img_dim[1])
+        if self._plan == 0 or self._plan[1] != key[1] or self._plan[0] < batch:
+            c.check(c.lib.var_ithor_plan(c.handle, int(batch), int(key[1])), "var_ithor_plan")
+            self._plan = key
+
+    def forward(self, image, sound_positive, sound_negative, is_train=False):
+        flat = self.flat_parameters()
+        if not flat.is_cuda:
+            raise VarHipError("IthorVARPretextNet runs on the GPU only: call .to('cuda') (no CPU fallback)")
+        if flat.numel() != Context.get(flat.device.index).lib.var_ithor_param_count():
+            raise VarHipError("parameter arena does not match var_ithor_param_count()")
+        for t, nm in ((image, "image"), (sound_positive, "sound_positive"), (sound_negative, "sound_negative")):
+            if t is not None and not t.is_cuda:
+                raise VarHipError(f"{nm} must be a CUDA tensor (no CPU fallback)")
+        if image is not None:
+            if image.dtype != torch.uint8:
+                image = image.float()
+            if image.shape[1] < 3 or tuple(image.shape[2:]) != tuple(self.config.img_dim[1:]):
+                raise VarHipError(f"image shape {tuple(image.shape)} does not match img_dim {self.config.img_dim}")
+            image = image.contiguous()
+        run_pos = sound_positive is not None and (not torch.isinf(sound_positive).all())   # pretext_base.py:29
+        pos = sound_positive.float().contiguous() if run_pos else None
+        neg = sound_negative.float().contiguous() if sound_negative is not None else None
+        for s, nm in ((pos, "sound_positive"), (neg, "sound_negative")):
+            if s is not None and tuple(s.shape[1:]) != (1, 600, 40):
+                raise VarHipError(f"{nm} shape {tuple(s.shape)} is not (B,1,600,40)")
+        image_feat = image_feat_raw = pos_sound_raw = sound_feat_negative = None
+        if image is not None or pos is not None or neg is not None:
+            params = self._params_in_order()
+            need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+            outs = _IthorFn.apply(self, need_grad, image, pos, neg, *params)
+            if image is not None:
+                image_feat, image_feat_raw = outs[0], outs[3]
+            if pos is not None:
+                self.cached_sound = outs[1]
+                pos_sound_raw = outs[4]
+            if neg is not None:
+                sound_feat_negative = outs[2]
+        return {'image_feat': image_feat, 'sound_feat_positive': self.cached_sound,
+                'sound_feat_negative': sound_feat_negative, 'image_BCE': None, 'sound_BCE': None,
+                'image_feat_raw': image_feat_raw, 'pos_sound_raw': pos_sound_raw}
+
+
+class IthorTrainer:
+    """The step body of VAR_Pretext.trainRepresentation (VAR/pretext_VAR.py:55-70) for the iTHOR model:
+    var_ithor_loss_grad (forward, TripletMarginLoss, backward) + var_adam_step on flat arenas."""
+
+    def __init__(self, model, lr=1e-4, weight_decay=1e-6, margin=1.0, betas=(0.9, 0.999), eps=1e-8):
+        self.model = model
+        self.lr, self.wd, self.margin, self.betas, self.eps = lr, weight_decay, margin, betas, eps
+        flat = model.flat_parameters()
+        if not flat.is_cuda:
+            raise VarHipError("IthorTrainer needs the model on the GPU (no CPU fallback)")
+        self.ctx = Context.get(flat.device.index)
+        self.grads = torch.zeros_like(flat)
+        self.exp_avg = torch.zeros_like(flat)
+        self.exp_avg_sq = torch.zeros_like(flat)
+        self.loss_buf = torch.zeros(1, dtype=torch.float32, device=flat.device)
+        self.step_count = 0
+
+    def loss_and_grads(self, image, pos, neg, inv_count=None, feats=False):
+        m, c = self.model, self.ctx
+        flat = m.flat_parameters()
+        B = image.shape[0]
+        m._ensure_plan(c, B)
+        if image.dtype != torch.uint8:
+            image = image.float()
+        image, pos, neg = image.contiguous(), pos.float().contiguous(), neg.float().contiguous()
+        out = torch.empty((B, 9), dtype=torch.float32, device=flat.device) if feats else None
+        c.check(c.lib.var_ithor_loss_grad(c.handle, current_stream_handle(), ptr(flat), ptr(image),
+                                          int(image.dtype == torch.uint8), image.stride(0), ptr(pos), ptr(neg), B,
+                                          m.config.img_dim[1], float(self.margin),
+                                          float(1.0 / B if inv_count is None else inv_count), ptr(self.grads),
+                                          ptr(self.loss_buf), ptr(out)), "var_ithor_loss_grad")
+        self._keep = (image, pos, neg)
+        return self.loss_buf, out
+
+    def adam(self):
+        c = self.ctx
+        flat = self.model.flat_parameters()
+        self.step_count += 1
+        c.check(c.lib.var_adam_step(c.handle, current_stream_handle(), ptr(flat), ptr(self.grads), ptr(self.exp_avg),
+                                    ptr(self.exp_avg_sq), flat.numel(), float(self.lr), float(self.betas[0]),
+                                    float(self.betas[1]), float(self.eps), float(self.wd), self.step_count),
+                "var_adam_step")
+
+    def step(self, image, pos, neg):
+        loss, _ = self.loss_and_grads(image, pos, neg)
+        self.adam()
+        return loss
