@@ -274,6 +274,65 @@ struct ConvDgradP {
     __device__ void store(const CM& cm, int n, float v, int) const { dx[cm.off + (long)n * d.H * d.W] = v; }
 };
 
+// The same for stride 2 in both directions, without the structural zeros: an input pixel only meets the filter taps
+// of its own parity (ky = (y+PH) mod 2, kx likewise), so the pixels are processed in four parity classes (grid.z)
+// whose K runs over (co, taps of that parity) -- a quarter of the products of the plain gather form.
+// m = (b, y', x') with y = 2y'+cy, x = 2x'+cx; k = (co, i, j) with ky = ry+2i, kx = rx+2j.
+template <class G, bool SEQ>
+struct ConvDgradS2P {
+    static constexpr bool A_KFAST = false, B_KFAST = false;
+    static constexpr int NKY = (G::KH + 1) / 2, NKX = (G::KW + 1) / 2, NTAP = NKY * NKX;
+    int M, N, K, nsplit;
+    ConvDims d;
+    int H2, W2; float inv_h2w2, inv_w2;
+    const float* gy; const float* w; float* dx;
+    struct AM { long goff; int oy0, ox0; bool ok; };
+    struct AK { int co, i, j; bool ok; };
+    struct BN { int noff; bool ok; };
+    struct BK { int koff; bool ok; };
+    struct CM { long off; bool ok; };
+    __device__ AM a_m(int m, int z) const {
+        AM s; const int cy = z >> 1, cx = z & 1;
+        int pix; const int b = fdiv(m < M ? m : 0, H2 * W2, inv_h2w2, pix);
+        int xp; const int yp = fdiv(pix, W2, inv_w2, xp);
+        s.ok = m < M && 2 * yp + cy < d.H && 2 * xp + cx < d.W;
+        s.goff = (long)b * d.COUT * d.HO * d.WO;
+        s.oy0 = yp + ((cy + G::PH - ((cy + G::PH) & 1)) >> 1);
+        s.ox0 = xp + ((cx + G::PW - ((cx + G::PW) & 1)) >> 1);
+        return s;
+    }
+    __device__ AK a_k(int k, int z) const {
+        AK s; const int ry = ((z >> 1) + G::PH) & 1, rx = ((z & 1) + G::PW) & 1;
+        s.co = k / NTAP; const int r = k - s.co * NTAP;
+        s.i = r / NKX; s.j = r - s.i * NKX;
+        s.ok = k < K && ry + 2 * s.i < G::KH && rx + 2 * s.j < G::KW;
+        return s;
+    }
+    __device__ float a(const AM& sm, const AK& sk) const {
+        const int oy = sm.oy0 - sk.i, ox = sm.ox0 - sk.j;
+        if (!(sm.ok && sk.ok) || (unsigned)oy >= (unsigned)d.HO || (unsigned)ox >= (unsigned)d.WO) return 0.f;
+        if (SEQ) return gy[sm.goff + ((long)oy * d.COUT + sk.co) * d.WO + ox];
+        return gy[sm.goff + ((long)sk.co * d.HO + oy) * d.WO + ox];
+    }
+    __device__ BN b_n(int n, int) const { return BN{n * G::KHW, n < N}; }
+    __device__ BK b_k(int k, int z) const {
+        const int ry = ((z >> 1) + G::PH) & 1, rx = ((z & 1) + G::PW) & 1;
+        const int co = k / NTAP, r = k - co * NTAP;
+        const int i = r / NKX, j = r - i * NKX;
+        const int ky = ry + 2 * i, kx = rx + 2 * j;
+        return BK{co * d.CIN * G::KHW + ky * G::KW + kx, k < K && ky < G::KH && kx < G::KW};
+    }
+    __device__ float b(const BK& sk, const BN& sn) const { return (sk.ok && sn.ok) ? w[sk.koff + sn.noff] : 0.f; }
+    __device__ CM c_m(int m, int z) const {
+        const int cy = z >> 1, cx = z & 1;
+        int pix; const int b = fdiv(m, H2 * W2, inv_h2w2, pix);
+        int xp; const int yp = fdiv(pix, W2, inv_w2, xp);
+        const int y = 2 * yp + cy, x = 2 * xp + cx;
+        return CM{(long)b * d.CIN * d.H * d.W + (long)y * d.W + x, y < d.H && x < d.W};
+    }
+    __device__ void store(const CM& cm, int n, float v, int) const { if (cm.ok) dx[cm.off + (long)n * d.H * d.W] = v; }
+};
+
 // dw[co][ci][ky][kx] += sum_{b,oy,ox} gy[b][co][oy][ox] * x[b][ci][oy*SH+ky-PH][ox*SW+kx-PW]:
 // m = j = (ci, ky, kx), n = co, k = (b, oy, ox); both operands are read along k (pixels).  K is split over
 // grid.z and the partial sums are added with float atomics into a zeroed dw.

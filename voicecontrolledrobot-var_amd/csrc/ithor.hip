@@ -139,20 +139,23 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 // one GRU time step, both directions (torch.nn.GRU gate order r, z, n):
 //   r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h' = (1 - z) * n + z * h
 // GI (dir, clip*T + t, 1536) holds x W_ih^T + b_ih, GH (dir, clip, 1536) holds h W_hh^T + b_hh.
-__global__ void gru_gate_fwd_kernel(const float* __restrict__ GI, const float* __restrict__ GH, const float* __restrict__ hprev,
+// GH holds h W_hh^T WITHOUT the bias (split-K partial sums added atomically); it is cleared here for the next step.
+__global__ void gru_gate_fwd_kernel(const float* __restrict__ GI, float* __restrict__ GH, const float* __restrict__ hprev,
                                     float* __restrict__ hnext, float* __restrict__ R, float* __restrict__ Z,
-                                    float* __restrict__ Nn, float* __restrict__ GHN, int nclips, int step, long dirGI,
-                                    long dirH, long dirS, int save) {
+                                    float* __restrict__ Nn, float* __restrict__ GHN, const float* __restrict__ b_hh,
+                                    long dirP, int nclips, int step, long dirGI, long dirH, long dirS, int save) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nclips * kGh) return;
     const int dir = blockIdx.y;
     const int clip = i / kGh, j = i - clip * kGh;
     const int t = dir ? kSeq - 1 - step : step;
     const float* gi = GI + dir * dirGI + ((long)clip * kSeq + t) * kG3;
-    const float* gh = GH + (long)dir * nclips * kG3 + (long)clip * kG3;
-    const float r = sigmoidf_(gi[j] + gh[j]);
-    const float z = sigmoidf_(gi[kGh + j] + gh[kGh + j]);
-    const float ghn = gh[2 * kGh + j];
+    float* gh = GH + (long)dir * nclips * kG3 + (long)clip * kG3;
+    const float* bh = b_hh + dir * dirP;
+    const float r = sigmoidf_(gi[j] + (gh[j] + bh[j]));
+    const float z = sigmoidf_(gi[kGh + j] + (gh[kGh + j] + bh[kGh + j]));
+    const float ghn = gh[2 * kGh + j] + bh[2 * kGh + j];
+    gh[j] = 0.f; gh[kGh + j] = 0.f; gh[2 * kGh + j] = 0.f;
     const float n = tanhf(gi[2 * kGh + j] + r * ghn);
     const float hp = hprev[dir * dirH + i];
     hnext[dir * dirH + i] = (1.f - z) * n + z * hp;
@@ -235,10 +238,19 @@ static int conv_fwd(var_ctx* c, hipStream_t s, const ConvDims& d, const void* x,
 }
 template <class G, bool SEQ>
 static int conv_dgrad(var_ctx* c, hipStream_t s, const ConvDims& d, const float* gy, const float* w, float* dx) {
-    ConvDgradP<G, SEQ> p{};
-    p.M = d.B * d.H * d.W; p.N = d.CIN; p.K = d.COUT * G::KHW; p.nsplit = 1;
-    p.d = d; p.gy = gy; p.w = w; p.dx = dx;
-    return gg_launch(c, s, p);
+    if constexpr (G::SH == 2 && G::SW == 2) {
+        ConvDgradS2P<G, SEQ> p{};
+        p.H2 = (d.H + 1) / 2; p.W2 = (d.W + 1) / 2;
+        p.inv_h2w2 = 1.f / (float)(p.H2 * p.W2); p.inv_w2 = 1.f / (float)p.W2;
+        p.M = d.B * p.H2 * p.W2; p.N = d.CIN; p.K = d.COUT * ConvDgradS2P<G, SEQ>::NTAP; p.nsplit = 1;
+        p.d = d; p.gy = gy; p.w = w; p.dx = dx;
+        return gg_launch(c, s, p, 4);
+    } else {
+        ConvDgradP<G, SEQ> p{};
+        p.M = d.B * d.H * d.W; p.N = d.CIN; p.K = d.COUT * G::KHW; p.nsplit = 1;
+        p.d = d; p.gy = gy; p.w = w; p.dx = dx;
+        return gg_launch(c, s, p);
+    }
 }
 template <class G, bool U8, bool SEQ>
 static int conv_wgrad(var_ctx* c, hipStream_t s, const ConvDims& d, const void* x, const float* gy, float* dw) {
@@ -292,6 +304,13 @@ static int relu_mask(var_ctx* c, hipStream_t s, float* g, const float* act, long
     hipLaunchKernelGGL(relu_mask_kernel, g1(n), dim3(256), 0, s, g, act, n);
     IT_CHECK(c);
     return VAR_OK;
+}
+
+// K splits of a small recurrent product so that about two workgroups per CU are in flight
+static int rec_split(int tiles, int kchunks) {
+    int ns = (512 + tiles - 1) / tiles;
+    if (ns > kchunks / 4) ns = kchunks / 4;
+    return ns < 1 ? 1 : ns;
 }
 
 using G3s1 = Geo<3, 3, 1, 1, 1, 1>;
@@ -364,16 +383,19 @@ static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* imag
             RUN(gg_launch(c, s, p, 2));
         }
         for (int d = 0; d < 2; ++d) VAR_HIP_CHECK(c, hipMemsetAsync(st->Hb + d * dirH, 0, sizeof(float) * nclips * kGh, s));
+        VAR_HIP_CHECK(c, hipMemsetAsync(st->GH, 0, sizeof(float) * 2 * nclips * kG3, s));
         for (int step = 0; step < kSeq; ++step) {
-            DenseP<true, true, 0> p{};
-            p.M = kG3; p.N = nclips; p.K = kGh; p.nsplit = 1;
+            // split over K and summed with atomics into GH, which the gate kernel clears again as it reads it
+            DenseP<true, true, 2> p{};
+            p.M = kG3; p.N = nclips; p.K = kGh;
             p.A = P + L.w_hh[0]; p.sam = kGh; p.sak = 1; p.zA = dirP;
             p.Bm = st->Hb + (long)step * nclips * kGh; p.sbk = 1; p.sbn = kGh; p.zB = dirH;
-            p.C = st->GH; p.scm = 1; p.scn = kG3; p.zC = (long)nclips * kG3; p.bias = P + L.b_hh[0]; p.zbias = dirP;
+            p.C = st->GH; p.scm = 1; p.scn = kG3; p.zC = (long)nclips * kG3;
+            p.nsplit = rec_split(12 * ((nclips + 63) / 64) * 2, kGh / GG_KC);
             RUN(gg_launch(c, s, p, 2));
             hipLaunchKernelGGL(gru_gate_fwd_kernel, dim3((nclips * kGh + 255) / 256, 2), dim3(256), 0, s, st->GI, st->GH,
                                st->Hb + (long)step * nclips * kGh, st->Hb + (long)(step + 1) * nclips * kGh, st->R, st->Z,
-                               st->Nn, st->GHN, nclips, step, dirGI, dirH, dirS, save ? 1 : 0);
+                               st->Nn, st->GHN, P + L.b_hh[0], dirP, nclips, step, dirGI, dirH, dirS, save ? 1 : 0);
             IT_CHECK(c);
         }
         hipLaunchKernelGGL(gru_concat_kernel, g1((long)nclips * kSRaw), dim3(256), 0, s,
@@ -459,8 +481,9 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
                                dirGI, dirH, dirS, dirDGH);
             IT_CHECK(c);
             if (step == 0) break;                               // h_0 = 0 has no consumer
-            DenseP<false, true, 1> p{};
-            p.M = kGh; p.N = nclips; p.K = kG3; p.nsplit = 1;
+            DenseP<false, true, 2> p{};
+            p.M = kGh; p.N = nclips; p.K = kG3;
+            p.nsplit = rec_split(4 * ((nclips + 63) / 64) * 2, kG3 / GG_KC);
             p.A = P + L.w_hh[0]; p.sam = 1; p.sak = kGh; p.zA = dirP;
             p.Bm = st->DGH + (long)step * nclips * kG3; p.sbk = 1; p.sbn = kG3; p.zB = dirDGH;
             p.C = st->DH; p.scm = 1; p.scn = kGh; p.zC = (long)nclips * kGh;
