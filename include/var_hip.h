@@ -187,6 +187,15 @@ int var_ithor_loss_grad(var_ctx* ctx, void* stream, const float* params,
                         float margin, float inv_count,
                         float* grads, float* loss_out, float* feats_out);
 
+/* The iTHOR/FSC audio front-end: python_speech_features.mfcc as called at Envs/audioLoader.py:158-161 (pre-emphasis
+ * .97, 400/160 frames with a zero-padded tail, np.hamming, |rfft_512|^2/512, 40 triangles, log, orthonormal DCT-II,
+ * lifter 22, coefficient 0 = log frame energy; int16 samples NOT normalised) + processSoundFeat (:241-252).
+ * Arguments as var_mfcc; T = 1 + ceil((len-400)/160) frames per clip (1 if len <= 400), out (nclips,1,out_frames,40)
+ * f32 (the library computes float64; this kernel float32).  The tables are built on the first call (the only
+ * call of this entry that allocates: make it once outside graph capture). */
+int var_mfcc_psf(var_ctx* ctx, void* stream, const int16_t* pcm, const int* lens, const int* clip_index,
+                 int nclips, int pcm_stride, int out_frames, float* out);
+
 /* Measurement and testing hooks -------------------------------------------------
  * var_profile_select: record HIP events, on the launch stream, around every launch of one
  * kernel family (tag in [0, var_profile_tag_count()), -1 = off); var_profile_read returns the

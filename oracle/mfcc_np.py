@@ -132,3 +132,53 @@ def synth_clips(n, seed=0, n_samples=16000, lens=None):
         x = 3000.0 * rng.standard_normal(n_samples) + 8000.0 * np.sin(2 * np.pi * f * t)
         out[i] = np.round(np.clip(x, -32767, 32767)).astype(np.int16)
     return out
+
+
+# ---- python_speech_features 0.6 (requirements.txt:13), the iTHOR / FSC branch of Envs/audioLoader.py:158-161 --------
+# The package is absent from the build image, so this is a restatement of its published algorithm (base.py / sigproc.py
+# of release 0.6) with the reference's call parameters: "parity unpinned" against the dependency itself.
+def _round_half_up(x):
+    return int(np.floor(x + 0.5))
+
+
+def psf_filterbanks(nfilt=40, nfft=512, samplerate=16000, lowfreq=0, highfreq=None):
+    highfreq = highfreq or samplerate / 2
+    lowmel = 2595 * np.log10(1 + lowfreq / 700.)
+    highmel = 2595 * np.log10(1 + highfreq / 700.)
+    melpoints = np.linspace(lowmel, highmel, nfilt + 2)
+    bins = np.floor((nfft + 1) * (700 * (10 ** (melpoints / 2595.0) - 1)) / samplerate)
+    fb = np.zeros([nfilt, nfft // 2 + 1])
+    for j in range(nfilt):
+        for i in range(int(bins[j]), int(bins[j + 1])):
+            fb[j, i] = (i - bins[j]) / (bins[j + 1] - bins[j])
+        for i in range(int(bins[j + 1]), int(bins[j + 2])):
+            fb[j, i] = (bins[j + 2] - i) / (bins[j + 2] - bins[j + 1])
+    return fb
+
+
+def mfcc_psf(signal, samplerate=16000, winlen=0.025, winstep=0.01, numcep=40, nfilt=40, nfft=512, preemph=0.97,
+             ceplifter=22, append_energy=True):
+    """mfcc(signal, fs, winlen=.025, winstep=.01, numcep=40, nfilt=40, nfft=512, winfunc=np.hamming) -> (T, 40) f64."""
+    from scipy.fftpack import dct
+    sig = np.asarray(signal)
+    sig = np.append(sig[0], sig[1:] - preemph * sig[:-1])                       # sigproc.preemphasis
+    frame_len, frame_step = _round_half_up(winlen * samplerate), _round_half_up(winstep * samplerate)
+    slen = len(sig)
+    numframes = 1 if slen <= frame_len else 1 + int(np.ceil((1.0 * slen - frame_len) / frame_step))
+    padlen = int((numframes - 1) * frame_step + frame_len)
+    padsignal = np.concatenate((sig, np.zeros((padlen - slen,))))
+    idx = np.tile(np.arange(0, frame_len), (numframes, 1)) + \
+        np.tile(np.arange(0, numframes * frame_step, frame_step), (frame_len, 1)).T
+    frames = padsignal[idx.astype(np.int32)] * np.hamming(frame_len)            # sigproc.framesig
+    pspec = 1.0 / nfft * np.square(np.absolute(np.fft.rfft(frames, nfft)))      # sigproc.powspec
+    energy = np.sum(pspec, 1)
+    energy = np.where(energy == 0, np.finfo(float).eps, energy)
+    feat = np.dot(pspec, psf_filterbanks(nfilt, nfft, samplerate).T)
+    feat = np.where(feat == 0, np.finfo(float).eps, feat)
+    feat = np.log(feat)
+    feat = dct(feat, type=2, axis=1, norm='ortho')[:, :numcep]
+    n = np.arange(numcep)
+    feat = (1 + (ceplifter / 2.) * np.sin(np.pi * n / ceplifter)) * feat        # lifter
+    if append_energy:
+        feat[:, 0] = np.log(energy)
+    return feat

@@ -172,3 +172,31 @@ def test_rejects_cpu_tensors_and_bad_shapes(var_amd):
         m(torch.zeros(1, 3, 96, 96), None, None)
     with pytest.raises(var_amd.VarHipError):
         m(None, torch.zeros(1, 1, 100, 40, device="cuda"), None)
+
+
+def test_psf_mfcc_vs_oracle(var_amd):
+    """var_mfcc_psf (python_speech_features branch, Envs/audioLoader.py:158-161 + :241-252) against the numpy
+    restatement: 6 s clips, ragged lengths, a clip shorter than one window, the empty class."""
+    from oracle import mfcc_np
+    rng = np.random.default_rng(9)
+    nmax = 96000
+    lens = [96000, 50001, 16000, 400, 300, 0, 95999]
+    pcm = np.zeros((len(lens), nmax), dtype=np.int16)
+    for i, n in enumerate(lens):
+        t = np.arange(n) / 16000.0
+        f0 = rng.uniform(100, 4000)
+        pcm[i, :n] = np.round(np.clip(3000 * rng.standard_normal(n) + 8000 * np.sin(2 * np.pi * f0 * t), -32767, 32767))
+    out = var_amd.mfcc_psf(cuda(pcm), torch.tensor(lens, dtype=torch.int32), out_frames=600).cpu().numpy()
+    assert out.shape == (len(lens), 1, 600, 40)
+    for i, n in enumerate(lens):
+        if n == 0:
+            assert np.all(out[i] == 0)
+            continue
+        ref = mfcc_np.mfcc_psf(pcm[i, :n])
+        ref = mfcc_np.process_sound_feat(ref, (1, 600, 40))
+        T = min(600, 1 if n <= 400 else 1 + int(np.ceil((n - 400) / 160)))
+        assert np.all(out[i, 0, T:] == 0)
+        np.testing.assert_allclose(out[i], ref, atol=2e-3, rtol=1e-4, err_msg=f"clip {i} len {n}")
+    # truncation to fewer frames than the clip has (audioLoader.py:245-246)
+    out2 = var_amd.mfcc_psf(cuda(pcm[:1]), None, out_frames=100).cpu().numpy()
+    np.testing.assert_allclose(out2[0], out[0][:, :100], atol=1e-6)

@@ -47,3 +47,28 @@ def test_shapes_and_padding():
     tone = np.round(20000 * np.sin(2 * np.pi * 1000 * t)).astype(np.int16)
     mel = mfcc_np.power_spectrogram((tone / 32768.0).astype(np.float32)) @ mfcc_np.mel_filterbank()
     assert abs(int(mel[50].argmax()) - int(mfcc_np.mel_filterbank()[32].argmax())) <= 1
+
+
+def test_psf_mfcc_oracle_known_properties():
+    """python_speech_features branch (Envs/audioLoader.py:158-161): frame count, energy coefficient, silence floor,
+    filterbank shape -- properties of the published algorithm (the package itself is absent: parity unpinned)."""
+    from oracle import mfcc_np
+    rng = np.random.default_rng(3)
+    x = np.round(3000 * rng.standard_normal(16000)).astype(np.int16)
+    f = mfcc_np.mfcc_psf(x)
+    assert f.shape == (1 + int(np.ceil((16000 - 400) / 160)), 40) and f.dtype == np.float64
+    assert mfcc_np.mfcc_psf(x[:300]).shape == (1, 40)
+    fb = mfcc_np.psf_filterbanks()
+    assert fb.shape == (40, 257) and fb.min() >= 0 and fb.max() <= 1.0
+    # coefficient 0 is the log of the frame energy = log(sum |rfft|^2 / 512) of the pre-emphasised, windowed frame
+    y = np.append(x[0], x[1:] - 0.97 * x[:-1].astype(np.float64))
+    fr = y[160:560] * np.hamming(400)
+    e = np.sum(np.abs(np.fft.rfft(fr, 512)) ** 2) / 512
+    assert abs(f[1, 0] - np.log(e)) < 1e-9
+    # silence: every filterbank energy is replaced by eps before the log
+    z = mfcc_np.mfcc_psf(np.zeros(1000, dtype=np.int16))
+    assert np.allclose(z[:, 0], np.log(np.finfo(float).eps))
+    # scaling the signal by c adds 2 log c to coefficient 0 and sqrt(40)*2 log c to ... only the DC cepstrum: c1.. unchanged
+    f2 = mfcc_np.mfcc_psf((x // 2 * 2).astype(np.int16))
+    f4 = mfcc_np.mfcc_psf(((x // 2 * 2) // 2).astype(np.int16))
+    assert np.allclose(f2[:, 1:], f4[:, 1:], atol=1e-9) and np.allclose(f2[:, 0] - f4[:, 0], 2 * np.log(2.0), atol=1e-9)

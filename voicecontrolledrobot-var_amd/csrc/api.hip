@@ -85,6 +85,7 @@ int var_destroy(var_ctx* c) {
     if (c->wpack) (void)hipFree(c->wpack);
     if (c->loss_buf) (void)hipFree(c->loss_buf);
     if (c->mfcc_tab) (void)hipFree(c->mfcc_tab);
+    if (c->mfcc_psf_tab) (void)hipFree(c->mfcc_psf_tab);
     if (c->pack_segs_dev) (void)hipFree(c->pack_segs_dev);
     for (int i = 0; i < 2; i++) {
         if (c->ev_fork[i]) (void)hipEventDestroy(c->ev_fork[i]);

@@ -146,6 +146,7 @@ struct var_ctx {
     hipEvent_t ev_w[5] = {nullptr};       // wgrad of layer l done (recorded on side2)
     hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
     float* mfcc_buf = nullptr;            // (2*maxB, 100, 40) when the front-end runs inside the step
+    float* mfcc_psf_tab = nullptr;        // tables of the python_speech_features front-end (mfcc_psf.hip), built on first use
     void* ith = nullptr;                  // iTHOR model state (ithor.hip), created by var_ithor_plan
 };
 

@@ -46,3 +46,24 @@ def mfcc(pcm, lens=None, out_frames=100, clip_index=None):
     ctx.check(ctx.lib.var_mfcc(ctx.handle, current_stream_handle(), ptr(pcm), ptr(lens), ptr(clip_index), n, stride,
                                int(out_frames), ptr(out)), "var_mfcc")
     return out
+
+
+def mfcc_psf(pcm, lens=None, out_frames=600, clip_index=None):
+    """int16 PCM (nclips, nsamples) on the GPU -> (nclips, 1, out_frames, 40) f32: the python_speech_features
+    branch of Envs/audioLoader.py:158-161 (iTHOR / FSC clips, signal not normalised) + :241-252."""
+    _require_cuda(pcm)
+    if pcm.dtype != torch.int16 or pcm.dim() != 2 or pcm.shape[1] % 2:
+        raise VarHipError("mfcc_psf expects an int16 (nclips, even nsamples) tensor")
+    pcm = pcm.contiguous()
+    stride = pcm.shape[1]
+    n = pcm.shape[0] if clip_index is None else clip_index.numel()
+    if clip_index is not None:
+        clip_index = clip_index.to(device=pcm.device, dtype=torch.int32).contiguous()
+    if lens is None:
+        lens = torch.full((n,), stride, dtype=torch.int32, device=pcm.device)
+    lens = lens.to(device=pcm.device, dtype=torch.int32).contiguous()
+    out = torch.empty((n, 1, out_frames, 40), dtype=torch.float32, device=pcm.device)
+    ctx = Context.get(pcm.device.index)
+    ctx.check(ctx.lib.var_mfcc_psf(ctx.handle, current_stream_handle(), ptr(pcm), ptr(lens), ptr(clip_index), n, stride,
+                                   int(out_frames), ptr(out)), "var_mfcc_psf")
+    return out
