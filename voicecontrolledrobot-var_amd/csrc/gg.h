@@ -233,6 +233,7 @@ struct ConvDgradP {
     int M, N, K, nsplit;
     ConvDims d;
     const float* gy; const float* w; float* dx;
+    const float* mask;       // optional: the (post-ReLU) activation dx belongs to; dx is zeroed where it is not positive
     struct AM { long goff; int ty0, tx0; bool ok; };
     struct AK { int co, ky, kx; bool ok; };
     struct BN { int noff; bool ok; };
@@ -271,7 +272,11 @@ struct ConvDgradP {
         int pix; const int b = fdiv(m, d.H * d.W, d.inv_hw, pix);
         return CM{(long)b * d.CIN * d.H * d.W + pix};
     }
-    __device__ void store(const CM& cm, int n, float v, int) const { dx[cm.off + (long)n * d.H * d.W] = v; }
+    __device__ void store(const CM& cm, int n, float v, int) const {
+        const long o = cm.off + (long)n * d.H * d.W;
+        if (mask && !(mask[o] > 0.f)) v = 0.f;
+        dx[o] = v;
+    }
 };
 
 // The same for stride 2 in both directions, without the structural zeros: an input pixel only meets the filter taps
@@ -286,6 +291,7 @@ struct ConvDgradS2P {
     ConvDims d;
     int H2, W2; float inv_h2w2, inv_w2;
     const float* gy; const float* w; float* dx;
+    const float* mask;
     struct AM { long goff; int oy0, ox0; bool ok; };
     struct AK { int co, i, j; bool ok; };
     struct BN { int noff; bool ok; };
@@ -330,7 +336,12 @@ struct ConvDgradS2P {
         const int y = 2 * yp + cy, x = 2 * xp + cx;
         return CM{(long)b * d.CIN * d.H * d.W + (long)y * d.W + x, y < d.H && x < d.W};
     }
-    __device__ void store(const CM& cm, int n, float v, int) const { if (cm.ok) dx[cm.off + (long)n * d.H * d.W] = v; }
+    __device__ void store(const CM& cm, int n, float v, int) const {
+        if (!cm.ok) return;
+        const long o = cm.off + (long)n * d.H * d.W;
+        if (mask && !(mask[o] > 0.f)) v = 0.f;
+        dx[o] = v;
+    }
 };
 
 // dw[co][ci][ky][kx] += sum_{b,oy,ox} gy[b][co][oy][ox] * x[b][ci][oy*SH+ky-PH][ox*SW+kx-PW]:

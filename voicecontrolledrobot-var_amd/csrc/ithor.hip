@@ -134,6 +134,25 @@ __global__ void __launch_bounds__(256) chan_sum_kernel(const float* __restrict__
     if (threadIdx.x == 0) atomicAdd(out + c, red[0]);
 }
 
+// the same sum when `inner` is small (rows of C*inner contiguous floats: Linear / GRU gate gradients with inner 1, the
+// sequence-layout sound map with inner 7): lanes walk the row, so the reads are coalesced
+__global__ void __launch_bounds__(256) col_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int rows, int cols,
+                                                     int inner) {
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
+    const int per = (rows + gridDim.y - 1) / gridDim.y;
+    const int lo = blockIdx.y * per, hi = min(rows, lo + per);
+    float acc = 0.f;
+    if (col < cols)
+        for (int r = lo + ty; r < hi; r += 4) acc += g[(long)r * cols + col];
+    __shared__ float red[4][64];
+    red[ty][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (ty == 0 && col < cols) {
+        acc = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        atomicAdd(out + col / inner, acc);
+    }
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
 // one GRU time step, both directions (torch.nn.GRU gate order r, z, n):
@@ -237,18 +256,19 @@ static int conv_fwd(var_ctx* c, hipStream_t s, const ConvDims& d, const void* x,
     return gg_launch(c, s, p);
 }
 template <class G, bool SEQ>
-static int conv_dgrad(var_ctx* c, hipStream_t s, const ConvDims& d, const float* gy, const float* w, float* dx) {
+static int conv_dgrad(var_ctx* c, hipStream_t s, const ConvDims& d, const float* gy, const float* w, float* dx,
+                      const float* mask = nullptr) {
     if constexpr (G::SH == 2 && G::SW == 2) {
         ConvDgradS2P<G, SEQ> p{};
         p.H2 = (d.H + 1) / 2; p.W2 = (d.W + 1) / 2;
         p.inv_h2w2 = 1.f / (float)(p.H2 * p.W2); p.inv_w2 = 1.f / (float)p.W2;
         p.M = d.B * p.H2 * p.W2; p.N = d.CIN; p.K = d.COUT * ConvDgradS2P<G, SEQ>::NTAP; p.nsplit = 1;
-        p.d = d; p.gy = gy; p.w = w; p.dx = dx;
+        p.d = d; p.gy = gy; p.w = w; p.dx = dx; p.mask = mask;
         return gg_launch(c, s, p, 4);
     } else {
         ConvDgradP<G, SEQ> p{};
         p.M = d.B * d.H * d.W; p.N = d.CIN; p.K = d.COUT * G::KHW; p.nsplit = 1;
-        p.d = d; p.gy = gy; p.w = w; p.dx = dx;
+        p.d = d; p.gy = gy; p.w = w; p.dx = dx; p.mask = mask;
         return gg_launch(c, s, p);
     }
 }
@@ -265,6 +285,14 @@ static int conv_wgrad(var_ctx* c, hipStream_t s, const ConvDims& d, const void* 
     return gg_launch(c, s, p);
 }
 static int chan_sum(var_ctx* c, hipStream_t s, const float* g, float* out, int outer, int C, int inner) {
+    if (inner < 64) {
+        const int cols = C * inner;
+        int chunks = (outer + 255) / 256;
+        if (chunks > 128) chunks = 128;
+        hipLaunchKernelGGL(col_sum_kernel, dim3((cols + 63) / 64, chunks), dim3(256), 0, s, g, out, outer, cols, inner);
+        IT_CHECK(c);
+        return VAR_OK;
+    }
     long tot = (long)outer * inner;
     int chunks = (int)((tot + 8191) / 8192);
     if (chunks > 64) chunks = 64;
@@ -446,9 +474,8 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             RUN((conv_wgrad<G3s1, false, false>(c, s, d, xin, st->ga[l], G + L.iw[l - 1])));
             RUN(chan_sum(c, s, st->ga[l], G + L.ib[l - 1], B, kICh[l], hin * hin));
             float* dx = l == 2 ? st->ga[1] : st->gp[l - 1];
-            RUN((conv_dgrad<G3s1, false>(c, s, d, st->ga[l], P + L.iw[l - 1], dx)));
+            RUN((conv_dgrad<G3s1, false>(c, s, d, st->ga[l], P + L.iw[l - 1], dx, l == 2 ? st->a[1] : nullptr)));
         }
-        RUN(relu_mask(c, s, st->ga[1], st->a[1], (long)B * 32 * hs[0] * hs[0]));
         {
             ConvDims d = img_dims(st, 1, B);
             d.xb = st->bstride;
@@ -525,15 +552,13 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             const ConvDims d = snd_dims(3, nclips);
             RUN((conv_wgrad<GS3, false, true>(c, s, d, st->s[2], st->gs[3], G + L.sw[2])));
             RUN(chan_sum(c, s, st->gs[3], G + L.sb[2], nclips * kSeq, 64, 7));
-            RUN((conv_dgrad<GS3, true>(c, s, d, st->gs[3], P + L.sw[2], st->gs[2])));
-            RUN(relu_mask(c, s, st->gs[2], st->s[2], (long)nclips * 64 * 150 * 13));
+            RUN((conv_dgrad<GS3, true>(c, s, d, st->gs[3], P + L.sw[2], st->gs[2], st->s[2])));
         }
         {
             const ConvDims d = snd_dims(2, nclips);
             RUN((conv_wgrad<GS2, false, false>(c, s, d, st->s[1], st->gs[2], G + L.sw[1])));
             RUN(chan_sum(c, s, st->gs[2], G + L.sb[1], nclips, 64, 150 * 13));
-            RUN((conv_dgrad<GS2, false>(c, s, d, st->gs[2], P + L.sw[1], st->gs[1])));
-            RUN(relu_mask(c, s, st->gs[1], st->s[1], (long)nclips * 64 * 300 * 20));
+            RUN((conv_dgrad<GS2, false>(c, s, d, st->gs[2], P + L.sw[1], st->gs[1], st->s[1])));
         }
         {
             int off = 0;
