@@ -200,3 +200,44 @@ def test_psf_mfcc_vs_oracle(var_amd):
     # truncation to fewer frames than the clip has (audioLoader.py:245-246)
     out2 = var_amd.mfcc_psf(cuda(pcm[:1]), None, out_frames=100).cpu().numpy()
     np.testing.assert_allclose(out2[0], out[0][:, :100], atol=1e-6)
+
+
+def test_shard_gradients_add_up_to_the_full_batch(var_amd, fx):
+    """Data-parallel convention: shard gradients computed with inv_count = 1/B_global sum to
+    the full-batch gradient -- what the ONE all-reduce of IthorTrainer.step relies on."""
+    m = seeded_model(var_amd, int(fx["seed"]))
+    tr = var_amd.IthorTrainer(m)
+    img, pos, neg = cuda(fx["image"]), cuda(fx["sound_positive"]), cuda(fx["sound_negative"])
+    tr.loss_and_grads(img, pos, neg)
+    full = tr.gbuf.clone()
+    acc = torch.zeros_like(full)
+    for r in range(2):
+        tr.loss_and_grads(img[r:r + 1], pos[r:r + 1], neg[r:r + 1], global_batch=2)
+        acc += tr.gbuf
+    assert abs(acc[-1].item() - full[-1].item()) < 1e-6
+    assert l2_rel(acc[:-1].cpu().numpy(), full[:-1].cpu().numpy()) < 1e-5
+
+
+def test_train_loop_checkpoint_and_projection(var_amd, fx, tmp_path):
+    """train_representation (VAR/pretext_VAR.py:44-91) with the iTHOR model: MultiStepLR [20,30]
+    (Envs/ai2thor/config.py:47-48), legacy .pt that the reference-shaped module loads, progress.csv;
+    project_representation = pretext.py:147-203 without the plot."""
+    from oracle.torch_oracle import IthorNetCPU
+    m = seeded_model(var_amd, int(fx["seed"]))
+    img, pos, neg = cuda(fx["image"]), cuda(fx["sound_positive"]), cuda(fx["sound_negative"])
+    gt = torch.tensor([1, 3])
+    batches = lambda: iter([(img, pos, neg, gt)])
+    losses = var_amd.train_representation(m, batches, epochs=2, milestones=(20, 30), save_dir=str(tmp_path),
+                                          save_interval=10, log=lambda *a: None)
+    np.testing.assert_allclose(losses, fx["losses"], atol=2e-4)
+    sd = torch.load(os.path.join(str(tmp_path), "1.pt"), map_location="cpu")
+    ref = IthorNetCPU()
+    ref.load_state_dict(sd)                                   # same 36 keys and shapes as the reference
+    assert open(os.path.join(str(tmp_path), "progress.csv")).read().splitlines()[0] == "avg_loss"
+    a, s, g = var_amd.project_representation(m, batches)
+    assert a.shape == (2, 3) and s.shape == (2, 3) and list(g) == [1, 3]
+    with torch.no_grad():
+        ra, rp, _ = ref((torch.from_numpy(fx["image"]) / 255.).float(), torch.from_numpy(fx["sound_positive"]),
+                        torch.from_numpy(fx["sound_negative"]))
+    np.testing.assert_allclose(a, ra.numpy(), atol=1e-4)
+    np.testing.assert_allclose(s, rp.numpy(), atol=1e-4)

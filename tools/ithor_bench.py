@@ -57,7 +57,7 @@ def main():
     print(json.dumps({"workload": "ithor pretext step" if not a.fwd_only else "ithor forward", "batch": a.batch,
                       "hw": a.hw, "ms_per_step": round(ms, 3), "triplets_per_s": round(a.batch / ms * 1e3, 1),
                       "tflops": round(a.batch * flop / ms / 1e9, 2), "dtype": "f32",
-                      "loss": float(tr.loss_buf.item()) if not a.fwd_only else None}))
+                      "loss": float(tr.loss.item()) if not a.fwd_only else None}))
 
 
 if __name__ == "__main__":

@@ -182,48 +182,94 @@ class IthorVARPretextNet(nn.Module):
 
 class IthorTrainer:
     """The step body of VAR_Pretext.trainRepresentation (VAR/pretext_VAR.py:55-70) for the iTHOR model:
-    var_ithor_loss_grad (forward, TripletMarginLoss, backward) + var_adam_step on flat arenas."""
+    var_ithor_loss_grad (forward, TripletMarginLoss, backward) + var_adam_step on flat arenas.  Same surface as
+    VARTrainer (lr, step, loss, loss_and_grads, allreduce, adam); under torch.distributed each rank takes its shard
+    of the global batch, the loss/gradients are scaled by 1/B_global and ONE sum all-reduce (RCCL) carries the
+    gradient arena and the loss slot (15.4 MB, BASELINE config 4)."""
 
-    def __init__(self, model, lr=1e-4, weight_decay=1e-6, margin=1.0, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, model, lr=1e-4, weight_decay=1e-6, betas=(0.9, 0.999), eps=1e-8, margin=1.0,
+                 process_group=None):
         self.model = model
         self.lr, self.wd, self.margin, self.betas, self.eps = lr, weight_decay, margin, betas, eps
         flat = model.flat_parameters()
         if not flat.is_cuda:
             raise VarHipError("IthorTrainer needs the model on the GPU (no CPU fallback)")
+        self.dev = flat.device
         self.ctx = Context.get(flat.device.index)
-        self.grads = torch.zeros_like(flat)
+        self.n = flat.numel()
+        self.gbuf = torch.zeros(self.n + 1, dtype=torch.float32, device=self.dev)   # [gradients | loss]
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
-        self.loss_buf = torch.zeros(1, dtype=torch.float32, device=flat.device)
         self.step_count = 0
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
 
-    def loss_and_grads(self, image, pos, neg, inv_count=None, feats=False):
+    @property
+    def grads(self):
+        return self.gbuf[:self.n]
+
+    @property
+    def loss(self):
+        return self.gbuf[self.n:]
+
+    @property
+    def loss_buf(self):
+        return self.loss
+
+    def loss_and_grads(self, image, pos, neg, global_batch=None, feats=False):
         m, c = self.model, self.ctx
         flat = m.flat_parameters()
+        for t in (image, pos, neg):
+            if t is None or not t.is_cuda:
+                raise VarHipError("IthorTrainer needs CUDA tensors (image, pos, neg) -- no CPU fallback")
         B = image.shape[0]
         m._ensure_plan(c, B)
         if image.dtype != torch.uint8:
             image = image.float()
         image, pos, neg = image.contiguous(), pos.float().contiguous(), neg.float().contiguous()
+        gb = B * self.world if global_batch is None else global_batch
         out = torch.empty((B, 9), dtype=torch.float32, device=flat.device) if feats else None
         c.check(c.lib.var_ithor_loss_grad(c.handle, current_stream_handle(), ptr(flat), ptr(image),
                                           int(image.dtype == torch.uint8), image.stride(0), ptr(pos), ptr(neg), B,
-                                          m.config.img_dim[1], float(self.margin),
-                                          float(1.0 / B if inv_count is None else inv_count), ptr(self.grads),
-                                          ptr(self.loss_buf), ptr(out)), "var_ithor_loss_grad")
+                                          m.config.img_dim[1], float(self.margin), 1.0 / gb, ptr(self.gbuf),
+                                          self.gbuf.data_ptr() + 4 * self.n, ptr(out)), "var_ithor_loss_grad")
         self._keep = (image, pos, neg)
-        return self.loss_buf, out
+        return self.loss, out
+
+    def allreduce(self):
+        if self.world > 1:
+            torch.distributed.all_reduce(self.gbuf, op=torch.distributed.ReduceOp.SUM, group=self.pg)
 
     def adam(self):
         c = self.ctx
         flat = self.model.flat_parameters()
         self.step_count += 1
-        c.check(c.lib.var_adam_step(c.handle, current_stream_handle(), ptr(flat), ptr(self.grads), ptr(self.exp_avg),
-                                    ptr(self.exp_avg_sq), flat.numel(), float(self.lr), float(self.betas[0]),
+        c.check(c.lib.var_adam_step(c.handle, current_stream_handle(), ptr(flat), ptr(self.gbuf), ptr(self.exp_avg),
+                                    ptr(self.exp_avg_sq), self.n, float(self.lr), float(self.betas[0]),
                                     float(self.betas[1]), float(self.eps), float(self.wd), self.step_count),
                 "var_adam_step")
 
-    def step(self, image, pos, neg):
-        loss, _ = self.loss_and_grads(image, pos, neg)
+    def step(self, image, pos, neg, global_batch=None):
+        self.loss_and_grads(image, pos, neg, global_batch)
+        self.allreduce()
         self.adam()
-        return loss
+        return self.loss
+
+
+def project_representation(model, batches):
+    """pretext.py:147-203 (project2representation_with_ground_truth) without the plotting: run the frozen encoder
+    over `batches()` = (image, sound_positive, sound_negative, gt) and return (image_feat (N,3), sound_feat (N,3),
+    gt (N,)) numpy arrays for the scatter / t-SNE check.  Works for both VARPretextNet models."""
+    was_training = model.training
+    model.eval()
+    img, snd, gts = [], [], []
+    with torch.no_grad():
+        for image, sp, _sn, gt in batches():
+            d = model(image, sp, None)
+            img.append(d['image_feat'].cpu().numpy().copy())
+            snd.append(d['sound_feat_positive'].cpu().numpy().copy())
+            gts.append(np.asarray(gt.cpu() if torch.is_tensor(gt) else gt).reshape(-1))
+    model.train(was_training)
+    return np.concatenate(img), np.concatenate(snd), np.concatenate(gts)

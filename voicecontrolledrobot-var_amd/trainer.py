@@ -311,7 +311,9 @@ def train_representation(model, batches, epochs, lr=1e-4, weight_decay=1e-6, mil
                          margin=1.0, save_dir=None, save_interval=10, start_ep=0, log=print):
     """The loop of VAR/pretext_VAR.py:44-91.  `batches()` yields (image, sound_positive, sound_negative, gt)
     CUDA tensors for one epoch.  Returns the per-epoch average losses."""
-    tr = VARTrainer(model, lr=lr, weight_decay=weight_decay, margin=margin)
+    from .ithor import IthorTrainer, IthorVARPretextNet
+    trainer_cls = IthorTrainer if isinstance(model, IthorVARPretextNet) else VARTrainer
+    tr = trainer_cls(model, lr=lr, weight_decay=weight_decay, margin=margin)
     model.train()
     loss_list = []
     for ep in range(epochs):
