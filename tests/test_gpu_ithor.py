@@ -241,3 +241,22 @@ def test_train_loop_checkpoint_and_projection(var_amd, fx, tmp_path):
                         torch.from_numpy(fx["sound_negative"]))
     np.testing.assert_allclose(a, ra.numpy(), atol=1e-4)
     np.testing.assert_allclose(s, rp.numpy(), atol=1e-4)
+
+
+def test_step_from_pcm_equals_explicit_front_end(var_amd, fx):
+    """IthorTrainer.step_from_pcm = mfcc_psf (python_speech_features branch) + step; clips gathered from a pool."""
+    pool = var_amd.SyntheticTripletPool(16, hw=96, task_num=4, clips_per_class=4, seed=3)
+    idx, cp = pool.sample_indices(3)
+    img, pcm, lens = pool.gather(idx, cp)
+    losses = []
+    for use_pcm in (True, False):
+        m = seeded_model(var_amd, int(fx["seed"]))
+        tr = var_amd.IthorTrainer(m)
+        if use_pcm:
+            losses.append(tr.step_from_pcm(img, pcm, lens).item())
+        else:
+            f = var_amd.mfcc_psf(pcm, lens, out_frames=600)
+            assert torch.all(f[lens == 0] == 0)
+            losses.append(tr.step(img, f[:3], f[3:]).item())
+        flat = m.flat_parameters().clone()
+    assert losses[0] == losses[1] and np.isfinite(losses[0])

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--hw", type=int, default=96)
     ap.add_argument("--fwd-only", action="store_true")
+    ap.add_argument("--features", action="store_true", help="feed precomputed (1,600,40) features instead of PCM")
     a = ap.parse_args()
     torch.manual_seed(977)
     cfg = types.SimpleNamespace(img_dim=(3, a.hw, a.hw), sound_dim=(1, 600, 40), representationDim=3)
@@ -35,13 +36,19 @@ def main():
     img = torch.randint(0, 256, (a.batch, 3, a.hw, a.hw), dtype=torch.uint8, device="cuda", generator=g)
     pos = torch.randn((a.batch, 1, 600, 40), device="cuda", generator=g) * 6
     neg = torch.randn((a.batch, 1, 600, 40), device="cuda", generator=g) * 6
+    # 6 s int16 clips resident in HBM (Envs/ai2thor: FSC utterances up to 96000 samples), ragged lengths
+    pcm = torch.randint(-8000, 8000, (2 * a.batch, 96000), dtype=torch.int16, device="cuda", generator=g)
+    lens = torch.randint(30000, 96001, (2 * a.batch,), dtype=torch.int32, device="cuda", generator=g)
+    lens[::5] = 0                                            # 20 % "empty" class
 
     def one():
         if a.fwd_only:
             with torch.no_grad():
                 m(img, pos, neg)
-        else:
+        elif a.features:
             tr.step(img, pos, neg)
+        else:
+            tr.step_from_pcm(img, pcm, lens)                 # MFCC front-end inside the step
 
     for _ in range(a.warmup):
         one()

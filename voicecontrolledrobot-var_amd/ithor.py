@@ -257,6 +257,15 @@ class IthorTrainer:
         self.adam()
         return self.loss
 
+    def step_from_pcm(self, image, pcm, lens, global_batch=None):
+        """The step with the data-loader's audio work folded in (dataset.py:64-89 + Envs/audioLoader.py:158-161,
+        241-252): pcm int16 (2B, n) = [pos | neg] clips resident in HBM (e.g. TripletPool.gather), lens (2B) valid
+        samples (0 = the "empty" class => all-zero features); python_speech_features MFCC on the GPU, then step."""
+        from .ops import mfcc_psf
+        B = image.shape[0]
+        feats = mfcc_psf(pcm, lens, out_frames=self.model.config.sound_dim[1])
+        return self.step(image, feats[:B], feats[B:], global_batch)
+
 
 def project_representation(model, batches):
     """pretext.py:147-203 (project2representation_with_ground_truth) without the plotting: run the frozen encoder
