@@ -151,10 +151,171 @@ static int gg_launch(var_ctx* c, hipStream_t s, const P& p, int batches = 1) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// The convolutions use a second loader, gg2_kernel: same tile, K chunk, LDS layout and MFMA loop as gg_kernel, but the
+// operands are SEPARABLE gathers
+//     A(m,k) = ok ? srcA[ fA(m) + gA(k) ] : 0,   ok = one side's bit set contained in the other's
+// (a convolution's address is base(pixel) + offset(channel, tap), and "tap (ky,kx) of pixel (y,x) lies inside the
+// map" is bit ky of a row mask and bit 16+kx of a column mask of the pixel).  The k-side (offset, bits) pairs of the 16
+// k of a chunk are computed once per chunk by one wave into a small LDS table, two chunks ahead; every other thread
+// pays one LDS read, an AND, a compare and an add per element, and the loads are branch-free (clamped to element 0
+// and zeroed by a select).  The first version computed the channel/tap split and the bounds tests per element:
+// ~320 VALU/branch instructions per 16 MFMAs, i.e. VALU-bound.
+struct SepM { int base; unsigned mask; };     // per m (or n)
+struct SepK { int off; unsigned bits; };      // per k
+constexpr unsigned SEP_OK = 1u << 30;         // "index in range": set in every valid mask and in all bits
+constexpr unsigned SEP_BAD = 1u << 31;        // never in a mask: bits of an out-of-range k
+
+template <class P, int NT>
+__global__ void __launch_bounds__(256) gg2_kernel(const P p) {
+    constexpr int AS = GG_MT + 4, BS = NT + 4;
+    constexpr int NB = NT / 32;
+    __shared__ float As[2][GG_KC][AS];
+    __shared__ float Bs[2][GG_KC][BS];
+    __shared__ SepK ktA[2][GG_KC];
+    __shared__ SepK ktB[2][GG_KC];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.x * GG_MT, n0 = blockIdx.y * NT;
+    const int nsplit = p.nsplit;
+    const int bz = blockIdx.z / nsplit, sz = blockIdx.z - bz * nsplit;
+    const int kchunks = (p.k_extent(bz) + GG_KC - 1) / GG_KC;
+    const int per = (kchunks + nsplit - 1) / nsplit;
+    const int c_lo = sz * per, c_hi = min(kchunks, c_lo + per);
+    if (c_lo >= c_hi) { if (nsplit > 1 || kchunks == 0) return; }
+
+    constexpr int NA = GG_MT * GG_KC / 256;
+    constexpr int NBE = NT * GG_KC / 256;
+    SepM am[P::A_KFAST ? NA : 1];
+    SepM bn[P::B_KFAST ? NBE : 1];
+    if (P::A_KFAST) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) am[P::A_KFAST ? i : 0] = p.a_m(m0 + (tid >> 4) + 16 * i, bz);
+    } else {
+        am[0] = p.a_m(m0 + (tid & (GG_MT - 1)), bz);
+    }
+    if (P::B_KFAST) {
+#pragma unroll
+        for (int i = 0; i < NBE; ++i) bn[P::B_KFAST ? i : 0] = p.b_n(n0 + (tid >> 4) + 16 * i, bz);
+    } else {
+        bn[0] = p.b_n(n0 + (tid & (NT - 1)), bz);
+    }
+
+    // k-side table of chunk `chunk`, computed by the 16 first lanes of one wave (the waves take turns)
+    auto ktable = [&](int chunk) {
+        if (wave == (chunk & 3) && lane < GG_KC) {
+            ktA[chunk & 1][lane] = p.a_k(chunk * GG_KC + lane, bz);
+            ktB[chunk & 1][lane] = p.b_k(chunk * GG_KC + lane, bz);
+        }
+    };
+    auto fetchA = [&](const SepM& sm, const SepK& sk) -> float {
+        const bool ok = P::A_K_IN_M ? (sm.mask & sk.bits) == sk.bits : (sm.mask & sk.bits) == sm.mask;
+        const float v = p.a_load(ok ? sm.base + sk.off : 0);
+        return ok ? v : 0.f;
+    };
+    auto fetchB = [&](const SepM& sn, const SepK& sk) -> float {
+        const bool ok = (sn.mask & sk.bits) == sk.bits;
+        const float v = p.b_load(ok ? sn.base + sk.off : 0);
+        return ok ? v : 0.f;
+    };
+    float ra[NA], rb[NBE];
+    auto gload = [&](int chunk) {
+        const SepK* ta = ktA[chunk & 1];
+        const SepK* tb = ktB[chunk & 1];
+        if (P::A_KFAST) {
+            const SepK ak = ta[tid & 15];
+#pragma unroll
+            for (int i = 0; i < NA; ++i) ra[i] = fetchA(am[P::A_KFAST ? i : 0], ak);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) ra[i] = fetchA(am[0], ta[(tid >> 7) + 2 * i]);
+        }
+        if (P::B_KFAST) {
+            const SepK bk = tb[tid & 15];
+#pragma unroll
+            for (int i = 0; i < NBE; ++i) rb[i] = fetchB(bn[P::B_KFAST ? i : 0], bk);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NBE; ++i) rb[i] = fetchB(bn[0], tb[tid / NT + (256 / NT) * i]);
+        }
+    };
+    auto lstore = [&](int buf) {
+        if (P::A_KFAST) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) As[buf][tid & 15][(tid >> 4) + 16 * i] = ra[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) As[buf][(tid >> 7) + 2 * i][tid & (GG_MT - 1)] = ra[i];
+        }
+        if (P::B_KFAST) {
+#pragma unroll
+            for (int i = 0; i < NBE; ++i) Bs[buf][tid & 15][(tid >> 4) + 16 * i] = rb[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NBE; ++i) Bs[buf][tid / NT + (256 / NT) * i][tid & (NT - 1)] = rb[i];
+        }
+    };
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+    ktable(c_lo);
+    ktable(c_lo + 1);
+    __syncthreads();
+    if (c_lo < c_hi) {
+        gload(c_lo);
+        lstore(0);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int c = c_lo; c < c_hi; ++c) {
+        const int cur = (c - c_lo) & 1;
+        if (c + 1 < c_hi) gload(c + 1);
+        ktable(c + 2);                       // slot of chunk c, whose table was last read in the previous iteration
+#pragma unroll
+        for (int kk = 0; kk < GG_KC / 2; ++kk) {
+            const float av = As[cur][2 * kk + half][32 * wave + l31];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(Bs[cur][2 * kk + half][32 * b + l31], av, acc[b], 0, 0, 0);
+        }
+        if (c + 1 < c_hi) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    const int m = m0 + 32 * wave + l31;
+    if (m < p.M) {
+        const typename P::CM cm = p.c_m(m, bz);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (n < p.N) p.store(cm, n, acc[b][r], bz);
+            }
+    }
+}
+
+template <class P>
+static int gg2_launch(var_ctx* c, hipStream_t s, const P& p, int batches = 1) {
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return VAR_OK;
+    dim3 grid((p.M + GG_MT - 1) / GG_MT, 1, batches * p.nsplit);
+    if (p.N <= 32) {
+        hipLaunchKernelGGL((gg2_kernel<P, 32>), grid, dim3(256), 0, s, p);
+    } else {
+        grid.y = (p.N + 63) / 64;
+        hipLaunchKernelGGL((gg2_kernel<P, 64>), grid, dim3(256), 0, s, p);
+    }
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}
+
 // Convolution policies.  Geometry of the filter is compile-time, tensor sizes are run-time.
 template <int KH_, int KW_, int SH_, int SW_, int PH_, int PW_>
 struct Geo {
     static constexpr int KH = KH_, KW = KW_, SH = SH_, SW = SW_, PH = PH_, PW = PW_, KHW = KH_ * KW_;
+    static_assert(KH_ <= 15 && KW_ <= 13, "row taps in mask bits 0..14, column taps in bits 16..28");
 };
 
 struct ConvDims {
@@ -174,42 +335,45 @@ inline ConvDims conv_dims(int B, int CIN, int H, int W, int COUT, int KH, int KW
     return d;
 }
 
+// bit t of the result: 0 <= start + t*step < limit, for t < n  (row / column masks of a pixel)
+__device__ __forceinline__ unsigned tap_mask(int start, int step, int n, int limit) {
+    unsigned m = 0;
+#pragma unroll
+    for (int t = 0; t < n; ++t) m |= ((unsigned)(start + t * step) < (unsigned)limit) ? (1u << t) : 0u;
+    return m;
+}
+
 // y = relu(conv(x, w) + bias).  m = (b, oy, ox), n = cout, k = (ci, ky, kx) -- the filter's own OIHW order, so
 // B(k, n) = w[n*K + k].  SEQ: write (b, oy, n, ox) instead of NCHW, the layout the GRU reads as (b, t, 448).
 template <class G, bool U8, bool SEQ>
 struct ConvFwdP {
-    static constexpr bool A_KFAST = false, B_KFAST = true;
+    static constexpr bool A_KFAST = false, B_KFAST = true, A_K_IN_M = true;
     int M, N, K, nsplit;
     ConvDims d;
     const void* x; const float* w; const float* bias; float* y;
-    struct AM { long xoff; int iy0, ix0; bool ok; };
-    struct AK { int coff, ky, kx; bool ok; };
-    struct BN { int woff; bool ok; };
-    struct BK { int k; bool ok; };
     struct CM { long off; };
-    __device__ AM a_m(int m, int) const {
-        AM s; s.ok = m < M;
-        int pix; const int b = fdiv(s.ok ? m : 0, d.HO * d.WO, d.inv_howo, pix);
+    __device__ int k_extent(int) const { return K; }
+    __device__ SepM a_m(int m, int) const {
+        int pix; const int b = fdiv(m < M ? m : 0, d.HO * d.WO, d.inv_howo, pix);
         int ox; const int oy = fdiv(pix, d.WO, d.inv_wo, ox);
-        s.xoff = (long)b * d.xb; s.iy0 = oy * G::SH - G::PH; s.ix0 = ox * G::SW - G::PW;
+        const int iy0 = oy * G::SH - G::PH, ix0 = ox * G::SW - G::PW;
+        SepM s;
+        s.base = (int)(b * d.xb) + iy0 * d.W + ix0;
+        s.mask = m < M ? (SEP_OK | tap_mask(iy0, 1, G::KH, d.H) | (tap_mask(ix0, 1, G::KW, d.W) << 16)) : 0u;
         return s;
     }
-    __device__ AK a_k(int k, int) const {
-        AK s; s.ok = k < K;
+    __device__ SepK a_k(int k, int) const {
         const int ci = k / G::KHW, r = k - ci * G::KHW;
-        s.ky = r / G::KW; s.kx = r - s.ky * G::KW; s.coff = ci * d.H * d.W;
-        return s;
+        const int ky = r / G::KW, kx = r - ky * G::KW;
+        return SepK{ci * d.H * d.W + ky * d.W + kx, k < K ? (SEP_OK | (1u << ky) | (1u << (16 + kx))) : SEP_BAD};
     }
-    __device__ float a(const AM& sm, const AK& sk) const {
-        const int iy = sm.iy0 + sk.ky, ix = sm.ix0 + sk.kx;
-        if (!(sm.ok && sk.ok) || (unsigned)iy >= (unsigned)d.H || (unsigned)ix >= (unsigned)d.W) return 0.f;
-        const long o = sm.xoff + sk.coff + iy * d.W + ix;
+    __device__ float a_load(int o) const {
         if (U8) return (float)((const uint8_t*)x)[o] / 255.f;      // dataset.py:67-68
         return ((const float*)x)[o];
     }
-    __device__ BN b_n(int n, int) const { return BN{n * K, n < N}; }
-    __device__ BK b_k(int k, int) const { return BK{k, k < K}; }
-    __device__ float b(const BK& sk, const BN& sn) const { return (sk.ok && sn.ok) ? w[sn.woff + sk.k] : 0.f; }
+    __device__ SepM b_n(int n, int) const { return SepM{n * K, n < N ? SEP_OK : 0u}; }
+    __device__ SepK b_k(int k, int) const { return SepK{k, k < K ? SEP_OK : SEP_BAD}; }
+    __device__ float b_load(int o) const { return w[o]; }
     __device__ CM c_m(int m, int) const {
         int pix; const int b = fdiv(m, d.HO * d.WO, d.inv_howo, pix);
         if (SEQ) {
@@ -224,50 +388,40 @@ struct ConvFwdP {
     }
 };
 
-// dx = conv_transpose(gy, w): m = (b, y, x) input pixel, n = ci, k = (co, ky, kx);
-// A(m,k) = gy[b][co][(y+PH-ky)/SH][(x+PW-kx)/SW] where that divides and lies inside, B(k,n) = w[co][n][ky][kx].
-// gy must already carry the ReLU mask of its layer.  SEQ: gy in (b, oy, co, ox) layout.
-template <class G, bool SEQ>
+// dx = conv_transpose(gy, w) for stride 1: m = (b, y, x) input pixel, n = ci, k = (co, ky, kx);
+// A(m,k) = gy[b][co][y+PH-ky][x+PW-kx] where that lies inside, B(k,n) = w[co][n][ky][kx].
+// gy must already carry the ReLU mask of its layer; `mask` (optional) is the activation dx belongs to.
+template <class G>
 struct ConvDgradP {
-    static constexpr bool A_KFAST = false, B_KFAST = false;
+    static_assert(G::SH == 1 && G::SW == 1, "stride 2 uses ConvDgradS2P");
+    static constexpr bool A_KFAST = false, B_KFAST = false, A_K_IN_M = true;
     int M, N, K, nsplit;
     ConvDims d;
     const float* gy; const float* w; float* dx;
-    const float* mask;       // optional: the (post-ReLU) activation dx belongs to; dx is zeroed where it is not positive
-    struct AM { long goff; int ty0, tx0; bool ok; };
-    struct AK { int co, ky, kx; bool ok; };
-    struct BN { int noff; bool ok; };
-    struct BK { int koff; bool ok; };
+    const float* mask;
     struct CM { long off; };
-    __device__ AM a_m(int m, int) const {
-        AM s; s.ok = m < M;
-        int pix; const int b = fdiv(s.ok ? m : 0, d.H * d.W, d.inv_hw, pix);
+    __device__ int k_extent(int) const { return K; }
+    __device__ SepM a_m(int m, int) const {
+        int pix; const int b = fdiv(m < M ? m : 0, d.H * d.W, d.inv_hw, pix);
         int xx; const int yy = fdiv(pix, d.W, d.inv_w, xx);
-        s.goff = (long)b * d.COUT * d.HO * d.WO; s.ty0 = yy + G::PH; s.tx0 = xx + G::PW;
+        const int ty0 = yy + G::PH, tx0 = xx + G::PW;
+        SepM s;
+        s.base = b * d.COUT * d.HO * d.WO + ty0 * d.WO + tx0;
+        s.mask = m < M ? (SEP_OK | tap_mask(ty0, -1, G::KH, d.HO) | (tap_mask(tx0, -1, G::KW, d.WO) << 16)) : 0u;
         return s;
     }
-    __device__ AK a_k(int k, int) const {
-        AK s; s.ok = k < K;
-        s.co = k / G::KHW; const int r = k - s.co * G::KHW;
-        s.ky = r / G::KW; s.kx = r - s.ky * G::KW;
-        return s;
-    }
-    __device__ float a(const AM& sm, const AK& sk) const {
-        const int ty = sm.ty0 - sk.ky, tx = sm.tx0 - sk.kx;
-        if (!(sm.ok && sk.ok) || ty < 0 || tx < 0) return 0.f;
-        if (G::SH == 2 && (ty & 1)) return 0.f;
-        if (G::SW == 2 && (tx & 1)) return 0.f;
-        const int oy = G::SH == 2 ? ty >> 1 : ty, ox = G::SW == 2 ? tx >> 1 : tx;
-        if (oy >= d.HO || ox >= d.WO) return 0.f;
-        if (SEQ) return gy[sm.goff + ((long)oy * d.COUT + sk.co) * d.WO + ox];
-        return gy[sm.goff + ((long)sk.co * d.HO + oy) * d.WO + ox];
-    }
-    __device__ BN b_n(int n, int) const { return BN{n * G::KHW, n < N}; }
-    __device__ BK b_k(int k, int) const {
+    __device__ SepK a_k(int k, int) const {
         const int co = k / G::KHW, r = k - co * G::KHW;
-        return BK{co * d.CIN * G::KHW + r, k < K};
+        const int ky = r / G::KW, kx = r - ky * G::KW;
+        return SepK{co * d.HO * d.WO - ky * d.WO - kx, k < K ? (SEP_OK | (1u << ky) | (1u << (16 + kx))) : SEP_BAD};
     }
-    __device__ float b(const BK& sk, const BN& sn) const { return (sk.ok && sn.ok) ? w[sk.koff + sn.noff] : 0.f; }
+    __device__ float a_load(int o) const { return gy[o]; }
+    __device__ SepM b_n(int n, int) const { return SepM{n * G::KHW, n < N ? SEP_OK : 0u}; }
+    __device__ SepK b_k(int k, int) const {
+        const int co = k / G::KHW, r = k - co * G::KHW;
+        return SepK{co * d.CIN * G::KHW + r, k < K ? SEP_OK : SEP_BAD};
+    }
+    __device__ float b_load(int o) const { return w[o]; }
     __device__ CM c_m(int m, int) const {
         int pix; const int b = fdiv(m, d.H * d.W, d.inv_hw, pix);
         return CM{(long)b * d.CIN * d.H * d.W + pix};
@@ -282,53 +436,50 @@ struct ConvDgradP {
 // The same for stride 2 in both directions, without the structural zeros: an input pixel only meets the filter taps
 // of its own parity (ky = (y+PH) mod 2, kx likewise), so the pixels are processed in four parity classes (grid.z)
 // whose K runs over (co, taps of that parity) -- a quarter of the products of the plain gather form.
-// m = (b, y', x') with y = 2y'+cy, x = 2x'+cx; k = (co, i, j) with ky = ry+2i, kx = rx+2j.
+// m = (b, y', x') with y = 2y'+cy, x = 2x'+cx; k = (co, i, j) with ky = ry+2i, kx = rx+2j, i < nky(class), j < nkx.
 template <class G, bool SEQ>
 struct ConvDgradS2P {
-    static constexpr bool A_KFAST = false, B_KFAST = false;
-    static constexpr int NKY = (G::KH + 1) / 2, NKX = (G::KW + 1) / 2, NTAP = NKY * NKX;
-    int M, N, K, nsplit;
+    static constexpr bool A_KFAST = false, B_KFAST = false, A_K_IN_M = true;
+    static constexpr int NKY = (G::KH + 1) / 2, NKX = (G::KW + 1) / 2;
+    int M, N, K, nsplit;     // K = COUT * NKY * NKX (the largest class); a class's own extent is k_extent(z)
     ConvDims d;
     int H2, W2; float inv_h2w2, inv_w2;
     const float* gy; const float* w; float* dx;
     const float* mask;
-    struct AM { long goff; int oy0, ox0; bool ok; };
-    struct AK { int co, i, j; bool ok; };
-    struct BN { int noff; bool ok; };
-    struct BK { int koff; bool ok; };
     struct CM { long off; bool ok; };
-    __device__ AM a_m(int m, int z) const {
-        AM s; const int cy = z >> 1, cx = z & 1;
+    __device__ static int ry_of(int z) { return ((z >> 1) + G::PH) & 1; }
+    __device__ static int rx_of(int z) { return ((z & 1) + G::PW) & 1; }
+    __device__ static int nky_of(int z) { return (G::KH - ry_of(z) + 1) / 2; }
+    __device__ static int nkx_of(int z) { return (G::KW - rx_of(z) + 1) / 2; }
+    __device__ int k_extent(int z) const { return d.COUT * nky_of(z) * nkx_of(z); }
+    __device__ SepM a_m(int m, int z) const {
+        const int cy = z >> 1, cx = z & 1;
         int pix; const int b = fdiv(m < M ? m : 0, H2 * W2, inv_h2w2, pix);
         int xp; const int yp = fdiv(pix, W2, inv_w2, xp);
-        s.ok = m < M && 2 * yp + cy < d.H && 2 * xp + cx < d.W;
-        s.goff = (long)b * d.COUT * d.HO * d.WO;
-        s.oy0 = yp + ((cy + G::PH - ((cy + G::PH) & 1)) >> 1);
-        s.ox0 = xp + ((cx + G::PW - ((cx + G::PW) & 1)) >> 1);
+        const bool ok = m < M && 2 * yp + cy < d.H && 2 * xp + cx < d.W;
+        const int oy0 = yp + ((cy + G::PH - ry_of(z)) >> 1), ox0 = xp + ((cx + G::PW - rx_of(z)) >> 1);
+        SepM s;
+        s.base = b * d.COUT * d.HO * d.WO + (SEQ ? oy0 * d.COUT * d.WO + ox0 : oy0 * d.WO + ox0);
+        s.mask = ok ? (SEP_OK | tap_mask(oy0, -1, NKY, d.HO) | (tap_mask(ox0, -1, NKX, d.WO) << 16)) : 0u;
         return s;
     }
-    __device__ AK a_k(int k, int z) const {
-        AK s; const int ry = ((z >> 1) + G::PH) & 1, rx = ((z & 1) + G::PW) & 1;
-        s.co = k / NTAP; const int r = k - s.co * NTAP;
-        s.i = r / NKX; s.j = r - s.i * NKX;
-        s.ok = k < K && ry + 2 * s.i < G::KH && rx + 2 * s.j < G::KW;
-        return s;
+    __device__ void split(int k, int z, int& co, int& i, int& j) const {
+        const int nkx = nkx_of(z), ntap = nky_of(z) * nkx;
+        co = k / ntap; const int r = k - co * ntap;
+        i = r / nkx; j = r - i * nkx;
     }
-    __device__ float a(const AM& sm, const AK& sk) const {
-        const int oy = sm.oy0 - sk.i, ox = sm.ox0 - sk.j;
-        if (!(sm.ok && sk.ok) || (unsigned)oy >= (unsigned)d.HO || (unsigned)ox >= (unsigned)d.WO) return 0.f;
-        if (SEQ) return gy[sm.goff + ((long)oy * d.COUT + sk.co) * d.WO + ox];
-        return gy[sm.goff + ((long)sk.co * d.HO + oy) * d.WO + ox];
+    __device__ SepK a_k(int k, int z) const {
+        int co, i, j; split(k, z, co, i, j);
+        const int off = SEQ ? co * d.WO - i * d.COUT * d.WO - j : co * d.HO * d.WO - i * d.WO - j;
+        return SepK{off, k < k_extent(z) ? (SEP_OK | (1u << i) | (1u << (16 + j))) : SEP_BAD};
     }
-    __device__ BN b_n(int n, int) const { return BN{n * G::KHW, n < N}; }
-    __device__ BK b_k(int k, int z) const {
-        const int ry = ((z >> 1) + G::PH) & 1, rx = ((z & 1) + G::PW) & 1;
-        const int co = k / NTAP, r = k - co * NTAP;
-        const int i = r / NKX, j = r - i * NKX;
-        const int ky = ry + 2 * i, kx = rx + 2 * j;
-        return BK{co * d.CIN * G::KHW + ky * G::KW + kx, k < K && ky < G::KH && kx < G::KW};
+    __device__ float a_load(int o) const { return gy[o]; }
+    __device__ SepM b_n(int n, int) const { return SepM{n * G::KHW, n < N ? SEP_OK : 0u}; }
+    __device__ SepK b_k(int k, int z) const {
+        int co, i, j; split(k, z, co, i, j);
+        return SepK{co * d.CIN * G::KHW + (ry_of(z) + 2 * i) * G::KW + rx_of(z) + 2 * j, k < k_extent(z) ? SEP_OK : SEP_BAD};
     }
-    __device__ float b(const BK& sk, const BN& sn) const { return (sk.ok && sn.ok) ? w[sk.koff + sn.noff] : 0.f; }
+    __device__ float b_load(int o) const { return w[o]; }
     __device__ CM c_m(int m, int z) const {
         const int cy = z >> 1, cx = z & 1;
         int pix; const int b = fdiv(m, H2 * W2, inv_h2w2, pix);
@@ -345,54 +496,50 @@ struct ConvDgradS2P {
 };
 
 // dw[co][ci][ky][kx] += sum_{b,oy,ox} gy[b][co][oy][ox] * x[b][ci][oy*SH+ky-PH][ox*SW+kx-PW]:
-// m = j = (ci, ky, kx), n = co, k = (b, oy, ox); both operands are read along k (pixels).  K is split over
-// grid.z and the partial sums are added with float atomics into a zeroed dw.
+// m = j = (ci, ky, kx), n = co, k = (b, oy, ox); both operands are read along k (pixels).  Here the row/column masks
+// belong to k (the output pixel) and the single tap bits to m, so the containment test runs the other way
+// (A_K_IN_M = false).  K is split over grid.z and the partial sums are added with float atomics into a zeroed dw.
 template <class G, bool U8, bool SEQ>
 struct ConvWgradP {
-    static constexpr bool A_KFAST = true, B_KFAST = true;
+    static constexpr bool A_KFAST = true, B_KFAST = true, A_K_IN_M = false;
     int M, N, K, nsplit;
     ConvDims d;
     const void* x; const float* gy; float* dw;
-    struct AM { int off, dy, dx; bool ok; };
-    struct AK { long xoff; int iy0, ix0; bool ok; };
-    struct BN { int noff; bool ok; };
-    struct BK { long goff; bool ok; };
     struct CM { int j; };
-    __device__ AM a_m(int j, int) const {
-        AM s; s.ok = j < M;
-        const int jj = s.ok ? j : 0;
+    __device__ int k_extent(int) const { return K; }
+    __device__ SepM a_m(int j, int) const {
+        const int jj = j < M ? j : 0;
         const int ci = jj / G::KHW, r = jj - ci * G::KHW;
         const int ky = r / G::KW, kx = r - ky * G::KW;
-        s.dy = ky - G::PH; s.dx = kx - G::PW; s.off = ci * d.H * d.W + s.dy * d.W + s.dx;
-        return s;
+        return SepM{ci * d.H * d.W + (ky - G::PH) * d.W + (kx - G::PW), j < M ? (SEP_OK | (1u << ky) | (1u << (16 + kx))) : SEP_BAD};
     }
-    __device__ AK a_k(int k, int) const {
-        AK s; s.ok = k < K;
-        int pix; const int b = fdiv(s.ok ? k : 0, d.HO * d.WO, d.inv_howo, pix);
+    __device__ SepK a_k(int k, int) const {
+        int pix; const int b = fdiv(k < K ? k : 0, d.HO * d.WO, d.inv_howo, pix);
         int ox; const int oy = fdiv(pix, d.WO, d.inv_wo, ox);
-        s.iy0 = oy * G::SH; s.ix0 = ox * G::SW; s.xoff = (long)b * d.xb + s.iy0 * d.W + s.ix0;
+        const int iy0 = oy * G::SH, ix0 = ox * G::SW;
+        SepK s;
+        s.off = (int)(b * d.xb) + iy0 * d.W + ix0;
+        s.bits = k < K ? (SEP_OK | tap_mask(iy0 - G::PH, 1, G::KH, d.H) | (tap_mask(ix0 - G::PW, 1, G::KW, d.W) << 16)) : 0u;
         return s;
     }
-    __device__ float a(const AM& sm, const AK& sk) const {
-        const int iy = sk.iy0 + sm.dy, ix = sk.ix0 + sm.dx;
-        if (!(sm.ok && sk.ok) || (unsigned)iy >= (unsigned)d.H || (unsigned)ix >= (unsigned)d.W) return 0.f;
-        const long o = sk.xoff + sm.off;
+    __device__ float a_load(int o) const {
         if (U8) return (float)((const uint8_t*)x)[o] / 255.f;
         return ((const float*)x)[o];
     }
-    __device__ BN b_n(int n, int) const { return BN{SEQ ? n * d.WO : n * d.HO * d.WO, n < N}; }
-    __device__ BK b_k(int k, int) const {
-        BK s; s.ok = k < K;
-        int pix; const int b = fdiv(s.ok ? k : 0, d.HO * d.WO, d.inv_howo, pix);
+    __device__ SepM b_n(int n, int) const { return SepM{SEQ ? n * d.WO : n * d.HO * d.WO, n < N ? SEP_OK : 0u}; }
+    __device__ SepK b_k(int k, int) const {
+        int pix; const int b = fdiv(k < K ? k : 0, d.HO * d.WO, d.inv_howo, pix);
+        SepK s;
         if (SEQ) {
             int ox; const int oy = fdiv(pix, d.WO, d.inv_wo, ox);
-            s.goff = ((long)(b * d.HO + oy) * d.COUT) * d.WO + ox;
+            s.off = ((b * d.HO + oy) * d.COUT) * d.WO + ox;
         } else {
-            s.goff = (long)b * d.COUT * d.HO * d.WO + pix;
+            s.off = b * d.COUT * d.HO * d.WO + pix;
         }
+        s.bits = k < K ? SEP_OK : SEP_BAD;
         return s;
     }
-    __device__ float b(const BK& sk, const BN& sn) const { return (sk.ok && sn.ok) ? gy[sk.goff + sn.noff] : 0.f; }
+    __device__ float b_load(int o) const { return gy[o]; }
     __device__ CM c_m(int j, int) const { return CM{j}; }
     __device__ void store(const CM& cm, int n, float v, int) const { atomicAdd(dw + (long)n * M + cm.j, v); }
 };

@@ -253,7 +253,7 @@ static int conv_fwd(var_ctx* c, hipStream_t s, const ConvDims& d, const void* x,
     ConvFwdP<G, U8, SEQ> p{};
     p.M = d.B * d.HO * d.WO; p.N = d.COUT; p.K = d.CIN * G::KHW; p.nsplit = 1;
     p.d = d; p.x = x; p.w = w; p.bias = bias; p.y = y;
-    return gg_launch(c, s, p);
+    return gg2_launch(c, s, p);
 }
 template <class G, bool SEQ>
 static int conv_dgrad(var_ctx* c, hipStream_t s, const ConvDims& d, const float* gy, const float* w, float* dx,
@@ -262,14 +262,15 @@ static int conv_dgrad(var_ctx* c, hipStream_t s, const ConvDims& d, const float*
         ConvDgradS2P<G, SEQ> p{};
         p.H2 = (d.H + 1) / 2; p.W2 = (d.W + 1) / 2;
         p.inv_h2w2 = 1.f / (float)(p.H2 * p.W2); p.inv_w2 = 1.f / (float)p.W2;
-        p.M = d.B * p.H2 * p.W2; p.N = d.CIN; p.K = d.COUT * ConvDgradS2P<G, SEQ>::NTAP; p.nsplit = 1;
+        p.M = d.B * p.H2 * p.W2; p.N = d.CIN; p.K = d.COUT * ConvDgradS2P<G, SEQ>::NKY * ConvDgradS2P<G, SEQ>::NKX; p.nsplit = 1;
         p.d = d; p.gy = gy; p.w = w; p.dx = dx; p.mask = mask;
-        return gg_launch(c, s, p, 4);
+        return gg2_launch(c, s, p, 4);
     } else {
-        ConvDgradP<G, SEQ> p{};
+        static_assert(!SEQ, "sequence layout only on the stride-2 sound layer");
+        ConvDgradP<G> p{};
         p.M = d.B * d.H * d.W; p.N = d.CIN; p.K = d.COUT * G::KHW; p.nsplit = 1;
         p.d = d; p.gy = gy; p.w = w; p.dx = dx; p.mask = mask;
-        return gg_launch(c, s, p);
+        return gg2_launch(c, s, p);
     }
 }
 template <class G, bool U8, bool SEQ>
@@ -282,7 +283,7 @@ static int conv_wgrad(var_ctx* c, hipStream_t s, const ConvDims& d, const void* 
     if (ns > kchunks / 8) ns = kchunks / 8 > 0 ? kchunks / 8 : 1;
     p.nsplit = ns;
     p.d = d; p.x = x; p.gy = gy; p.dw = dw;
-    return gg_launch(c, s, p);
+    return gg2_launch(c, s, p);
 }
 static int chan_sum(var_ctx* c, hipStream_t s, const float* g, float* out, int outer, int C, int inner) {
     if (inner < 64) {
