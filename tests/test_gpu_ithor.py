@@ -260,3 +260,15 @@ def test_step_from_pcm_equals_explicit_front_end(var_amd, fx):
             losses.append(tr.step(img, f[:3], f[3:]).item())
         flat = m.flat_parameters().clone()
     assert losses[0] == losses[1] and np.isfinite(losses[0])
+
+
+def test_gradients_are_bitwise_reproducible(var_amd, fx):
+    """No float atomics anywhere in the step: split-K partial sums go to slabs folded in fixed order."""
+    m = seeded_model(var_amd, int(fx["seed"]))
+    tr = var_amd.IthorTrainer(m)
+    img, pos, neg = cuda(fx["image"]), cuda(fx["sound_positive"]), cuda(fx["sound_negative"])
+    tr.loss_and_grads(img, pos, neg)
+    first = tr.gbuf.clone()
+    for _ in range(3):
+        tr.loss_and_grads(img, pos, neg)
+        assert torch.equal(tr.gbuf, first)

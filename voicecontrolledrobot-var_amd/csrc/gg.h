@@ -7,8 +7,8 @@
 // 256-thread workgroup, K in chunks of 16 through double-buffered LDS with the next chunk's global loads in
 // flight during the MFMAs.  Wave w owns columns [32w, 32w+32) and all NT rows: NT/32 accumulators of
 // v_mfma_f32_32x32x2f32.  A policy says for each operand whether consecutive lanes should walk m/n or k
-// (whichever is contiguous in memory), and splits its index arithmetic into a per-m (or per-n) part hoisted out
-// of the K loop and a per-k part.
+// (whichever is contiguous in memory), and gives its index arithmetic as a per-m (or per-n) part, computed once per
+// thread, plus a per-k part, computed once per K chunk for the whole workgroup.
 #pragma once
 #include "var_common.h"
 
@@ -25,148 +25,24 @@ __device__ __forceinline__ int fdiv(int k, int d, float inv, int& rem) {
 constexpr int GG_MT = 128;
 constexpr int GG_KC = 16;
 
-template <class P, int NT>
-__global__ void __launch_bounds__(256) gg_kernel(const P p) {
-    constexpr int AS = GG_MT + 4, BS = NT + 4;
-    constexpr int NB = NT / 32;
-    __shared__ float As[2][GG_KC][AS];
-    __shared__ float Bs[2][GG_KC][BS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int m0 = blockIdx.x * GG_MT, n0 = blockIdx.y * NT;
-    // grid.z = batches x K splits
-    const int nsplit = p.nsplit;
-    const int bz = blockIdx.z / nsplit, sz = blockIdx.z - bz * nsplit;
-    int kchunks = (p.K + GG_KC - 1) / GG_KC;
-    const int per = (kchunks + nsplit - 1) / nsplit;
-    const int c_lo = sz * per, c_hi = min(kchunks, c_lo + per);
-    if (c_lo >= c_hi && nsplit > 1) return;
-
-    // ---- loader mapping ----
-    constexpr int NA = GG_MT * GG_KC / 256;                 // 8 elements of A per thread and chunk
-    constexpr int NBE = NT * GG_KC / 256;                   // 4 | 2 elements of B
-    typename P::AM am[P::A_KFAST ? NA : 1];
-    typename P::BN bn[P::B_KFAST ? NBE : 1];
-    if (P::A_KFAST) {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) am[P::A_KFAST ? i : 0] = p.a_m(m0 + (tid >> 4) + 16 * i, bz);
-    } else {
-        am[0] = p.a_m(m0 + (tid & (GG_MT - 1)), bz);
-    }
-    if (P::B_KFAST) {
-#pragma unroll
-        for (int i = 0; i < NBE; ++i) bn[P::B_KFAST ? i : 0] = p.b_n(n0 + (tid >> 4) + 16 * i, bz);
-    } else {
-        bn[0] = p.b_n(n0 + (tid & (NT - 1)), bz);
-    }
-
-    float ra[NA], rb[NBE];
-    auto gload = [&](int chunk) {
-        const int k0 = chunk * GG_KC;
-        if (P::A_KFAST) {
-            const typename P::AK ak = p.a_k(k0 + (tid & 15), bz);
-#pragma unroll
-            for (int i = 0; i < NA; ++i) ra[i] = p.a(am[P::A_KFAST ? i : 0], ak);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NA; ++i) ra[i] = p.a(am[0], p.a_k(k0 + (tid >> 7) + 2 * i, bz));
-        }
-        if (P::B_KFAST) {
-            const typename P::BK bk = p.b_k(k0 + (tid & 15), bz);
-#pragma unroll
-            for (int i = 0; i < NBE; ++i) rb[i] = p.b(bk, bn[P::B_KFAST ? i : 0]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NBE; ++i) rb[i] = p.b(p.b_k(k0 + tid / NT + (256 / NT) * i, bz), bn[0]);
-        }
-    };
-    auto lstore = [&](int buf) {
-        if (P::A_KFAST) {
-#pragma unroll
-            for (int i = 0; i < NA; ++i) As[buf][tid & 15][(tid >> 4) + 16 * i] = ra[i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < NA; ++i) As[buf][(tid >> 7) + 2 * i][tid & (GG_MT - 1)] = ra[i];
-        }
-        if (P::B_KFAST) {
-#pragma unroll
-            for (int i = 0; i < NBE; ++i) Bs[buf][tid & 15][(tid >> 4) + 16 * i] = rb[i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < NBE; ++i) Bs[buf][tid / NT + (256 / NT) * i][tid & (NT - 1)] = rb[i];
-        }
-    };
-
-    f32x16 acc[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-
-    if (c_lo < c_hi) {
-        gload(c_lo);
-        lstore(0);
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int c = c_lo; c < c_hi; ++c) {
-        const int cur = (c - c_lo) & 1;
-        if (c + 1 < c_hi) gload(c + 1);
-#pragma unroll
-        for (int kk = 0; kk < GG_KC / 2; ++kk) {
-            const float av = As[cur][2 * kk + half][32 * wave + l31];
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(Bs[cur][2 * kk + half][32 * b + l31], av, acc[b], 0, 0, 0);
-        }
-        if (c + 1 < c_hi) lstore(cur ^ 1);
-        __syncthreads();
-    }
-
-    const int m = m0 + 32 * wave + l31;
-    if (m < p.M) {
-        const typename P::CM cm = p.c_m(m, bz);
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = n0 + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (n < p.N) p.store(cm, n, acc[b][r], bz);
-            }
-    }
-}
-
-template <class P>
-static int gg_launch(var_ctx* c, hipStream_t s, const P& p, int batches = 1) {
-    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return VAR_OK;
-    dim3 grid((p.M + GG_MT - 1) / GG_MT, 1, batches * p.nsplit);
-    if (p.N <= 32) {
-        grid.y = 1;
-        hipLaunchKernelGGL((gg_kernel<P, 32>), grid, dim3(256), 0, s, p);
-    } else {
-        grid.y = (p.N + 63) / 64;
-        hipLaunchKernelGGL((gg_kernel<P, 64>), grid, dim3(256), 0, s, p);
-    }
-    VAR_HIP_CHECK(c, hipGetLastError());
-    return VAR_OK;
-}
-
 // ------------------------------------------------------------------------------------------------------------
-// The convolutions use a second loader, gg2_kernel: same tile, K chunk, LDS layout and MFMA loop as gg_kernel, but the
-// operands are SEPARABLE gathers
+// The kernel.  Both operands are SEPARABLE gathers
 //     A(m,k) = ok ? srcA[ fA(m) + gA(k) ] : 0,   ok = one side's bit set contained in the other's
 // (a convolution's address is base(pixel) + offset(channel, tap), and "tap (ky,kx) of pixel (y,x) lies inside the
 // map" is bit ky of a row mask and bit 16+kx of a column mask of the pixel).  The k-side (offset, bits) pairs of the 16
 // k of a chunk are computed once per chunk by one wave into a small LDS table, two chunks ahead; every other thread
-// pays one LDS read, an AND, a compare and an add per element, and the loads are branch-free (clamped to element 0
-// and zeroed by a select).  The first version computed the channel/tap split and the bounds tests per element:
-// ~320 VALU/branch instructions per 16 MFMAs, i.e. VALU-bound.
-struct SepM { int base; unsigned mask; };     // per m (or n)
-struct SepK { int off; unsigned bits; };      // per k
+// pays one LDS read, an AND, a compare and an add per element.  Offsets are 32-bit BYTE offsets from the operand's
+// base pointer (scalar base + vector offset addressing, no 64-bit arithmetic per element; every operand is < 4 GB);
+// the loads are branch-free (clamped to offset 0) and the zeroing select is deferred to the LDS store, so that the
+// loads of chunk c+1 stay in flight across the MFMAs of chunk c.  The first version computed the channel/tap split
+// and the bounds tests per element: ~320 VALU/branch instructions per 16 MFMAs, i.e. VALU-bound.
+struct SepM { unsigned base; unsigned mask; };     // per m (or n): byte offset, validity mask
+struct SepK { unsigned off; unsigned bits; };      // per k
 constexpr unsigned SEP_OK = 1u << 30;         // "index in range": set in every valid mask and in all bits
 constexpr unsigned SEP_BAD = 1u << 31;        // never in a mask: bits of an out-of-range k
 
 template <class P, int NT>
-__global__ void __launch_bounds__(256) gg2_kernel(const P p) {
+__global__ void __launch_bounds__(256) gg_kernel(const P p) {
     constexpr int AS = GG_MT + 4, BS = NT + 4;
     constexpr int NB = NT / 32;
     __shared__ float As[2][GG_KC][AS];
@@ -206,51 +82,41 @@ __global__ void __launch_bounds__(256) gg2_kernel(const P p) {
             ktB[chunk & 1][lane] = p.b_k(chunk * GG_KC + lane, bz);
         }
     };
-    auto fetchA = [&](const SepM& sm, const SepK& sk) -> float {
-        const bool ok = P::A_K_IN_M ? (sm.mask & sk.bits) == sk.bits : (sm.mask & sk.bits) == sm.mask;
-        const float v = p.a_load(ok ? sm.base + sk.off : 0);
-        return ok ? v : 0.f;
-    };
-    auto fetchB = [&](const SepM& sn, const SepK& sk) -> float {
-        const bool ok = (sn.mask & sk.bits) == sk.bits;
-        const float v = p.b_load(ok ? sn.base + sk.off : 0);
-        return ok ? v : 0.f;
-    };
     float ra[NA], rb[NBE];
+    unsigned oka = 0, okb = 0;                 // validity of the elements in flight, applied at the LDS store
     auto gload = [&](int chunk) {
         const SepK* ta = ktA[chunk & 1];
         const SepK* tb = ktB[chunk & 1];
-        if (P::A_KFAST) {
-            const SepK ak = ta[tid & 15];
+        oka = 0; okb = 0;
 #pragma unroll
-            for (int i = 0; i < NA; ++i) ra[i] = fetchA(am[P::A_KFAST ? i : 0], ak);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NA; ++i) ra[i] = fetchA(am[0], ta[(tid >> 7) + 2 * i]);
+        for (int i = 0; i < NA; ++i) {
+            const SepM sm = am[P::A_KFAST ? i : 0];
+            const SepK sk = P::A_KFAST ? ta[tid & 15] : ta[(tid >> 7) + 2 * i];
+            const bool ok = P::A_K_IN_M ? (sm.mask & sk.bits) == sk.bits : (sm.mask & sk.bits) == sm.mask;
+            ra[i] = p.a_load(ok ? sm.base + sk.off : 0u);
+            oka |= ok ? (1u << i) : 0u;
         }
-        if (P::B_KFAST) {
-            const SepK bk = tb[tid & 15];
 #pragma unroll
-            for (int i = 0; i < NBE; ++i) rb[i] = fetchB(bn[P::B_KFAST ? i : 0], bk);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NBE; ++i) rb[i] = fetchB(bn[0], tb[tid / NT + (256 / NT) * i]);
+        for (int i = 0; i < NBE; ++i) {
+            const SepM sn = bn[P::B_KFAST ? i : 0];
+            const SepK sk = P::B_KFAST ? tb[tid & 15] : tb[tid / NT + (256 / NT) * i];
+            const bool ok = (sn.mask & sk.bits) == sk.bits;
+            rb[i] = p.b_load(ok ? sn.base + sk.off : 0u);
+            okb |= ok ? (1u << i) : 0u;
         }
     };
     auto lstore = [&](int buf) {
-        if (P::A_KFAST) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) As[buf][tid & 15][(tid >> 4) + 16 * i] = ra[i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < NA; ++i) As[buf][(tid >> 7) + 2 * i][tid & (GG_MT - 1)] = ra[i];
+        for (int i = 0; i < NA; ++i) {
+            const float v = (oka >> i) & 1u ? ra[i] : 0.f;
+            if (P::A_KFAST) As[buf][tid & 15][(tid >> 4) + 16 * i] = v;
+            else As[buf][(tid >> 7) + 2 * i][tid & (GG_MT - 1)] = v;
         }
-        if (P::B_KFAST) {
 #pragma unroll
-            for (int i = 0; i < NBE; ++i) Bs[buf][tid & 15][(tid >> 4) + 16 * i] = rb[i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < NBE; ++i) Bs[buf][tid / NT + (256 / NT) * i][tid & (NT - 1)] = rb[i];
+        for (int i = 0; i < NBE; ++i) {
+            const float v = (okb >> i) & 1u ? rb[i] : 0.f;
+            if (P::B_KFAST) Bs[buf][tid & 15][(tid >> 4) + 16 * i] = v;
+            else Bs[buf][tid / NT + (256 / NT) * i][tid & (NT - 1)] = v;
         }
     };
 
@@ -286,7 +152,7 @@ __global__ void __launch_bounds__(256) gg2_kernel(const P p) {
 
     const int m = m0 + 32 * wave + l31;
     if (m < p.M) {
-        const typename P::CM cm = p.c_m(m, bz);
+        const typename P::CM cm = p.c_m(m, bz, sz);
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -298,14 +164,14 @@ __global__ void __launch_bounds__(256) gg2_kernel(const P p) {
 }
 
 template <class P>
-static int gg2_launch(var_ctx* c, hipStream_t s, const P& p, int batches = 1) {
+static int gg_launch(var_ctx* c, hipStream_t s, const P& p, int batches = 1) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return VAR_OK;
     dim3 grid((p.M + GG_MT - 1) / GG_MT, 1, batches * p.nsplit);
     if (p.N <= 32) {
-        hipLaunchKernelGGL((gg2_kernel<P, 32>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((gg_kernel<P, 32>), grid, dim3(256), 0, s, p);
     } else {
         grid.y = (p.N + 63) / 64;
-        hipLaunchKernelGGL((gg2_kernel<P, 64>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((gg_kernel<P, 64>), grid, dim3(256), 0, s, p);
     }
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
@@ -335,6 +201,11 @@ inline ConvDims conv_dims(int B, int CIN, int H, int W, int COUT, int KH, int KW
     return d;
 }
 
+// float at a 32-bit byte offset from a base pointer (scalar base + vector offset addressing)
+__device__ __forceinline__ float ldf(const void* base, unsigned byte_off) {
+    return *(const float*)((const char*)base + byte_off);
+}
+
 // bit t of the result: 0 <= start + t*step < limit, for t < n  (row / column masks of a pixel)
 __device__ __forceinline__ unsigned tap_mask(int start, int step, int n, int limit) {
     unsigned m = 0;
@@ -348,6 +219,7 @@ __device__ __forceinline__ unsigned tap_mask(int start, int step, int n, int lim
 template <class G, bool U8, bool SEQ>
 struct ConvFwdP {
     static constexpr bool A_KFAST = false, B_KFAST = true, A_K_IN_M = true;
+    static constexpr unsigned ES = U8 ? 1u : 4u;
     int M, N, K, nsplit;
     ConvDims d;
     const void* x; const float* w; const float* bias; float* y;
@@ -358,23 +230,23 @@ struct ConvFwdP {
         int ox; const int oy = fdiv(pix, d.WO, d.inv_wo, ox);
         const int iy0 = oy * G::SH - G::PH, ix0 = ox * G::SW - G::PW;
         SepM s;
-        s.base = (int)(b * d.xb) + iy0 * d.W + ix0;
+        s.base = (unsigned)((int)(b * d.xb) + iy0 * d.W + ix0) * ES;
         s.mask = m < M ? (SEP_OK | tap_mask(iy0, 1, G::KH, d.H) | (tap_mask(ix0, 1, G::KW, d.W) << 16)) : 0u;
         return s;
     }
     __device__ SepK a_k(int k, int) const {
         const int ci = k / G::KHW, r = k - ci * G::KHW;
         const int ky = r / G::KW, kx = r - ky * G::KW;
-        return SepK{ci * d.H * d.W + ky * d.W + kx, k < K ? (SEP_OK | (1u << ky) | (1u << (16 + kx))) : SEP_BAD};
+        return SepK{(unsigned)(ci * d.H * d.W + ky * d.W + kx) * ES, k < K ? (SEP_OK | (1u << ky) | (1u << (16 + kx))) : SEP_BAD};
     }
-    __device__ float a_load(int o) const {
-        if (U8) return (float)((const uint8_t*)x)[o] / 255.f;      // dataset.py:67-68
-        return ((const float*)x)[o];
+    __device__ float a_load(unsigned o) const {
+        if (U8) return (float)*((const uint8_t*)x + o) / 255.f;      // dataset.py:67-68
+        return ldf(x, o);
     }
-    __device__ SepM b_n(int n, int) const { return SepM{n * K, n < N ? SEP_OK : 0u}; }
-    __device__ SepK b_k(int k, int) const { return SepK{k, k < K ? SEP_OK : SEP_BAD}; }
-    __device__ float b_load(int o) const { return w[o]; }
-    __device__ CM c_m(int m, int) const {
+    __device__ SepM b_n(int n, int) const { return SepM{(unsigned)(n * K) * 4u, n < N ? SEP_OK : 0u}; }
+    __device__ SepK b_k(int k, int) const { return SepK{(unsigned)k * 4u, k < K ? SEP_OK : SEP_BAD}; }
+    __device__ float b_load(unsigned o) const { return ldf(w, o); }
+    __device__ CM c_m(int m, int, int) const {
         int pix; const int b = fdiv(m, d.HO * d.WO, d.inv_howo, pix);
         if (SEQ) {
             int ox; const int oy = fdiv(pix, d.WO, d.inv_wo, ox);
@@ -406,23 +278,23 @@ struct ConvDgradP {
         int xx; const int yy = fdiv(pix, d.W, d.inv_w, xx);
         const int ty0 = yy + G::PH, tx0 = xx + G::PW;
         SepM s;
-        s.base = b * d.COUT * d.HO * d.WO + ty0 * d.WO + tx0;
+        s.base = (unsigned)(b * d.COUT * d.HO * d.WO + ty0 * d.WO + tx0) * 4u;
         s.mask = m < M ? (SEP_OK | tap_mask(ty0, -1, G::KH, d.HO) | (tap_mask(tx0, -1, G::KW, d.WO) << 16)) : 0u;
         return s;
     }
     __device__ SepK a_k(int k, int) const {
         const int co = k / G::KHW, r = k - co * G::KHW;
         const int ky = r / G::KW, kx = r - ky * G::KW;
-        return SepK{co * d.HO * d.WO - ky * d.WO - kx, k < K ? (SEP_OK | (1u << ky) | (1u << (16 + kx))) : SEP_BAD};
+        return SepK{(unsigned)(co * d.HO * d.WO - ky * d.WO - kx) * 4u, k < K ? (SEP_OK | (1u << ky) | (1u << (16 + kx))) : SEP_BAD};
     }
-    __device__ float a_load(int o) const { return gy[o]; }
-    __device__ SepM b_n(int n, int) const { return SepM{n * G::KHW, n < N ? SEP_OK : 0u}; }
+    __device__ float a_load(unsigned o) const { return ldf(gy, o); }
+    __device__ SepM b_n(int n, int) const { return SepM{(unsigned)(n * G::KHW) * 4u, n < N ? SEP_OK : 0u}; }
     __device__ SepK b_k(int k, int) const {
         const int co = k / G::KHW, r = k - co * G::KHW;
-        return SepK{co * d.CIN * G::KHW + r, k < K ? SEP_OK : SEP_BAD};
+        return SepK{(unsigned)(co * d.CIN * G::KHW + r) * 4u, k < K ? SEP_OK : SEP_BAD};
     }
-    __device__ float b_load(int o) const { return w[o]; }
-    __device__ CM c_m(int m, int) const {
+    __device__ float b_load(unsigned o) const { return ldf(w, o); }
+    __device__ CM c_m(int m, int, int) const {
         int pix; const int b = fdiv(m, d.H * d.W, d.inv_hw, pix);
         return CM{(long)b * d.CIN * d.H * d.W + pix};
     }
@@ -459,7 +331,7 @@ struct ConvDgradS2P {
         const bool ok = m < M && 2 * yp + cy < d.H && 2 * xp + cx < d.W;
         const int oy0 = yp + ((cy + G::PH - ry_of(z)) >> 1), ox0 = xp + ((cx + G::PW - rx_of(z)) >> 1);
         SepM s;
-        s.base = b * d.COUT * d.HO * d.WO + (SEQ ? oy0 * d.COUT * d.WO + ox0 : oy0 * d.WO + ox0);
+        s.base = (unsigned)(b * d.COUT * d.HO * d.WO + (SEQ ? oy0 * d.COUT * d.WO + ox0 : oy0 * d.WO + ox0)) * 4u;
         s.mask = ok ? (SEP_OK | tap_mask(oy0, -1, NKY, d.HO) | (tap_mask(ox0, -1, NKX, d.WO) << 16)) : 0u;
         return s;
     }
@@ -471,16 +343,17 @@ struct ConvDgradS2P {
     __device__ SepK a_k(int k, int z) const {
         int co, i, j; split(k, z, co, i, j);
         const int off = SEQ ? co * d.WO - i * d.COUT * d.WO - j : co * d.HO * d.WO - i * d.WO - j;
-        return SepK{off, k < k_extent(z) ? (SEP_OK | (1u << i) | (1u << (16 + j))) : SEP_BAD};
+        return SepK{(unsigned)off * 4u, k < k_extent(z) ? (SEP_OK | (1u << i) | (1u << (16 + j))) : SEP_BAD};
     }
-    __device__ float a_load(int o) const { return gy[o]; }
-    __device__ SepM b_n(int n, int) const { return SepM{n * G::KHW, n < N ? SEP_OK : 0u}; }
+    __device__ float a_load(unsigned o) const { return ldf(gy, o); }
+    __device__ SepM b_n(int n, int) const { return SepM{(unsigned)(n * G::KHW) * 4u, n < N ? SEP_OK : 0u}; }
     __device__ SepK b_k(int k, int z) const {
         int co, i, j; split(k, z, co, i, j);
-        return SepK{co * d.CIN * G::KHW + (ry_of(z) + 2 * i) * G::KW + rx_of(z) + 2 * j, k < k_extent(z) ? SEP_OK : SEP_BAD};
+        return SepK{(unsigned)(co * d.CIN * G::KHW + (ry_of(z) + 2 * i) * G::KW + rx_of(z) + 2 * j) * 4u,
+                    k < k_extent(z) ? SEP_OK : SEP_BAD};
     }
-    __device__ float b_load(int o) const { return w[o]; }
-    __device__ CM c_m(int m, int z) const {
+    __device__ float b_load(unsigned o) const { return ldf(w, o); }
+    __device__ CM c_m(int m, int z, int) const {
         const int cy = z >> 1, cx = z & 1;
         int pix; const int b = fdiv(m, H2 * W2, inv_h2w2, pix);
         int xp; const int yp = fdiv(pix, W2, inv_w2, xp);
@@ -498,80 +371,85 @@ struct ConvDgradS2P {
 // dw[co][ci][ky][kx] += sum_{b,oy,ox} gy[b][co][oy][ox] * x[b][ci][oy*SH+ky-PH][ox*SW+kx-PW]:
 // m = j = (ci, ky, kx), n = co, k = (b, oy, ox); both operands are read along k (pixels).  Here the row/column masks
 // belong to k (the output pixel) and the single tap bits to m, so the containment test runs the other way
-// (A_K_IN_M = false).  K is split over grid.z and the partial sums are added with float atomics into a zeroed dw.
+// (A_K_IN_M = false).  K is split over grid.z: split s writes its partial sums into slab s (plain stores), a
+// fixed-order slab_reduce adds them to dw -- no float atomics, bitwise reproducible.  Unsplit: dw += directly.
 template <class G, bool U8, bool SEQ>
 struct ConvWgradP {
     static constexpr bool A_KFAST = true, B_KFAST = true, A_K_IN_M = false;
+    static constexpr unsigned ES = U8 ? 1u : 4u;
     int M, N, K, nsplit;
     ConvDims d;
     const void* x; const float* gy; float* dw;
-    struct CM { int j; };
+    float* slab;             // nsplit slabs of M*N floats (used when nsplit > 1)
+    struct CM { float* q; };
     __device__ int k_extent(int) const { return K; }
     __device__ SepM a_m(int j, int) const {
         const int jj = j < M ? j : 0;
         const int ci = jj / G::KHW, r = jj - ci * G::KHW;
         const int ky = r / G::KW, kx = r - ky * G::KW;
-        return SepM{ci * d.H * d.W + (ky - G::PH) * d.W + (kx - G::PW), j < M ? (SEP_OK | (1u << ky) | (1u << (16 + kx))) : SEP_BAD};
+        return SepM{(unsigned)(ci * d.H * d.W + (ky - G::PH) * d.W + (kx - G::PW)) * ES,
+                    j < M ? (SEP_OK | (1u << ky) | (1u << (16 + kx))) : SEP_BAD};
     }
     __device__ SepK a_k(int k, int) const {
         int pix; const int b = fdiv(k < K ? k : 0, d.HO * d.WO, d.inv_howo, pix);
         int ox; const int oy = fdiv(pix, d.WO, d.inv_wo, ox);
         const int iy0 = oy * G::SH, ix0 = ox * G::SW;
         SepK s;
-        s.off = (int)(b * d.xb) + iy0 * d.W + ix0;
+        s.off = (unsigned)((int)(b * d.xb) + iy0 * d.W + ix0) * ES;
         s.bits = k < K ? (SEP_OK | tap_mask(iy0 - G::PH, 1, G::KH, d.H) | (tap_mask(ix0 - G::PW, 1, G::KW, d.W) << 16)) : 0u;
         return s;
     }
-    __device__ float a_load(int o) const {
-        if (U8) return (float)((const uint8_t*)x)[o] / 255.f;
-        return ((const float*)x)[o];
+    __device__ float a_load(unsigned o) const {
+        if (U8) return (float)*((const uint8_t*)x + o) / 255.f;
+        return ldf(x, o);
     }
-    __device__ SepM b_n(int n, int) const { return SepM{SEQ ? n * d.WO : n * d.HO * d.WO, n < N ? SEP_OK : 0u}; }
+    __device__ SepM b_n(int n, int) const { return SepM{(unsigned)(SEQ ? n * d.WO : n * d.HO * d.WO) * 4u, n < N ? SEP_OK : 0u}; }
     __device__ SepK b_k(int k, int) const {
         int pix; const int b = fdiv(k < K ? k : 0, d.HO * d.WO, d.inv_howo, pix);
         SepK s;
         if (SEQ) {
             int ox; const int oy = fdiv(pix, d.WO, d.inv_wo, ox);
-            s.off = ((b * d.HO + oy) * d.COUT) * d.WO + ox;
+            s.off = (unsigned)(((b * d.HO + oy) * d.COUT) * d.WO + ox) * 4u;
         } else {
-            s.off = b * d.COUT * d.HO * d.WO + pix;
+            s.off = (unsigned)(b * d.COUT * d.HO * d.WO + pix) * 4u;
         }
         s.bits = k < K ? SEP_OK : SEP_BAD;
         return s;
     }
-    __device__ float b_load(int o) const { return gy[o]; }
-    __device__ CM c_m(int j, int) const { return CM{j}; }
-    __device__ void store(const CM& cm, int n, float v, int) const { atomicAdd(dw + (long)n * M + cm.j, v); }
+    __device__ float b_load(unsigned o) const { return ldf(gy, o); }
+    __device__ CM c_m(int j, int, int sz) const { return CM{(nsplit > 1 ? slab + (long)sz * M * N : dw) + j}; }
+    __device__ void store(const CM& cm, int n, float v, int) const {
+        float* q = cm.q + (long)n * M;
+        *q = nsplit > 1 ? v : *q + v;
+    }
 };
 
 // ------------------------------------------------------------------------------------------------------------
 // Dense products with run-time strides: C[m*scm + n*scn] (=|+=) sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]
 // (+ bias[m]) (ReLU).  AKF/BKF: the operand is contiguous along k.  `z` (grid.z batch, e.g. GRU direction) moves
-// every pointer by its batch stride.  MODE 0: store, 1: add to C (one owner per element), 2: atomic add (split K).
+// every pointer by its batch stride.  MODE 0: store, 1: add to C (one owner per element), 2: K split over grid.z,
+// split s stores its partial sums at C + s*sC (the consumer adds the nsplit slabs in fixed order; no atomics).
 template <bool AKF, bool BKF, int MODE>
 struct DenseP {
-    static constexpr bool A_KFAST = AKF, B_KFAST = BKF;
+    static constexpr bool A_KFAST = AKF, B_KFAST = BKF, A_K_IN_M = true;
     int M, N, K, nsplit;
     const float* A; long sam, sak, zA;
     const float* Bm; long sbk, sbn, zB;
-    float* C; long scm, scn, zC;
+    float* C; long scm, scn, zC, sC;
     const float* bias; long zbias;
     int relu;
-    struct AM { long off; bool ok; };
-    struct AK { long off; bool ok; };
-    struct BN { long off; bool ok; };
-    struct BK { long off; bool ok; };
     struct CM { long off; int m; };
-    __device__ AM a_m(int m, int z) const { return AM{z * zA + m * sam, m < M}; }
-    __device__ AK a_k(int k, int) const { return AK{k * sak, k < K}; }
-    __device__ float a(const AM& sm, const AK& sk) const { return (sm.ok && sk.ok) ? A[sm.off + sk.off] : 0.f; }
-    __device__ BN b_n(int n, int z) const { return BN{z * zB + n * sbn, n < N}; }
-    __device__ BK b_k(int k, int) const { return BK{k * sbk, k < K}; }
-    __device__ float b(const BK& sk, const BN& sn) const { return (sk.ok && sn.ok) ? Bm[sk.off + sn.off] : 0.f; }
-    __device__ CM c_m(int m, int z) const { return CM{z * zC + m * scm, m}; }
+    __device__ int k_extent(int) const { return K; }
+    __device__ SepM a_m(int m, int z) const { return SepM{(unsigned)(z * zA + m * sam) * 4u, m < M ? SEP_OK : 0u}; }
+    __device__ SepK a_k(int k, int) const { return SepK{(unsigned)(k * sak) * 4u, k < K ? SEP_OK : SEP_BAD}; }
+    __device__ float a_load(unsigned o) const { return ldf(A, o); }
+    __device__ SepM b_n(int n, int z) const { return SepM{(unsigned)(z * zB + n * sbn) * 4u, n < N ? SEP_OK : 0u}; }
+    __device__ SepK b_k(int k, int) const { return SepK{(unsigned)(k * sbk) * 4u, k < K ? SEP_OK : SEP_BAD}; }
+    __device__ float b_load(unsigned o) const { return ldf(Bm, o); }
+    __device__ CM c_m(int m, int z, int sz) const { return CM{z * zC + m * scm + (MODE == 2 ? sz * sC : 0), m}; }
     __device__ void store(const CM& cm, int n, float v, int z) const {
         float* q = C + cm.off + n * scn;
-        if (MODE == 2) { atomicAdd(q, v); return; }
+        if (MODE == 2) { *q = v; return; }
         if (bias) v += bias[z * zbias + cm.m];
         if (MODE == 1) v += *q;
         if (relu) v = v > 0.f ? v : 0.f;

@@ -53,7 +53,9 @@ struct ithor_state {
     float *a[7] = {nullptr}, *p[6] = {nullptr}, *ga[7] = {nullptr}, *gp[6] = {nullptr};
     float *s[4] = {nullptr}, *gs[4] = {nullptr};          // sound conv outputs 1..3 (3 in sequence layout)
     float *GI = nullptr, *GH = nullptr, *Hb = nullptr, *R = nullptr, *Z = nullptr, *Nn = nullptr, *GHN = nullptr;
-    float *DGI = nullptr, *DGH = nullptr, *DH = nullptr;
+    float *DGI = nullptr, *DGH = nullptr, *DH = nullptr, *DHP = nullptr;
+    float *slab = nullptr, *bslab = nullptr;              // split-K partial sums / bias-sum partials
+    int gh_split = 1, dh_split = 1;
     float *sraw = nullptr, *gsraw = nullptr;              // (clips,1024)
     float *hid_i = nullptr, *ghid_i = nullptr, *hid_s1 = nullptr, *ghid_s1 = nullptr, *hid_s2 = nullptr, *ghid_s2 = nullptr;
     float *raw = nullptr, *graw = nullptr, *emb = nullptr, *gemb = nullptr;   // (3B,3) [img | pos | neg]
@@ -113,8 +115,25 @@ __global__ void relu_mask_kernel(float* __restrict__ g, const float* __restrict_
     if (i < n && !(act[i] > 0.f)) g[i] = 0.f;
 }
 
-// out[c] += sum_{o < outer} sum_{i < inner} g[(o*C + c)*inner + i]   (bias gradients of every layer kind)
-__global__ void __launch_bounds__(256) chan_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int outer,
+// Fixed-order fold of partial sums: out[i] += sum_{s < nsplit} sum_{q < inner} slabs[s*stride + i*inner + q]
+// (split-K weight gradients, bias-sum partials): what makes the gradients bitwise reproducible without atomics.
+__global__ void __launch_bounds__(256) slab_reduce_kernel(float* __restrict__ out, const float* __restrict__ slabs, int n,
+                                                         int nsplit, long stride, int inner) {
+    // 64 outputs per workgroup; the four waves take the slabs s = w, w+4, ... and their sums are added in wave order
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (i < n)
+        for (int s = w; s < nsplit; s += 4)
+            for (int q = 0; q < inner; ++q) acc += slabs[s * stride + (long)i * inner + q];
+    __shared__ float red[4][64];
+    red[w][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (w == 0 && i < n) out[i] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// part[chunk*C + c] = sum over the chunk's share of {o < outer, i < inner} of g[(o*C + c)*inner + i]  (bias gradients
+// of the NCHW maps: long contiguous runs per channel)
+__global__ void __launch_bounds__(256) chan_sum_kernel(const float* __restrict__ g, float* __restrict__ part, int outer,
                                                       int C, int inner) {
     const int c = blockIdx.x;
     const long per = ((long)outer * inner + gridDim.y - 1) / gridDim.y;
@@ -131,13 +150,13 @@ __global__ void __launch_bounds__(256) chan_sum_kernel(const float* __restrict__
         if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) atomicAdd(out + c, red[0]);
+    if (threadIdx.x == 0) part[blockIdx.y * C + c] = red[0];
 }
 
-// the same sum when `inner` is small (rows of C*inner contiguous floats: Linear / GRU gate gradients with inner 1, the
-// sequence-layout sound map with inner 7): lanes walk the row, so the reads are coalesced
-__global__ void __launch_bounds__(256) col_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int rows, int cols,
-                                                     int inner) {
+// the same when `inner` is small (rows of cols = C*inner contiguous floats: Linear / GRU gate gradients with inner 1,
+// the sequence-layout sound map with inner 7): lanes walk the row, so the reads are coalesced;
+// part[chunk*cols + col] = column sums over the chunk's rows (the fold adds the `inner` columns of a channel)
+__global__ void __launch_bounds__(256) col_sum_kernel(const float* __restrict__ g, float* __restrict__ part, int rows, int cols) {
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
     const int per = (rows + gridDim.y - 1) / gridDim.y;
     const int lo = blockIdx.y * per, hi = min(rows, lo + per);
@@ -147,10 +166,8 @@ __global__ void __launch_bounds__(256) col_sum_kernel(const float* __restrict__ 
     __shared__ float red[4][64];
     red[ty][threadIdx.x & 63] = acc;
     __syncthreads();
-    if (ty == 0 && col < cols) {
-        acc = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        atomicAdd(out + col / inner, acc);
-    }
+    if (ty == 0 && col < cols)
+        part[(long)blockIdx.y * cols + col] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
@@ -158,8 +175,8 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 // one GRU time step, both directions (torch.nn.GRU gate order r, z, n):
 //   r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h' = (1 - z) * n + z * h
 // GI (dir, clip*T + t, 1536) holds x W_ih^T + b_ih, GH (dir, clip, 1536) holds h W_hh^T + b_hh.
-// GH holds h W_hh^T WITHOUT the bias (split-K partial sums added atomically); it is cleared here for the next step.
-__global__ void gru_gate_fwd_kernel(const float* __restrict__ GI, float* __restrict__ GH, const float* __restrict__ hprev,
+// GH holds h W_hh^T WITHOUT the bias as `nsplit` split-K partial slabs, added here in fixed order.
+__global__ void gru_gate_fwd_kernel(const float* __restrict__ GI, const float* __restrict__ GH, int nsplit, const float* __restrict__ hprev,
                                     float* __restrict__ hnext, float* __restrict__ R, float* __restrict__ Z,
                                     float* __restrict__ Nn, float* __restrict__ GHN, const float* __restrict__ b_hh,
                                     long dirP, int nclips, int step, long dirGI, long dirH, long dirS, int save) {
@@ -169,12 +186,16 @@ __global__ void gru_gate_fwd_kernel(const float* __restrict__ GI, float* __restr
     const int clip = i / kGh, j = i - clip * kGh;
     const int t = dir ? kSeq - 1 - step : step;
     const float* gi = GI + dir * dirGI + ((long)clip * kSeq + t) * kG3;
-    float* gh = GH + (long)dir * nclips * kG3 + (long)clip * kG3;
+    const float* gh = GH + (long)dir * nclips * kG3 + (long)clip * kG3;
     const float* bh = b_hh + dir * dirP;
-    const float r = sigmoidf_(gi[j] + (gh[j] + bh[j]));
-    const float z = sigmoidf_(gi[kGh + j] + (gh[kGh + j] + bh[kGh + j]));
-    const float ghn = gh[2 * kGh + j] + bh[2 * kGh + j];
-    gh[j] = 0.f; gh[kGh + j] = 0.f; gh[2 * kGh + j] = 0.f;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) {
+        const float* q = gh + (long)sp * 2 * nclips * kG3;
+        g0 += q[j]; g1 += q[kGh + j]; g2 += q[2 * kGh + j];
+    }
+    const float r = sigmoidf_(gi[j] + (g0 + bh[j]));
+    const float z = sigmoidf_(gi[kGh + j] + (g1 + bh[kGh + j]));
+    const float ghn = g2 + bh[2 * kGh + j];
     const float n = tanhf(gi[2 * kGh + j] + r * ghn);
     const float hp = hprev[dir * dirH + i];
     hnext[dir * dirH + i] = (1.f - z) * n + z * hp;
@@ -186,7 +207,8 @@ __global__ void gru_gate_fwd_kernel(const float* __restrict__ GI, float* __restr
 
 // backward of that step: from dh (in place -> dh * z, the direct path to h_prev) to the gate pre-activation
 // gradients, DGI in (dir, clip*T + t, 1536) and DGH in (dir, step, clip, 1536).
-__global__ void gru_gate_bwd_kernel(float* __restrict__ DH, const float* __restrict__ hprev, const float* __restrict__ R,
+__global__ void gru_gate_bwd_kernel(float* __restrict__ DH, const float* __restrict__ DHP, int nparts,
+                                    const float* __restrict__ hprev, const float* __restrict__ R,
                                     const float* __restrict__ Z, const float* __restrict__ Nn, const float* __restrict__ GHN,
                                     float* __restrict__ DGI, float* __restrict__ DGH, int nclips, int step, long dirGI,
                                     long dirH, long dirS, long dirDGH) {
@@ -197,7 +219,8 @@ __global__ void gru_gate_bwd_kernel(float* __restrict__ DH, const float* __restr
     const int t = dir ? kSeq - 1 - step : step;
     const long o = dir * dirS + (long)step * nclips * kGh + i;
     const float r = R[o], z = Z[o], n = Nn[o], ghn = GHN[o];
-    const float dh = DH[(long)dir * nclips * kGh + i];
+    float dh = DH[(long)dir * nclips * kGh + i];          // direct path (dh * z of the later step, or the head's gradient)
+    for (int sp = 0; sp < nparts; ++sp) dh += DHP[(long)sp * 2 * nclips * kGh + (long)dir * nclips * kGh + i];   // + dgh W_hh
     const float hp = hprev[dir * dirH + i];
     const float dn_pre = dh * (1.f - z) * (1.f - n * n);
     const float dz_pre = dh * (hp - n) * z * (1.f - z);
@@ -253,7 +276,7 @@ static int conv_fwd(var_ctx* c, hipStream_t s, const ConvDims& d, const void* x,
     ConvFwdP<G, U8, SEQ> p{};
     p.M = d.B * d.HO * d.WO; p.N = d.COUT; p.K = d.CIN * G::KHW; p.nsplit = 1;
     p.d = d; p.x = x; p.w = w; p.bias = bias; p.y = y;
-    return gg2_launch(c, s, p);
+    return gg_launch(c, s, p);
 }
 template <class G, bool SEQ>
 static int conv_dgrad(var_ctx* c, hipStream_t s, const ConvDims& d, const float* gy, const float* w, float* dx,
@@ -264,15 +287,42 @@ static int conv_dgrad(var_ctx* c, hipStream_t s, const ConvDims& d, const float*
         p.inv_h2w2 = 1.f / (float)(p.H2 * p.W2); p.inv_w2 = 1.f / (float)p.W2;
         p.M = d.B * p.H2 * p.W2; p.N = d.CIN; p.K = d.COUT * ConvDgradS2P<G, SEQ>::NKY * ConvDgradS2P<G, SEQ>::NKX; p.nsplit = 1;
         p.d = d; p.gy = gy; p.w = w; p.dx = dx; p.mask = mask;
-        return gg2_launch(c, s, p, 4);
+        return gg_launch(c, s, p, 4);
     } else {
         static_assert(!SEQ, "sequence layout only on the stride-2 sound layer");
         ConvDgradP<G> p{};
         p.M = d.B * d.H * d.W; p.N = d.CIN; p.K = d.COUT * G::KHW; p.nsplit = 1;
         p.d = d; p.gy = gy; p.w = w; p.dx = dx; p.mask = mask;
-        return gg2_launch(c, s, p);
+        return gg_launch(c, s, p);
     }
 }
+static constexpr long kSlabFloats = 24L << 20;        // split-K slabs (96 MB)
+static constexpr long kBiasSlabFloats = 1L << 20;
+
+// the kernel gives split s the chunks [s*per, (s+1)*per), per = ceil(chunks / nsplit): trim nsplit so that no split
+// is empty (an empty split would leave its slab unwritten)
+static int eff_split(int K, int ns) {
+    const int kchunks = (K + GG_KC - 1) / GG_KC;
+    if (ns < 1) ns = 1;
+    if (ns > kchunks) ns = kchunks;
+    const int per = (kchunks + ns - 1) / ns;
+    return (kchunks + per - 1) / per;
+}
+
+// K splits of a small recurrent product so that about two workgroups per CU are in flight
+static int rec_split(int tiles, int kchunks, int cap) {
+    int ns = (256 + tiles - 1) / tiles;        // the consumer reads every partial slab: keep the count small
+    if (ns > cap) ns = cap;
+    if (ns > kchunks / 4) ns = kchunks / 4;
+    return eff_split(kchunks * GG_KC, ns);
+}
+
+static int slab_reduce(var_ctx* c, hipStream_t s, float* out, const float* slabs, int n, int nsplit, long stride, int inner = 1) {
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, s, out, slabs, n, nsplit, stride, inner);
+    IT_CHECK(c);
+    return VAR_OK;
+}
+
 template <class G, bool U8, bool SEQ>
 static int conv_wgrad(var_ctx* c, hipStream_t s, const ConvDims& d, const void* x, const float* gy, float* dw) {
     ConvWgradP<G, U8, SEQ> p{};
@@ -281,26 +331,31 @@ static int conv_wgrad(var_ctx* c, hipStream_t s, const ConvDims& d, const void* 
     int ns = (1024 + tiles - 1) / tiles;                    // about 4 workgroups per CU
     const int kchunks = (p.K + GG_KC - 1) / GG_KC;
     if (ns > kchunks / 8) ns = kchunks / 8 > 0 ? kchunks / 8 : 1;
-    p.nsplit = ns;
-    p.d = d; p.x = x; p.gy = gy; p.dw = dw;
-    return gg2_launch(c, s, p);
+    if ((long)ns * p.M * p.N > kSlabFloats) ns = (int)(kSlabFloats / ((long)p.M * p.N));
+    p.nsplit = eff_split(p.K, ns);
+    p.d = d; p.x = x; p.gy = gy; p.dw = dw; p.slab = ith(c)->slab;
+    int r = gg_launch(c, s, p);
+    if (r != VAR_OK) return r;
+    if (p.nsplit > 1) return slab_reduce(c, s, dw, p.slab, p.M * p.N, p.nsplit, (long)p.M * p.N);
+    return VAR_OK;
 }
 static int chan_sum(var_ctx* c, hipStream_t s, const float* g, float* out, int outer, int C, int inner) {
+    float* part = ith(c)->bslab;
     if (inner < 64) {
         const int cols = C * inner;
         int chunks = (outer + 255) / 256;
-        if (chunks > 128) chunks = 128;
-        hipLaunchKernelGGL(col_sum_kernel, dim3((cols + 63) / 64, chunks), dim3(256), 0, s, g, out, outer, cols, inner);
+        if (chunks > 32) chunks = 32;
+        hipLaunchKernelGGL(col_sum_kernel, dim3((cols + 63) / 64, chunks), dim3(256), 0, s, g, part, outer, cols);
         IT_CHECK(c);
-        return VAR_OK;
+        return slab_reduce(c, s, out, part, C, chunks, cols, inner);
     }
     long tot = (long)outer * inner;
     int chunks = (int)((tot + 8191) / 8192);
-    if (chunks > 64) chunks = 64;
+    if (chunks > 32) chunks = 32;
     if (chunks < 1) chunks = 1;
-    hipLaunchKernelGGL(chan_sum_kernel, dim3(C, chunks), dim3(256), 0, s, g, out, outer, C, inner);
+    hipLaunchKernelGGL(chan_sum_kernel, dim3(C, chunks), dim3(256), 0, s, g, part, outer, C, inner);
     IT_CHECK(c);
-    return VAR_OK;
+    return slab_reduce(c, s, out, part, C, chunks, C);
 }
 
 // Y (rows, O) = X (rows, K) W^T + b, optional ReLU
@@ -315,7 +370,7 @@ static int linear_fwd(var_ctx* c, hipStream_t s, const float* X, const float* W,
 static int linear_bwd(var_ctx* c, hipStream_t s, const float* X, const float* W, const float* dY, float* dW, float* db,
                       float* dX, int rows, int K, int O) {
     {
-        DenseP<false, false, 2> p{};
+        DenseP<false, false, 0> p{};
         p.M = K; p.N = O; p.K = rows; p.nsplit = 1;
         p.A = X; p.sam = 1; p.sak = K; p.Bm = dY; p.sbk = O; p.sbn = 1; p.C = dW; p.scm = 1; p.scn = K;
         int r = gg_launch(c, s, p); if (r) return r;
@@ -333,13 +388,6 @@ static int relu_mask(var_ctx* c, hipStream_t s, float* g, const float* act, long
     hipLaunchKernelGGL(relu_mask_kernel, g1(n), dim3(256), 0, s, g, act, n);
     IT_CHECK(c);
     return VAR_OK;
-}
-
-// K splits of a small recurrent product so that about two workgroups per CU are in flight
-static int rec_split(int tiles, int kchunks) {
-    int ns = (512 + tiles - 1) / tiles;
-    if (ns > kchunks / 4) ns = kchunks / 4;
-    return ns < 1 ? 1 : ns;
 }
 
 using G3s1 = Geo<3, 3, 1, 1, 1, 1>;
@@ -412,17 +460,16 @@ static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* imag
             RUN(gg_launch(c, s, p, 2));
         }
         for (int d = 0; d < 2; ++d) VAR_HIP_CHECK(c, hipMemsetAsync(st->Hb + d * dirH, 0, sizeof(float) * nclips * kGh, s));
-        VAR_HIP_CHECK(c, hipMemsetAsync(st->GH, 0, sizeof(float) * 2 * nclips * kG3, s));
         for (int step = 0; step < kSeq; ++step) {
-            // split over K and summed with atomics into GH, which the gate kernel clears again as it reads it
+            // split over K into partial slabs of GH that the gate kernel adds in fixed order
             DenseP<true, true, 2> p{};
             p.M = kG3; p.N = nclips; p.K = kGh;
             p.A = P + L.w_hh[0]; p.sam = kGh; p.sak = 1; p.zA = dirP;
             p.Bm = st->Hb + (long)step * nclips * kGh; p.sbk = 1; p.sbn = kGh; p.zB = dirH;
-            p.C = st->GH; p.scm = 1; p.scn = kG3; p.zC = (long)nclips * kG3;
-            p.nsplit = rec_split(12 * ((nclips + 63) / 64) * 2, kGh / GG_KC);
+            p.C = st->GH; p.scm = 1; p.scn = kG3; p.zC = (long)nclips * kG3; p.sC = 2L * nclips * kG3;
+            p.nsplit = rec_split(12 * ((nclips + 63) / 64) * 2, kGh / GG_KC, 4);
             RUN(gg_launch(c, s, p, 2));
-            hipLaunchKernelGGL(gru_gate_fwd_kernel, dim3((nclips * kGh + 255) / 256, 2), dim3(256), 0, s, st->GI, st->GH,
+            hipLaunchKernelGGL(gru_gate_fwd_kernel, dim3((nclips * kGh + 255) / 256, 2), dim3(256), 0, s, st->GI, st->GH, p.nsplit,
                                st->Hb + (long)step * nclips * kGh, st->Hb + (long)(step + 1) * nclips * kGh, st->R, st->Z,
                                st->Nn, st->GHN, P + L.b_hh[0], dirP, nclips, step, dirGI, dirH, dirS, save ? 1 : 0);
             IT_CHECK(c);
@@ -503,34 +550,40 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
         hipLaunchKernelGGL(gru_concat_kernel, g1((long)nclips * kSRaw), dim3(256), 0, s, st->DH, st->gsraw, nclips,
                            (long)nclips * kGh, 1);
         IT_CHECK(c);
+        const int dh_split = rec_split(4 * ((nclips + 63) / 64) * 2, kG3 / GG_KC, 8);
         for (int step = kSeq - 1; step >= 0; --step) {
-            hipLaunchKernelGGL(gru_gate_bwd_kernel, dim3((nclips * kGh + 255) / 256, 2), dim3(256), 0, s, st->DH,
+            hipLaunchKernelGGL(gru_gate_bwd_kernel, dim3((nclips * kGh + 255) / 256, 2), dim3(256), 0, s, st->DH, st->DHP,
+                               step == kSeq - 1 ? 0 : dh_split,
                                st->Hb + (long)step * nclips * kGh, st->R, st->Z, st->Nn, st->GHN, st->DGI, st->DGH, nclips, step,
                                dirGI, dirH, dirS, dirDGH);
             IT_CHECK(c);
             if (step == 0) break;                               // h_0 = 0 has no consumer
             DenseP<false, true, 2> p{};
             p.M = kGh; p.N = nclips; p.K = kG3;
-            p.nsplit = rec_split(4 * ((nclips + 63) / 64) * 2, kG3 / GG_KC);
+            p.nsplit = dh_split;
             p.A = P + L.w_hh[0]; p.sam = 1; p.sak = kGh; p.zA = dirP;
             p.Bm = st->DGH + (long)step * nclips * kG3; p.sbk = 1; p.sbn = kG3; p.zB = dirDGH;
-            p.C = st->DH; p.scm = 1; p.scn = kGh; p.zC = (long)nclips * kGh;
+            p.C = st->DHP; p.scm = 1; p.scn = kGh; p.zC = (long)nclips * kGh; p.sC = 2L * nclips * kGh;
             RUN(gg_launch(c, s, p, 2));
         }
         {   // dW_hh[dir][g][j] = sum_{step,clip} DGH[dir][step,clip][g] * h_prev[dir][step,clip][j]
             DenseP<false, false, 2> p{};
             p.M = kGh; p.N = kG3; p.K = kSeq * nclips;
-            p.nsplit = p.K >= 2048 ? 8 : (p.K >= 512 ? 4 : 1);
+            p.nsplit = eff_split(p.K, p.K >= 2048 ? 8 : (p.K >= 512 ? 4 : 1));
+            const long one = (long)kG3 * kGh;                       // per direction; slabs hold [split][dir][g][j]
             p.A = st->Hb; p.sam = 1; p.sak = kGh; p.zA = dirH;
             p.Bm = st->DGH; p.sbk = kG3; p.sbn = 1; p.zB = dirDGH;
-            p.C = G + L.w_hh[0]; p.scm = 1; p.scn = kGh; p.zC = dirP;
+            p.C = st->slab; p.scm = 1; p.scn = kGh; p.zC = one; p.sC = 2 * one;
             RUN(gg_launch(c, s, p, 2));
+            for (int d = 0; d < 2; ++d) RUN(slab_reduce(c, s, G + L.w_hh[d], st->slab + d * one, (int)one, p.nsplit, 2 * one));
             // dW_ih[dir][g][i] = sum_{clip,t} DGI[dir][clip,t][g] * X[clip,t][i]
+            const long onei = (long)kG3 * kGin;
             p.M = kGin; p.N = kG3; p.K = rows;
             p.A = st->s[3]; p.sam = 1; p.sak = kGin; p.zA = 0;
             p.Bm = st->DGI; p.sbk = kG3; p.sbn = 1; p.zB = dirGI;
-            p.C = G + L.w_ih[0]; p.scm = 1; p.scn = kGin; p.zC = dirP;
+            p.C = st->slab; p.scm = 1; p.scn = kGin; p.zC = onei; p.sC = 2 * onei;
             RUN(gg_launch(c, s, p, 2));
+            for (int d = 0; d < 2; ++d) RUN(slab_reduce(c, s, G + L.w_ih[d], st->slab + d * onei, (int)onei, p.nsplit, 2 * onei));
         }
         for (int d = 0; d < 2; ++d) {
             RUN(chan_sum(c, s, st->DGI + d * dirGI, G + L.b_ih[d], rows, kG3, 1));
@@ -618,7 +671,8 @@ int var_ithor_plan(var_ctx* c, int max_batch, int img_hw) {
     for (int l = 2; l <= 5; ++l) { op[l] = take(psz[l]); ogp[l] = take(psz[l]); }
     for (int l = 1; l <= 3; ++l) { os[l] = take(ssz[l]); ogs[l] = take(ssz[l]); }
     const long oGI = take(2 * rows * kG3), oDGI = take(2 * rows * kG3), oDGH = take(2 * rows * kG3);
-    const long oGH = take(2 * C2 * kG3), oHb = take(2 * (kSeq + 1) * C2 * kGh);
+    const long oGH = take(2 * (C2 + 2048) * kG3), oHb = take(2 * (kSeq + 1) * C2 * kGh);    // GH: up to 8 split-K slabs
+    const long oDHP = take(2 * (C2 + 6144) * kGh), oslab = take(kSlabFloats), obslab = take(kBiasSlabFloats);
     const long oR = take(2 * rows * kGh), oZ = take(2 * rows * kGh), oN = take(2 * rows * kGh), oGHN = take(2 * rows * kGh);
     const long oDH = take(2 * C2 * kGh), osraw = take(C2 * kSRaw), ogsraw = take(C2 * kSRaw);
     const long ohi = take(B * 128), oghi = take(B * 128), ohs1 = take(C2 * 128), oghs1 = take(C2 * 128);
@@ -630,6 +684,7 @@ int var_ithor_plan(var_ctx* c, int max_batch, int img_hw) {
     for (int l = 2; l <= 5; ++l) { st->p[l] = w + op[l]; st->gp[l] = w + ogp[l]; }
     for (int l = 1; l <= 3; ++l) { st->s[l] = w + os[l]; st->gs[l] = w + ogs[l]; }
     st->GI = w + oGI; st->DGI = w + oDGI; st->DGH = w + oDGH; st->GH = w + oGH; st->Hb = w + oHb;
+    st->DHP = w + oDHP; st->slab = w + oslab; st->bslab = w + obslab;
     st->R = w + oR; st->Z = w + oZ; st->Nn = w + oN; st->GHN = w + oGHN; st->DH = w + oDH;
     st->sraw = w + osraw; st->gsraw = w + ogsraw;
     st->hid_i = w + ohi; st->ghid_i = w + oghi; st->hid_s1 = w + ohs1; st->ghid_s1 = w + oghs1;
