@@ -187,6 +187,24 @@ int var_ithor_loss_grad(var_ctx* ctx, void* stream, const float* params,
                         float margin, float inv_count,
                         float* grads, float* loss_out, float* feats_out);
 
+/* RL actor-critic forward ---------------------------------------------------------------
+ * Policy.act up to the sampling (models/ppo/model.py:57-69): armNet_VAR.forward (models/RL/arm_RL_model.py:99-134, the
+ * 96x96 image branch, recurrent: one GRU(128 -> 512) step from rnn_hxs * masks, models/ppo/model.py:118-121) and the
+ * mean layer of DiagGaussian (models/ppo/distributions.py:65-84).  Kuka configuration: representationDim 3,
+ * robotStateDim 2, RLRecurrentInputSize 128, RLRecurrentSize 512, RLActionHiddenSize 128, actionDim 2
+ * (fourInARow/config.py:67-106, kuka/env_config.py:37).  params = Policy.state_dict() back to back in registration
+ * order (base.gru.*, base.imgCNN.{0,2,5,7,10,12,15,17}, base.motorMlp, cnnMlp, imgMotorMlp, imgMotorMlp2, soundMlp,
+ * fusionMlp, mlp_all, actor, critic, critic_linear, dist.fc_mean, dist.logstd._bias): var_armnet_param_count() floats.
+ *   image (B,3,96,96) u8 (divided by 255) or f32; image_feat (B,3), robot_pose (B,2), goal_sound_feat (B,3),
+ *   rnn_hxs (B,512), masks (B,1)  ->  value (B,1), actor_features (B,128), action_mean (B,2, may be NULL),
+ *   rnn_hxs_out (B,512).  Sampling / log-probabilities (a handful of flops) stay with the caller. */
+int var_armnet_param_count(void);
+int var_armnet_plan(var_ctx* ctx, int max_batch);
+int var_armnet_forward(var_ctx* ctx, void* stream, const float* params, const void* image, int image_is_u8,
+                       long image_bstride, const float* image_feat, const float* robot_pose,
+                       const float* goal_sound_feat, const float* rnn_hxs, const float* masks, int B,
+                       float* value, float* actor_features, float* action_mean, float* rnn_hxs_out);
+
 /* The iTHOR/FSC audio front-end: python_speech_features.mfcc as called at Envs/audioLoader.py:158-161 (pre-emphasis
  * .97, 400/160 frames with a zero-padded tail, np.hamming, |rfft_512|^2/512, 40 triangles, log, orthonormal DCT-II,
  * lifter 22, coefficient 0 = log frame energy; int16 samples NOT normalised) + processSoundFeat (:241-252).

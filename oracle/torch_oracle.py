@@ -101,3 +101,95 @@ def ithor_seeded(seed=977):
     m = IthorNetCPU()
     m.train()
     return m
+
+
+# ---- RL actor-critic ---------------------------------------------------------------
+def _ortho(m, gain):
+    nn.init.orthogonal_(m.weight.data, gain=gain)
+    nn.init.constant_(m.bias.data, 0)
+    return m
+
+
+class _ArmBase(nn.Module):
+    """models/RL/arm_RL_model.py:armNet_VAR (96x96 branch) on top of models/ppo/model.py:NNBase, restated from
+    torch.nn layers with the reference's construction order, initialisers (orthogonal, gain sqrt 2; GRU weights
+    orthogonal, biases 0) and its torch.rand shape probe, so that a seed reproduces the reference's weights."""
+
+    def __init__(self, representation_dim=3, robot_state_dim=2, rin=128, rh=512, action_hidden=128):
+        super().__init__()
+        self.gru = nn.GRU(rin, rh)
+        for name, p in self.gru.named_parameters():
+            if 'bias' in name:
+                nn.init.constant_(p, 0)
+            elif 'weight' in name:
+                nn.init.orthogonal_(p)
+        self.imgCNN = nn.Sequential(
+            nn.Conv2d(3, 32, 3, stride=1, padding=1), nn.ReLU(), nn.Conv2d(32, 32, 3, stride=1, padding=1), nn.ReLU(),
+            nn.MaxPool2d(2, stride=2),
+            nn.Conv2d(32, 64, 3, stride=1, padding=1), nn.ReLU(), nn.Conv2d(64, 64, 3, stride=1, padding=1), nn.ReLU(),
+            nn.MaxPool2d(2, stride=2),
+            nn.Conv2d(64, 128, 3, stride=1, padding=1), nn.ReLU(), nn.Conv2d(128, 128, 3, stride=1, padding=1), nn.ReLU(),
+            nn.MaxPool2d(2, stride=2),
+            nn.Conv2d(128, 256, 3, stride=2, padding=0), nn.ReLU(), nn.Conv2d(256, 128, 3, stride=1, padding=0), nn.ReLU(),
+            nn.Flatten())
+        self.imgCNN(torch.rand((1, 3, 96, 96)))               # get_layer_output_shape's probe (models/ppo/model.py:7-8)
+        g = 2 ** 0.5
+        lin = lambda i, o: _ortho(nn.Linear(i, o), g)         # noqa: E731
+        self.motorMlp = nn.Sequential(lin(representation_dim + robot_state_dim, 256), nn.ReLU(), lin(256, 512), nn.ReLU(),
+                                      lin(512, 256), nn.ReLU())
+        self.cnnMlp = nn.Sequential(lin(1152, 512), nn.ReLU(), lin(512, 256), nn.ReLU())
+        self.imgMotorMlp = nn.Sequential(lin(256, 256), nn.ReLU(), lin(256, rin), nn.ReLU())
+        self.imgMotorMlp2 = nn.Sequential(lin(rh, 256), nn.ReLU())
+        self.soundMlp = nn.Sequential(lin(representation_dim, 128), nn.ReLU(), lin(128, 256), nn.ReLU(), lin(256, 256), nn.ReLU())
+        self.fusionMlp = nn.Sequential(lin(256, 512), nn.ReLU(), lin(512, 256), nn.ReLU())
+        self.mlp_all = nn.Sequential(lin(256, 256), nn.ReLU(), lin(256, 128), nn.ReLU())
+        self.actor = nn.Sequential(lin(128, 128), nn.ReLU(), lin(128, action_hidden), nn.ReLU())
+        self.critic = nn.Sequential(lin(128, 128), nn.ReLU(), lin(128, 128), nn.ReLU())
+        self.critic_linear = lin(128, 1)
+
+    def forward(self, obs, rnn_hxs, masks):
+        image_flatten = self.cnnMlp(self.imgCNN(obs['image']))
+        motor = self.motorMlp(torch.cat([obs['image_feat'], obs['robot_pose']], dim=1))
+        image_motor = self.imgMotorMlp(image_flatten + motor)
+        x, h = self.gru(image_motor.unsqueeze(0), (rnn_hxs * masks).unsqueeze(0))     # models/ppo/model.py:118-121
+        image_motor, rnn_hxs = x.squeeze(0), h.squeeze(0)
+        fusion = self.fusionMlp(self.soundMlp(obs['goal_sound_feat']) + image_flatten)
+        x = self.mlp_all(fusion + self.imgMotorMlp2(image_motor))
+        return self.critic_linear(self.critic(x)), self.actor(x), rnn_hxs
+
+
+class _AddBias(nn.Module):
+    def __init__(self, n):
+        super().__init__()
+        self._bias = nn.Parameter(torch.zeros(n).unsqueeze(1))
+
+
+class _DiagGaussian(nn.Module):
+    def __init__(self, num_inputs, num_outputs):
+        super().__init__()
+        self.fc_mean = _ortho(nn.Linear(num_inputs, num_outputs), 1)
+        self.logstd = _AddBias(num_outputs)
+
+
+class ArmNetCPU(nn.Module):
+    """Policy(base='arm_VAR') of models/ppo/model.py:15-69 with a Box action space: base + DiagGaussian; act() in
+    deterministic mode returns (value, mean action, log-prob of the mean, rnn_hxs)."""
+
+    def __init__(self, num_actions=2):
+        super().__init__()
+        self.base = _ArmBase()
+        self.dist = _DiagGaussian(128, num_actions)
+
+    def act_deterministic(self, obs, rnn_hxs, masks):
+        value, feats, rnn_hxs = self.base(obs, rnn_hxs, masks)
+        mean = self.dist.fc_mean(feats)
+        std = self.dist.logstd._bias.t().view(1, -1).expand_as(mean).exp()
+        logp = torch.distributions.Normal(mean, std).log_prob(mean).sum(-1, keepdim=True)
+        return value, mean, logp, rnn_hxs, feats
+
+
+def armnet_seeded(seed=453):
+    torch.manual_seed(seed)
+    m = ArmNetCPU()
+    m.eval()
+    return m

@@ -1,0 +1,92 @@
+"""GPU parity of the RL actor-critic forward (var_armnet_forward through
+ArmNetPolicy.act) against the fixture the reference's Policy produced (tests/golden/armnet_b8.npz) and against the CPU
+oracle with identical weights."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle.torch_oracle import armnet_seeded  # noqa: E402  (checker only)
+
+
+class Box:
+    def __init__(self, n):
+        self.shape = (n,)
+
+
+CFG = types.SimpleNamespace(img_dim=(3, 96, 96), representationDim=3, robotStateDim=2)
+KW = {'recurrent': True, 'recurrentInputSize': 128, 'recurrentSize': 512, 'actionHiddenSize': 128}
+
+
+@pytest.fixture(scope="module")
+def var_amd():
+    import var_amd as m
+    assert torch.cuda.is_available()
+    return m
+
+
+@pytest.fixture(scope="module")
+def fx(golden_dir):
+    return dict(np.load(os.path.join(golden_dir, "armnet_b8.npz")))
+
+
+def cuda(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def make(var_amd, ref):
+    m = var_amd.ArmNetPolicy(None, Box(2), config=CFG, base='arm_VAR', base_kwargs=KW)
+    m.load_state_dict(ref.state_dict())                       # same 63 keys and shapes as the reference's Policy
+    return m.to("cuda")
+
+
+def obs_of(fx, u8):
+    img = cuda(fx['image'])
+    return {'image': img if u8 else (img / 255.).float(), 'image_feat': cuda(fx['image_feat']),
+            'robot_pose': cuda(fx['robot_pose']), 'goal_sound_feat': cuda(fx['goal_sound_feat'])}
+
+
+def test_act_vs_reference_fixture_and_oracle(var_amd, fx):
+    ref = armnet_seeded(int(fx["seed"]))
+    m = make(var_amd, ref)
+    assert [k for k, _ in m.state_dict().items()] == [str(k) for k in fx["names"]]
+    assert m.is_recurrent and m.recurrent_hidden_state_size == 512
+    for u8 in (False, True):
+        v, a, lp, h = m.act(obs_of(fx, u8), cuda(fx['rnn_hxs']), cuda(fx['masks']), deterministic=True)
+        v2, a2, _, h2 = m.act(obs_of(fx, u8), h, torch.ones(8, 1, device="cuda"), deterministic=True)
+        for got, name in ((v, 'value'), (a, 'action'), (lp, 'action_log_probs'), (h, 'rnn_hxs_out'), (v2, 'value2'),
+                          (a2, 'action2'), (h2, 'rnn_hxs_out2')):
+            np.testing.assert_allclose(got.cpu().numpy(), fx[name], rtol=1e-3, atol=1e-4, err_msg=name)
+    # identical weights on both sides: tighter
+    obs_cpu = {'image': (torch.from_numpy(fx['image']) / 255.).float(), 'image_feat': torch.from_numpy(fx['image_feat']),
+               'robot_pose': torch.from_numpy(fx['robot_pose']), 'goal_sound_feat': torch.from_numpy(fx['goal_sound_feat'])}
+    with torch.no_grad():
+        rv, ra, rlp, rh, rf = ref.act_deterministic(obs_cpu, torch.from_numpy(fx['rnn_hxs']), torch.from_numpy(fx['masks']))
+    v, a, lp, h = m.act(obs_of(fx, False), cuda(fx['rnn_hxs']), cuda(fx['masks']), deterministic=True)
+    np.testing.assert_allclose(v.cpu().numpy(), rv.numpy(), atol=2e-5)
+    np.testing.assert_allclose(a.cpu().numpy(), ra.numpy(), atol=2e-5)
+    np.testing.assert_allclose(h.cpu().numpy(), rh.numpy(), atol=2e-5)
+    np.testing.assert_allclose(m.get_value(obs_of(fx, False), cuda(fx['rnn_hxs']), cuda(fx['masks'])).cpu().numpy(), rv.numpy(), atol=2e-5)
+
+
+def test_sampling_and_rejections(var_amd, fx):
+    ref = armnet_seeded(int(fx["seed"]))
+    m = make(var_amd, ref)
+    torch.manual_seed(0)
+    v, a, lp, h = m.act(obs_of(fx, True), cuda(fx['rnn_hxs']), cuda(fx['masks']))
+    assert a.shape == (8, 2) and lp.shape == (8, 1) and torch.isfinite(a).all()
+    mean = m.act(obs_of(fx, True), cuda(fx['rnn_hxs']), cuda(fx['masks']), deterministic=True)[1]
+    # log-prob of the sampled action under N(mean, 1) (logstd is zero at initialisation)
+    expect = (-0.5 * (a - mean) ** 2 - 0.5 * np.log(2 * np.pi)).sum(-1, keepdim=True)
+    np.testing.assert_allclose(lp.cpu().numpy(), expect.cpu().numpy(), atol=1e-5)
+    with pytest.raises(NotImplementedError):
+        m.evaluate_actions(None, None, None, None)
+    with pytest.raises(var_amd.VarHipError):
+        m.act({k: t.cpu() for k, t in obs_of(fx, True).items()}, cuda(fx['rnn_hxs']), cuda(fx['masks']))
+    with pytest.raises(var_amd.VarHipError):
+        var_amd.ArmNetPolicy(None, Box(2), config=types.SimpleNamespace(img_dim=(3, 84, 84), representationDim=3, robotStateDim=2),
+                             base='arm_VAR', base_kwargs=KW)

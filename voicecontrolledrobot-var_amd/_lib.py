@@ -48,6 +48,9 @@ _SIGNATURES = {
     "var_mfcc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "var_arm_loss_grad_pcm": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
     "var_arm_loss_grad_gather": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
+    "var_armnet_param_count": (_i, []),
+    "var_armnet_plan": (_i, [_vp, _i]),
+    "var_armnet_forward": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "var_mfcc_psf": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "var_ithor_param_count": (_i, []),
     "var_ithor_plan": (_i, [_vp, _i, _i]),

@@ -81,6 +81,7 @@ int var_destroy(var_ctx* c) {
     CHECK_CTX(c);
     (void)hipSetDevice(c->device);
     ithor_free(c);
+    armnet_free(c);
     if (c->ws) (void)hipFree(c->ws);
     if (c->wpack) (void)hipFree(c->wpack);
     if (c->loss_buf) (void)hipFree(c->loss_buf);
