@@ -43,3 +43,48 @@ for name, snd in (("graph: image + goal sound", goal), ("graph: image only (goal
         r.step(img, snd)
     torch.cuda.synchronize()
     print(f"{name:34s} {1e6 * (time.perf_counter() - t0) / n:8.1f} us per step (B={B}, replayed graph incl. input copies)")
+
+# ---- second half of config 5: the actor-critic forward (Policy.act, models/ppo/model.py:57-69) ----
+class _Box:
+    def __init__(self, n):
+        self.shape = (n,)
+
+
+_Box.__name__ = "Box"
+acfg = types.SimpleNamespace(img_dim=(3, 96, 96), representationDim=3, robotStateDim=2)
+torch.manual_seed(453)
+ac = var_amd.ArmNetPolicy(None, _Box(2), config=acfg, base='arm_VAR',
+                          base_kwargs={'recurrent': True, 'recurrentInputSize': 128, 'recurrentSize': 512,
+                                       'actionHiddenSize': 128}).to("cuda")
+obs = {'image': torch.randint(0, 256, (B, 3, 96, 96), dtype=torch.uint8, device="cuda"),
+       'image_feat': torch.randn(B, 3, device="cuda"), 'robot_pose': torch.randn(B, 2, device="cuda"),
+       'goal_sound_feat': torch.randn(B, 3, device="cuda")}
+hxs, masks = torch.zeros(B, 512, device="cuda"), torch.ones(B, 1, device="cuda")
+for _ in range(20):
+    v, a, lp, hxs = ac.act(obs, hxs, masks)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+n = 300
+for _ in range(n):
+    v, a, lp, hxs = ac.act(obs, hxs, masks)
+torch.cuda.synchronize()
+print(f"{'actor-critic act()':34s} {1e6 * (time.perf_counter() - t0) / n:8.1f} us per step (B={B}, eager, incl. sampling)")
+# the same forward as a replayed graph over static buffers
+g = torch.cuda.CUDAGraph()
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    ac._base_forward(obs, hxs, masks)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=side):
+        outs = ac._base_forward(obs, hxs, masks)
+torch.cuda.synchronize()
+for _ in range(20):
+    g.replay()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+n = 1000
+for _ in range(n):
+    g.replay()
+torch.cuda.synchronize()
+print(f"{'graph: actor-critic forward':34s} {1e6 * (time.perf_counter() - t0) / n:8.1f} us per step (B={B}, replayed graph)")

@@ -49,6 +49,7 @@ struct arm_state {
     float* ws = nullptr;
     float *a[9] = {nullptr}, *p[4] = {nullptr};      // conv outputs 1..8, pooled maps 1..3
     float *t0 = nullptr, *t1 = nullptr, *t2 = nullptr, *t3 = nullptr;   // (B,512) scratch rows
+    float* slab = nullptr;
     float *flat_img = nullptr, *motor = nullptr, *sound = nullptr, *fusion = nullptr, *h0 = nullptr, *gi = nullptr, *gh = nullptr;
 };
 
@@ -95,14 +96,34 @@ inline dim3 g1(long n) { return dim3((unsigned)((n + 255) / 256)); }
 #define AN_CHECK(c) VAR_HIP_CHECK(c, hipGetLastError())
 #define RUN(x) do { int r_ = (x); if (r_ != VAR_OK) return r_; } while (0)
 
+constexpr long kSlab = 8L << 20;             // floats of split-K scratch
+
 template <class G, bool U8>
-int conv(var_ctx* c, hipStream_t s, const ConvDims& d, const void* x, const float* w, const float* bias, float* y) {
+int conv(var_ctx* c, hipStream_t s, arm_state* st, const ConvDims& d, const void* x, const float* w, const float* bias, float* y) {
     ConvFwdP<G, U8, false> p{};
-    p.M = d.B * d.HO * d.WO; p.N = d.COUT; p.K = d.CIN * G::KHW; p.nsplit = 1;
-    p.d = d; p.x = x; p.w = w; p.bias = bias; p.y = y;
-    return gg_launch(c, s, p);
+    p.M = d.B * d.HO * d.WO; p.N = d.COUT; p.K = d.CIN * G::KHW;
+    const long out = (long)p.M * p.N;
+    p.nsplit = gg_small_split(((p.M + GG_MT - 1) / GG_MT) * ((p.N + 63) / 64), p.K, out, kSlab);
+    p.d = d; p.x = x; p.w = w; p.bias = bias; p.y = y; p.slab = st->slab; p.sstride = out;
+    RUN(gg_launch(c, s, p));
+    if (p.nsplit > 1) {
+        hipLaunchKernelGGL(gg_finish_kernel, g1(out), dim3(256), 0, s, y, st->slab, out, p.nsplit, out, bias, d.COUT, d.HO * d.WO, 1);
+        AN_CHECK(c);
+    }
+    return VAR_OK;
 }
-int linear(var_ctx* c, hipStream_t s, const float* P, const Lin& l, const float* X, float* Y, int rows, int relu) {
+int linear(var_ctx* c, hipStream_t s, arm_state* st, const float* P, const Lin& l, const float* X, float* Y, int rows, int relu) {
+    const long out = (long)rows * l.out;
+    const int ns = gg_small_split(((l.out + GG_MT - 1) / GG_MT) * ((rows + 63) / 64), l.in, out, kSlab);
+    if (ns > 1) {
+        DenseP<true, true, 2> p{};
+        p.M = l.out; p.N = rows; p.K = l.in; p.nsplit = ns;
+        p.A = P + l.w; p.sam = l.in; p.sak = 1; p.Bm = X; p.sbk = 1; p.sbn = l.in; p.C = st->slab; p.scm = 1; p.scn = l.out; p.sC = out;
+        RUN(gg_launch(c, s, p));
+        hipLaunchKernelGGL(gg_finish_kernel, g1(out), dim3(256), 0, s, Y, st->slab, out, ns, out, P + l.b, l.out, 1, relu);
+        AN_CHECK(c);
+        return VAR_OK;
+    }
     DenseP<true, true, 0> p{};
     p.M = l.out; p.N = rows; p.K = l.in; p.nsplit = 1;
     p.A = P + l.w; p.sam = l.in; p.sak = 1; p.Bm = X; p.sbk = 1; p.sbn = l.in; p.C = Y; p.scm = 1; p.scn = l.out;
@@ -143,14 +164,14 @@ int var_armnet_plan(var_ctx* c, int max_batch) {
     op[1] = take(B * 32 * 48 * 48); op[2] = take(B * 64 * 24 * 24); op[3] = take(B * 128 * 12 * 12);
     const long ot0 = take(B * 512), ot1 = take(B * 512), ot2 = take(B * 512), ot3 = take(B * 512);
     const long ofl = take(B * 256), omo = take(B * 256), osn = take(B * 256), ofu = take(B * 256), oh0 = take(B * kRh);
-    const long ogi = take(B * 3 * kRh), ogh = take(B * 3 * kRh);
+    const long ogi = take(B * 3 * kRh), ogh = take(B * 3 * kRh), oslab = take(kSlab);
     VAR_HIP_CHECK(c, hipMalloc((void**)&st->ws, (size_t)total * sizeof(float)));
     float* w = st->ws;
     for (int l = 1; l <= 8; ++l) st->a[l] = w + oa[l];
     for (int l = 1; l <= 3; ++l) st->p[l] = w + op[l];
     st->t0 = w + ot0; st->t1 = w + ot1; st->t2 = w + ot2; st->t3 = w + ot3;
     st->flat_img = w + ofl; st->motor = w + omo; st->sound = w + osn; st->fusion = w + ofu; st->h0 = w + oh0;
-    st->gi = w + ogi; st->gh = w + ogh;
+    st->gi = w + ogi; st->gh = w + ogh; st->slab = w + oslab;
     return VAR_OK;
 }
 
@@ -186,62 +207,62 @@ int var_armnet_forward(var_ctx* c, void* stream, const float* params, const void
     {
         ConvDims d = dims(1, 96, 1, 1);
         d.xb = image_bstride;
-        if (image_is_u8) RUN((conv<S1, true>(c, s, d, image, P + L.cw[0], P + L.cb[0], st->a[1])));
-        else RUN((conv<S1, false>(c, s, d, image, P + L.cw[0], P + L.cb[0], st->a[1])));
+        if (image_is_u8) RUN((conv<S1, true>(c, s, st, d, image, P + L.cw[0], P + L.cb[0], st->a[1])));
+        else RUN((conv<S1, false>(c, s, st, d, image, P + L.cw[0], P + L.cb[0], st->a[1])));
     }
-    RUN((conv<S1, false>(c, s, dims(2, 96, 1, 1), st->a[1], P + L.cw[1], P + L.cb[1], st->a[2])));
+    RUN((conv<S1, false>(c, s, st, dims(2, 96, 1, 1), st->a[1], P + L.cw[1], P + L.cb[1], st->a[2])));
     RUN(pool(st->a[2], st->p[1], 32, 96));
-    RUN((conv<S1, false>(c, s, dims(3, 48, 1, 1), st->p[1], P + L.cw[2], P + L.cb[2], st->a[3])));
-    RUN((conv<S1, false>(c, s, dims(4, 48, 1, 1), st->a[3], P + L.cw[3], P + L.cb[3], st->a[4])));
+    RUN((conv<S1, false>(c, s, st, dims(3, 48, 1, 1), st->p[1], P + L.cw[2], P + L.cb[2], st->a[3])));
+    RUN((conv<S1, false>(c, s, st, dims(4, 48, 1, 1), st->a[3], P + L.cw[3], P + L.cb[3], st->a[4])));
     RUN(pool(st->a[4], st->p[2], 64, 48));
-    RUN((conv<S1, false>(c, s, dims(5, 24, 1, 1), st->p[2], P + L.cw[4], P + L.cb[4], st->a[5])));
-    RUN((conv<S1, false>(c, s, dims(6, 24, 1, 1), st->a[5], P + L.cw[5], P + L.cb[5], st->a[6])));
+    RUN((conv<S1, false>(c, s, st, dims(5, 24, 1, 1), st->p[2], P + L.cw[4], P + L.cb[4], st->a[5])));
+    RUN((conv<S1, false>(c, s, st, dims(6, 24, 1, 1), st->a[5], P + L.cw[5], P + L.cb[5], st->a[6])));
     RUN(pool(st->a[6], st->p[3], 128, 24));
-    RUN((conv<S2P0, false>(c, s, dims(7, 12, 2, 0), st->p[3], P + L.cw[6], P + L.cb[6], st->a[7])));
-    RUN((conv<S1P0, false>(c, s, dims(8, 5, 1, 0), st->a[7], P + L.cw[7], P + L.cb[7], st->a[8])));
+    RUN((conv<S2P0, false>(c, s, st, dims(7, 12, 2, 0), st->p[3], P + L.cw[6], P + L.cb[6], st->a[7])));
+    RUN((conv<S1P0, false>(c, s, st, dims(8, 5, 1, 0), st->a[7], P + L.cw[7], P + L.cb[7], st->a[8])));
     // image_flatten = cnnMlp(flatten)
-    RUN(linear(c, s, P, L.cnn[0], st->a[8], st->t0, B, 1));
-    RUN(linear(c, s, P, L.cnn[1], st->t0, st->flat_img, B, 1));
+    RUN(linear(c, s, st, P, L.cnn[0], st->a[8], st->t0, B, 1));
+    RUN(linear(c, s, st, P, L.cnn[1], st->t0, st->flat_img, B, 1));
     // motor = motorMlp(cat(image_feat, robot_pose))
     hipLaunchKernelGGL(an_cat_kernel, g1(B * 5), dim3(256), 0, s, image_feat, kRepr, robot_pose, kRobot, st->t0, B);
     AN_CHECK(c);
-    RUN(linear(c, s, P, L.motor[0], st->t0, st->t1, B, 1));
-    RUN(linear(c, s, P, L.motor[1], st->t1, st->t2, B, 1));
-    RUN(linear(c, s, P, L.motor[2], st->t2, st->motor, B, 1));
+    RUN(linear(c, s, st, P, L.motor[0], st->t0, st->t1, B, 1));
+    RUN(linear(c, s, st, P, L.motor[1], st->t1, st->t2, B, 1));
+    RUN(linear(c, s, st, P, L.motor[2], st->t2, st->motor, B, 1));
     // imageMotor = imgMotorMlp(image_flatten + motor)
     hipLaunchKernelGGL(an_add_kernel, g1(B * 256), dim3(256), 0, s, st->flat_img, st->motor, st->t0, B * 256);
     AN_CHECK(c);
-    RUN(linear(c, s, P, L.im[0], st->t0, st->t1, B, 1));
-    RUN(linear(c, s, P, L.im[1], st->t1, st->t2, B, 1));                       // (B,128)
+    RUN(linear(c, s, st, P, L.im[0], st->t0, st->t1, B, 1));
+    RUN(linear(c, s, st, P, L.im[1], st->t1, st->t2, B, 1));                       // (B,128)
     // one GRU step from hxs * masks (models/ppo/model.py:118-121)
     hipLaunchKernelGGL(an_mask_kernel, g1(B * kRh), dim3(256), 0, s, rnn_hxs, masks, st->h0, B, kRh);
     AN_CHECK(c);
     {
         const Lin ih{L.g_wih, L.g_bih, kRin, 3 * kRh}, hh{L.g_whh, L.g_bhh, kRh, 3 * kRh};
-        RUN(linear(c, s, P, ih, st->t2, st->gi, B, 0));
-        RUN(linear(c, s, P, hh, st->h0, st->gh, B, 0));
+        RUN(linear(c, s, st, P, ih, st->t2, st->gi, B, 0));
+        RUN(linear(c, s, st, P, hh, st->h0, st->gh, B, 0));
         hipLaunchKernelGGL(an_gru_cell_kernel, g1(B * kRh), dim3(256), 0, s, st->gi, st->gh, st->h0, st->t3, rnn_hxs_out, B, kRh);
         AN_CHECK(c);
     }
-    RUN(linear(c, s, P, L.im2, st->t3, st->t0, B, 1));                         // imageMotorRnn (B,256)
+    RUN(linear(c, s, st, P, L.im2, st->t3, st->t0, B, 1));                         // imageMotorRnn (B,256)
     // sound, fusion
-    RUN(linear(c, s, P, L.snd[0], goal_sound_feat, st->t1, B, 1));
-    RUN(linear(c, s, P, L.snd[1], st->t1, st->t2, B, 1));
-    RUN(linear(c, s, P, L.snd[2], st->t2, st->sound, B, 1));
+    RUN(linear(c, s, st, P, L.snd[0], goal_sound_feat, st->t1, B, 1));
+    RUN(linear(c, s, st, P, L.snd[1], st->t1, st->t2, B, 1));
+    RUN(linear(c, s, st, P, L.snd[2], st->t2, st->sound, B, 1));
     hipLaunchKernelGGL(an_add_kernel, g1(B * 256), dim3(256), 0, s, st->sound, st->flat_img, st->t1, B * 256);
     AN_CHECK(c);
-    RUN(linear(c, s, P, L.fus[0], st->t1, st->t2, B, 1));
-    RUN(linear(c, s, P, L.fus[1], st->t2, st->fusion, B, 1));
+    RUN(linear(c, s, st, P, L.fus[0], st->t1, st->t2, B, 1));
+    RUN(linear(c, s, st, P, L.fus[1], st->t2, st->fusion, B, 1));
     hipLaunchKernelGGL(an_add_kernel, g1(B * 256), dim3(256), 0, s, st->fusion, st->t0, st->t1, B * 256);
     AN_CHECK(c);
-    RUN(linear(c, s, P, L.all[0], st->t1, st->t2, B, 1));
-    RUN(linear(c, s, P, L.all[1], st->t2, st->t3, B, 1));                      // x (B,128)
-    RUN(linear(c, s, P, L.critic[0], st->t3, st->t0, B, 1));
-    RUN(linear(c, s, P, L.critic[1], st->t0, st->t1, B, 1));
-    RUN(linear(c, s, P, L.clin, st->t1, value, B, 0));
-    RUN(linear(c, s, P, L.actor[0], st->t3, st->t0, B, 1));
-    RUN(linear(c, s, P, L.actor[1], st->t0, actor_features, B, 1));
-    if (action_mean) RUN(linear(c, s, P, L.mean, actor_features, action_mean, B, 0));
+    RUN(linear(c, s, st, P, L.all[0], st->t1, st->t2, B, 1));
+    RUN(linear(c, s, st, P, L.all[1], st->t2, st->t3, B, 1));                      // x (B,128)
+    RUN(linear(c, s, st, P, L.critic[0], st->t3, st->t0, B, 1));
+    RUN(linear(c, s, st, P, L.critic[1], st->t0, st->t1, B, 1));
+    RUN(linear(c, s, st, P, L.clin, st->t1, value, B, 0));
+    RUN(linear(c, s, st, P, L.actor[0], st->t3, st->t0, B, 1));
+    RUN(linear(c, s, st, P, L.actor[1], st->t0, actor_features, B, 1));
+    if (action_mean) RUN(linear(c, s, st, P, L.mean, actor_features, action_mean, B, 0));
     return VAR_OK;
 }
 

@@ -223,6 +223,8 @@ struct ConvFwdP {
     int M, N, K, nsplit;
     ConvDims d;
     const void* x; const float* w; const float* bias; float* y;
+    float* slab; long sstride;      // nsplit > 1: split s stores raw partial sums at slab + s*sstride (y's layout);
+                                    // gg_finish adds them in order, then bias and ReLU (small-batch inference)
     struct CM { long off; };
     __device__ int k_extent(int) const { return K; }
     __device__ SepM a_m(int m, int) const {
@@ -246,17 +248,20 @@ struct ConvFwdP {
     __device__ SepM b_n(int n, int) const { return SepM{(unsigned)(n * K) * 4u, n < N ? SEP_OK : 0u}; }
     __device__ SepK b_k(int k, int) const { return SepK{(unsigned)k * 4u, k < K ? SEP_OK : SEP_BAD}; }
     __device__ float b_load(unsigned o) const { return ldf(w, o); }
-    __device__ CM c_m(int m, int, int) const {
+    __device__ CM c_m(int m, int, int sz) const {
         int pix; const int b = fdiv(m, d.HO * d.WO, d.inv_howo, pix);
+        const long so = nsplit > 1 ? sz * sstride : 0;
         if (SEQ) {
             int ox; const int oy = fdiv(pix, d.WO, d.inv_wo, ox);
-            return CM{((long)(b * d.HO + oy) * d.COUT) * d.WO + ox};
+            return CM{so + ((long)(b * d.HO + oy) * d.COUT) * d.WO + ox};
         }
-        return CM{(long)b * d.COUT * d.HO * d.WO + pix};
+        return CM{so + (long)b * d.COUT * d.HO * d.WO + pix};
     }
     __device__ void store(const CM& cm, int n, float v, int) const {
+        const long o = cm.off + (long)n * (SEQ ? d.WO : d.HO * d.WO);
+        if (nsplit > 1) { slab[o] = v; return; }
         v += bias[n];
-        y[cm.off + (long)n * (SEQ ? d.WO : d.HO * d.WO)] = v > 0.f ? v : 0.f;
+        y[o] = v > 0.f ? v : 0.f;
     }
 };
 
@@ -456,3 +461,24 @@ struct DenseP {
         *q = v;
     }
 };
+
+// out[i] = act(bias[(i / plane) % C] + sum_{s < nsplit} slabs[s*stride + i]): the tail of a split-K forward product
+static __global__ void gg_finish_kernel(float* __restrict__ out, const float* __restrict__ slabs, long n, int nsplit,
+                                        long stride, const float* __restrict__ bias, int C, int plane, int relu) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = bias ? bias[(i / plane) % C] : 0.f;
+    for (int s = 0; s < nsplit; ++s) v += slabs[s * stride + i];
+    out[i] = relu ? (v > 0.f ? v : 0.f) : v;
+}
+
+// K splits that bring a small product to about one workgroup per CU, each split at least 2 chunks, none empty
+static inline int gg_small_split(int tiles, int K, long out_floats, long slab_floats) {
+    const int kchunks = (K + GG_KC - 1) / GG_KC;
+    int ns = (256 + tiles - 1) / tiles;
+    if (ns > kchunks / 2) ns = kchunks / 2;
+    if ((long)ns * out_floats > slab_floats) ns = (int)(slab_floats / out_floats);
+    if (ns < 2) return 1;
+    const int per = (kchunks + ns - 1) / ns;
+    return (kchunks + per - 1) / per;
+}
