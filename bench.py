@@ -74,6 +74,119 @@ def cpu_baseline(seconds=10.0):
                       f"torch.nn CPU restatement of the reference step, {cores} threads, {dt:.1f} s"}
 
 
+# ---- BASELINE.json configs[3] shape on ONE model replica per GPU: the iTHOR model (fp32 here; config 4 names bf16) ----
+ITHOR_FLOPS_FWD = 3318e6
+ITHOR_FLOPS_STEP = 3 * ITHOR_FLOPS_FWD - 2 * 96 * 96 * 27 * 32 - 2 * (2 * 300 * 20 * 121 * 64)   # no dX for the first convs
+ITHOR_S2_FLOPS_PER_CLIP = 2 * 150 * 13 * 64 * (64 * 11 * 5)     # the 11x5 sound convolution, any of its 3 directions
+
+
+def ithor_cpu_baseline(seconds=12.0, batch=8):
+    from oracle.torch_oracle import ithor_seeded
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    m = ithor_seeded(977)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=1e-6)
+    crit = torch.nn.TripletMarginLoss(margin=1.0, p=2)
+    g = torch.Generator().manual_seed(0)
+    img = (torch.randint(0, 256, (batch, 3, 96, 96), dtype=torch.uint8, generator=g) / 255.).float()
+    pos = torch.randn(batch, 1, 600, 40, generator=g) * 6
+    neg = torch.randn(batch, 1, 600, 40, generator=g) * 6
+
+    def one():
+        opt.zero_grad()
+        a, p, n = m(img, pos, neg)
+        crit(a, p, n).backward()
+        opt.step()
+    one()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds and n >= 2:
+            break
+    return {"value": round(n * batch / dt, 2), "unit": "triplets/s", "cores": cores, "kind": "port",
+            "sample": f"{n} steps of batch {batch} (96x96 images, precomputed (1,600,40) features in RAM), torch.nn CPU "
+                      f"restatement of the reference's iTHOR step, {cores} threads, {dt:.1f} s"}
+
+
+def main_ithor(args, rank, local_rank, world, dev):
+    """`--workload ithor`: the same contract for the reference's second pretext model."""
+    import var_amd
+    from var_amd._lib import Context
+    B = args.batch
+    cfg = types.SimpleNamespace(img_dim=(3, 96, 96), sound_dim=(1, 600, 40), representationDim=3)
+    torch.manual_seed(977)                                      # iTHOR pretextEnvSeed; identical weights on every rank
+    model = var_amd.IthorVARPretextNet(cfg).to(dev)
+    tr = var_amd.IthorTrainer(model, lr=1e-4, weight_decay=1e-6, margin=1.0)
+    g = torch.Generator(device=dev).manual_seed(rank)
+    img = torch.randint(0, 256, (B, 3, 96, 96), dtype=torch.uint8, device=dev, generator=g)
+    pcm = torch.randint(-8000, 8000, (2 * B, 96000), dtype=torch.int16, device=dev, generator=g)
+    lens = torch.randint(30000, 96001, (2 * B,), dtype=torch.int32, device=dev, generator=g)
+    lens[::5] = 0                                               # 20 % "empty" class
+    ctx = Context.get(local_rank)
+
+    def step():
+        tr.step_from_pcm(img, pcm, lens, global_batch=B * world)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    roof = None
+    if not args.no_roofline:
+        names = ctx.tag_names()
+        best = None
+        for tag in range(len(names)):
+            if "11x5" not in names[tag]:
+                continue
+            ctx.profile_select(tag)
+            for _ in range(3):
+                step()
+            ms, n = ctx.profile_read()
+            if n and (best is None or ms / n > best[1]):
+                best = (tag, ms / n, n)
+        ctx.profile_select(-1)
+        if best:
+            flops = ITHOR_S2_FLOPS_PER_CLIP * 2 * B
+            ach = flops / (best[1] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": names[best[0]], "achieved": round(ach, 2), "peak": F32_MFMA_PEAK,
+                    "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK, 4), "traffic": None,
+                    "avg_us": round(1e3 * best[1], 1), "launches": best[2], "flops_per_launch": flops}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t.item())
+    if rank == 0:
+        value = args.steps * B * world / dt
+        out = {"metric": "pretext triplets/sec (iTHOR model: 96x96 RGB + 16 kHz/6 s audio)", "value": round(value, 1),
+               "unit": "triplets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "iTHOR pretext step (BASELINE.json configs[3] shapes, fp32), batch per GPU as given: u8 "
+                                      "96x96 image + 2 int16 clips of up to 6 s resident in HBM -> python_speech_features "
+                                      "MFCC -> fwd + triplet loss + bwd + Adam",
+                          "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "launch": "eager",
+                          "final_loss": round(float(tr.loss.item()), 6)},
+               "mfma_frac_whole_step": round(value / world * ITHOR_FLOPS_STEP / 1e12 / F32_MFMA_PEAK, 4)}
+        if roof:
+            out["roofline"] = roof
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = ithor_cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
 def tag_flops(tag):
     """Algorithmic FLOPs per triplet of a profiled conv kernel family (tags: 0-4 forward, 5-9 weight
     gradient, 11-14 data gradient of layer tag % 5) in the default (fused) configuration: tag 1 = forward head
@@ -122,6 +235,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
+    ap.add_argument("--workload", choices=("kuka", "ithor"), default="kuka",
+                    help="kuka = BASELINE.json's metric (default); ithor = the reference's second pretext model")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -135,6 +250,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1 or "RANK" in os.environ:
         torch.distributed.init_process_group("nccl", device_id=dev)
+
+    if args.workload == "ithor":
+        if args.steps == 200 and args.warmup == 20:           # the defaults are sized for the 0.37 ms Kuka step
+            args.steps, args.warmup = 20, 3
+        return main_ithor(args, rank, local_rank, world, dev)
 
     import var_amd
     from var_amd._lib import Context

@@ -446,7 +446,10 @@ static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* imag
                                              st->s[1] + (long)off * 64 * 300 * 20)));
             off += B;
         }
-        RUN((conv_fwd<GS2, false, false>(c, s, snd_dims(2, nclips), st->s[1], P + L.sw[1], P + L.sb[1], st->s[2])));
+        {
+            ProfScope prof(c, s, TAG_ITHOR_S2_FWD);
+            RUN((conv_fwd<GS2, false, false>(c, s, snd_dims(2, nclips), st->s[1], P + L.sw[1], P + L.sb[1], st->s[2])));
+        }
         RUN((conv_fwd<GS3, false, true>(c, s, snd_dims(3, nclips), st->s[2], P + L.sw[2], P + L.sb[2], st->s[3])));
         const int rows = nclips * kSeq;
         const long dirP = L.w_ih[1] - L.w_ih[0];
@@ -610,9 +613,15 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
         }
         {
             const ConvDims d = snd_dims(2, nclips);
-            RUN((conv_wgrad<GS2, false, false>(c, s, d, st->s[1], st->gs[2], G + L.sw[1])));
+            {
+                ProfScope prof(c, s, TAG_ITHOR_S2_WGRAD);
+                RUN((conv_wgrad<GS2, false, false>(c, s, d, st->s[1], st->gs[2], G + L.sw[1])));
+            }
             RUN(chan_sum(c, s, st->gs[2], G + L.sb[1], nclips, 64, 150 * 13));
-            RUN((conv_dgrad<GS2, false>(c, s, d, st->gs[2], P + L.sw[1], st->gs[1], st->s[1])));
+            {
+                ProfScope prof(c, s, TAG_ITHOR_S2_DGRAD);
+                RUN((conv_dgrad<GS2, false>(c, s, d, st->gs[2], P + L.sw[1], st->gs[1], st->s[1])));
+            }
         }
         {
             int off = 0;

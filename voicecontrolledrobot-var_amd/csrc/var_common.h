@@ -87,7 +87,9 @@ enum VarTag {
     TAG_IMG_WREDUCE = 15,
     TAG_SND_FWD = 16, TAG_SND_DGRAD = 17, TAG_SND_WGRAD = 18, TAG_SND_REDUCE = 19,
     TAG_HEADS_FWD = 20, TAG_HEADS_BWD_ROWS = 21, TAG_HEADS_BWD_W = 22, TAG_TRIPLET = 23,
-    TAG_ADAM = 24, TAG_PACK = 25, TAG_MFCC = 26, TAG_COUNT = 27
+    TAG_ADAM = 24, TAG_PACK = 25, TAG_MFCC = 26,
+    TAG_ITHOR_S2_FWD = 27, TAG_ITHOR_S2_DGRAD = 28, TAG_ITHOR_S2_WGRAD = 29,   // the 11x5 sound convolution of the iTHOR model
+    TAG_COUNT = 30
 };
 constexpr int kProfMaxPairs = 4096;
 
