@@ -153,8 +153,16 @@ def main_ithor(args, rank, local_rank, world, dev):
         if best:
             flops = ITHOR_S2_FLOPS_PER_CLIP * 2 * B
             ach = flops / (best[1] * 1e-3) / 1e12
+            traffic = None
+            try:                                                # HBM bytes per launch from the committed PMC passes
+                with open(os.path.join(ROOT, "profiles", "r01_ithor_pmc.json")) as f:
+                    k = json.load(f)["kernels"][names[best[0]]]
+                if B == 256:
+                    traffic = k["fetch_bytes"] + k["write_bytes"]
+            except (OSError, KeyError, ValueError):
+                pass
             roof = {"bound": "mfma", "kernel": names[best[0]], "achieved": round(ach, 2), "peak": F32_MFMA_PEAK,
-                    "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK, 4), "traffic": traffic,
                     "avg_us": round(1e3 * best[1], 1), "launches": best[2], "flops_per_launch": flops}
     barrier()
     t0 = time.perf_counter()
