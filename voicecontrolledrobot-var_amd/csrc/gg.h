@@ -41,45 +41,45 @@ struct SepK { unsigned off; unsigned bits; };      // per k
 constexpr unsigned SEP_OK = 1u << 30;         // "index in range": set in every valid mask and in all bits
 constexpr unsigned SEP_BAD = 1u << 31;        // never in a mask: bits of an out-of-range k
 
-template <class P, int NT>
+template <class P, int NT, int KC>
 __global__ void __launch_bounds__(256) gg_kernel(const P p) {
     constexpr int AS = GG_MT + 4, BS = NT + 4;
     constexpr int NB = NT / 32;
-    __shared__ float As[2][GG_KC][AS];
-    __shared__ float Bs[2][GG_KC][BS];
-    __shared__ SepK ktA[2][GG_KC];
-    __shared__ SepK ktB[2][GG_KC];
+    __shared__ float As[2][KC][AS];
+    __shared__ float Bs[2][KC][BS];
+    __shared__ SepK ktA[2][KC];
+    __shared__ SepK ktB[2][KC];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int m0 = blockIdx.x * GG_MT, n0 = blockIdx.y * NT;
     const int nsplit = p.nsplit;
     const int bz = blockIdx.z / nsplit, sz = blockIdx.z - bz * nsplit;
-    const int kchunks = (p.k_extent(bz) + GG_KC - 1) / GG_KC;
+    const int kchunks = (p.k_extent(bz) + KC - 1) / KC;
     const int per = (kchunks + nsplit - 1) / nsplit;
     const int c_lo = sz * per, c_hi = min(kchunks, c_lo + per);
     if (c_lo >= c_hi) { if (nsplit > 1 || kchunks == 0) return; }
 
-    constexpr int NA = GG_MT * GG_KC / 256;
-    constexpr int NBE = NT * GG_KC / 256;
+    constexpr int NA = GG_MT * KC / 256;
+    constexpr int NBE = NT * KC / 256;
     SepM am[P::A_KFAST ? NA : 1];
     SepM bn[P::B_KFAST ? NBE : 1];
     if (P::A_KFAST) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) am[P::A_KFAST ? i : 0] = p.a_m(m0 + (tid >> 4) + 16 * i, bz);
+        for (int i = 0; i < NA; ++i) am[P::A_KFAST ? i : 0] = p.a_m(m0 + tid / KC + (256 / KC) * i, bz);
     } else {
         am[0] = p.a_m(m0 + (tid & (GG_MT - 1)), bz);
     }
     if (P::B_KFAST) {
 #pragma unroll
-        for (int i = 0; i < NBE; ++i) bn[P::B_KFAST ? i : 0] = p.b_n(n0 + (tid >> 4) + 16 * i, bz);
+        for (int i = 0; i < NBE; ++i) bn[P::B_KFAST ? i : 0] = p.b_n(n0 + tid / KC + (256 / KC) * i, bz);
     } else {
         bn[0] = p.b_n(n0 + (tid & (NT - 1)), bz);
     }
 
-    // k-side table of chunk `chunk`, computed by the 16 first lanes of one wave (the waves take turns)
+    // k-side table of chunk `chunk`, computed by the KC first lanes of one wave (the waves take turns)
     auto ktable = [&](int chunk) {
-        if (wave == (chunk & 3) && lane < GG_KC) {
-            ktA[chunk & 1][lane] = p.a_k(chunk * GG_KC + lane, bz);
-            ktB[chunk & 1][lane] = p.b_k(chunk * GG_KC + lane, bz);
+        if (wave == (chunk & 3) && lane < KC) {
+            ktA[chunk & 1][lane] = p.a_k(chunk * KC + lane, bz);
+            ktB[chunk & 1][lane] = p.b_k(chunk * KC + lane, bz);
         }
     };
     float ra[NA], rb[NBE];
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256) gg_kernel(const P p) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const SepM sm = am[P::A_KFAST ? i : 0];
-            const SepK sk = P::A_KFAST ? ta[tid & 15] : ta[(tid >> 7) + 2 * i];
+            const SepK sk = P::A_KFAST ? ta[tid % KC] : ta[(tid >> 7) + 2 * i];
             const bool ok = P::A_K_IN_M ? (sm.mask & sk.bits) == sk.bits : (sm.mask & sk.bits) == sm.mask;
             ra[i] = p.a_load(ok ? sm.base + sk.off : 0u);
             oka |= ok ? (1u << i) : 0u;
@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(256) gg_kernel(const P p) {
 #pragma unroll
         for (int i = 0; i < NBE; ++i) {
             const SepM sn = bn[P::B_KFAST ? i : 0];
-            const SepK sk = P::B_KFAST ? tb[tid & 15] : tb[tid / NT + (256 / NT) * i];
+            const SepK sk = P::B_KFAST ? tb[tid % KC] : tb[tid / NT + (256 / NT) * i];
             const bool ok = (sn.mask & sk.bits) == sk.bits;
             rb[i] = p.b_load(ok ? sn.base + sk.off : 0u);
             okb |= ok ? (1u << i) : 0u;
@@ -109,13 +109,13 @@ __global__ void __launch_bounds__(256) gg_kernel(const P p) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const float v = (oka >> i) & 1u ? ra[i] : 0.f;
-            if (P::A_KFAST) As[buf][tid & 15][(tid >> 4) + 16 * i] = v;
+            if (P::A_KFAST) As[buf][tid % KC][tid / KC + (256 / KC) * i] = v;
             else As[buf][(tid >> 7) + 2 * i][tid & (GG_MT - 1)] = v;
         }
 #pragma unroll
         for (int i = 0; i < NBE; ++i) {
             const float v = (okb >> i) & 1u ? rb[i] : 0.f;
-            if (P::B_KFAST) Bs[buf][tid & 15][(tid >> 4) + 16 * i] = v;
+            if (P::B_KFAST) Bs[buf][tid % KC][tid / KC + (256 / KC) * i] = v;
             else Bs[buf][tid / NT + (256 / NT) * i][tid & (NT - 1)] = v;
         }
     };
@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(256) gg_kernel(const P p) {
         if (c + 1 < c_hi) gload(c + 1);
         ktable(c + 2);                       // slot of chunk c, whose table was last read in the previous iteration
 #pragma unroll
-        for (int kk = 0; kk < GG_KC / 2; ++kk) {
+        for (int kk = 0; kk < KC / 2; ++kk) {
             const float av = As[cur][2 * kk + half][32 * wave + l31];
 #pragma unroll
             for (int b = 0; b < NB; ++b)
@@ -163,15 +163,15 @@ __global__ void __launch_bounds__(256) gg_kernel(const P p) {
     }
 }
 
-template <class P>
+template <class P, int KC = GG_KC>
 static int gg_launch(var_ctx* c, hipStream_t s, const P& p, int batches = 1) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return VAR_OK;
     dim3 grid((p.M + GG_MT - 1) / GG_MT, 1, batches * p.nsplit);
     if (p.N <= 32) {
-        hipLaunchKernelGGL((gg_kernel<P, 32>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((gg_kernel<P, 32, KC>), grid, dim3(256), 0, s, p);
     } else {
         grid.y = (p.N + 63) / 64;
-        hipLaunchKernelGGL((gg_kernel<P, 64>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((gg_kernel<P, 64, KC>), grid, dim3(256), 0, s, p);
     }
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;

@@ -301,8 +301,8 @@ static constexpr long kBiasSlabFloats = 1L << 20;
 
 // the kernel gives split s the chunks [s*per, (s+1)*per), per = ceil(chunks / nsplit): trim nsplit so that no split
 // is empty (an empty split would leave its slab unwritten)
-static int eff_split(int K, int ns) {
-    const int kchunks = (K + GG_KC - 1) / GG_KC;
+static int eff_split(int K, int ns, int kc = GG_KC) {
+    const int kchunks = (K + kc - 1) / kc;
     if (ns < 1) ns = 1;
     if (ns > kchunks) ns = kchunks;
     const int per = (kchunks + ns - 1) / ns;
@@ -329,12 +329,14 @@ static int conv_wgrad(var_ctx* c, hipStream_t s, const ConvDims& d, const void* 
     p.M = d.CIN * G::KHW; p.N = d.COUT; p.K = d.B * d.HO * d.WO;
     const int tiles = ((p.M + GG_MT - 1) / GG_MT) * ((p.N + 63) / 64);
     int ns = (1024 + tiles - 1) / tiles;                    // about 4 workgroups per CU
-    const int kchunks = (p.K + GG_KC - 1) / GG_KC;
-    if (ns > kchunks / 8) ns = kchunks / 8 > 0 ? kchunks / 8 : 1;
+    // both operands are read along k (pixels): chunks of 32 k make the runs per lane group twice as long
+    constexpr int KC = 32;
+    const int kchunks = (p.K + KC - 1) / KC;
+    if (ns > kchunks / 4) ns = kchunks / 4 > 0 ? kchunks / 4 : 1;
     if ((long)ns * p.M * p.N > kSlabFloats) ns = (int)(kSlabFloats / ((long)p.M * p.N));
-    p.nsplit = eff_split(p.K, ns);
+    p.nsplit = eff_split(p.K, ns, KC);
     p.d = d; p.x = x; p.gy = gy; p.dw = dw; p.slab = ith(c)->slab;
-    int r = gg_launch(c, s, p);
+    int r = gg_launch<ConvWgradP<G, U8, SEQ>, KC>(c, s, p);
     if (r != VAR_OK) return r;
     if (p.nsplit > 1) return slab_reduce(c, s, dw, p.slab, p.M * p.N, p.nsplit, (long)p.M * p.N);
     return VAR_OK;
