@@ -272,3 +272,32 @@ def test_gradients_are_bitwise_reproducible(var_amd, fx):
     for _ in range(3):
         tr.loss_and_grads(img, pos, neg)
         assert torch.equal(tr.gbuf, first)
+
+
+def test_large_ragged_batch_is_consistent_with_its_parts(var_amd, fx):
+    """Size-independent properties at a bench-like size the CPU oracle cannot reach: per-sample independence of the
+    forward (B = 301 vs its two parts) and additivity of the gradient over a partition of the batch."""
+    m = seeded_model(var_amd, int(fx["seed"]))
+    g = torch.Generator(device="cuda").manual_seed(5)
+    B = 301
+    img = torch.randint(0, 256, (B, 3, 96, 96), dtype=torch.uint8, device="cuda", generator=g)
+    pos = torch.randn((B, 1, 600, 40), device="cuda", generator=g) * 6
+    neg = torch.randn((B, 1, 600, 40), device="cuda", generator=g) * 6
+    with torch.no_grad():
+        full = m(img, pos, neg)
+        a = {k: v.clone() for k, v in full.items() if v is not None}
+        lo = m(img[:173], pos[:173], neg[:173])
+        lo = {k: v.clone() for k, v in lo.items() if v is not None}
+        hi = m(img[173:], pos[173:], neg[173:])
+    for k in ("image_feat", "sound_feat_positive", "sound_feat_negative", "image_feat_raw", "pos_sound_raw"):
+        both = torch.cat([lo[k], hi[k]])
+        np.testing.assert_allclose(a[k].cpu().numpy(), both.cpu().numpy(), atol=2e-5, rtol=1e-4, err_msg=k)
+    tr = var_amd.IthorTrainer(m)
+    tr.loss_and_grads(img, pos, neg)
+    whole = tr.gbuf.clone()
+    acc = torch.zeros_like(whole)
+    for sl in (slice(0, 173), slice(173, B)):
+        tr.loss_and_grads(img[sl], pos[sl], neg[sl], global_batch=B)
+        acc += tr.gbuf
+    assert abs(acc[-1].item() - whole[-1].item()) < 1e-5
+    assert l2_rel(acc[:-1].cpu().numpy(), whole[:-1].cpu().numpy()) < 1e-4
