@@ -187,6 +187,20 @@ int var_ithor_loss_grad(var_ctx* ctx, void* stream, const float* params,
                         float margin, float inv_count,
                         float* grads, float* loss_out, float* feats_out);
 
+/* Collectives ----------------------------------------------------------------------------------
+ * For hosts without torch.distributed: one RCCL communicator per context.  Rank 0 obtains a 128-byte unique id
+ * (var_comm_unique_id), the host ships it to the other ranks over its own channel, every rank calls var_comm_init.
+ * var_allreduce_grads: in-place sum over the ranks of the flat gradient arena (append the loss as one more float and
+ * it travels in the same message) -- the ONE exchange of the data-parallel step, between var_*_loss_grad
+ * (inv_count = 1/B_global) and var_adam_step.  var_allgather_emb: global[r*n_local ...] = rank r's `local`
+ * (embeddings for an in-batch-negatives loss; BASELINE config 3's extension).  Stream-ordered like every other
+ * entry.  librccl.so is opened on first use (dlopen), not at load time. */
+int var_comm_unique_id(var_ctx* ctx, void* id128);
+int var_comm_init(var_ctx* ctx, int rank, int nranks, const void* id128);
+int var_comm_destroy(var_ctx* ctx);
+int var_allreduce_grads(var_ctx* ctx, void* stream, float* flat_grad, long n);
+int var_allgather_emb(var_ctx* ctx, void* stream, const float* local, float* global, long n_local);
+
 /* RL actor-critic forward ---------------------------------------------------------------
  * Policy.act up to the sampling (models/ppo/model.py:57-69): armNet_VAR.forward (models/RL/arm_RL_model.py:99-134, the
  * 96x96 image branch, recurrent: one GRU(128 -> 512) step from rnn_hxs * masks, models/ppo/model.py:118-121) and the

@@ -365,3 +365,37 @@ def test_data_parallel_replay_path_equals_eager_steps(var_amd, golden_dir):
     assert np.allclose(losses_a, losses_b, rtol=0, atol=1e-6), (losses_a, losses_b)
     pa = ma.flat_parameters().cpu().numpy()
     assert np.mean(np.abs(pa - pb) < 2e-6) > 0.995 and np.max(np.abs(pa - pb)) < 5e-3
+
+
+def test_rccl_collectives_through_the_c_abi(var_amd, golden_dir):
+    """var_comm_* / var_allreduce_grads / var_allgather_emb with a one-rank communicator (all a one-GPU box can hold;
+    the multi-rank convention is covered by tests/test_dp_gloo.py): identity all-reduce, all-gather copy, and a
+    trainer step routed through the C-ABI collective equals the plain step."""
+    comm = var_amd.RcclComm(0)
+    uid = comm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm.init(0, 1, uid)
+    x = torch.arange(1000, dtype=torch.float32, device="cuda") * 0.5
+    ref = x.clone()
+    comm.allreduce(x)
+    out = comm.allgather(ref[:27].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref) and torch.equal(out, ref[:27])
+    sd = load(golden_dir, "kuka_weights.npz")
+    fx = load(golden_dir, "kuka_h84.npz")
+    losses = []
+    for use in (False, True):
+        m = make_model(var_amd, sd, 84)
+        tr = var_amd.VARTrainer(m)
+        if use:
+            tr.use_rccl(comm)
+        tr.step(cuda(fx['image']), cuda(fx['sound_positive']), cuda(fx['sound_negative']))
+        losses.append(tr.loss.item())
+        flat = m.flat_parameters().clone()
+        if use:
+            assert torch.equal(flat, prev)
+        prev = flat
+    assert losses[0] == losses[1]
+    comm.destroy()
+    with pytest.raises(var_amd.VarHipError):
+        comm.allreduce(x)

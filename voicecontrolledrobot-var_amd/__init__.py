@@ -12,6 +12,7 @@ from .layout import N_PARAMS, PARAM_SPECS  # noqa: F401
 from .model import VARPretextNet  # noqa: F401
 from .ithor import IthorTrainer, IthorVARPretextNet, project_representation  # noqa: F401
 from .actor_critic import ArmNetPolicy  # noqa: F401
+from .comm import RcclComm  # noqa: F401
 from .trainer import VARTrainer, train_representation, multistep_lr  # noqa: F401
 from .data import SyntheticTripletPool, TripletPool, choose_negative_id, load_wav_clips, process_sound_feat  # noqa: F401
 from .ops import mfcc, mfcc_psf, triplet_margin_loss  # noqa: F401

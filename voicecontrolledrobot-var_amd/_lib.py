@@ -48,6 +48,11 @@ _SIGNATURES = {
     "var_mfcc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "var_arm_loss_grad_pcm": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
     "var_arm_loss_grad_gather": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
+    "var_comm_unique_id": (_i, [_vp, _vp]),
+    "var_comm_init": (_i, [_vp, _i, _i, _vp]),
+    "var_comm_destroy": (_i, [_vp]),
+    "var_allreduce_grads": (_i, [_vp, _vp, _vp, _l]),
+    "var_allgather_emb": (_i, [_vp, _vp, _vp, _vp, _l]),
     "var_armnet_param_count": (_i, []),
     "var_armnet_plan": (_i, [_vp, _i]),
     "var_armnet_forward": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),

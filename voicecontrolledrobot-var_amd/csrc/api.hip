@@ -80,6 +80,7 @@ int var_init(int device_id, var_ctx** out) {
 int var_destroy(var_ctx* c) {
     CHECK_CTX(c);
     (void)hipSetDevice(c->device);
+    comm_free(c);
     ithor_free(c);
     armnet_free(c);
     if (c->ws) (void)hipFree(c->ws);

@@ -149,6 +149,7 @@ struct var_ctx {
     hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
     float* mfcc_buf = nullptr;            // (2*maxB, 100, 40) when the front-end runs inside the step
     float* mfcc_psf_tab = nullptr;        // tables of the python_speech_features front-end (mfcc_psf.hip), built on first use
+    void* comm = nullptr; int comm_rank = 0, comm_size = 1;   // RCCL communicator (comm.hip), created by var_comm_init
     void* arm = nullptr;                  // actor-critic state (armnet.hip), created by var_armnet_plan
     void* ith = nullptr;                  // iTHOR model state (ithor.hip), created by var_ithor_plan
 };
@@ -181,6 +182,7 @@ static inline int conv_out(int h) { return (h - 1) / 2 + 1; }   // 3x3 s2 p1
 int mfcc_build_tables(var_ctx* c);
 void ithor_free(var_ctx* c);
 void armnet_free(var_ctx* c);
+void comm_free(var_ctx* c);
 int pack_table_upload(var_ctx* c);
 size_t img_slab_floats();
 int img_wgrad_groups(int layer);

@@ -238,8 +238,16 @@ class IthorTrainer:
         self._keep = (image, pos, neg)
         return self.loss, out
 
+    def use_rccl(self, comm):
+        """Route the all-reduce through the C ABI (comm.RcclComm) instead of torch.distributed."""
+        self.rccl = comm
+        self.world = comm.size
+        return self
+
     def allreduce(self):
-        if self.world > 1:
+        if getattr(self, "rccl", None) is not None:
+            self.rccl.allreduce(self.gbuf)
+        elif self.world > 1:
             torch.distributed.all_reduce(self.gbuf, op=torch.distributed.ReduceOp.SUM, group=self.pg)
 
     def adam(self):

@@ -75,8 +75,17 @@ class VARTrainer:
                                         B, self.hw, float(self.margin), 1.0 / gb, ptr(self.gbuf),
                                         self.gbuf.data_ptr() + 4 * N_PARAMS, None), "var_arm_loss_grad")
 
+    def use_rccl(self, comm):
+        """Route the gradient all-reduce through the C ABI (comm.RcclComm, var_allreduce_grads) instead of
+        torch.distributed; `comm.size` becomes the world size of the loss / gradient scaling."""
+        self.rccl = comm
+        self.world = comm.size
+        return self
+
     def allreduce(self):
-        if self.world > 1 or (self.force_collective and torch.distributed.is_initialized()):
+        if getattr(self, "rccl", None) is not None:
+            self.rccl.allreduce(self.gbuf)
+        elif self.world > 1 or (self.force_collective and torch.distributed.is_initialized()):
             torch.distributed.all_reduce(self.gbuf, op=torch.distributed.ReduceOp.SUM, group=self.pg)
 
     def adam(self):
