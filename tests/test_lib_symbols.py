@@ -66,3 +66,38 @@ def test_negative_id_rule_and_padding():
     assert p.shape == (1, 100, 40) and p[0, :51].all() and not p[0, 51:].any()
     assert var_amd.process_sound_feat(np.ones((101, 40), np.float32)).shape == (1, 100, 40)
     assert abs(var_amd.multistep_lr(1e-4, [10, 30, 50], 0.2, 30) - 4e-6) < 1e-18
+
+
+def test_ithor_and_actor_critic_module_layouts_match_reference_fixtures(golden_dir):
+    """CPU-side: the drop-in modules carry the reference's state_dict keys/shapes, the seed reproduces the iTHOR
+    weights bit for bit, the arena sizes equal the C ABI's counts, and CPU use fails loudly (no fallback)."""
+    import types
+    import var_amd
+    lib = var_amd.load_library()
+    g = np.load(os.path.join(golden_dir, "ithor_h96.npz"))
+    torch.manual_seed(int(g["seed"]))
+    m = var_amd.IthorVARPretextNet(types.SimpleNamespace(img_dim=(3, 96, 96), sound_dim=(1, 600, 40), representationDim=3))
+    sd = m.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["names"]]
+    for k, v in sd.items():
+        f = v.numpy().reshape(-1).astype(np.float64)
+        assert tuple(v.shape) == tuple(g["shape." + k])
+        assert np.array_equal(np.concatenate([[f.sum(), np.abs(f).sum()], f[:8]]), g["check." + k]), k
+    assert m.flat_parameters().numel() == lib.var_ithor_param_count() == 3849126
+    with pytest.raises(var_amd.VarHipError):
+        m(torch.zeros(1, 3, 96, 96), None, None)
+    with pytest.raises(var_amd.VarHipError):
+        var_amd.IthorTrainer(m)
+
+    class Box:
+        shape = (2,)
+    a = np.load(os.path.join(golden_dir, "armnet_b8.npz"))
+    ac = var_amd.ArmNetPolicy(None, Box(), config=types.SimpleNamespace(img_dim=(3, 96, 96), representationDim=3, robotStateDim=2),
+                              base='arm_VAR', base_kwargs={'recurrent': True, 'recurrentInputSize': 128, 'recurrentSize': 512,
+                                                           'actionHiddenSize': 128})
+    sd = ac.state_dict()
+    assert list(sd.keys()) == [str(k) for k in a["names"]]
+    assert all(tuple(v.shape) == tuple(a["shape." + k]) for k, v in sd.items())
+    assert sum(v.numel() for v in sd.values()) == lib.var_armnet_param_count()
+    with pytest.raises(var_amd.VarHipError):
+        ac.act({'image': torch.zeros(1, 3, 96, 96)}, torch.zeros(1, 512), torch.ones(1, 1))
