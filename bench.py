@@ -117,7 +117,8 @@ def main_ithor(args, rank, local_rank, world, dev):
     B = args.batch
     cfg = types.SimpleNamespace(img_dim=(3, 96, 96), sound_dim=(1, 600, 40), representationDim=3)
     torch.manual_seed(977)                                      # iTHOR pretextEnvSeed; identical weights on every rank
-    model = var_amd.IthorVARPretextNet(cfg).to(dev)
+    model = var_amd.IthorVARPretextNet(cfg).to(dev).set_precision("bf16" if args.dtype == "bf16" else "fp32")
+    peak = 2500.0 if args.dtype == "bf16" else F32_MFMA_PEAK      # dense MFMA peak of the operand type, TFLOP/s
     tr = var_amd.IthorTrainer(model, lr=1e-4, weight_decay=1e-6, margin=1.0)
     g = torch.Generator(device=dev).manual_seed(rank)
     img = torch.randint(0, 256, (B, 3, 96, 96), dtype=torch.uint8, device=dev, generator=g)
@@ -157,12 +158,12 @@ def main_ithor(args, rank, local_rank, world, dev):
             try:                                                # HBM bytes per launch from the committed PMC passes
                 with open(os.path.join(ROOT, "profiles", "r01_ithor_pmc.json")) as f:
                     k = json.load(f)["kernels"][names[best[0]]]
-                if B == 256:
+                if B == 256 and args.dtype == "f32":
                     traffic = k["fetch_bytes"] + k["write_bytes"]
             except (OSError, KeyError, ValueError):
                 pass
-            roof = {"bound": "mfma", "kernel": names[best[0]], "achieved": round(ach, 2), "peak": F32_MFMA_PEAK,
-                    "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK, 4), "traffic": traffic,
+            roof = {"bound": "mfma", "kernel": names[best[0]], "achieved": round(ach, 2), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                     "avg_us": round(1e3 * best[1], 1), "launches": best[2], "flops_per_launch": flops}
     barrier()
     t0 = time.perf_counter()
@@ -179,13 +180,13 @@ def main_ithor(args, rank, local_rank, world, dev):
         out = {"metric": "pretext triplets/sec (iTHOR model: 96x96 RGB + 16 kHz/6 s audio)", "value": round(value, 1),
                "unit": "triplets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "iTHOR pretext step (BASELINE.json configs[3] shapes, fp32), batch per GPU as given: u8 "
+               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": "iTHOR pretext step (BASELINE.json configs[3] shapes), batch per GPU as given: u8 "
                                       "96x96 image + 2 int16 clips of up to 6 s resident in HBM -> python_speech_features "
                                       "MFCC -> fwd + triplet loss + bwd + Adam",
                           "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "launch": "eager",
                           "final_loss": round(float(tr.loss.item()), 6)},
-               "mfma_frac_whole_step": round(value / world * ITHOR_FLOPS_STEP / 1e12 / F32_MFMA_PEAK, 4)}
+               "mfma_frac_whole_step": round(value / world * ITHOR_FLOPS_STEP / 1e12 / peak, 4)}
         if roof:
             out["roofline"] = roof
         if not args.no_cpu_baseline and world == 1:
@@ -243,6 +244,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="ithor workload only: operand precision of the products (bf16 = BASELINE config 4's; accumulation fp32)")
     ap.add_argument("--workload", choices=("kuka", "ithor"), default="kuka",
                     help="kuka = BASELINE.json's metric (default); ithor = the reference's second pretext model")
     args = ap.parse_args()

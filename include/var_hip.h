@@ -173,6 +173,11 @@ int var_mfcc(var_ctx* ctx, void* stream, const int16_t* pcm, const int* lens, co
  * var_adam_step / var_triplet_fwd_bwd are shared with the Kuka model. */
 int var_ithor_param_count(void);
 int var_ithor_plan(var_ctx* ctx, int max_batch, int img_hw);
+/* Operand precision of every product of the iTHOR model: 0 = fp32 (default; the parity path), 1 = bf16 operands
+ * (round to nearest even) with fp32 accumulation on v_mfma_f32_32x32x16_bf16 -- BASELINE config 4's stated precision;
+ * activations, gradients, parameters and the optimiser state stay fp32.  -1 = query.  Returns the previous setting
+ * (or a negative error code); call after var_ithor_plan. */
+int var_ithor_set_bf16(var_ctx* ctx, int on);
 int var_ithor_encoder_fwd(var_ctx* ctx, void* stream, const float* params,
                           const void* image, int image_is_u8, long image_bstride,
                           const float* snd_pos, const float* snd_neg, int B, int H,

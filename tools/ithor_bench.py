@@ -26,11 +26,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--hw", type=int, default=96)
     ap.add_argument("--fwd-only", action="store_true")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32", help="operand precision of the products")
     ap.add_argument("--features", action="store_true", help="feed precomputed (1,600,40) features instead of PCM")
     a = ap.parse_args()
     torch.manual_seed(977)
     cfg = types.SimpleNamespace(img_dim=(3, a.hw, a.hw), sound_dim=(1, 600, 40), representationDim=3)
     m = var_amd.IthorVARPretextNet(cfg).to("cuda")
+    m.set_precision("bf16" if a.dtype == "bf16" else "fp32")
     tr = var_amd.IthorTrainer(m)
     g = torch.Generator(device="cuda").manual_seed(0)
     img = torch.randint(0, 256, (a.batch, 3, a.hw, a.hw), dtype=torch.uint8, device="cuda", generator=g)
@@ -63,7 +65,7 @@ def main():
     flop = FLOP_FWD if a.fwd_only else FLOP_STEP
     print(json.dumps({"workload": "ithor pretext step" if not a.fwd_only else "ithor forward", "batch": a.batch,
                       "hw": a.hw, "ms_per_step": round(ms, 3), "triplets_per_s": round(a.batch / ms * 1e3, 1),
-                      "tflops": round(a.batch * flop / ms / 1e9, 2), "dtype": "f32",
+                      "tflops": round(a.batch * flop / ms / 1e9, 2), "dtype": a.dtype,
                       "loss": float(tr.loss.item()) if not a.fwd_only else None}))
 
 

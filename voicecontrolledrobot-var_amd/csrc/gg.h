@@ -41,7 +41,14 @@ struct SepK { unsigned off; unsigned bits; };      // per k
 constexpr unsigned SEP_OK = 1u << 30;         // "index in range": set in every valid mask and in all bits
 constexpr unsigned SEP_BAD = 1u << 31;        // never in a mask: bits of an out-of-range k
 
-template <class P, int NT, int KC>
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
+
+// BF = true: the operands are rounded to bf16 (v_cvt_pk_bf16_f32, round to nearest even) on their way from the fp32 LDS
+// tile into v_mfma_f32_32x32x16_bf16 (lane (r, h) supplies k = 8h..8h+7); accumulation stays fp32.  Same loader, same
+// tiles: 2 MFMAs of 32 cycles per 16 k instead of 16 of 64 -- BASELINE config 4's stated precision.
+template <class P, int NT, int KC, bool BF>
 __global__ void __launch_bounds__(256) gg_kernel(const P p) {
     constexpr int AS = GG_MT + 4, BS = NT + 4;
     constexpr int NB = NT / 32;
@@ -139,12 +146,37 @@ __global__ void __launch_bounds__(256) gg_kernel(const P p) {
         const int cur = (c - c_lo) & 1;
         if (c + 1 < c_hi) gload(c + 1);
         ktable(c + 2);                       // slot of chunk c, whose table was last read in the previous iteration
+        if constexpr (BF) {
 #pragma unroll
-        for (int kk = 0; kk < KC / 2; ++kk) {
-            const float av = As[cur][2 * kk + half][32 * wave + l31];
+            for (int q = 0; q < KC / 16; ++q) {
+                const int k0 = 16 * q + 8 * half;
+                bf16x8_ av;
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
-                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(Bs[cur][2 * kk + half][32 * b + l31], av, acc[b], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    const bf16x2_ t = __builtin_convertvector(
+                        f32x2_{As[cur][k0 + 2 * j][32 * wave + l31], As[cur][k0 + 2 * j + 1][32 * wave + l31]}, bf16x2_);
+                    av[2 * j] = t[0]; av[2 * j + 1] = t[1];
+                }
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    bf16x8_ bv;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bf16x2_ t = __builtin_convertvector(
+                            f32x2_{Bs[cur][k0 + 2 * j][32 * b + l31], Bs[cur][k0 + 2 * j + 1][32 * b + l31]}, bf16x2_);
+                        bv[2 * j] = t[0]; bv[2 * j + 1] = t[1];
+                    }
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, acc[b], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < KC / 2; ++kk) {
+                const float av = As[cur][2 * kk + half][32 * wave + l31];
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(Bs[cur][2 * kk + half][32 * b + l31], av, acc[b], 0, 0, 0);
+            }
         }
         if (c + 1 < c_hi) lstore(cur ^ 1);
         __syncthreads();
@@ -163,15 +195,15 @@ __global__ void __launch_bounds__(256) gg_kernel(const P p) {
     }
 }
 
-template <class P, int KC = GG_KC>
+template <class P, int KC = GG_KC, bool BF = false>
 static int gg_launch(var_ctx* c, hipStream_t s, const P& p, int batches = 1) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return VAR_OK;
     dim3 grid((p.M + GG_MT - 1) / GG_MT, 1, batches * p.nsplit);
     if (p.N <= 32) {
-        hipLaunchKernelGGL((gg_kernel<P, 32, KC>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((gg_kernel<P, 32, KC, BF>), grid, dim3(256), 0, s, p);
     } else {
         grid.y = (p.N + 63) / 64;
-        hipLaunchKernelGGL((gg_kernel<P, 64, KC>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((gg_kernel<P, 64, KC, BF>), grid, dim3(256), 0, s, p);
     }
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;

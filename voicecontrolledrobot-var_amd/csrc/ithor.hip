@@ -56,6 +56,7 @@ struct ithor_state {
     float *DGI = nullptr, *DGH = nullptr, *DH = nullptr, *DHP = nullptr;
     float *slab = nullptr, *bslab = nullptr;              // split-K partial sums / bias-sum partials
     int gh_split = 1, dh_split = 1;
+    bool bf16 = false;
     float *sraw = nullptr, *gsraw = nullptr;              // (clips,1024)
     float *hid_i = nullptr, *ghid_i = nullptr, *hid_s1 = nullptr, *ghid_s1 = nullptr, *hid_s2 = nullptr, *ghid_s2 = nullptr;
     float *raw = nullptr, *graw = nullptr, *emb = nullptr, *gemb = nullptr;   // (3B,3) [img | pos | neg]
@@ -68,12 +69,22 @@ struct ithor_state {
 
 static inline ithor_state* ith(var_ctx* c) { return (ithor_state*)c->ith; }
 
+// every product of the model goes through here: fp32 operands, or bf16 operands (fp32 accumulate) when the context
+// was switched with var_ithor_set_bf16
+template <int KC = GG_KC, class P>
+static int gg(var_ctx* c, hipStream_t s, const P& p, int batches = 1);
+
 void ithor_free(var_ctx* c) {
     ithor_state* st = ith(c);
     if (!st) return;
     if (st->ws) (void)hipFree(st->ws);
     delete st;
     c->ith = nullptr;
+}
+
+template <int KC, class P>
+static int gg(var_ctx* c, hipStream_t s, const P& p, int batches) {
+    return ith(c)->bf16 ? gg_launch<P, KC, true>(c, s, p, batches) : gg_launch<P, KC, false>(c, s, p, batches);
 }
 
 // ---- element-wise kernels ---------------------------------------------------------------------------------------
@@ -276,7 +287,7 @@ static int conv_fwd(var_ctx* c, hipStream_t s, const ConvDims& d, const void* x,
     ConvFwdP<G, U8, SEQ> p{};
     p.M = d.B * d.HO * d.WO; p.N = d.COUT; p.K = d.CIN * G::KHW; p.nsplit = 1;
     p.d = d; p.x = x; p.w = w; p.bias = bias; p.y = y;
-    return gg_launch(c, s, p);
+    return gg(c, s, p);
 }
 template <class G, bool SEQ>
 static int conv_dgrad(var_ctx* c, hipStream_t s, const ConvDims& d, const float* gy, const float* w, float* dx,
@@ -287,13 +298,13 @@ static int conv_dgrad(var_ctx* c, hipStream_t s, const ConvDims& d, const float*
         p.inv_h2w2 = 1.f / (float)(p.H2 * p.W2); p.inv_w2 = 1.f / (float)p.W2;
         p.M = d.B * p.H2 * p.W2; p.N = d.CIN; p.K = d.COUT * ConvDgradS2P<G, SEQ>::NKY * ConvDgradS2P<G, SEQ>::NKX; p.nsplit = 1;
         p.d = d; p.gy = gy; p.w = w; p.dx = dx; p.mask = mask;
-        return gg_launch(c, s, p, 4);
+        return gg(c, s, p, 4);
     } else {
         static_assert(!SEQ, "sequence layout only on the stride-2 sound layer");
         ConvDgradP<G> p{};
         p.M = d.B * d.H * d.W; p.N = d.CIN; p.K = d.COUT * G::KHW; p.nsplit = 1;
         p.d = d; p.gy = gy; p.w = w; p.dx = dx; p.mask = mask;
-        return gg_launch(c, s, p);
+        return gg(c, s, p);
     }
 }
 static constexpr long kSlabFloats = 24L << 20;        // split-K slabs (96 MB)
@@ -336,7 +347,7 @@ static int conv_wgrad(var_ctx* c, hipStream_t s, const ConvDims& d, const void* 
     if ((long)ns * p.M * p.N > kSlabFloats) ns = (int)(kSlabFloats / ((long)p.M * p.N));
     p.nsplit = eff_split(p.K, ns, KC);
     p.d = d; p.x = x; p.gy = gy; p.dw = dw; p.slab = ith(c)->slab;
-    int r = gg_launch<ConvWgradP<G, U8, SEQ>, KC>(c, s, p);
+    int r = gg<KC>(c, s, p);
     if (r != VAR_OK) return r;
     if (p.nsplit > 1) return slab_reduce(c, s, dw, p.slab, p.M * p.N, p.nsplit, (long)p.M * p.N);
     return VAR_OK;
@@ -366,7 +377,7 @@ static int linear_fwd(var_ctx* c, hipStream_t s, const float* X, const float* W,
     DenseP<true, true, 0> p{};
     p.M = O; p.N = rows; p.K = K; p.nsplit = 1;
     p.A = W; p.sam = K; p.sak = 1; p.Bm = X; p.sbk = 1; p.sbn = K; p.C = Y; p.scm = 1; p.scn = O; p.bias = b; p.relu = relu;
-    return gg_launch(c, s, p);
+    return gg(c, s, p);
 }
 // backward of that layer from dY (already masked by the layer's own ReLU): dW += dY^T X, db += colsum(dY), dX = dY W
 static int linear_bwd(var_ctx* c, hipStream_t s, const float* X, const float* W, const float* dY, float* dW, float* db,
@@ -375,14 +386,14 @@ static int linear_bwd(var_ctx* c, hipStream_t s, const float* X, const float* W,
         DenseP<false, false, 0> p{};
         p.M = K; p.N = O; p.K = rows; p.nsplit = 1;
         p.A = X; p.sam = 1; p.sak = K; p.Bm = dY; p.sbk = O; p.sbn = 1; p.C = dW; p.scm = 1; p.scn = K;
-        int r = gg_launch(c, s, p); if (r) return r;
+        int r = gg(c, s, p); if (r) return r;
     }
     int r = chan_sum(c, s, dY, db, rows, O, 1); if (r) return r;
     if (dX) {
         DenseP<false, true, 0> p{};
         p.M = K; p.N = rows; p.K = O; p.nsplit = 1;
         p.A = W; p.sam = 1; p.sak = K; p.Bm = dY; p.sbk = 1; p.sbn = O; p.C = dX; p.scm = 1; p.scn = K;
-        r = gg_launch(c, s, p); if (r) return r;
+        r = gg(c, s, p); if (r) return r;
     }
     return VAR_OK;
 }
@@ -462,7 +473,7 @@ static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* imag
             p.A = P + L.w_ih[0]; p.sam = kGin; p.sak = 1; p.zA = dirP;
             p.Bm = st->s[3]; p.sbk = 1; p.sbn = kGin; p.zB = 0;
             p.C = st->GI; p.scm = 1; p.scn = kG3; p.zC = dirGI; p.bias = P + L.b_ih[0]; p.zbias = dirP;
-            RUN(gg_launch(c, s, p, 2));
+            RUN(gg(c, s, p, 2));
         }
         for (int d = 0; d < 2; ++d) VAR_HIP_CHECK(c, hipMemsetAsync(st->Hb + d * dirH, 0, sizeof(float) * nclips * kGh, s));
         for (int step = 0; step < kSeq; ++step) {
@@ -473,7 +484,7 @@ static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* imag
             p.Bm = st->Hb + (long)step * nclips * kGh; p.sbk = 1; p.sbn = kGh; p.zB = dirH;
             p.C = st->GH; p.scm = 1; p.scn = kG3; p.zC = (long)nclips * kG3; p.sC = 2L * nclips * kG3;
             p.nsplit = rec_split(12 * ((nclips + 63) / 64) * 2, kGh / GG_KC, 4);
-            RUN(gg_launch(c, s, p, 2));
+            RUN(gg(c, s, p, 2));
             hipLaunchKernelGGL(gru_gate_fwd_kernel, dim3((nclips * kGh + 255) / 256, 2), dim3(256), 0, s, st->GI, st->GH, p.nsplit,
                                st->Hb + (long)step * nclips * kGh, st->Hb + (long)(step + 1) * nclips * kGh, st->R, st->Z,
                                st->Nn, st->GHN, P + L.b_hh[0], dirP, nclips, step, dirGI, dirH, dirS, save ? 1 : 0);
@@ -569,7 +580,7 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             p.A = P + L.w_hh[0]; p.sam = 1; p.sak = kGh; p.zA = dirP;
             p.Bm = st->DGH + (long)step * nclips * kG3; p.sbk = 1; p.sbn = kG3; p.zB = dirDGH;
             p.C = st->DHP; p.scm = 1; p.scn = kGh; p.zC = (long)nclips * kGh; p.sC = 2L * nclips * kGh;
-            RUN(gg_launch(c, s, p, 2));
+            RUN(gg(c, s, p, 2));
         }
         {   // dW_hh[dir][g][j] = sum_{step,clip} DGH[dir][step,clip][g] * h_prev[dir][step,clip][j]
             DenseP<false, false, 2> p{};
@@ -579,7 +590,7 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             p.A = st->Hb; p.sam = 1; p.sak = kGh; p.zA = dirH;
             p.Bm = st->DGH; p.sbk = kG3; p.sbn = 1; p.zB = dirDGH;
             p.C = st->slab; p.scm = 1; p.scn = kGh; p.zC = one; p.sC = 2 * one;
-            RUN(gg_launch(c, s, p, 2));
+            RUN(gg(c, s, p, 2));
             for (int d = 0; d < 2; ++d) RUN(slab_reduce(c, s, G + L.w_hh[d], st->slab + d * one, (int)one, p.nsplit, 2 * one));
             // dW_ih[dir][g][i] = sum_{clip,t} DGI[dir][clip,t][g] * X[clip,t][i]
             const long onei = (long)kG3 * kGin;
@@ -587,7 +598,7 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             p.A = st->s[3]; p.sam = 1; p.sak = kGin; p.zA = 0;
             p.Bm = st->DGI; p.sbk = kG3; p.sbn = 1; p.zB = dirGI;
             p.C = st->slab; p.scm = 1; p.scn = kGin; p.zC = onei; p.sC = 2 * onei;
-            RUN(gg_launch(c, s, p, 2));
+            RUN(gg(c, s, p, 2));
             for (int d = 0; d < 2; ++d) RUN(slab_reduce(c, s, G + L.w_ih[d], st->slab + d * onei, (int)onei, p.nsplit, 2 * onei));
         }
         for (int d = 0; d < 2; ++d) {
@@ -599,12 +610,12 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             p.M = kGin; p.N = rows; p.K = kG3; p.nsplit = 1;
             p.A = P + L.w_ih[0]; p.sam = 1; p.sak = kGin; p.Bm = st->DGI; p.sbk = 1; p.sbn = kG3;
             p.C = st->gs[3]; p.scm = 1; p.scn = kGin;
-            RUN(gg_launch(c, s, p));
+            RUN(gg(c, s, p));
             DenseP<false, true, 1> q{};
             q.M = kGin; q.N = rows; q.K = kG3; q.nsplit = 1;
             q.A = P + L.w_ih[1]; q.sam = 1; q.sak = kGin; q.Bm = st->DGI + dirGI; q.sbk = 1; q.sbn = kG3;
             q.C = st->gs[3]; q.scm = 1; q.scn = kGin;
-            RUN(gg_launch(c, s, q));
+            RUN(gg(c, s, q));
         }
         RUN(relu_mask(c, s, st->gs[3], st->s[3], (long)rows * kGin));
         {
@@ -716,6 +727,15 @@ static int copy_out(var_ctx* c, hipStream_t s, const float* src, float* dst, lon
     hipLaunchKernelGGL(copy_rows_kernel, g1(n), dim3(256), 0, s, src, dst, n);
     IT_CHECK(c);
     return VAR_OK;
+}
+
+int var_ithor_set_bf16(var_ctx* c, int on) {
+    CHECK_CTX(c);
+    ithor_state* st = ith(c);
+    if (!st) { VAR_SET_ERR(c, "var_ithor_set_bf16: var_ithor_plan first"); return VAR_ERR_PLAN; }
+    const int old = st->bf16 ? 1 : 0;
+    if (on >= 0) st->bf16 = on != 0;
+    return old;
 }
 
 int var_ithor_encoder_fwd(var_ctx* c, void* stream, const float* params, const void* image, int image_is_u8,

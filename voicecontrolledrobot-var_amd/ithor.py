@@ -88,6 +88,7 @@ class IthorVARPretextNet(nn.Module):
         self._flat = None
         self._gflat = None
         self._plan = 0
+        self._bf16 = False
         self._flatten_params()
 
     @staticmethod
@@ -141,6 +142,16 @@ class IthorVARPretextNet(nn.Module):
         if self._plan == 0 or self._plan[1] != key[1] or self._plan[0] < batch:
             c.check(c.lib.var_ithor_plan(c.handle, int(batch), int(key[1])), "var_ithor_plan")
             self._plan = key
+        if c.lib.var_ithor_set_bf16(c.handle, -1) != int(self._bf16):     # the plan is per context, the choice per model
+            c.lib.var_ithor_set_bf16(c.handle, int(self._bf16))
+
+    def set_precision(self, name):
+        """'fp32' (default, the parity path) or 'bf16': bf16 operands with fp32 accumulation in every product
+        (BASELINE config 4's stated precision); parameters, activations, gradients and Adam state stay fp32."""
+        if name not in ("fp32", "bf16"):
+            raise VarHipError("precision is 'fp32' or 'bf16'")
+        self._bf16 = name == "bf16"
+        return self
 
     def forward(self, image, sound_positive, sound_negative, is_train=False):
         flat = self.flat_parameters()
