@@ -191,7 +191,7 @@ def main_ithor(args, rank, local_rank, world, dev):
             out["roofline"] = roof
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = ithor_cpu_baseline()
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
@@ -235,6 +235,27 @@ def pmc_traffic(tag_name, hw):
     return None
 
 
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+    """Keep stdout for the ONE JSON line: RCCL prints a banner (ROCm version / hostname / library path) to fd 1 when a
+    communicator comes up, so fd 1 is pointed at stderr for the run and the result is written to the saved descriptor."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        print(line, flush=True)
+    else:
+        os.write(_REAL_STDOUT, (line + "\n").encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -250,6 +271,7 @@ def main():
                     help="kuka = BASELINE.json's metric (default); ithor = the reference's second pretext model")
     args = ap.parse_args()
 
+    quiet_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -395,7 +417,7 @@ def main():
                                "flops_per_launch": flops}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
