@@ -276,6 +276,72 @@ class IthorTrainer:
         self.adam()
         return self.loss
 
+    def set_lr(self, lr):
+        self.lr = lr
+        if getattr(self, "_g_lr", None) is not None:
+            self._g_lr.fill_(float(lr))
+
+    def capture_step(self, image, pcm, lens, global_batch=None):
+        """Capture step_from_pcm over STATIC CUDA tensors (image u8|f32 (B,3,H,H), pcm int16 (2B,n), lens int32 (2B)) into
+        a HIP graph and return replay(): the step's ~700 launches (2 x 73 dependent recurrent products and gate kernels
+        in each direction of time) then cost one graph launch.  The caller refreshes the static tensors in place between
+        replays (e.g. TripletPool.gather(..., out_img=, out_pcm=, out_len=)).  Step count and learning rate live on the
+        device (var_adam_step_dev; set_lr updates the latter).  Under data parallelism the all-reduce stays eager
+        between two graphs."""
+        m, c = self.model, self.ctx
+        flat = m.flat_parameters()
+        B = image.shape[0]
+        for t in (image, pcm, lens):
+            if not (t.is_cuda and t.is_contiguous()):
+                raise VarHipError("capture_step needs contiguous CUDA tensors")
+        if pcm.dtype != torch.int16 or lens.dtype != torch.int32 or image.dtype not in (torch.uint8, torch.float32):
+            raise VarHipError("capture_step: image u8|f32, pcm int16, lens int32")
+        frames = m.config.sound_dim[1]
+        self.step_from_pcm(image, pcm, lens, global_batch)          # eager once: workspace plan, front-end tables
+        self._g_feats = torch.empty((2 * B, 1, frames, 40), dtype=torch.float32, device=self.dev)
+        self._g_lr = torch.full((1,), float(self.lr), dtype=torch.float32, device=self.dev)
+        self._g_step = torch.full((1,), int(self.step_count), dtype=torch.int32, device=self.dev)
+        gb = B * self.world if global_batch is None else global_batch
+        feats = self._g_feats
+
+        def body_grad():
+            s = current_stream_handle()
+            c.check(c.lib.var_mfcc_psf(c.handle, s, ptr(pcm), ptr(lens), None, 2 * B, pcm.shape[1], frames, ptr(feats)),
+                    "var_mfcc_psf")
+            c.check(c.lib.var_ithor_loss_grad(c.handle, s, ptr(flat), ptr(image), int(image.dtype == torch.uint8),
+                                              image.stride(0), ptr(feats[:B]), ptr(feats[B:]), B, m.config.img_dim[1],
+                                              float(self.margin), 1.0 / gb, ptr(self.gbuf),
+                                              self.gbuf.data_ptr() + 4 * self.n, None), "var_ithor_loss_grad")
+
+        def body_adam():
+            c.check(c.lib.var_adam_step_dev(c.handle, current_stream_handle(), ptr(flat), ptr(self.gbuf), ptr(self.exp_avg),
+                                            ptr(self.exp_avg_sq), self.n, ptr(self._g_lr), float(self.betas[0]),
+                                            float(self.betas[1]), float(self.eps), float(self.wd), ptr(self._g_step)),
+                    "var_adam_step_dev")
+
+        collective = self.world > 1 or getattr(self, "rccl", None) is not None
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream())
+        graphs = []
+        with torch.cuda.stream(side):
+            for bodies in ((body_grad,), (body_adam,)) if collective else ((body_grad, body_adam),):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    for b in bodies:
+                        b()
+                graphs.append(g)
+        torch.cuda.current_stream().wait_stream(side)
+        self._keep = (image, pcm, lens, graphs)
+
+        def replay():
+            graphs[0].replay()
+            if collective:
+                self.allreduce()
+                graphs[1].replay()
+            self.step_count += 1
+            return self.loss
+        return replay
+
     def step_from_pcm(self, image, pcm, lens, global_batch=None):
         """The step with the data-loader's audio work folded in (dataset.py:64-89 + Envs/audioLoader.py:158-161,
         241-252): pcm int16 (2B, n) = [pos | neg] clips resident in HBM (e.g. TripletPool.gather), lens (2B) valid
