@@ -273,6 +273,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="ithor workload only: operand precision of the products (bf16 = BASELINE config 4's; accumulation fp32)")
+    ap.add_argument("--head", choices=("triplet", "inbatch"), default="triplet",
+                    help="kuka workload: the reference's triplet loss (default, BASELINE's metric) or the in-batch-negatives "
+                         "contrastive head of configs[2] (extension; eager launches, MFCC features precomputed)")
     ap.add_argument("--workload", choices=("kuka", "ithor"), default="kuka",
                     help="kuka = BASELINE.json's metric (default); ithor = the reference's second pretext model")
     args = ap.parse_args()
@@ -307,7 +310,9 @@ def main():
     ctx = Context.get(local_rank)
     ctx.ensure_plan(B, HW)
 
-    use_graph = not args.no_graph and not os.environ.get("VAR_SERIAL")
+    use_graph = not args.no_graph and not os.environ.get("VAR_SERIAL") and args.head == "triplet"
+    if args.head == "inbatch":
+        args.no_roofline = True
     state = {"tab": None, "row": 0}
 
     def next_row():
@@ -319,6 +324,10 @@ def main():
 
     def eager_step():
         r = next_row()
+        if args.head == "inbatch":
+            feats = var_amd.mfcc(pool.clips, r[3 * B:], out_frames=100, clip_index=r[B:3 * B])
+            tr.step_inbatch(pool.images[r[:B].long()], feats[:B], feats[B:], tau=0.1)
+            return
         tr.step_from_dataset(pool.images, r[:B], pool.clips, r[B:3 * B], r[3 * B:], global_batch=B * world)
 
     step = eager_step
@@ -407,6 +416,7 @@ def main():
             "mfma_frac_whole_step": round(value / world * FLOPS_PER_TRIPLET / 1e12 / F32_MFMA_PEAK, 4),
         }
         out["config"]["launch"] = "hip-graph replay" if use_graph else "eager"
+        out["config"]["head"] = args.head
         if dom_tag is not None and roof_n and iso_n:
             # `achieved` is priced on the kernel's own duration (HIP events around it with every launch of the step
             # on one stream): that is what the committed rocprofv3 summary averages to as well.  With the sound CNN

@@ -192,6 +192,18 @@ int var_ithor_loss_grad(var_ctx* ctx, void* stream, const float* params,
                         float margin, float inv_count,
                         float* grads, float* loss_out, float* feats_out);
 
+/* In-batch-negatives contrastive head (BASELINE.json configs[2]; an EXTENSION without a reference counterpart --
+ * the reference trains with the explicit-negative triplet loss above).  anchor (B,3) = the local image embeddings,
+ * cand (M,3) = the candidate sound embeddings of the GLOBAL batch (every rank's [positives ; negatives],
+ * var_allgather_emb), target[i] = column of sample i's positive.
+ *   L = inv_count * sum_i [ logsumexp_j(-d_ij / tau) + d_{i,target[i]} / tau ],  d_ij = ||a_i - c_j + 1e-6||_2
+ * loss_out[0] = this rank's share of L; g_anchor (B,3) = dL/da; g_cand (M,3) = the gradient wrt every candidate from
+ * this rank's rows (sum over the ranks -- var_allreduce_grads on it -- and keep your own rows).  scratch: 2*B floats.
+ * One wavefront per row / per candidate, wave-shuffle softmax, no atomics. */
+int var_inbatch_loss_fwd_bwd(var_ctx* ctx, void* stream, const float* anchor, const float* cand, const int* target,
+                             int B, int M, float tau, float inv_count, float* scratch, float* loss_out,
+                             float* g_anchor, float* g_cand);
+
 /* Collectives ----------------------------------------------------------------------------------
  * For hosts without torch.distributed: one RCCL communicator per context.  Rank 0 obtains a 128-byte unique id
  * (var_comm_unique_id), the host ships it to the other ranks over its own channel, every rank calls var_comm_init.

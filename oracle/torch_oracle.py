@@ -193,3 +193,13 @@ def armnet_seeded(seed=453):
     m = ArmNetCPU()
     m.eval()
     return m
+
+
+# ---- in-batch-negatives contrastive head (extension; csrc/inbatch.hip) ---------------------------------------------
+def inbatch_contrastive_loss(anchor, cand, target, tau=0.1, inv_count=None):
+    """sum_i [logsumexp_j(-d_ij/tau) + d_{i,target[i]}/tau] * inv_count with d_ij = ||a_i - c_j + 1e-6||_2
+    (torch.nn.functional.pairwise_distance, the convention TripletMarginLoss uses); inv_count = 1/B by default, i.e.
+    cross-entropy over negative distances."""
+    d = F.pairwise_distance(anchor[:, None, :], cand[None, :, :], p=2, eps=1e-6)
+    loss = F.cross_entropy(-d / tau, target, reduction="sum")
+    return loss * (1.0 / anchor.shape[0] if inv_count is None else inv_count)

@@ -98,3 +98,55 @@ def test_ithor_two_rank_allreduce_equals_reference_full_batch(golden_dir):
         g = got[o:o + p.numel()]
         o += p.numel()
         np.testing.assert_allclose(g[::stride], fx["gsamp." + k], rtol=1e-4, atol=1e-7, err_msg=k)
+
+
+def _inbatch_worker(rank, world, port, out):
+    """The data-parallel schedule of VARTrainer.step_inbatch on gloo/CPU with the torch restatement of the loss:
+    all-gather of [pos ; neg], local rows vs all candidates, all-reduce of the candidate gradients, own slice."""
+    from oracle.torch_oracle import inbatch_contrastive_loss
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(100)
+    Bl = 5
+    emb = torch.nn.functional.normalize(torch.randn(world, 3, Bl, 3, generator=g), dim=-1)    # every rank's [a | p | n]
+    a = emb[rank, 0].clone().requires_grad_()
+    local = emb[rank, 1:].reshape(2 * Bl, 3).clone()
+    parts = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(parts, local)
+    cand = torch.cat(parts).requires_grad_()
+    target = torch.arange(Bl) + rank * 2 * Bl
+    loss = inbatch_contrastive_loss(a, cand, target, tau=0.1, inv_count=1.0 / (Bl * world))
+    loss.backward()
+    gc = cand.grad.clone()
+    dist.all_reduce(gc, op=dist.ReduceOp.SUM)
+    lsum = loss.detach().clone().reshape(1)
+    dist.all_reduce(lsum, op=dist.ReduceOp.SUM)
+    out.put((rank, lsum.item(), a.grad.numpy().copy(), gc[rank * 2 * Bl:(rank + 1) * 2 * Bl].numpy().copy()))
+    dist.destroy_process_group()
+
+
+def test_inbatch_negatives_two_rank_schedule_equals_full_batch():
+    from oracle.torch_oracle import inbatch_contrastive_loss
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_inbatch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(2)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(100)
+    Bl, world = 5, 2
+    emb = torch.nn.functional.normalize(torch.randn(world, 3, Bl, 3, generator=g), dim=-1)
+    a = emb[:, 0].reshape(world * Bl, 3).clone().requires_grad_()
+    cand = emb[:, 1:].reshape(world * 2 * Bl, 3).clone().requires_grad_()          # [p0 ; n0 ; p1 ; n1]
+    target = torch.cat([torch.arange(Bl) + r * 2 * Bl for r in range(world)])
+    full = inbatch_contrastive_loss(a, cand, target, tau=0.1)
+    full.backward()
+    for r, lsum, ga, gmine in got:
+        assert abs(lsum - full.item()) < 1e-6
+        np.testing.assert_allclose(ga, a.grad[r * Bl:(r + 1) * Bl].numpy(), atol=1e-6)
+        np.testing.assert_allclose(gmine, cand.grad[r * 2 * Bl:(r + 1) * 2 * Bl].numpy(), atol=1e-6)

@@ -399,3 +399,45 @@ def test_rccl_collectives_through_the_c_abi(var_amd, golden_dir):
     comm.destroy()
     with pytest.raises(var_amd.VarHipError):
         comm.allreduce(x)
+
+
+def test_inbatch_contrastive_head_vs_oracle(var_amd, golden_dir):
+    """The in-batch-negatives extension (csrc/inbatch.hip): loss and both gradients against the torch restatement;
+    row partition = the data-parallel convention (partial candidate gradients add up); and the whole training step
+    with that head against torch autograd through the CPU network."""
+    from oracle.torch_oracle import KukaNetCPU, inbatch_contrastive_loss as ref_loss
+    rng = np.random.default_rng(4)
+    B, M = 37, 2 * 37 + 21
+    unit = lambda x: (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+    a, cand = unit(rng.standard_normal((B, 3))), unit(rng.standard_normal((M, 3)))
+    target = rng.permutation(M)[:B].astype(np.int32)
+    loss, ga, gc = var_amd.inbatch_contrastive_loss(cuda(a), cuda(cand), cuda(target), tau=0.1)
+    ta, tc = torch.from_numpy(a).requires_grad_(), torch.from_numpy(cand).requires_grad_()
+    rl = ref_loss(ta, tc, torch.from_numpy(target).long(), tau=0.1)
+    rl.backward()
+    assert abs(loss.item() - rl.item()) < 1e-5 * max(1.0, abs(rl.item()))
+    np.testing.assert_allclose(ga.cpu().numpy(), ta.grad.numpy(), atol=2e-6, rtol=1e-4)
+    np.testing.assert_allclose(gc.cpu().numpy(), tc.grad.numpy(), atol=2e-6, rtol=1e-4)
+    # two "ranks" = two row blocks over the same candidates, inv_count = 1/B_global
+    parts = [var_amd.inbatch_contrastive_loss(cuda(a[sl]), cuda(cand), cuda(target[sl]), tau=0.1, inv_count=1.0 / B)
+             for sl in (slice(0, 20), slice(20, B))]
+    assert abs(parts[0][0].item() + parts[1][0].item() - loss.item()) < 1e-5
+    np.testing.assert_allclose((parts[0][2] + parts[1][2]).cpu().numpy(), gc.cpu().numpy(), atol=2e-6)
+    np.testing.assert_allclose(torch.cat([parts[0][1], parts[1][1]]).cpu().numpy(), ga.cpu().numpy(), atol=1e-6)
+    # full step: gradients of every parameter through the HIP encoder backward vs torch autograd on the CPU network
+    sd = load(golden_dir, "kuka_weights2.npz")
+    fx = load(golden_dir, "kuka_h84_w2.npz")
+    m = make_model(var_amd, sd, 84)
+    tr = var_amd.VARTrainer(m, lr=0.0)                                    # lr 0: the step leaves the gradients to read
+    tr.step_inbatch(cuda(fx['image']), cuda(fx['sound_positive']), cuda(fx['sound_negative']), tau=0.1)
+    ref = KukaNetCPU()
+    ref.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    n = fx['image'].shape[0]
+    ia, ip, in_ = ref((torch.from_numpy(fx['image']) / 255.).float(), torch.from_numpy(fx['sound_positive']),
+                      torch.from_numpy(fx['sound_negative']))
+    l = ref_loss(ia, torch.cat([ip, in_]), torch.arange(n), tau=0.1)
+    l.backward()
+    assert abs(tr.loss.item() - l.item()) < 1e-4
+    got = tr.grads.cpu().numpy()
+    want = np.concatenate([p.grad.numpy().reshape(-1) for p in ref.parameters()])
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) < 2e-3

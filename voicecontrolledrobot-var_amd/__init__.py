@@ -15,5 +15,5 @@ from .actor_critic import ArmNetPolicy  # noqa: F401
 from .comm import RcclComm  # noqa: F401
 from .trainer import VARTrainer, train_representation, multistep_lr  # noqa: F401
 from .data import SyntheticTripletPool, TripletPool, choose_negative_id, load_wav_clips, process_sound_feat  # noqa: F401
-from .ops import mfcc, mfcc_psf, triplet_margin_loss  # noqa: F401
+from .ops import inbatch_contrastive_loss, mfcc, mfcc_psf, triplet_margin_loss  # noqa: F401
 from .reward import IntrinsicReward, ReturnNormalizer, RunningMeanStd  # noqa: F401

@@ -48,6 +48,7 @@ _SIGNATURES = {
     "var_mfcc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "var_arm_loss_grad_pcm": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
     "var_arm_loss_grad_gather": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
+    "var_inbatch_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),
     "var_comm_unique_id": (_i, [_vp, _vp]),
     "var_comm_init": (_i, [_vp, _i, _i, _vp]),
     "var_comm_destroy": (_i, [_vp]),

@@ -67,3 +67,21 @@ def mfcc_psf(pcm, lens=None, out_frames=600, clip_index=None):
     ctx.check(ctx.lib.var_mfcc_psf(ctx.handle, current_stream_handle(), ptr(pcm), ptr(lens), ptr(clip_index), n, stride,
                                    int(out_frames), ptr(out)), "var_mfcc_psf")
     return out
+
+
+def inbatch_contrastive_loss(anchor, cand, target, tau=0.1, inv_count=None):
+    """In-batch-negatives contrastive head (csrc/inbatch.hip; an extension of the reference's triplet loss, BASELINE
+    config 3): anchor (B,3), cand (M,3) = every candidate sound embedding of the global batch, target (B) int32 =
+    column of each sample's positive.  Returns (loss[1], g_anchor (B,3), g_cand (M,3)); g_cand is this rank's partial."""
+    _require_cuda(anchor, cand, target)
+    a, cnd = anchor.contiguous().float(), cand.contiguous().float()
+    t = target.to(torch.int32).contiguous()
+    B, M = a.shape[0], cnd.shape[0]
+    ctx = Context.get(a.device.index)
+    loss = torch.empty(1, dtype=torch.float32, device=a.device)
+    ga, gc = torch.empty_like(a), torch.empty_like(cnd)
+    scratch = torch.empty(2 * B, dtype=torch.float32, device=a.device)
+    ctx.check(ctx.lib.var_inbatch_loss_fwd_bwd(ctx.handle, current_stream_handle(), ptr(a), ptr(cnd), ptr(t), B, M, float(tau),
+                                               float(1.0 / B if inv_count is None else inv_count), ptr(scratch), ptr(loss),
+                                               ptr(ga), ptr(gc)), "var_inbatch_loss_fwd_bwd")
+    return loss, ga, gc

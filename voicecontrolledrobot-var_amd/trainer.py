@@ -301,6 +301,48 @@ class VARTrainer:
         self.adam()
         return self.loss
 
+    def step_inbatch(self, image, pos, neg, tau=0.1):
+        """One optimisation step with the in-batch-negatives contrastive head instead of the triplet loss (BASELINE
+        config 3; an extension, csrc/inbatch.hip): every rank's [positive ; negative] sound embeddings are all-gathered
+        (9 KB per rank at B = 256), each rank scores its images against all of them, the candidate gradients are summed
+        with one small all-reduce and each rank back-propagates its own rows; then the usual gradient all-reduce + Adam.
+        Collectives go through torch.distributed, or through the C ABI when use_rccl() was called."""
+        from .ops import inbatch_contrastive_loss
+        self._check(image, pos, neg)
+        c, m = self.ctx, self.model
+        flat = m.flat_parameters()
+        B = image.shape[0]
+        c.ensure_plan(B, self.hw)
+        dev = self.dev
+        rccl = getattr(self, "rccl", None)
+        rank = rccl.rank if rccl is not None else (torch.distributed.get_rank(self.pg) if self.world > 1 else 0)
+        stream = current_stream_handle()
+        emb = torch.empty((3, B, 3), dtype=torch.float32, device=dev)          # [image | pos | neg]
+        c.check(c.lib.var_arm_encoder_fwd(c.handle, stream, ptr(flat), ptr(image), int(image.dtype == torch.uint8),
+                                          image.stride(0), ptr(pos), ptr(neg), B, self.hw, ptr(emb[0]), ptr(emb[1]), ptr(emb[2]),
+                                          None, None, 1), "var_arm_encoder_fwd")
+        local = emb[1:].reshape(2 * B, 3)
+        if rccl is not None and self.world > 1:
+            cand = rccl.allgather(local.reshape(-1)).view(-1, 3)
+        elif self.world > 1:
+            cand = torch.empty((self.world * 2 * B, 3), dtype=torch.float32, device=dev)
+            torch.distributed.all_gather_into_tensor(cand, local.contiguous(), group=self.pg)
+        else:
+            cand = local
+        target = torch.arange(B, dtype=torch.int32, device=dev) + rank * 2 * B
+        loss, ga, gc = inbatch_contrastive_loss(emb[0], cand, target, tau=tau, inv_count=1.0 / (B * self.world))
+        if rccl is not None and self.world > 1:
+            rccl.allreduce(gc.view(-1))
+        elif self.world > 1:
+            torch.distributed.all_reduce(gc, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        mine = gc[rank * 2 * B:(rank + 1) * 2 * B]
+        c.check(c.lib.var_arm_encoder_bwd(c.handle, stream, ptr(flat), ptr(ga), ptr(mine[:B].contiguous()),
+                                          ptr(mine[B:].contiguous()), ptr(self.gbuf)), "var_arm_encoder_bwd")
+        self.gbuf[N_PARAMS:].copy_(loss)
+        self.allreduce()
+        self.adam()
+        return self.loss
+
     def step_from_pcm(self, image, pcm, lens, global_batch=None):
         """Same without gathering: image (B,3,H,H), pcm int16 (2B, n) = [pos | neg], lens (2B) (0 = empty)."""
         B = image.shape[0]
