@@ -350,3 +350,28 @@ def test_graph_replayed_step_equals_eager_steps(var_amd, fx):
     assert lr_ == le
     assert torch.equal(rep.flat_parameters(), pe)
     assert tr.step_count == 3
+
+
+def test_c_abi_error_paths(var_amd):
+    """Errors come back as codes + var_last_error text, never as crashes: calls before a plan, NULL arguments, an odd
+    PCM stride, a batch above the plan."""
+    import ctypes
+    from var_amd._lib import Context
+    c = Context.get(0)
+    lib = c.lib
+    x = torch.zeros(16, device="cuda")
+    assert lib.var_ithor_plan(c.handle, 0, 96) < 0 and b"batch" in lib.var_last_error(c.handle)
+    assert lib.var_ithor_plan(c.handle, 2, 64) < 0 and b"3x3" in lib.var_last_error(c.handle)
+    assert lib.var_ithor_plan(c.handle, 2, 96) == 0
+    rc = lib.var_ithor_loss_grad(c.handle, None, x.data_ptr(), None, 1, 0, None, None, 2, 96, 1.0, 0.5, x.data_ptr(), None, None)
+    assert rc < 0 and b"required" in lib.var_last_error(c.handle)
+    rc = lib.var_ithor_encoder_fwd(c.handle, None, x.data_ptr(), None, 0, 0, None, None, 3, 96, None, None, None, None, None, 0)
+    assert rc < 0 and b"var_ithor_plan" in lib.var_last_error(c.handle)          # batch 3 > planned 2
+    rc = lib.var_mfcc_psf(c.handle, None, x.data_ptr(), x.data_ptr(), None, 1, 15, 10, x.data_ptr())
+    assert rc < 0 and b"even" in lib.var_last_error(c.handle)
+    rc = lib.var_inbatch_loss_fwd_bwd(c.handle, None, x.data_ptr(), x.data_ptr(), x.data_ptr(), 1, 1, ctypes.c_float(0.0),
+                                      ctypes.c_float(1.0), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr())
+    assert rc < 0
+    rc = lib.var_armnet_forward(c.handle, None, x.data_ptr(), x.data_ptr(), 0, 0, x.data_ptr(), x.data_ptr(), x.data_ptr(),
+                                x.data_ptr(), x.data_ptr(), 100000, x.data_ptr(), x.data_ptr(), None, x.data_ptr())
+    assert rc < 0 and b"var_armnet_plan" in lib.var_last_error(c.handle)

@@ -138,10 +138,9 @@ class IthorVARPretextNet(nn.Module):
         return r
 
     def _ensure_plan(self, c, batch):
-        key = (batch, self.config.img_dim[1])
-        if self._plan == 0 or self._plan[1] != key[1] or self._plan[0] < batch:
-            c.check(c.lib.var_ithor_plan(c.handle, int(batch), int(key[1])), "var_ithor_plan")
-            self._plan = key
+        # the workspace belongs to the context, not to this module: ask every time (a no-op when it already fits; another
+        # model with a different image size may have re-planned the context in between)
+        c.check(c.lib.var_ithor_plan(c.handle, int(batch), int(self.config.img_dim[1])), "var_ithor_plan")
         if c.lib.var_ithor_set_bf16(c.handle, -1) != int(self._bf16):     # the plan is per context, the choice per model
             c.lib.var_ithor_set_bf16(c.handle, int(self._bf16))
 
