@@ -365,8 +365,8 @@ def test_c_abi_error_paths(var_amd):
     assert lib.var_ithor_plan(c.handle, 2, 96) == 0
     rc = lib.var_ithor_loss_grad(c.handle, None, x.data_ptr(), None, 1, 0, None, None, 2, 96, 1.0, 0.5, x.data_ptr(), None, None)
     assert rc < 0 and b"required" in lib.var_last_error(c.handle)
-    rc = lib.var_ithor_encoder_fwd(c.handle, None, x.data_ptr(), None, 0, 0, None, None, 3, 96, None, None, None, None, None, 0)
-    assert rc < 0 and b"var_ithor_plan" in lib.var_last_error(c.handle)          # batch 3 > planned 2
+    rc = lib.var_ithor_encoder_fwd(c.handle, None, x.data_ptr(), None, 0, 0, None, None, 100000, 96, None, None, None, None, None, 0)
+    assert rc < 0 and b"var_ithor_plan" in lib.var_last_error(c.handle)          # batch above any plan: refused before any launch
     rc = lib.var_mfcc_psf(c.handle, None, x.data_ptr(), x.data_ptr(), None, 1, 15, 10, x.data_ptr())
     assert rc < 0 and b"even" in lib.var_last_error(c.handle)
     rc = lib.var_inbatch_loss_fwd_bwd(c.handle, None, x.data_ptr(), x.data_ptr(), x.data_ptr(), 1, 1, ctypes.c_float(0.0),
