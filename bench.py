@@ -273,6 +273,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="ithor workload only: operand precision of the products (bf16 = BASELINE config 4's; accumulation fp32)")
+    ap.add_argument("--hw", type=int, choices=(84, 96), default=84,
+                    help="kuka workload: image side; 84 = BASELINE's metric (default), 96 = the reference's default img_dim "
+                         "(no roofline leg: the FLOP table below is for 84)")
     ap.add_argument("--head", choices=("triplet", "inbatch"), default="triplet",
                     help="kuka workload: the reference's triplet loss (default, BASELINE's metric) or the in-batch-negatives "
                          "contrastive head of configs[2] (extension; eager launches, MFCC features precomputed)")
@@ -301,6 +304,10 @@ def main():
     import var_amd
     from var_amd._lib import Context
 
+    global HW, FLOPS_PER_TRIPLET
+    if args.hw != 84:
+        HW, FLOPS_PER_TRIPLET = args.hw, 70.282e6             # SURVEY.md section 8(d), Kuka @96
+        args.no_roofline = True
     B = args.batch
     cfg = types.SimpleNamespace(img_dim=(3, HW, HW), sound_dim=(1, 100, 40), representationDim=3)
     torch.manual_seed(453)                                     # pretextEnvSeed; identical weights on every rank
@@ -404,12 +411,12 @@ def main():
     if rank == 0:
         value = args.steps * B * world / dt
         out = {
-            "metric": "pretext triplets/sec (84x84 RGB + 16 kHz/1 s audio)",
+            "metric": f"pretext triplets/sec ({HW}x{HW} RGB + 16 kHz/1 s audio)",
             "value": round(value, 1), "unit": "triplets/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Kuka+GoogleCommand pretext step, batch 256 per GPU on MI355X, fp32: "
-                                   "u8 84x84 image + 2 int16 1 s clips per triplet resident in HBM -> MFCC -> "
+                                   f"u8 {HW}x{HW} image + 2 int16 1 s clips per triplet resident in HBM -> MFCC -> "
                                    "fwd + triplet loss + bwd + Adam (BASELINE.json configs[1])",
                        "per_gpu_batch": B, "global_batch": B * world, "image": [3, HW, HW], "audio": "16 kHz x 1 s int16 x 2",
                        "parallelism": f"dp{world}", "final_loss": round(loss, 6)},
