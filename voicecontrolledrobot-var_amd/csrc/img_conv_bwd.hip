@@ -545,7 +545,9 @@ int launch_img_bwd(var_ctx* c, hipStream_t s, hipStream_t sw, hipStream_t sr, co
     const bool fold_each = sr != sw;
     // VAR_NO_PAIR=1 (tuning aid): weight and data gradient of a layer as two launches
     static const bool allow_pair = !getenv("VAR_NO_PAIR");
-    const bool paired = allow_pair && H == 84 && sw == s && !fold_each;
+    const bool paired = allow_pair && sw == s && !fold_each;
+    // 84 x 84: layers 2-4 and the last grid; 96 x 96: layers 3-4 (the 12-wave data-gradient configurations that exist)
+    auto pair_ok = [&](int l) { return paired && (H == 84 ? l >= 2 : l >= 3); };
     for (int l = 4; l >= 0; --l) {
         if (l == 0 && fused_tail) {
             // layer 0's slabs were left by the tail kernel on s
@@ -553,16 +555,21 @@ int launch_img_bwd(var_ctx* c, hipStream_t s, hipStream_t sw, hipStream_t sr, co
             if ((rc = launch_img_wgrad_reduce(c, sr, grads, 0, fold_each ? 0 : 4)) != VAR_OK) return rc;
             break;
         }
-        if (paired && l >= 2) {
+        if (pair_ok(l)) {
             const float* gyl = c->gact[l + 1];
             const float* wdl = c->wpack + K.img_d[l];
-            if (l == 4) rc = launch_pair<W84_4, D84_4, false>(c, s, 4, xin[4], bs[4], gyl, wdl, c->act[4], c->gact[4], B);
-            else if (l == 3) rc = launch_pair<W84_3, G84_3, true>(c, s, 3, xin[3], bs[3], gyl, wdl, c->act[3], c->gact[3], B);
-            else rc = launch_pair<W84_2, D84_2, false>(c, s, 2, xin[2], bs[2], gyl, wdl, c->act[2], c->gact[2], B);
+            if (H == 84) {
+                if (l == 4) rc = launch_pair<W84_4, D84_4, false>(c, s, 4, xin[4], bs[4], gyl, wdl, c->act[4], c->gact[4], B);
+                else if (l == 3) rc = launch_pair<W84_3, G84_3, true>(c, s, 3, xin[3], bs[3], gyl, wdl, c->act[3], c->gact[3], B);
+                else rc = launch_pair<W84_2, D84_2, false>(c, s, 2, xin[2], bs[2], gyl, wdl, c->act[2], c->gact[2], B);
+            } else {
+                if (l == 4) rc = launch_pair<W96_4, D96_4, false>(c, s, 4, xin[4], bs[4], gyl, wdl, c->act[4], c->gact[4], B);
+                else rc = launch_pair<W96_3, G96_3, true>(c, s, 3, xin[3], bs[3], gyl, wdl, c->act[3], c->gact[3], B);
+            }
             if (rc != VAR_OK) return rc;
             continue;
         }
-        if (paired && l == 1 && fused_tail) {
+        if (paired && H == 84 && l == 1 && fused_tail) {
             rc = c->saved_u8 ? launch_last<W84_1, T84u>(c, s, B) : launch_last<W84_1, T84f>(c, s, B);
             if (rc != VAR_OK) return rc;
             continue;                                        // l = 0: the fold below
