@@ -446,6 +446,7 @@ using G84_3 = Dg16Cfg<64, 64, 11, 12>;            // conv 4's data gradient on 1
 using G96_3 = Dg16Cfg<64, 64, 12, 12>;
 using D96_1 = DgCfg<32, 32, 48, 8, 1, 3>;
 using D96_2 = DgCfg<32, 64, 24, 8, 2, 3>;
+using D96_2p = DgCfg<32, 64, 24, 10, 2, 4, 1>;    // 12-wave form for the paired grid: 2 bands of 10 rows, 4 items x 3 slices
 using D96_3 = DgCfg<64, 64, 12, 12, 1, 4, 1>;
 using D96_4 = DgCfg<64, 64, 6, 6, 3, 2, 2>;
 
@@ -546,8 +547,8 @@ int launch_img_bwd(var_ctx* c, hipStream_t s, hipStream_t sw, hipStream_t sr, co
     // VAR_NO_PAIR=1 (tuning aid): weight and data gradient of a layer as two launches
     static const bool allow_pair = !getenv("VAR_NO_PAIR");
     const bool paired = allow_pair && sw == s && !fold_each;
-    // 84 x 84: layers 2-4 and the last grid; 96 x 96: layers 3-4 (the 12-wave data-gradient configurations that exist)
-    auto pair_ok = [&](int l) { return paired && (H == 84 ? l >= 2 : l >= 3); };
+    // layers 2-4 at both sizes; the last grid (wgrad 1 + fused tail) at 84 x 84 only (the 96 tail runs 9 waves)
+    auto pair_ok = [&](int l) { return paired && l >= 2; };
     for (int l = 4; l >= 0; --l) {
         if (l == 0 && fused_tail) {
             // layer 0's slabs were left by the tail kernel on s
@@ -564,7 +565,8 @@ int launch_img_bwd(var_ctx* c, hipStream_t s, hipStream_t sw, hipStream_t sr, co
                 else rc = launch_pair<W84_2, D84_2, false>(c, s, 2, xin[2], bs[2], gyl, wdl, c->act[2], c->gact[2], B);
             } else {
                 if (l == 4) rc = launch_pair<W96_4, D96_4, false>(c, s, 4, xin[4], bs[4], gyl, wdl, c->act[4], c->gact[4], B);
-                else rc = launch_pair<W96_3, G96_3, true>(c, s, 3, xin[3], bs[3], gyl, wdl, c->act[3], c->gact[3], B);
+                else if (l == 3) rc = launch_pair<W96_3, G96_3, true>(c, s, 3, xin[3], bs[3], gyl, wdl, c->act[3], c->gact[3], B);
+                else rc = launch_pair<W96_2, D96_2p, false>(c, s, 2, xin[2], bs[2], gyl, wdl, c->act[2], c->gact[2], B);
             }
             if (rc != VAR_OK) return rc;
             continue;
