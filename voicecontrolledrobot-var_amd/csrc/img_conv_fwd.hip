@@ -279,7 +279,7 @@ int launch_img_fwd(var_ctx* c, hipStream_t s, const float* params, const void* i
     c->head_in_mid = false;
     // VAR_NO_MID=1 (tuning aid): conv 3, 4, 5 as separate kernels
     static const bool fused_mid = !getenv("VAR_NO_MID");
-    if (c->H == 84 && fused_mid) {
+    if (fused_mid) {
         static const bool head_in_mid = !getenv("VAR_NO_MID_HEAD");
         c->head_in_mid = head_in_mid;
         if ((rc = launch_img_fwd_mid(c, s, params, B, head_in_mid)) != VAR_OK) return rc;

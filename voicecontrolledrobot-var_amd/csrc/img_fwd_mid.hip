@@ -22,13 +22,16 @@ struct MidTile {
 
 // One conv layer of the workgroup's image.  xs: input tile (LDS), red: fold scratch (LDS, may alias xs),
 // xo: next layer's input tile (LDS, pre-zeroed pads) or nullptr, y: this image's output planes in HBM.
-template <int CIN, int COUT, int HIN, int NWI, int KY, int KC, int PLANE_O, int PW_O>
+// NPB_: pixel blocks to lay the work out on (0 = just enough for the map); a padded count lets 144-pixel maps
+// (96 x 96 inputs) share the 12-wave plan of the 121-pixel ones, the surplus lanes compute on pixel 0 and store nothing
+template <int CIN, int COUT, int HIN, int NWI, int KY, int KC, int PLANE_O, int PW_O, int NPB_ = 0>
 __device__ __forceinline__ void mid_layer(const float* __restrict__ xs, float* __restrict__ red, float* __restrict__ xo,
                                           const float* __restrict__ wp, const float* __restrict__ bias,
                                           float* __restrict__ y, int tid) {
     using T = MidTile<HIN>;
     constexpr int HO = T::HO, WO = HO, NPIX = HO * WO;
-    constexpr int NPB = (NPIX + 31) / 32, NBLK = COUT / 32, ITEMS = NPB * NBLK, IPW = ITEMS / NWI;
+    constexpr int NPB = NPB_ ? NPB_ : (NPIX + 31) / 32, NBLK = COUT / 32, ITEMS = NPB * NBLK, IPW = ITEMS / NWI;
+    static_assert(NPB * 32 >= NPIX, "the pixel blocks must cover the map");
     constexpr int KS = KY * KC;
     static_assert(NWI * KS == MID_NW && ITEMS % NWI == 0, "12 waves = item groups x K slices, whole items per wave");
     const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
@@ -201,7 +204,9 @@ struct MidCfg {
     // region A: conv-3 input tile, later the conv-3 fold scratch, then the conv-5 input tile (act4)
     // region B: conv-4 input tile (act3), later the fold scratch of conv 4 and conv 5
     static constexpr int X2 = 32 * T2::PLANE, X3 = 64 * T3::PLANE, X4 = 64 * T4::PLANE;
-    static constexpr int RED3 = 2 * 4 * 2 * 1024, RED4 = 2 * 4 * 1 * 1024, RED5 = 5 * 2 * 1 * 1024;
+    // conv 3 on 4 item groups x 3 filter rows: pixel blocks rounded up to a multiple of 2 so that the 8 | 12 items divide
+    static constexpr int NPB3 = ((H3 * H3 + 31) / 32 + 1) / 2 * 2, IPW3 = NPB3 * 2 / 4;
+    static constexpr int RED3 = 2 * 4 * IPW3 * 1024, RED4 = 2 * 4 * 1 * 1024, RED5 = 5 * 2 * 1 * 1024;
     static constexpr int A = ((X2 > RED3 ? X2 : RED3) + 3) & ~3;
     static constexpr int Bsz = ((X3 > RED5 ? X3 : RED5) + 3) & ~3;
     static constexpr int BIA = A + Bsz;                      // biases of the three layers (3 x 64)
@@ -210,6 +215,7 @@ struct MidCfg {
     static constexpr int LDS_FLOATS = HPS + 6 * kHid + kHid;
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
     static_assert(X4 <= A && RED4 <= Bsz, "aliasing plan");
+    static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU: the whole LDS");
 };
 
 template <class C, int H2>
@@ -231,7 +237,7 @@ img_fwd_mid_kernel(const float* __restrict__ x2, const float* __restrict__ w3, c
     lds_zero_cols<MID_NT>(ra, 32 * C::T2::IR, C::T2::PW, H2 + 1, C::T2::PW - H2 - 1, tid);
     stage_x_band<32, H2, H2, C::T2::IR, C::T2::PW, C::T2::PLANE, false, MID_NT>(ra, x2 + (size_t)b * 32 * H2 * H2, -1, true, tid);
     __syncthreads();
-    mid_layer<32, 64, H2, 4, 3, 1, C::T3::PLANE, C::T3::PW>(ra, ra, rb, w3, lds + C::BIA, y3 + (size_t)b * 64 * C::H3 * C::H3, tid);
+    mid_layer<32, 64, H2, 4, 3, 1, C::T3::PLANE, C::T3::PW, C::NPB3>(ra, ra, rb, w3, lds + C::BIA, y3 + (size_t)b * 64 * C::H3 * C::H3, tid);
     // region A is dead (conv 3's fold has been read): it becomes conv 5's input tile
     __syncthreads();
     lds_zero<MID_NT>(ra, (C::X4 + 3) & ~3, tid);
@@ -280,23 +286,28 @@ img_fwd_mid_kernel(const float* __restrict__ x2, const float* __restrict__ w3, c
 }
 }  // namespace
 
-// conv 3 + conv 4 + conv 5 of the image CNN for 84 x 84 inputs (act2 21 x 21); leaves act[3], act[4], act[5] and,
-// with_head, the image head's hidden layer (hid_i) and 128 -> 3 partials (head_part rows [0, B))
-int launch_img_fwd_mid(var_ctx* c, hipStream_t s, const float* params, int B, bool with_head) {
-    using C = MidCfg<21>;
-    ProfScope prof(c, s, TAG_IMG_FWD0 + 2);
+// conv 3 + conv 4 + conv 5 of the image CNN (act2 21 x 21 for 84 x 84 inputs, 24 x 24 for 96 x 96); leaves act[3],
+// act[4], act[5] and, with_head, the image head's hidden layer (hid_i) and 128 -> 3 partials (head_part rows [0, B))
+template <int H2>
+static int launch_mid(var_ctx* c, hipStream_t s, const float* params, int B, bool with_head) {
+    using C = MidCfg<H2>;
     static bool attr_set = false;
     if (!attr_set) {
-        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)img_fwd_mid_kernel<C, 21>,
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)img_fwd_mid_kernel<C, H2>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         attr_set = true;
     }
     const ParamLayout& L = c->pl;
     const PackLayout& K = c->kl;
-    hipLaunchKernelGGL((img_fwd_mid_kernel<C, 21>), dim3(B), dim3(MID_NT), C::LDS_BYTES, s, c->act[2],
+    hipLaunchKernelGGL((img_fwd_mid_kernel<C, H2>), dim3(B), dim3(MID_NT), C::LDS_BYTES, s, c->act[2],
                        c->wpack + K.img_f[2], params + L.img_b[2], c->wpack + K.img_f[3], params + L.img_b[3],
                        c->wpack + K.img_f[4], params + L.img_b[4], c->act[3], c->act[4], c->act[5],
                        with_head ? c->wpack + K.ih_w0t : nullptr, params + L.ih_b0, params + L.ih_w1, c->hid_i, c->head_part);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
+}
+
+int launch_img_fwd_mid(var_ctx* c, hipStream_t s, const float* params, int B, bool with_head) {
+    ProfScope prof(c, s, TAG_IMG_FWD0 + 2);
+    return c->H == 84 ? launch_mid<21>(c, s, params, B, with_head) : launch_mid<24>(c, s, params, B, with_head);
 }
