@@ -186,7 +186,7 @@ def main_ithor(args, rank, local_rank, world, dev):
         out = {"metric": "pretext triplets/sec (iTHOR model: 96x96 RGB + 16 kHz/6 s audio)", "value": round(value, 1),
                "unit": "triplets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "n_ranks_seen": args.n_ranks_seen,
                "config": {"workload": "iTHOR pretext step (BASELINE.json configs[3] shapes), batch per GPU as given: u8 "
                                       "96x96 image + 2 int16 clips of up to 6 s resident in HBM -> python_speech_features "
                                       "MFCC -> fwd + triplet loss + bwd + Adam",
@@ -262,6 +262,22 @@ def emit(line):
         os.write(_REAL_STDOUT, (line + "\n").encode())
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N
+    bench.py <same arguments>` as a CHILD process (this process has not touched the GPU and never will), pass rank
+    0's JSON line through on stdout and exit with the children's return code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    rc = subprocess.call(cmd, env=dict(os.environ, OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4")))
+    raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -281,20 +297,32 @@ def main():
                          "contrastive head of configs[2] (extension; eager launches, MFCC features precomputed)")
     ap.add_argument("--workload", choices=("kuka", "ithor"), default="kuka",
                     help="kuka = BASELINE.json's metric (default); ithor = the reference's second pretext model")
+    ap.add_argument("--pool", type=int, default=4096,
+                    help="kuka workload: triplets in the HBM-resident synthetic pool (16384 = 1.4 GB > the 256 MB Infinity Cache)")
     args = ap.parse_args()
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, as children, BEFORE this process touches
+        # the GPU (a process that has initialised HIP must never exec another program on this pool)
+        return launch_ranks(args.gpus)
 
     quiet_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    n_dev = torch.cuda.device_count()                          # counting devices does not initialise HIP
+    if n_dev < world or local_rank >= n_dev:
+        sys.stderr.write(f"bench.py: --gpus {world} needs {world} visible devices, found {n_dev} "
+                         f"(rank {rank}, local rank {local_rank})\n")
+        raise SystemExit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or "RANK" in os.environ:
         torch.distributed.init_process_group("nccl", device_id=dev)
+    args.n_ranks_seen = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
 
     if args.workload == "ithor":
         if args.steps == 200 and args.warmup == 20:           # the defaults are sized for the 0.37 ms Kuka step
@@ -313,7 +341,7 @@ def main():
     torch.manual_seed(453)                                     # pretextEnvSeed; identical weights on every rank
     model = var_amd.VARPretextNet(cfg).to(dev)
     tr = var_amd.VARTrainer(model, lr=1e-4, weight_decay=1e-6, margin=1.0)
-    pool = var_amd.SyntheticTripletPool(4096, hw=HW, seed=rank, clips_per_class=64, device=dev).freeze_pairs()
+    pool = var_amd.SyntheticTripletPool(args.pool, hw=HW, seed=rank, clips_per_class=64, device=dev).freeze_pairs()
     ctx = Context.get(local_rank)
     ctx.ensure_plan(B, HW)
 
@@ -415,6 +443,7 @@ def main():
             "value": round(value, 1), "unit": "triplets/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "n_ranks_seen": args.n_ranks_seen,
             "config": {"workload": "Kuka+GoogleCommand pretext step, batch 256 per GPU on MI355X, fp32: "
                                    f"u8 {HW}x{HW} image + 2 int16 1 s clips per triplet resident in HBM -> MFCC -> "
                                    "fwd + triplet loss + bwd + Adam (BASELINE.json configs[1])",

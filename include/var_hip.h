@@ -57,9 +57,28 @@ int var_param_count(void);                  /* == VAR_N_PARAMS */
  * allocates; call it outside the step loop / graph capture. */
 int var_plan(var_ctx* ctx, int max_batch, int img_hw);
 
-/* Re-derive the kernel-side weight images (conv filters re-laid as [tap][cin][cout]
- * and [tap][cout][cin]) from the parameter arena.  Must follow every change of the
- * parameters (load_state_dict, optimiser step); var_adam_step does it itself. */
+/* Generation counters.  var_plan_generation: bumped by every re-plan (var_plan / var_ithor_plan growing the
+ * workspace); a superseded workspace stays allocated until var_destroy, so HIP graphs captured against it keep
+ * replaying on valid memory.  var_saved_generation: id (> 0) of the forward whose activations the workspace
+ * currently holds for var_arm_encoder_bwd, 0 = none -- a host that interleaves forwards of several models
+ * (autograd) compares it with the id it noted after its own forward before calling the backward. */
+int var_plan_generation(var_ctx* ctx);
+int var_saved_generation(var_ctx* ctx);
+
+/* Kernel-side weight images, one per MODEL.  The kernels read conv filters re-laid as [tap][cin][cout] and
+ * [tap][cout][cin] ("packed image", 1.2 MB) next to the parameter arena.  A host with several models on one
+ * device -- the reference's RL stage keeps a frozen copy of the encoder beside the policy
+ * (Envs/vec_env/vec_pretext_normalize.py:82-94) -- creates one image per model and binds it before that model's
+ * calls; var_weights_bind(ctx, NULL) selects the context's own default image.  Binding is host state read at
+ * launch time (like hipSetDevice): a captured graph keeps the image that was bound during capture.
+ * var_pack_weights re-derives the BOUND image from `params` and records that arena; it must follow every change
+ * of the parameters made outside this library (load_state_dict); var_adam_step* keep the bound image current by
+ * themselves.  Every var_arm_* entry checks that the bound image was packed from the `params` it is given and
+ * returns VAR_ERR_STATE otherwise. */
+typedef struct var_weights var_weights;
+int var_weights_create(var_ctx* ctx, var_weights** out);
+int var_weights_destroy(var_ctx* ctx, var_weights* w);
+int var_weights_bind(var_ctx* ctx, var_weights* w);
 int var_pack_weights(var_ctx* ctx, void* stream, const float* params);
 
 /* Encoder ------------------------------------------------------------------
@@ -97,7 +116,8 @@ int var_triplet_fwd_bwd(var_ctx* ctx, void* stream, const float* a, const float*
 
 /* One fused training-step body: zero_grad -> model(image,pos,neg) -> triplet loss ->
  * backward (VAR/pretext_VAR.py:56-68), everything up to but excluding optimizer.step().
- * grads (arena) and loss_out[0] are overwritten.  feats_out (B,9) = [a|p|n] or NULL. */
+ * grads (arena) and loss_out[0] are overwritten.  feats_out: NULL, or 9*B floats = three (B,3) blocks
+ * [image_feat | pos_feat | neg_feat]. */
 int var_arm_loss_grad(var_ctx* ctx, void* stream, const float* params,
                       const void* image, int image_is_u8, long image_bstride,
                       const float* mfcc_pos, const float* mfcc_neg, int B, int H,
@@ -146,13 +166,13 @@ int var_adam_step_dev(var_ctx* ctx, void* stream, float* params, const float* gr
  * DataLoader(shuffle=True), VAR/pretext_VAR.py:26-31,55) is walked on the DEVICE: at the end of the step row
  * (*cursor_dev + 1) mod n_rows is copied into index_row (the buffer the captured var_arm_loss_grad_pcm reads) and
  * *cursor_dev is advanced, so a replay needs no host-side copy.  One kernel launch does the Adam update, the
- * re-pack of the weight images, the step count and the row fetch.  ahead_from > 0: entries [ahead_from, row_ints) of
- * the row are taken one row further ahead (row cursor + 2) -- the data-parallel pipeline computes the MFCC features of
- * step k+1 before the optimiser step of step k, so its clip entries run one step ahead of the image entries. */
+ * re-pack of the weight images, the step count and the row fetch.  ahead != 0: index_row holds TWO rows,
+ * [row cursor+1 | row cursor+2] -- the data-parallel pipeline computes the MFCC features of step k+1 before the
+ * optimiser step of step k, so its front-end reads the second copy while the gradient pass reads the first. */
 int var_adam_step_graph(var_ctx* ctx, void* stream, float* params, const float* grads, float* exp_avg,
                         float* exp_avg_sq, long n, const float* lr_dev, float beta1, float beta2, float eps,
                         float weight_decay, int* step_dev, const int* index_table, int row_ints, int n_rows,
-                        int* cursor_dev, int* index_row, int ahead_from);
+                        int* cursor_dev, int* index_row, int ahead);
 
 /* Audio front-end: Envs/audioLoader.py:147-157 (torchaudio MFCC branch) + :241-252
  * (processSoundFeat).  pcm: rows of `pcm_stride` int16 samples; output clip i reads row
@@ -183,6 +203,7 @@ int var_ithor_encoder_fwd(var_ctx* ctx, void* stream, const float* params,
                           const float* snd_pos, const float* snd_neg, int B, int H,
                           float* image_feat, float* pos_feat, float* neg_feat,
                           float* image_raw, float* pos_raw, int save_for_bwd);
+int var_ithor_saved_generation(var_ctx* ctx);     /* as var_saved_generation, for the iTHOR workspace */
 int var_ithor_encoder_bwd(var_ctx* ctx, void* stream, const float* params,
                           const float* g_image_feat, const float* g_pos_feat, const float* g_neg_feat,
                           float* grads);

@@ -1,0 +1,135 @@
+"""Host logic of VARTrainer / TripletPool on the CPU: the trainer's own code (index-row layouts, ragged last batch,
+replay bookkeeping, device-side cursor protocol) driven through tests/_oracle_ctx.py, against the torch restatement of
+the reference step (oracle/torch_oracle.py:CPUTrainer) fed the same batches.  No HIP compute here -- the GPU suite
+(tests/test_gpu_parity.py) runs the same scenarios on the real library."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import var_amd
+from oracle import mfcc_np
+from oracle.torch_oracle import CPUTrainer
+from tests._oracle_ctx import OracleContext
+
+
+def _cfg(hw=84):
+    return types.SimpleNamespace(img_dim=(3, hw, hw), sound_dim=(1, 100, 40), representationDim=3)
+
+
+def _pool(n_items, seed=3):
+    # 2 clips per class keeps the numpy MFCC of the oracle context cheap
+    return var_amd.SyntheticTripletPool(n_items, hw=84, seed=seed, clips_per_class=2, device="cpu").freeze_pairs()
+
+
+def _features(pool, clip_idx, lens):
+    out = np.zeros((len(clip_idx), 1, 100, 40), np.float32)
+    clips = pool.clips.numpy()
+    for i, (c, n) in enumerate(zip(clip_idx.tolist(), lens.tolist())):
+        if n > 0:
+            out[i] = mfcc_np.process_sound_feat(mfcc_np.mfcc_torchaudio(clips[c, :n], dtype=np.float32))
+    return torch.from_numpy(out)
+
+
+def test_epoch_table_keeps_the_short_last_batch():
+    """DataLoader(drop_last=False) of the reference (dataset.py:157-162): 300 triplets at batch 128 are 3 steps, 128 /
+    128 / 44; every item appears exactly once per epoch."""
+    pool = var_amd.SyntheticTripletPool(300, hw=84, seed=1, clips_per_class=2, device="cpu").freeze_pairs()
+    assert pool.steps_per_epoch(128) == 3 and pool.tail_batch(128) == 44
+    assert pool.steps_per_epoch(128, drop_last=True) == 2 and pool.tail_batch(128, drop_last=True) == 0
+    tab = pool.epoch_index_table(128)
+    assert tab.shape == (3, 640) and tab.dtype == torch.int32
+    seen = torch.cat([tab[0, :128], tab[1, :128], tab[2, :44]]).long()
+    assert sorted(seen.tolist()) == list(range(300))
+    # the short row is packed [image (44) | clips (88) | lens (88)] and zero beyond
+    idx = tab[2, :44].long()
+    assert torch.equal(tab[2, 44:88], pool.clip_tab[0, idx]) and torch.equal(tab[2, 88:132], pool.clip_tab[1, idx])
+    assert torch.equal(tab[2, 132:176], pool.len_tab[0, idx]) and torch.equal(tab[2, 176:220], pool.len_tab[1, idx])
+    assert int(tab[2, 220:].abs().sum()) == 0
+    assert pool.epoch_index_table(128, drop_last=True).shape == (2, 640)
+    assert pool.index_table(128, 7).shape[0] == 9                      # whole epochs
+
+
+def test_replayed_ragged_epochs_equal_reference_steps():
+    """Two epochs of 22 triplets at batch 8 (8 / 8 / 6) through capture_epoch_steps(tail_batch=6): per-step losses and
+    the final parameters equal the reference step (torch restatement) on the same batches, the short batch averaged
+    over ITS size as TripletMarginLoss(reduction='mean') does."""
+    torch.manual_seed(11)
+    model = var_amd.VARPretextNet(_cfg())
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ctx = OracleContext()
+    tr = var_amd.VARTrainer(model, lr=1e-3, _ctx=ctx)
+    pool = _pool(22)
+    B, spe, bt = 8, pool.steps_per_epoch(8), pool.tail_batch(8)
+    assert (spe, bt) == (3, 6)
+    table = pool.index_table(B, 2 * spe)
+    replay, _load = tr.capture_epoch_steps(pool.images, pool.clips, B, table, steps_per_epoch=spe, tail_batch=bt)
+    ref = CPUTrainer(state_dict=sd, lr=1e-3)
+    for row in range(2 * spe):
+        Bs = bt if row % spe == spe - 1 else B
+        r = table[row]
+        want = ref.step(pool.images[r[:Bs].long()], _features(pool, r[Bs:2 * Bs], r[3 * Bs:4 * Bs]),
+                        _features(pool, r[2 * Bs:3 * Bs], r[4 * Bs:5 * Bs]))
+        got = float(replay().item())
+        assert abs(got - want) < 2e-6, (row, got, want)
+    sizes = [c[1] for c in ctx.lib.calls if c[0] == "loss_grad_pcm"]
+    assert sizes == [8, 8, 6, 8, 8, 6]
+    assert [round(1 / c[2]) for c in ctx.lib.calls if c[0] == "loss_grad_pcm"] == sizes      # mean over each batch
+    flat_ref = torch.cat([ref.model.state_dict()[k].reshape(-1) for k, _ in var_amd.PARAM_SPECS])
+    assert float((model.flat_parameters() - flat_ref).abs().max()) < 2e-6
+    assert tr.step_count == 6
+    # a 7th replay wraps to row 0 of the table (full batch again)
+    replay()
+    assert [c[1] for c in ctx.lib.calls if c[0] == "loss_grad_pcm"][-1] == 8
+
+
+def test_ragged_table_arguments_are_checked():
+    model = var_amd.VARPretextNet(_cfg())
+    tr = var_amd.VARTrainer(model, _ctx=OracleContext())
+    pool = _pool(22)
+    table = pool.index_table(8, 3)
+    with pytest.raises(var_amd.VarHipError):
+        tr.capture_epoch_steps(pool.images, pool.clips, 8, table, steps_per_epoch=2, tail_batch=6)   # 3 % 2 != 0
+    with pytest.raises(var_amd.VarHipError):
+        tr.capture_epoch_steps(pool.images, pool.clips, 8, table, steps_per_epoch=3, tail_batch=8)   # tail == batch
+    with pytest.raises(var_amd.VarHipError):
+        tr.capture_epoch_steps(pool.images, pool.clips, 8, table.long(), steps_per_epoch=3, tail_batch=6)
+
+
+def test_trainer_without_a_device_context_refuses_the_cpu():
+    """The seam above is for tests: the product has no CPU path."""
+    with pytest.raises(var_amd.VarHipError):
+        var_amd.VARTrainer(var_amd.VARPretextNet(_cfg()))
+
+
+def test_two_level_clip_draw_and_load_num(tmp_path):
+    """Envs/audioLoader.py:174-176 picks a dataset, then a clip: with datasets of 1 and 9 clips per class the single
+    clip of the small dataset is drawn about half of the time (a flat draw would give 10 %).  dataset.py:150-154:
+    loadNum picks a random subset of the pickles."""
+    import pickle
+    task_num, n = 4, 4000
+    clips = np.zeros((task_num * 10, 16), np.int16)
+    pool = var_amd.TripletPool(np.zeros((n, 3, 84, 84), np.uint8), np.zeros(n, np.int64), np.ones(n, np.int64), clips,
+                               np.full(40, 16, np.int32), np.arange(task_num) * 10, np.full(task_num, 10), task_num,
+                               device="cpu")
+    ds_start = np.stack([np.arange(task_num) * 10, np.arange(task_num) * 10 + 1], axis=1)     # dataset 0: 1 clip, dataset 1: 9
+    pool.set_datasets(ds_start, np.tile([1, 9], (task_num, 1))).freeze_pairs()
+    pos = pool.clip_tab[0]
+    assert int(pos.min()) >= 0 and int(pos.max()) <= 9                    # class 0 only
+    frac = float((pos == 0).float().mean())
+    assert 0.45 < frac < 0.55, frac
+    # a class missing from one dataset never draws from it
+    pool.set_datasets(ds_start, np.tile([0, 9], (task_num, 1))).freeze_pairs()
+    assert int((pool.clip_tab[0] == 0).sum()) == 0
+    paths = []
+    for k in range(5):
+        p = tmp_path / f"data_{k}.pickle"
+        with open(p, "wb") as f:
+            pickle.dump([{"image": np.full((3, 84, 84), k, np.uint8), "ground_truth": np.array([k % 4]),
+                          "sound_negative_id": np.array([(k + 1) % 4])} for _ in range(3)], f)
+        paths.append(str(p))
+    args = (clips, np.full(40, 16, np.int32), np.arange(task_num) * 10, np.full(task_num, 10), task_num)
+    sub = var_amd.TripletPool.from_pickles(paths, *args, device="cpu", load_num=2)
+    assert sub.n_items == 6 and len(set(sub.images[:, 0, 0, 0].tolist())) == 2
+    assert var_amd.TripletPool.from_pickles(paths, *args, device="cpu", load_num='all').n_items == 15

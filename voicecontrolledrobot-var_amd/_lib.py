@@ -37,6 +37,11 @@ _SIGNATURES = {
     "var_last_error": (ctypes.c_char_p, [_vp]),
     "var_param_count": (_i, []),
     "var_plan": (_i, [_vp, _i, _i]),
+    "var_plan_generation": (_i, [_vp]),
+    "var_saved_generation": (_i, [_vp]),
+    "var_weights_create": (_i, [_vp, ctypes.POINTER(_vp)]),
+    "var_weights_destroy": (_i, [_vp, _vp]),
+    "var_weights_bind": (_i, [_vp, _vp]),
     "var_pack_weights": (_i, [_vp, _vp, _vp]),
     "var_arm_encoder_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i]),
     "var_arm_encoder_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -62,6 +67,7 @@ _SIGNATURES = {
     "var_ithor_plan": (_i, [_vp, _i, _i]),
     "var_ithor_set_bf16": (_i, [_vp, _i]),
     "var_ithor_encoder_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i]),
+    "var_ithor_saved_generation": (_i, [_vp]),
     "var_ithor_encoder_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "var_ithor_loss_grad": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
     "var_profile_tag_count": (_i, []),
@@ -117,6 +123,31 @@ class Context:
         if rc != 0:
             raise VarHipError(f"{what} failed ({rc}): {self.lib.var_last_error(self.handle).decode()}")
 
+    def stream(self):
+        """The caller's current HIP stream as the void* the C ABI takes."""
+        return current_stream_handle()
+
+    def new_weights(self):
+        return Weights(self)
+
+    def capture(self, groups):
+        """Capture each group of bodies (callables that enqueue C-ABI launches on the current stream) into one HIP
+        graph; returns one replay callable per group."""
+        import torch
+        dev = torch.device("cuda", self.device_index)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        graphs = []
+        with torch.cuda.stream(side):
+            for bodies in groups:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    for body in bodies:
+                        body()
+                graphs.append(g)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        return [g.replay for g in graphs]
+
     def ensure_plan(self, batch, hw):
         if self.plan[1] != hw or self.plan[0] < batch:
             self.check(self.lib.var_plan(self.handle, int(batch), int(hw)), "var_plan")
@@ -151,6 +182,37 @@ class Context:
         if rc != 0:
             raise VarHipError(f"hipMemcpy failed ({rc})")
         return out
+
+
+class Weights:
+    """Per-model packed weight image (var_weights_create / _bind / var_pack_weights): the kernels read conv filters
+    re-laid for the matrix cores next to the parameter arena; each model owns its copy, so a training model and a
+    frozen encoder can alternate on one device context."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = _vp()
+        ctx.check(ctx.lib.var_weights_create(ctx.handle, ctypes.byref(h)), "var_weights_create")
+        self.handle = h
+        self.key = None                    # what the image was last packed from (model-side change detector)
+
+    def bind(self):
+        c = self.ctx
+        c.check(c.lib.var_weights_bind(c.handle, self.handle), "var_weights_bind")
+
+    def pack(self, flat, key=None):
+        c = self.ctx
+        self.bind()
+        c.check(c.lib.var_pack_weights(c.handle, c.stream(), flat.data_ptr()), "var_pack_weights")
+        self.key = key
+
+    def __del__(self):
+        try:
+            if self.handle and self.ctx.handle:
+                self.ctx.lib.var_weights_destroy(self.ctx.handle, self.handle)
+        except Exception:                  # interpreter shutdown
+            pass
+        self.handle = None
 
 
 def ptr(t):

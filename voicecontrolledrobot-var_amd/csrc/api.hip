@@ -44,7 +44,10 @@ int var_init(int device_id, var_ctx** out) {
         return VAR_ERR_ARG;
     }
     e = hipSetDevice(device_id);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->wpack, sizeof(float) * (size_t)c->kl.total);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->default_w.data, sizeof(float) * (size_t)c->kl.total);
+    c->default_w.owner = c;
+    c->bound = &c->default_w;
+    c->wpack = c->default_w.data;
     if (e == hipSuccess) e = hipMalloc((void**)&c->loss_buf, sizeof(float) * 64);
     if (e == hipSuccess) e = hipMemset(c->loss_buf, 0, sizeof(float) * 64);
     c->done_ctr = (unsigned*)(c->loss_buf + 32);
@@ -84,7 +87,9 @@ int var_destroy(var_ctx* c) {
     ithor_free(c);
     armnet_free(c);
     if (c->ws) (void)hipFree(c->ws);
-    if (c->wpack) (void)hipFree(c->wpack);
+    for (int i = 0; i < c->n_retired; i++) (void)hipFree(c->retired[i]);
+    free(c->retired);
+    if (c->default_w.data) (void)hipFree(c->default_w.data);
     if (c->loss_buf) (void)hipFree(c->loss_buf);
     if (c->mfcc_tab) (void)hipFree(c->mfcc_tab);
     if (c->mfcc_psf_tab) (void)hipFree(c->mfcc_psf_tab);
@@ -107,6 +112,64 @@ int var_destroy(var_ctx* c) {
     return VAR_OK;
 }
 
+int retire_block(var_ctx* c, void* p) {
+    if (c->n_retired == c->cap_retired) {
+        const int cap = c->cap_retired ? 2 * c->cap_retired : 8;
+        void** q = (void**)realloc(c->retired, sizeof(void*) * cap);
+        if (!q) { VAR_SET_ERR(c, "var_plan: out of host memory"); return VAR_ERR_HIP; }
+        c->retired = q; c->cap_retired = cap;
+    }
+    c->retired[c->n_retired++] = p;
+    return VAR_OK;
+}
+
+int var_plan_generation(var_ctx* c) { return c ? c->plan_gen : VAR_ERR_ARG; }
+int var_saved_generation(var_ctx* c) { return c ? (c->saved_B > 0 ? c->saved_gen : 0) : VAR_ERR_ARG; }
+
+int var_weights_create(var_ctx* c, var_weights** out) {
+    CHECK_CTX(c);
+    if (!out) return VAR_ERR_ARG;
+    *out = nullptr;
+    SET_DEVICE(c);
+    var_weights* w = new (std::nothrow) var_weights();
+    if (!w) return VAR_ERR_HIP;
+    w->owner = c;
+    hipError_t e = hipMalloc((void**)&w->data, sizeof(float) * (size_t)c->kl.total);
+    if (e != hipSuccess) { VAR_SET_ERR(c, "var_weights_create: %s", hipGetErrorString(e)); delete w; return VAR_ERR_HIP; }
+    *out = w;
+    return VAR_OK;
+}
+
+int var_weights_destroy(var_ctx* c, var_weights* w) {
+    CHECK_CTX(c);
+    if (!w || w->owner != c || w == &c->default_w) { VAR_SET_ERR(c, "var_weights_destroy: not a handle of this context"); return VAR_ERR_ARG; }
+    SET_DEVICE(c);
+    if (c->bound == w) { c->bound = &c->default_w; c->wpack = c->default_w.data; }
+    // like a superseded workspace, the image may still be referenced by captured graphs: retire it
+    int rc = retire_block(c, w->data);
+    delete w;
+    return rc;
+}
+
+int var_weights_bind(var_ctx* c, var_weights* w) {
+    CHECK_CTX(c);
+    if (!w) w = &c->default_w;
+    if (w->owner != c) { VAR_SET_ERR(c, "var_weights_bind: handle belongs to another context"); return VAR_ERR_ARG; }
+    c->bound = w;
+    c->wpack = w->data;
+    return VAR_OK;
+}
+
+// every entry that reads the packed image checks that it was packed from the arena it is given
+static int check_weights(var_ctx* c, const float* params, const char* who) {
+    if (c->bound->params != params) {
+        VAR_SET_ERR(c, "%s: the bound weight image was %s -- var_weights_bind + var_pack_weights first", who,
+                    c->bound->params ? "packed from another parameter arena" : "never packed");
+        return VAR_ERR_STATE;
+    }
+    return VAR_OK;
+}
+
 int var_plan(var_ctx* c, int max_batch, int img_hw) {
     CHECK_CTX(c);
     if (max_batch <= 0 || (img_hw != 84 && img_hw != 96)) {
@@ -115,7 +178,10 @@ int var_plan(var_ctx* c, int max_batch, int img_hw) {
     }
     SET_DEVICE(c);
     if (c->ws && c->maxB >= max_batch && c->H == img_hw) return VAR_OK;
-    if (c->ws) { VAR_HIP_CHECK(c, hipFree(c->ws)); c->ws = nullptr; }
+    // A superseded workspace is retired, not freed: HIP graphs captured against it (VARTrainer.capture_*,
+    // IntrinsicReward.capture) keep replaying on their own, still valid, buffers.  Freed in var_destroy.
+    if (c->ws) { int rc = retire_block(c, c->ws); if (rc != VAR_OK) return rc; c->ws = nullptr; }
+    c->plan_gen++;
     const size_t B = (size_t)max_batch;
     int hs[6];
     hs[0] = img_hw;
@@ -165,6 +231,7 @@ int var_pack_weights(var_ctx* c, void* stream, const float* params) {
     CHECK_CTX(c);
     if (!params) { VAR_SET_ERR(c, "var_pack_weights: null params"); return VAR_ERR_ARG; }
     SET_DEVICE(c);
+    c->bound->params = params;
     return launch_pack_weights(c, (hipStream_t)stream, params);
 }
 
@@ -227,6 +294,7 @@ static int encoder_fwd(var_ctx* c, hipStream_t s, const float* params, const voi
         if ((rc = join_side(c, s, 0)) != VAR_OK) return rc;
     }
     c->saved_B = B;
+    c->saved_gen = ++c->fwd_gen;
     c->saved_image = image;
     c->saved_u8 = is_u8;
     c->saved_bstride = bstride;
@@ -245,6 +313,7 @@ int var_arm_encoder_fwd(var_ctx* c, void* stream, const float* params, const voi
     if (image && image_bstride < 3L * H * H) { VAR_SET_ERR(c, "var_arm_encoder_fwd: image stride %ld < 3*H*H", image_bstride); return VAR_ERR_ARG; }
     int rc = check_plan(c, B, H, "var_arm_encoder_fwd");
     if (rc != VAR_OK) return rc;
+    if ((rc = check_weights(c, params, "var_arm_encoder_fwd")) != VAR_OK) return rc;
     SET_DEVICE(c);
     hipStream_t s = (hipStream_t)stream;
     if ((rc = encoder_fwd(c, s, params, image, image_is_u8, image_bstride, nullptr, mfcc_pos, mfcc_neg, nullptr, B)) != VAR_OK) return rc;
@@ -293,6 +362,7 @@ int var_arm_encoder_bwd(var_ctx* c, void* stream, const float* params, const flo
     CHECK_CTX(c);
     if (!params || !grads) { VAR_SET_ERR(c, "var_arm_encoder_bwd: null params/grads"); return VAR_ERR_ARG; }
     if (c->saved_B <= 0) { VAR_SET_ERR(c, "var_arm_encoder_bwd: no forward saved (save_for_bwd=1 required)"); return VAR_ERR_STATE; }
+    { int rc = check_weights(c, params, "var_arm_encoder_bwd"); if (rc != VAR_OK) return rc; }
     SET_DEVICE(c);
     hipStream_t s = (hipStream_t)stream;
     const int B = c->saved_B;
@@ -320,6 +390,7 @@ static int loss_grad_impl(var_ctx* c, hipStream_t s, const float* params, const 
     if (image_bstride < 3L * H * H) { VAR_SET_ERR(c, "%s: image stride %ld < 3*H*H", who, image_bstride); return VAR_ERR_ARG; }
     int rc = check_plan(c, B, H, who);
     if (rc != VAR_OK) return rc;
+    if ((rc = check_weights(c, params, who)) != VAR_OK) return rc;
     SET_DEVICE(c);
     // The training step proper (all three branches, no embedding output requested) takes the fused path: no finish
     // and no triplet kernel on the caller's chain.  VAR_NO_FUSED_LOSS=1 (tuning aid) keeps the separate kernels.
@@ -387,7 +458,7 @@ int var_adam_step(var_ctx* c, void* stream, float* params, const float* grads, f
     hipStream_t s = (hipStream_t)stream;
     int rc = launch_adam(c, s, params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step);
     if (rc != VAR_OK) return rc;
-    if (n == VAR_N_PARAMS) return launch_pack_weights(c, s, params);
+    if (n == VAR_N_PARAMS && c->bound->params == params) return launch_pack_weights(c, s, params);
     return VAR_OK;
 }
 
@@ -413,7 +484,7 @@ int var_adam_step_graph(var_ctx* c, void* stream, float* params, const float* gr
     }
     SET_DEVICE(c);
     return launch_adam_dev(c, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, lr_dev, beta1, beta2, eps,
-                           weight_decay, step_dev, n == VAR_N_PARAMS, index_table, row_ints, n_rows, cursor_dev, index_row,
+                           weight_decay, step_dev, n == VAR_N_PARAMS && c->bound->params == params, index_table, row_ints, n_rows, cursor_dev, index_row,
                            ahead_from);
 }
 
@@ -510,6 +581,8 @@ int var_debug_buffer(var_ctx* c, const char* name, void** ptr, long* nfloats) {
         if (!strcmp(name, a)) { *ptr = c->sact[l]; *nfloats = n; return VAR_OK; }
         if (!strcmp(name, g)) { *ptr = c->gsact[l]; *nfloats = n; return VAR_OK; }
     }
+    if (!strcmp(name, "hid_i")) { *ptr = c->hid_i; *nfloats = (long)B * kHid; return VAR_OK; }
+    if (!strcmp(name, "hid_s")) { *ptr = c->hid_s; *nfloats = 2 * (long)B * kHid; return VAR_OK; }
     if (!strcmp(name, "emb")) { *ptr = c->emb; *nfloats = 9 * (long)B; return VAR_OK; }
     if (!strcmp(name, "mfcc")) { *ptr = c->mfcc_buf; *nfloats = 2 * (long)B * VAR_MFCC_FRAMES * VAR_MFCC_COEFFS; return VAR_OK; }
     if (!strcmp(name, "relu1")) { *ptr = (float*)c->relu1; *nfloats = (long)c->maxB * c->hs[1] * c->hs[1]; return VAR_OK; }

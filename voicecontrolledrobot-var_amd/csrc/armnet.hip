@@ -150,7 +150,12 @@ int var_armnet_plan(var_ctx* c, int max_batch) {
     VAR_HIP_CHECK(c, hipSetDevice(c->device));
     arm_state* st = (arm_state*)c->arm;
     if (st && st->maxB >= max_batch) return VAR_OK;
-    armnet_free(c);
+    if (st) {      // retire (do not free) the superseded workspace: a captured act() graph may still replay on it
+        if (st->ws) { int rc = retire_block(c, st->ws); if (rc != VAR_OK) return rc; }
+        delete st;
+        c->arm = nullptr;
+    }
+    c->plan_gen++;
     st = new arm_state();
     c->arm = st;
     st->L = make_layout();

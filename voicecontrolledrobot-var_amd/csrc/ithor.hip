@@ -62,6 +62,7 @@ struct ithor_state {
     float *raw = nullptr, *graw = nullptr, *emb = nullptr, *gemb = nullptr;   // (3B,3) [img | pos | neg]
     float* loss = nullptr;
     // saved forward
+    int gen = 0;                                          // generation id of the saved forward (var_ithor_saved_generation)
     int B = 0, nclips = 0; bool has_img = false, has_pos = false, has_neg = false;
     const void* image = nullptr; int is_u8 = 0; long bstride = 0;
     const float *pos = nullptr, *neg = nullptr;
@@ -427,7 +428,7 @@ static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* imag
     ithor_state* st = ith(c);
     const IthorLayout& L = st->L;
     const int* hs = st->hs;
-    st->B = B; st->has_img = image != nullptr; st->has_pos = pos != nullptr; st->has_neg = neg != nullptr;
+    st->B = B; st->gen = ++c->fwd_gen; st->has_img = image != nullptr; st->has_pos = pos != nullptr; st->has_neg = neg != nullptr;
     st->image = image; st->is_u8 = is_u8; st->bstride = bstride; st->pos = pos; st->neg = neg;
     const int nclips = (pos ? B : 0) + (neg ? B : 0);
     st->nclips = nclips;
@@ -671,7 +672,12 @@ int var_ithor_plan(var_ctx* c, int max_batch, int img_hw) {
     VAR_HIP_CHECK(c, hipSetDevice(c->device));
     ithor_state* st = ith(c);
     if (st && st->maxB >= max_batch && st->H == img_hw) return VAR_OK;
-    ithor_free(c);
+    if (st) {      // retire (do not free) the superseded workspace: captured graphs may still replay on it
+        if (st->ws) { int rc = retire_block(c, st->ws); if (rc != VAR_OK) return rc; }
+        delete st;
+        c->ith = nullptr;
+    }
+    c->plan_gen++;
     st = new ithor_state();
     c->ith = st;
     st->L = make_ithor_layout();
@@ -761,7 +767,14 @@ int var_ithor_encoder_fwd(var_ctx* c, void* stream, const float* params, const v
         off = B;
     }
     if (snd_neg) RUN(copy_out(c, s, st->emb + 3 * mB + 3L * off, neg_feat, 3L * B));
+    if (!save_for_bwd) st->B = 0;              // the recurrent states were not kept: no backward from this forward
     return VAR_OK;
+}
+
+int var_ithor_saved_generation(var_ctx* c) {
+    if (!c) return VAR_ERR_ARG;
+    ithor_state* st = ith(c);
+    return (st && st->B > 0) ? st->gen : 0;
 }
 
 int var_ithor_encoder_bwd(var_ctx* c, void* stream, const float* params, const float* g_image_feat,

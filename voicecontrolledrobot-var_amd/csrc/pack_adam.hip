@@ -118,10 +118,12 @@ adam_pack_dev_kernel(const PackSeg* __restrict__ segs, int nseg, float* __restri
     if (blockIdx.x == 0 && idx_table) {
         int next = cursor[0] + 1;
         if (next >= n_rows) next = 0;
-        int next2 = next + 1;                                // entries [ahead_from, row_ints) run one row further ahead
+        int next2 = next + 1;                                // ahead: a second copy, one row further on, behind the first
         if (next2 >= n_rows) next2 = 0;
-        for (int e = threadIdx.x; e < row_ints; e += 256)
-            idx_row[e] = idx_table[(size_t)((ahead_from > 0 && e >= ahead_from) ? next2 : next) * row_ints + e];
+        for (int e = threadIdx.x; e < row_ints; e += 256) {
+            idx_row[e] = idx_table[(size_t)next * row_ints + e];
+            if (ahead_from > 0) idx_row[row_ints + e] = idx_table[(size_t)next2 * row_ints + e];
+        }
         __syncthreads();
         if (threadIdx.x == 0) cursor[0] = next;
     }

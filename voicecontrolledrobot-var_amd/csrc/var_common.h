@@ -93,6 +93,14 @@ enum VarTag {
 };
 constexpr int kProfMaxPairs = 4096;
 
+// One packed weight image per MODEL (var_weights_create / var_weights_bind): a training model and a frozen
+// copy of the encoder can share a device context without trampling each other's kernel-side filters.
+struct var_weights {
+    float* data = nullptr;          // PackLayout::total floats
+    const float* params = nullptr;  // the arena the image was last packed from (guards against a stale binding)
+    var_ctx* owner = nullptr;
+};
+
 struct var_ctx {
     int device = 0;
     char err[512] = {0};
@@ -103,7 +111,13 @@ struct var_ctx {
     int hs[6] = {0};
     char* ws = nullptr;           // one hipMalloc, carved below
     size_t ws_bytes = 0;
-    float* wpack = nullptr;
+    float* wpack = nullptr;       // = bound->data: the packed image the launchers read (var_weights_bind)
+    var_weights default_w;        // the context's own image, bound until the host binds a per-model one
+    var_weights* bound = nullptr;
+    void** retired = nullptr; int n_retired = 0, cap_retired = 0;   // superseded workspaces: kept alive until var_destroy,
+                                                                    // captured graphs keep their (old, self-consistent) pointers
+    int plan_gen = 0;             // bumped by every re-plan
+    int fwd_gen = 0, saved_gen = 0;   // generation id of the forward whose activations the workspace holds (0 = none)
     float* act[6] = {nullptr};    // act[l] = output of image conv l (l = 1..5), post-ReLU, NCHW
     float* gact[6] = {nullptr};   // d(loss)/d(pre-activation of conv l output)
     float* sact[5] = {nullptr};   // sound activations for 2B clips: [l] l = 1..4, layout (clip, 32, T_l)
@@ -179,6 +193,7 @@ struct ProfScope {
 
 static inline int conv_out(int h) { return (h - 1) / 2 + 1; }   // 3x3 s2 p1
 
+extern "C" int retire_block(var_ctx* c, void* p);   // api.hip: keep a superseded device block alive until var_destroy
 int mfcc_build_tables(var_ctx* c);
 void ithor_free(var_ctx* c);
 void armnet_free(var_ctx* c);

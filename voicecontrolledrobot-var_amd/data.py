@@ -88,11 +88,17 @@ class TripletPool:
         self._gen.manual_seed(seed + 2)
 
     @classmethod
-    def from_pickles(cls, paths, clips, clip_len, class_start, class_count, task_num, seed=0, device="cuda"):
+    def from_pickles(cls, paths, clips, clip_len, class_start, class_count, task_num, seed=0, device="cuda",
+                     load_num=None):
         """The reference's collected data: each pickle is a list of dicts {'image': u8 (3,H,W), 'ground_truth':
         int (1,), 'sound_negative_id': int (1,) (optional)} (pretext.py:82-92).  A missing negative id is drawn
-        by the rule of dataset.py:73-78 (choose_negative_id)."""
+        by the rule of dataset.py:73-78 (choose_negative_id).  load_num: as loadEnvData's `loadNum`
+        (dataset.py:150-154) -- a random subset of that many pickle files instead of all of them ('all' / None)."""
         import pickle
+        paths = list(paths)
+        if load_num is not None and load_num != 'all' and int(load_num) < len(paths):
+            pick = np.random.default_rng(seed + 7).choice(len(paths), size=int(load_num), replace=False)
+            paths = [paths[i] for i in sorted(pick.tolist())]
         items = []
         for path in paths:
             with open(path, "rb") as f:                         # the authors' own format; only load trusted files
@@ -107,9 +113,30 @@ class TripletPool:
                        for g, it in zip(gt, items)])
         return cls(images, gt, sn, clips, clip_len, class_start, class_count, task_num, seed=seed, device=device)
 
+    def set_datasets(self, ds_start, ds_count):
+        """Two-level clip draw of Envs/audioLoader.py:174-176: the clips of a class come from several datasets
+        (GoogleCommand, NSynth, ...); the reference first picks a DATASET uniformly, then a clip inside it, so clips
+        of a small dataset are drawn more often than a flat draw over the class would.  ds_start / ds_count:
+        (n_classes, n_datasets) first clip row and clip count of each (class, dataset) block of `clips` (count 0 = the
+        dataset has no clip of that class and is never picked)."""
+        self.ds_start = torch.as_tensor(np.asarray(ds_start)).to(torch.int64).to(self.device)
+        self.ds_count = torch.as_tensor(np.asarray(ds_count)).to(torch.int64).to(self.device)
+        if self.ds_start.shape != self.ds_count.shape or int((self.ds_count > 0).sum(1).min()) < 1:
+            raise ValueError("every class needs a clip in at least one dataset")
+        return self
+
     def _clip_ids(self, cls_ids, shape):
         """A random clip of each class id (class taskNum -> any clip, its length is forced to 0)."""
         c = torch.clamp(cls_ids, max=self.task_num - 1)
+        if getattr(self, "ds_count", None) is not None:         # dataset first, then clip (audioLoader.py:174-176)
+            cnt = self.ds_count[c]                               # (..., n_datasets)
+            avail = (cnt > 0).to(torch.float32)
+            u = torch.rand(shape, device=self.device, generator=self._gen)
+            k = torch.minimum((u * avail.sum(-1)).long(), avail.sum(-1).long() - 1)      # k-th non-empty dataset
+            ds = ((torch.cumsum(avail, -1) - 1 == k[..., None]) & (cnt > 0)).to(torch.int64).argmax(-1)
+            n = torch.gather(cnt, -1, ds[..., None])[..., 0]
+            v = torch.rand(shape, device=self.device, generator=self._gen)
+            return torch.gather(self.ds_start[c], -1, ds[..., None])[..., 0] + torch.minimum((v * n).long(), n - 1)
         if self.cpc is not None:                                # uniform classes: the draw the synthetic pool always made
             cp = torch.randint(0, self.cpc, shape, device=self.device, generator=self._gen)
         else:
@@ -143,21 +170,42 @@ class TripletPool:
         idx = self._perm[sl]
         return self._perm32[sl], self.clip_tab[:, idx].reshape(-1), self.len_tab[:, idx].reshape(-1)
 
-    def epoch_index_table(self, batch):
-        """(steps, 5*batch) int32: rows [image_index | clip_index (2B) | lens (2B)] of one shuffled epoch
-        (drop_last), built with a handful of device ops per EPOCH instead of per step."""
-        steps = self.n_items // batch
-        perm = torch.randperm(self.n_items, device=self.device, generator=self._gen)[:steps * batch]
-        idx = perm.view(steps, batch)
-        clip = self.clip_tab[:, perm].view(2, steps, batch).permute(1, 0, 2).reshape(steps, 2 * batch)
-        lens = self.len_tab[:, perm].view(2, steps, batch).permute(1, 0, 2).reshape(steps, 2 * batch)
-        return torch.cat([idx.to(torch.int32), clip, lens], dim=1).contiguous()
+    def steps_per_epoch(self, batch, drop_last=False):
+        """len(DataLoader): ceil(N / batch) with the reference's drop_last=False (VAR/pretext_VAR.py:24)."""
+        return self.n_items // batch if drop_last else -(-self.n_items // batch)
 
-    def index_table(self, batch, min_rows):
+    def tail_batch(self, batch, drop_last=False):
+        """Size of the short last batch of an epoch (0 = none): 300 triplets at batch 128 -> 44."""
+        return 0 if drop_last else self.n_items % batch
+
+    def epoch_index_table(self, batch, drop_last=False):
+        """(steps, 5*batch) int32: rows [image_index | clip_index (2B) | lens (2B)] of one shuffled epoch, built with
+        a handful of device ops per EPOCH instead of per step.  drop_last=False (the reference's DataLoader,
+        dataset.py:157-162): when batch does not divide the pool the last row is the SHORT batch -- its Bt =
+        tail_batch(batch) samples packed at the head of the row in the same layout [image_index (Bt) | clip_index
+        (2 Bt) | lens (2 Bt)], the rest of the row zero (VARTrainer.capture_epoch_steps(tail_batch=Bt) runs it)."""
+        full = self.n_items // batch
+        perm = torch.randperm(self.n_items, device=self.device, generator=self._gen)
+
+        def rows(p, steps, b):
+            idx = p.view(steps, b)
+            clip = self.clip_tab[:, p].view(2, steps, b).permute(1, 0, 2).reshape(steps, 2 * b)
+            lens = self.len_tab[:, p].view(2, steps, b).permute(1, 0, 2).reshape(steps, 2 * b)
+            return torch.cat([idx.to(torch.int32), clip, lens], dim=1)
+
+        tab = rows(perm[:full * batch], full, batch)
+        bt = self.tail_batch(batch, drop_last)
+        if bt:
+            tail = torch.zeros((1, 5 * batch), dtype=torch.int32, device=self.device)
+            tail[:, :5 * bt] = rows(perm[full * batch:], 1, bt)
+            tab = torch.cat([tab, tail], dim=0)
+        return tab.contiguous()
+
+    def index_table(self, batch, min_rows, drop_last=False):
         """At least `min_rows` step rows: whole shuffled epochs (epoch_index_table) back to back."""
         parts, rows = [], 0
         while rows < min_rows:
-            parts.append(self.epoch_index_table(batch))
+            parts.append(self.epoch_index_table(batch, drop_last))
             rows += parts[-1].shape[0]
         return torch.cat(parts, dim=0).contiguous()
 

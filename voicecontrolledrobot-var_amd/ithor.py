@@ -33,6 +33,7 @@ class _IthorFn(torch.autograd.Function):
                 "var_ithor_encoder_fwd")
         ctx.module = module
         ctx.keep = (image, pos, neg)
+        ctx.gen = c.lib.var_ithor_saved_generation(c.handle) if need_grad else 0
         outs = (image_feat, pos_feat, neg_feat, image_raw, pos_raw)
         ctx.present = [o is not None for o in outs]
         dummy = torch.zeros(0, device=dev)
@@ -45,7 +46,12 @@ class _IthorFn(torch.autograd.Function):
         module = ctx.module
         flat = module._flat
         c = Context.get(flat.device.index)
-        gflat = module._grad_arena()
+        if not ctx.gen or c.lib.var_ithor_saved_generation(c.handle) != ctx.gen:
+            raise VarHipError("backward of a forward whose activations are gone: the device context keeps ONE saved "
+                              "forward (a later forward of this or another model overwrote it, or it ran under "
+                              "no_grad) -- run forward and backward back to back")
+        # a fresh buffer per backward: autograd may keep the returned views as .grad (AccumulateGrad steals them)
+        gflat = torch.empty_like(flat)
         gs = [g.contiguous().float() if (present and g is not None) else None
               for g, present in zip((g_if, g_pf, g_nf), ctx.present[:3])]
         c.check(c.lib.var_ithor_encoder_bwd(c.handle, current_stream_handle(), ptr(flat), ptr(gs[0]), ptr(gs[1]),
@@ -86,7 +92,6 @@ class IthorVARPretextNet(nn.Module):
         self.soundTriplet = nn.Sequential(nn.Linear(2 * 512, 128), nn.ReLU(), nn.Linear(128, 64), nn.ReLU(),
                                           nn.Linear(64, config.representationDim))
         self._flat = None
-        self._gflat = None
         self._plan = 0
         self._bf16 = False
         self._flatten_params()
@@ -111,7 +116,6 @@ class IthorVARPretextNet(nn.Module):
             p.data = flat[o:o + p.numel()].view(p.shape)
             o += p.numel()
         self._flat = flat
-        self._gflat = None
 
     def _arena_intact(self):
         o = self._flat.data_ptr()
@@ -120,11 +124,6 @@ class IthorVARPretextNet(nn.Module):
                 return False
             o += 4 * p.numel()
         return True
-
-    def _grad_arena(self):
-        if self._gflat is None or self._gflat.device != self._flat.device:
-            self._gflat = torch.empty_like(self._flat)
-        return self._gflat
 
     def flat_parameters(self):
         if not self._arena_intact():

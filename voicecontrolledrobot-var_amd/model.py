@@ -31,7 +31,7 @@ class _EncoderFn(torch.autograd.Function):
         H = module.config.img_dim[1]
         c.ensure_plan(B, H)
         stream = current_stream_handle()
-        c.check(c.lib.var_pack_weights(c.handle, stream, ptr(flat)), "var_pack_weights")
+        module.hip_weights(c)                  # this model's packed image: bound, re-packed only if the parameters changed
         mk = lambda n: torch.empty((B, n), dtype=torch.float32, device=dev)
         image_feat = mk(3) if image is not None else None
         image_raw = mk(576) if image is not None else None
@@ -47,6 +47,7 @@ class _EncoderFn(torch.autograd.Function):
         ctx.module = module
         ctx.keep = (image, pos, neg)          # the C side re-reads the inputs in backward
         ctx.B = B
+        ctx.gen = c.lib.var_saved_generation(c.handle) if need_grad else 0
         outs = (image_feat, pos_feat, neg_feat, image_raw, pos_raw)
         ctx.present = [o is not None for o in outs]
         dummy = torch.zeros(0, device=dev)
@@ -59,7 +60,13 @@ class _EncoderFn(torch.autograd.Function):
         module = ctx.module
         flat = module._flat
         c = Context.get(flat.device.index)
-        gflat = module._grad_arena()
+        if not ctx.gen or c.lib.var_saved_generation(c.handle) != ctx.gen:
+            raise VarHipError("backward of a forward whose activations are gone: the device context keeps ONE saved "
+                              "forward (a later forward of this or another model overwrote it, or it ran under "
+                              "no_grad) -- run forward and backward back to back")
+        module.hip_weights(c)
+        # a fresh buffer per backward: autograd may keep the returned views as .grad (AccumulateGrad steals them)
+        gflat = torch.empty(N_PARAMS, dtype=torch.float32, device=flat.device)
         gs = []
         for g, present in zip((g_if, g_pf, g_nf), ctx.present[:3]):
             gs.append(g.contiguous().float() if (present and g is not None) else None)
@@ -113,7 +120,7 @@ class VARPretextNet(nn.Module):
         self.soundTriplet = nn.Sequential(nn.Linear(160, 128), nn.ReLU(),
                                           nn.Linear(128, config.representationDim))
         self._flat = None
-        self._gflat = None
+        self._weights = None
         self._flatten_params()
 
     # ---- flat parameter arena (what the C ABI reads; also the all-reduce / Adam buffer) ----
@@ -130,17 +137,28 @@ class VARPretextNet(nn.Module):
             flat[o:o + n].copy_(p.data.reshape(-1).float())
             p.data = flat[o:o + n].view(p.shape)
         self._flat = flat
-        self._gflat = None
 
     def _arena_intact(self):
         base = self._flat.data_ptr()
         return all(p.data_ptr() == base + 4 * o and p.dtype == torch.float32
                    for p, o in zip(self._named_in_order(), PARAM_OFFSETS))
 
-    def _grad_arena(self):
-        if self._gflat is None or self._gflat.device != self._flat.device:
-            self._gflat = torch.empty(N_PARAMS, dtype=torch.float32, device=self._flat.device)
-        return self._gflat
+    def hip_weights(self, ctx=None, force=False):
+        """This model's packed weight image on its device context, bound for the next C-ABI calls; re-packed when the
+        parameters changed since the last pack (load_state_dict, an external optimiser, .to(), edits of the arena --
+        torch's version counters tell) or when `force`d.  VARTrainer's own Adam keeps the image current by itself."""
+        flat = self.flat_parameters()
+        if ctx is None:
+            ctx = Context.get(flat.device.index)
+        w = self._weights
+        if w is None or w.ctx is not ctx:
+            w = self._weights = ctx.new_weights()
+        key = (flat.data_ptr(), flat._version, sum(p._version for p in self._named_in_order()))
+        if force or w.key != key:
+            w.pack(flat, key)
+        else:
+            w.bind()
+        return w
 
     def flat_parameters(self):
         if not self._arena_intact():

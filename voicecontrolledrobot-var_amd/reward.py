@@ -103,9 +103,10 @@ class IntrinsicReward:
         self._image_feat = torch.zeros((B, 3), device=dev)
         self._goal_feat = torch.zeros((B, 3), device=dev)
         self._reward = torch.zeros((B,), device=dev)
-        c.check(c.lib.var_pack_weights(c.handle, current_stream_handle(), ptr(flat)), "var_pack_weights")
+        w = m.hip_weights(c, force=True)        # the frozen model's own packed image; the graphs keep its address
 
         def body(with_goal):
+            w.bind()
             c.check(c.lib.var_arm_encoder_fwd(c.handle, current_stream_handle(), ptr(flat), ptr(self._img), 1,
                                               self._img.stride(0), ptr(self._goal) if with_goal else None, None, B, hw,
                                               ptr(self._image_feat), ptr(self._goal_feat) if with_goal else None,

@@ -8,9 +8,9 @@ import os
 
 import torch
 
-from ._lib import Context, VarHipError, current_stream_handle, ptr
+from ._lib import Context, VarHipError, ptr
 from .layout import N_PARAMS
-from .ops import mfcc as mfcc_op
+from .ops import mfcc as mfcc_op  # noqa: F401
 
 
 def multistep_lr(base_lr, milestones, gamma, epoch):
@@ -22,15 +22,29 @@ def multistep_lr(base_lr, milestones, gamma, epoch):
     return lr
 
 
+def _dist_on(pg):
+    return pg is not None or (torch.distributed.is_available() and torch.distributed.is_initialized())
+
+
 class VARTrainer:
+    """The step body of VAR/pretext_VAR.py:55-70 on the HIP library.
+
+    `_ctx` is the device context the launches go through; by default the HIP context of the model's GPU
+    (`Context.get`), and there is no other one in the product: a model on the CPU raises.  The parameter exists so
+    that the host logic of this class -- shard scaling, buffer slots, rank offsets, the order of collectives and
+    replays -- can be driven by the CPU test-suite (tests/_oracle_ctx.py binds the same C-ABI names to the oracle)
+    with world_size 2 on gloo."""
+
     def __init__(self, model, lr=1e-4, weight_decay=1e-6, betas=(0.9, 0.999), eps=1e-8, margin=1.0,
-                 process_group=None):
+                 process_group=None, _ctx=None):
         flat = model.flat_parameters()
-        if not flat.is_cuda:
-            raise VarHipError("VARTrainer needs the model on a GPU (no CPU fallback)")
+        if _ctx is None:
+            if not flat.is_cuda:
+                raise VarHipError("VARTrainer needs the model on a GPU (no CPU fallback)")
+            _ctx = Context.get(flat.device.index)
         self.model = model
         self.dev = flat.device
-        self.ctx = Context.get(self.dev.index)
+        self.ctx = _ctx
         self.lr, self.wd, self.betas, self.eps, self.margin = lr, weight_decay, betas, eps, margin
         self.hw = model.config.img_dim[1]
         # gradient arena with one extra slot for the loss so that ONE all-reduce carries both
@@ -39,20 +53,28 @@ class VARTrainer:
         self.exp_avg_sq = torch.zeros(N_PARAMS, dtype=torch.float32, device=self.dev)
         self.step_count = 0
         self.pg = process_group
-        self.world = 1
+        self.world, self.rank = 1, 0
+        self.rccl = None
         # VAR_FORCE_ALLREDUCE=1: run the data-parallel code path (RCCL all-reduce between two graphs) even with
         # one rank, to rehearse the multi-GPU step on a single-GPU box
         self.force_collective = os.environ.get("VAR_FORCE_ALLREDUCE") == "1"
-        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        if _dist_on(process_group):
             self.world = torch.distributed.get_world_size(process_group)
+            self.rank = torch.distributed.get_rank(process_group)
+            if self.world > 1:
+                # every replica starts from rank 0's parameters (ranks built from different seeds / checkpoints would
+                # otherwise drift apart silently: Adam is applied redundantly, never re-synchronised)
+                src = torch.distributed.get_global_rank(process_group, 0) if process_group is not None else 0
+                torch.distributed.broadcast(flat, src=src, group=process_group)
         self.pack()
 
     def pack(self):
-        """Refresh the packed weight images from the parameter arena (needed after loading a checkpoint or any
-        direct edit of the parameters; every optimiser step does it by itself)."""
-        c = self.ctx
-        c.check(c.lib.var_pack_weights(c.handle, current_stream_handle(), ptr(self.model.flat_parameters())),
-                "var_pack_weights")
+        """Refresh this model's packed weight image from the parameter arena (after loading a checkpoint or any direct
+        edit of the parameters; every optimiser step of this trainer keeps it current by itself)."""
+        self.weights = self.model.hip_weights(self.ctx, force=True)
+
+    def _bind(self):
+        self.weights.bind()
 
     @property
     def grads(self):
@@ -63,205 +85,242 @@ class VARTrainer:
         """Device scalar: the (global) mean triplet loss of the last step; reading it syncs."""
         return self.gbuf[N_PARAMS:]
 
+    def _loss_ptr(self):
+        return self.gbuf.data_ptr() + 4 * N_PARAMS
+
+    def sync_global_batch(self, local_batch):
+        """Sum of the ranks' local batch sizes (one small all-reduce, synchronises): the `global_batch` to pass when the
+        shards of a step may differ in size -- the default `B_local * world` is only right for equal shards."""
+        if self.rccl is not None and self.world > 1:
+            t = torch.tensor([float(local_batch)], dtype=torch.float32, device=self.dev)
+            self.rccl.allreduce(t)
+            return int(round(float(t.item())))
+        if self.world > 1:
+            t = torch.tensor([int(local_batch)], dtype=torch.int64, device=self.dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            return int(t.item())
+        return int(local_batch)
+
+    def _gb(self, B, global_batch):
+        return B * self.world if global_batch is None else int(global_batch)
+
     def loss_and_grads(self, image, pos, neg, global_batch=None):
         """fwd + loss + bwd into the gradient arena (no optimiser step, no collective)."""
         flat = self.model.flat_parameters()
         B = image.shape[0]
-        gb = B * self.world if global_batch is None else global_batch
         c = self.ctx
         c.ensure_plan(B, self.hw)
-        c.check(c.lib.var_arm_loss_grad(c.handle, current_stream_handle(), ptr(flat), ptr(image),
+        self._bind()
+        c.check(c.lib.var_arm_loss_grad(c.handle, c.stream(), ptr(flat), ptr(image),
                                         int(image.dtype == torch.uint8), image.stride(0), ptr(pos), ptr(neg),
-                                        B, self.hw, float(self.margin), 1.0 / gb, ptr(self.gbuf),
-                                        self.gbuf.data_ptr() + 4 * N_PARAMS, None), "var_arm_loss_grad")
+                                        B, self.hw, float(self.margin), 1.0 / self._gb(B, global_batch), ptr(self.gbuf),
+                                        self._loss_ptr(), None), "var_arm_loss_grad")
 
     def use_rccl(self, comm):
         """Route the gradient all-reduce through the C ABI (comm.RcclComm, var_allreduce_grads) instead of
-        torch.distributed; `comm.size` becomes the world size of the loss / gradient scaling."""
+        torch.distributed; `comm.size` / `comm.rank` become the world size / rank of the loss and gradient scaling."""
         self.rccl = comm
-        self.world = comm.size
+        self.world, self.rank = comm.size, comm.rank
         return self
 
-    def allreduce(self):
-        if getattr(self, "rccl", None) is not None:
+    def _collective(self):
+        return self.rccl is not None or self.world > 1 or (self.force_collective and torch.distributed.is_initialized())
+
+    def allreduce(self, async_op=False):
+        """The ONE exchange of the data-parallel step: in-place sum of [gradients | loss] over the ranks."""
+        if self.rccl is not None:
             self.rccl.allreduce(self.gbuf)
         elif self.world > 1 or (self.force_collective and torch.distributed.is_initialized()):
-            torch.distributed.all_reduce(self.gbuf, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            return torch.distributed.all_reduce(self.gbuf, op=torch.distributed.ReduceOp.SUM, group=self.pg,
+                                                async_op=async_op)
+        return None
 
     def adam(self):
         self.step_count += 1
         flat = self.model.flat_parameters()
         c = self.ctx
-        c.check(c.lib.var_adam_step(c.handle, current_stream_handle(), ptr(flat), ptr(self.gbuf),
+        self._bind()
+        c.check(c.lib.var_adam_step(c.handle, c.stream(), ptr(flat), ptr(self.gbuf),
                                     ptr(self.exp_avg), ptr(self.exp_avg_sq), N_PARAMS, float(self.lr),
                                     float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd),
                                     int(self.step_count)), "var_adam_step")
 
-    # ---- HIP-graph replay of the whole step (launch-bound otherwise: ~35 kernels + stream fork/joins) ----
-    def capture_dataset_step(self, images, pcm, batch, global_batch=None, _table=None):
-        """Capture step_from_dataset(images, idx, pcm, clip_idx, lens) once; returns replay(idx_row) where
-        idx_row is an int32 CUDA tensor of 5*batch entries [image_index | clip_index (2B) | lens (2B)].
-        Step count and learning rate live on the device (var_adam_step_dev); set_lr() updates the latter."""
+    # ---- HIP-graph replay of the whole step (launch-bound otherwise: ~20 kernels + stream fork/joins) ----
+    def _device_scalars(self, B):
         dev = self.dev
-        B = batch
-        self._g_idx = torch.zeros(5 * B, dtype=torch.int32, device=dev)
         self._g_lr = torch.full((1,), float(self.lr), dtype=torch.float32, device=dev)
         self._g_step = torch.full((1,), int(self.step_count), dtype=torch.int32, device=dev)
-        flat = self.model.flat_parameters()
-        c = self.ctx
-        c.ensure_plan(B, self.hw)
-        gb = B * self.world if global_batch is None else global_batch
-        img_idx, clip_idx, lens = self._g_idx[:B], self._g_idx[B:3 * B], self._g_idx[3 * B:]
 
-        def body_grad():
-            c.check(c.lib.var_arm_loss_grad_pcm(c.handle, current_stream_handle(), ptr(flat), ptr(images),
+    def _body_grad_pcm(self, images, pcm, idx, Bs, gb):
+        """Closure enqueueing gather + MFCC + fwd + loss + bwd for `Bs` samples whose indices sit PACKED at the head of
+        `idx`: [image_index (Bs) | clip_index (2 Bs) | lens (2 Bs)] (a full row is exactly that with Bs = batch; the short
+        last batch of an epoch uses the same layout with Bs < batch and the rest of the row unused)."""
+        c, flat = self.ctx, self.model.flat_parameters()
+        img_idx, clip_idx, lens = idx[:Bs], idx[Bs:3 * Bs], idx[3 * Bs:5 * Bs]
+
+        def body():
+            self._bind()
+            c.check(c.lib.var_arm_loss_grad_pcm(c.handle, c.stream(), ptr(flat), ptr(images),
                                                 int(images.dtype == torch.uint8), images.stride(0), ptr(img_idx),
-                                                ptr(pcm), pcm.stride(0), ptr(clip_idx), ptr(lens), B, self.hw,
+                                                ptr(pcm), pcm.stride(0), ptr(clip_idx), ptr(lens), Bs, self.hw,
                                                 float(self.margin), 1.0 / gb, ptr(self.gbuf),
-                                                self.gbuf.data_ptr() + 4 * N_PARAMS, None), "var_arm_loss_grad_pcm")
+                                                self._loss_ptr(), None), "var_arm_loss_grad_pcm")
+        return body
 
-        def body_adam():
-            tab, rows, row_ints = _table if _table is not None else (None, 0, 0)
-            c.check(c.lib.var_adam_step_graph(c.handle, current_stream_handle(), ptr(flat), ptr(self.gbuf),
+    def _body_adam(self, table=None, rows=0, row_ints=0, ahead=0):
+        c, flat = self.ctx, self.model.flat_parameters()
+
+        def body():
+            self._bind()
+            c.check(c.lib.var_adam_step_graph(c.handle, c.stream(), ptr(flat), ptr(self.gbuf),
                                               ptr(self.exp_avg), ptr(self.exp_avg_sq), N_PARAMS, ptr(self._g_lr),
                                               float(self.betas[0]), float(self.betas[1]), float(self.eps),
                                               float(self.wd), ptr(self._g_step),
-                                              ptr(tab) if tab is not None else None, row_ints, rows,
-                                              ptr(self._g_cursor) if tab is not None else None,
-                                              ptr(self._g_idx) if tab is not None else None, 0), "var_adam_step_graph")
+                                              ptr(table) if table is not None else None, row_ints, rows,
+                                              ptr(self._g_cursor) if table is not None else None,
+                                              ptr(self._g_idx) if table is not None else None, int(ahead)),
+                    "var_adam_step_graph")
+        return body
 
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream())
-        graphs = []
-        with torch.cuda.stream(side):
-            if self.world > 1 or self.force_collective:   # the RCCL all-reduce stays eager between two graphs
-                for body in (body_grad, body_adam):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=side):
-                        body()
-                    graphs.append(g)
-            else:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side):
-                    body_grad()
-                    body_adam()
-                graphs.append(g)
-        torch.cuda.current_stream().wait_stream(side)
+    def capture_dataset_step(self, images, pcm, batch, global_batch=None):
+        """Capture step_from_dataset(images, idx, pcm, clip_idx, lens) once; returns replay(idx_row) where
+        idx_row is an int32 tensor of 5*batch entries [image_index | clip_index (2B) | lens (2B)].
+        Step count and learning rate live on the device (var_adam_step_dev); set_lr() updates the latter."""
+        B = batch
+        self._g_idx = torch.zeros(5 * B, dtype=torch.int32, device=self.dev)
+        self._device_scalars(B)
+        self.ctx.ensure_plan(B, self.hw)
+        grad = self._body_grad_pcm(images, pcm, self._g_idx, B, self._gb(B, global_batch))
+        adam = self._body_adam()
+        if self._collective():                           # the all-reduce stays eager between two graphs
+            g_grad, g_adam = self.ctx.capture([[grad], [adam]])
+        else:
+            (g_grad,), g_adam = self.ctx.capture([[grad, adam]]), None
 
         def replay(idx_row):
-            if idx_row is not None:                      # None: the captured step walks its own index table
-                self._g_idx.copy_(idx_row, non_blocking=True)
-            graphs[0].replay()
-            if len(graphs) > 1:
+            self._g_idx.copy_(idx_row, non_blocking=True)
+            g_grad()
+            if g_adam is not None:
                 self.allreduce()
-                graphs[1].replay()
+                g_adam()
             self.step_count += 1
             return self.loss
         return replay
 
-    def capture_epoch_steps(self, images, pcm, batch, table, global_batch=None):
-        """Like capture_dataset_step, with the data-loader cursor on the device too: `table` is an int32 CUDA
-        tensor (rows, 5*batch) of step rows [image_index | clip_index (2B) | lens (2B)] (one or more shuffled epochs,
-        SyntheticTripletPool.index_table).  Returns (replay, load_table): replay() launches the captured step --
-        no host-side copy, the step itself fetches the next row (var_adam_step_graph); load_table(t) installs a
-        new table of the same shape (next epochs) and rewinds the cursor.  After `rows` replays without a new
-        table the walk starts over."""
-        dev = self.dev
+    def capture_epoch_steps(self, images, pcm, batch, table, global_batch=None, steps_per_epoch=None, tail_batch=0,
+                            tail_global_batch=None):
+        """The replayed step with the data-loader cursor on the device too: `table` is an int32 tensor (rows, 5*batch)
+        of step rows [image_index | clip_index (2B) | lens (2B)] (one or more shuffled epochs,
+        TripletPool.index_table).  Returns (replay, load_table): replay() launches the captured step -- no host-side
+        copy, the step itself fetches the next row (var_adam_step_graph); load_table(t) installs a new table of the
+        same shape (next epochs) and rewinds the cursor.  After `rows` replays without a new table the walk starts over.
+
+        Ragged epochs (the reference's DataLoader has drop_last=False, VAR/pretext_VAR.py:24): with `tail_batch` > 0
+        every `steps_per_epoch`-th row is the short last batch of its epoch, `tail_batch` samples packed at the head
+        of the row (TripletPool.epoch_index_table(drop_last=False)); a second graph captured for that size runs it,
+        with the loss averaged over `tail_batch` samples as TripletMarginLoss does.  rows % steps_per_epoch == 0."""
         B = batch
         rows, row_ints = int(table.shape[0]), int(table.shape[1])
-        assert row_ints == 5 * B and table.dtype == torch.int32 and table.is_cuda and table.is_contiguous()
+        if row_ints != 5 * B or table.dtype != torch.int32 or table.device != self.dev or not table.is_contiguous():
+            raise VarHipError("index table must be a contiguous int32 (rows, 5*batch) tensor on the trainer's device")
+        tail_batch = int(tail_batch)
+        if tail_batch:
+            if not (0 < tail_batch < B) or not steps_per_epoch or rows % steps_per_epoch:
+                raise VarHipError("ragged table: need 0 < tail_batch < batch and rows a multiple of steps_per_epoch")
         self._g_table = torch.empty_like(table)
-        self._g_cursor = torch.zeros(1, dtype=torch.int32, device=dev)
-        if self.world > 1 or self.force_collective:
-            return self._capture_epoch_steps_dp(images, pcm, B, table, global_batch)
-        replay_row = self.capture_dataset_step(images, pcm, B, global_batch, _table=(self._g_table, rows, row_ints))
-
-        def load_table(t):
-            assert t.shape == self._g_table.shape
-            self._g_table.copy_(t, non_blocking=True)
-            self._g_idx.copy_(t[0], non_blocking=True)
-            self._g_cursor.zero_()
-
-        load_table(table)
-
-        def replay():
-            return replay_row(None)
-        return replay, load_table
-
-    def _capture_epoch_steps_dp(self, images, pcm, B, table, global_batch):
-        """Data-parallel form of capture_epoch_steps.  The gradient all-reduce (RCCL, eager between graphs) has
-        nothing to overlap with inside the step -- every gradient is complete only at the end of the backward -- but
-        the audio front-end of the NEXT step does not depend on the weights: per step
-            graph [gather + fwd + loss + bwd, MFCC features of this step precomputed]
-            -> all_reduce(async) || MFCC of the next step (graph, on the caller's stream)
-            -> wait -> graph [Adam + re-pack]
-        so up to an MFCC kernel's worth (60 us) of collective latency is hidden."""
-        dev = self.dev
+        self._g_cursor = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self._device_scalars(B)
         c = self.ctx
-        flat = self.model.flat_parameters()
         c.ensure_plan(B, self.hw)
-        rows = int(table.shape[0])
-        gb = B * self.world if global_batch is None else global_batch
-        self._g_idx = torch.zeros(5 * B, dtype=torch.int32, device=dev)
-        self._g_lr = torch.full((1,), float(self.lr), dtype=torch.float32, device=dev)
-        self._g_step = torch.full((1,), int(self.step_count), dtype=torch.int32, device=dev)
-        self._g_mfcc = torch.zeros(2 * B, 1, 100, 40, dtype=torch.float32, device=dev)
-        img_idx, clip_idx, lens = self._g_idx[:B], self._g_idx[B:3 * B], self._g_idx[3 * B:]
+        dp = self._collective()
+        ahead = 1 if dp else 0
+        # data parallel: index_row holds [row k | row k+1]; the audio front-end runs one step ahead (second copy)
+        self._g_idx = torch.zeros((2 if dp else 1) * row_ints, dtype=torch.int32, device=self.dev)
+        adam = self._body_adam(self._g_table, rows, row_ints, ahead)
+        sizes = [(B, self._gb(B, global_batch))]
+        if tail_batch:
+            sizes.append((tail_batch, self._gb(tail_batch, tail_global_batch)))
+        state = {"row": 0}
 
-        def body_grad():
-            c.check(c.lib.var_arm_loss_grad_gather(c.handle, current_stream_handle(), ptr(flat), ptr(images),
-                                                   int(images.dtype == torch.uint8), images.stride(0), ptr(img_idx),
-                                                   ptr(self._g_mfcc), ptr(self._g_mfcc[B:]), B, self.hw,
-                                                   float(self.margin), 1.0 / gb, ptr(self.gbuf),
-                                                   self.gbuf.data_ptr() + 4 * N_PARAMS, None), "var_arm_loss_grad_gather")
+        def is_tail(row):
+            return bool(tail_batch) and row % steps_per_epoch == steps_per_epoch - 1
 
-        def body_front():
-            c.check(c.lib.var_mfcc(c.handle, current_stream_handle(), ptr(pcm), ptr(lens), ptr(clip_idx), 2 * B,
-                                   pcm.stride(0), 100, ptr(self._g_mfcc)), "var_mfcc")
+        if not dp:
+            graphs = [c.capture([[self._body_grad_pcm(images, pcm, self._g_idx, Bs, gb), adam]])[0] for Bs, gb in sizes]
 
-        def body_adam():
-            c.check(c.lib.var_adam_step_graph(c.handle, current_stream_handle(), ptr(flat), ptr(self.gbuf),
-                                              ptr(self.exp_avg), ptr(self.exp_avg_sq), N_PARAMS, ptr(self._g_lr),
-                                              float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                                              float(self.wd), ptr(self._g_step), ptr(self._g_table), 5 * B, rows,
-                                              ptr(self._g_cursor), ptr(self._g_idx), B), "var_adam_step_graph")
+            def load_table(t):
+                assert t.shape == self._g_table.shape
+                self._g_table.copy_(t, non_blocking=True)
+                self._g_idx.copy_(t[0], non_blocking=True)
+                self._g_cursor.zero_()
+                state["row"] = 0
 
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream())
-        graphs = []
-        with torch.cuda.stream(side):
-            body_front()                                   # warm-up outside capture
-            for body in (body_grad, body_front, body_adam):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side):
-                    body()
-                graphs.append(g)
-        torch.cuda.current_stream().wait_stream(side)
-        g_grad, g_front, g_adam = graphs
-        collective = self.world > 1 or (self.force_collective and torch.distributed.is_initialized())
+            def replay():
+                graphs[1 if is_tail(state["row"]) else 0]()
+                state["row"] = (state["row"] + 1) % rows
+                self.step_count += 1
+                return self.loss
+            load_table(table)
+            return replay, load_table
+
+        # ---- data parallel.  The gradient all-reduce (eager between graphs) has nothing to overlap with inside the
+        # step -- every gradient is complete only at the end of the backward -- but the audio front-end of the NEXT
+        # step does not depend on the weights: per step
+        #     graph [gather + fwd + loss + bwd, MFCC features of this step precomputed]
+        #     -> all_reduce(async) || MFCC of the next step (graph, on the caller's stream)
+        #     -> wait -> graph [Adam + re-pack + row fetch]
+        # so up to an MFCC kernel's worth (60 us) of collective latency is hidden.
+        flat = self.model.flat_parameters()
+        self._g_mfcc = torch.zeros(2 * B, 1, 100, 40, dtype=torch.float32, device=self.dev)
+        cur, nxt = self._g_idx[:row_ints], self._g_idx[row_ints:]
+
+        def body_grad(Bs, gb):
+            img_idx = cur[:Bs]
+
+            def body():
+                self._bind()
+                c.check(c.lib.var_arm_loss_grad_gather(c.handle, c.stream(), ptr(flat), ptr(images),
+                                                       int(images.dtype == torch.uint8), images.stride(0), ptr(img_idx),
+                                                       ptr(self._g_mfcc), ptr(self._g_mfcc[Bs:]), Bs, self.hw,
+                                                       float(self.margin), 1.0 / gb, ptr(self.gbuf),
+                                                       self._loss_ptr(), None), "var_arm_loss_grad_gather")
+            return body
+
+        def body_front(Bs):
+            clip_idx, lens = nxt[Bs:3 * Bs], nxt[3 * Bs:5 * Bs]
+
+            def body():
+                c.check(c.lib.var_mfcc(c.handle, c.stream(), ptr(pcm), ptr(lens), ptr(clip_idx), 2 * Bs,
+                                       pcm.stride(0), 100, ptr(self._g_mfcc)), "var_mfcc")
+            return body
+
+        body_front(B)()                                    # warm-up outside capture
+        g_grad = [c.capture([[body_grad(Bs, gb)]])[0] for Bs, gb in sizes]
+        g_front = [c.capture([[body_front(Bs)]])[0] for Bs, _ in sizes]
+        g_adam = c.capture([[adam]])[0]
 
         def load_table(t):
             assert t.shape == self._g_table.shape
             self._g_table.copy_(t, non_blocking=True)
-            self._g_idx.copy_(t[0], non_blocking=True)
-            g_front.replay()                               # features of row 0
-            self._g_idx[B:].copy_(t[1 % rows][B:], non_blocking=True)   # clip entries run one step ahead
+            nxt.copy_(t[0], non_blocking=True)
+            g_front[1 if is_tail(0) else 0]()              # features of row 0
+            cur.copy_(t[0], non_blocking=True)
+            nxt.copy_(t[1 % rows], non_blocking=True)
             self._g_cursor.zero_()
-
-        load_table(table)
+            state["row"] = 0
 
         def replay():
-            g_grad.replay()
-            work = None
-            if collective:
-                work = torch.distributed.all_reduce(self.gbuf, op=torch.distributed.ReduceOp.SUM, group=self.pg,
-                                                    async_op=True)
-            g_front.replay()                               # MFCC of the next step while the collective is in flight
+            row = state["row"]
+            g_grad[1 if is_tail(row) else 0]()
+            work = self.allreduce(async_op=True)
+            g_front[1 if is_tail((row + 1) % rows) else 0]()   # MFCC of the next step while the collective is in flight
             if work is not None:
                 work.wait()                                # the caller's stream waits for the collective
-            g_adam.replay()                                # ... and fetches the rows of the steps after
+            g_adam()                                       # ... and fetches the rows of the steps after
+            state["row"] = (row + 1) % rows
             self.step_count += 1
             return self.loss
+        load_table(table)
         return replay, load_table
 
     def set_lr(self, lr):
@@ -281,59 +340,71 @@ class VARTrainer:
         """One step with the data-loader work folded in (var_arm_loss_grad_pcm): sample b reads image row
         image_index[b] of the HBM-resident `images` (N,3,H,H) u8|f32; clips [pos | neg] read rows
         clip_index (2B) of `pcm` (M, n) int16 with lens (2B) valid samples (0 = "empty" class); the MFCC
-        front-end runs inside the step.  Index tensors are int32 CUDA."""
+        front-end runs inside the step.  Index tensors are int32 on the trainer's device."""
         flat = self.model.flat_parameters()
         B = image_index.numel()
-        gb = B * self.world if global_batch is None else global_batch
         for t in (image_index, clip_index, lens):
-            if t.dtype != torch.int32 or not t.is_cuda or not t.is_contiguous():
-                raise VarHipError("index / length tensors must be contiguous int32 CUDA tensors")
+            if t.dtype != torch.int32 or t.device != self.dev or not t.is_contiguous():
+                raise VarHipError("index / length tensors must be contiguous int32 tensors on the trainer's device")
         if pcm.dtype != torch.int16 or clip_index.numel() != 2 * B or lens.numel() != 2 * B:
             raise VarHipError("pcm must be int16 and clip_index / lens must hold 2*B entries")
+        if pcm.stride(0) % 2 or (pcm.dim() == 2 and pcm.stride(1) != 1):
+            raise VarHipError("pcm rows must be contiguous with an even stride (the front-end loads sample pairs)")
         c = self.ctx
         c.ensure_plan(B, self.hw)
-        c.check(c.lib.var_arm_loss_grad_pcm(c.handle, current_stream_handle(), ptr(flat), ptr(images),
+        self._bind()
+        c.check(c.lib.var_arm_loss_grad_pcm(c.handle, c.stream(), ptr(flat), ptr(images),
                                             int(images.dtype == torch.uint8), images.stride(0), ptr(image_index),
                                             ptr(pcm), pcm.stride(0), ptr(clip_index), ptr(lens), B, self.hw,
-                                            float(self.margin), 1.0 / gb, ptr(self.gbuf),
-                                            self.gbuf.data_ptr() + 4 * N_PARAMS, None), "var_arm_loss_grad_pcm")
+                                            float(self.margin), 1.0 / self._gb(B, global_batch), ptr(self.gbuf),
+                                            self._loss_ptr(), None), "var_arm_loss_grad_pcm")
         self.allreduce()
         self.adam()
         return self.loss
 
+    def _inbatch_head(self, anchor, cand, target, tau, inv_count):
+        c = self.ctx
+        B, M = anchor.shape[0], cand.shape[0]
+        loss = torch.empty(1, dtype=torch.float32, device=self.dev)
+        ga, gc = torch.empty_like(anchor), torch.empty_like(cand)
+        scratch = torch.empty(2 * B, dtype=torch.float32, device=self.dev)
+        c.check(c.lib.var_inbatch_loss_fwd_bwd(c.handle, c.stream(), ptr(anchor), ptr(cand), ptr(target), B, M, float(tau),
+                                               float(inv_count), ptr(scratch), ptr(loss), ptr(ga), ptr(gc)),
+                "var_inbatch_loss_fwd_bwd")
+        return loss, ga, gc
+
     def step_inbatch(self, image, pos, neg, tau=0.1):
         """One optimisation step with the in-batch-negatives contrastive head instead of the triplet loss (BASELINE
         config 3; an extension, csrc/inbatch.hip): every rank's [positive ; negative] sound embeddings are all-gathered
-        (9 KB per rank at B = 256), each rank scores its images against all of them, the candidate gradients are summed
+        (6 KB per rank at B = 256), each rank scores its images against all of them, the candidate gradients are summed
         with one small all-reduce and each rank back-propagates its own rows; then the usual gradient all-reduce + Adam.
-        Collectives go through torch.distributed, or through the C ABI when use_rccl() was called."""
-        from .ops import inbatch_contrastive_loss
+        Collectives go through torch.distributed, or through the C ABI when use_rccl() was called.  Equal shards."""
         self._check(image, pos, neg)
         c, m = self.ctx, self.model
         flat = m.flat_parameters()
         B = image.shape[0]
         c.ensure_plan(B, self.hw)
         dev = self.dev
-        rccl = getattr(self, "rccl", None)
-        rank = rccl.rank if rccl is not None else (torch.distributed.get_rank(self.pg) if self.world > 1 else 0)
-        stream = current_stream_handle()
+        rccl, rank, world = self.rccl, self.rank, self.world
+        stream = c.stream()
+        self._bind()
         emb = torch.empty((3, B, 3), dtype=torch.float32, device=dev)          # [image | pos | neg]
         c.check(c.lib.var_arm_encoder_fwd(c.handle, stream, ptr(flat), ptr(image), int(image.dtype == torch.uint8),
                                           image.stride(0), ptr(pos), ptr(neg), B, self.hw, ptr(emb[0]), ptr(emb[1]), ptr(emb[2]),
                                           None, None, 1), "var_arm_encoder_fwd")
         local = emb[1:].reshape(2 * B, 3)
-        if rccl is not None and self.world > 1:
+        if rccl is not None and world > 1:
             cand = rccl.allgather(local.reshape(-1)).view(-1, 3)
-        elif self.world > 1:
-            cand = torch.empty((self.world * 2 * B, 3), dtype=torch.float32, device=dev)
+        elif world > 1:
+            cand = torch.empty((world * 2 * B, 3), dtype=torch.float32, device=dev)
             torch.distributed.all_gather_into_tensor(cand, local.contiguous(), group=self.pg)
         else:
             cand = local
         target = torch.arange(B, dtype=torch.int32, device=dev) + rank * 2 * B
-        loss, ga, gc = inbatch_contrastive_loss(emb[0], cand, target, tau=tau, inv_count=1.0 / (B * self.world))
-        if rccl is not None and self.world > 1:
+        loss, ga, gc = self._inbatch_head(emb[0], cand.contiguous(), target, tau, 1.0 / (B * world))
+        if rccl is not None and world > 1:
             rccl.allreduce(gc.view(-1))
-        elif self.world > 1:
+        elif world > 1:
             torch.distributed.all_reduce(gc, op=torch.distributed.ReduceOp.SUM, group=self.pg)
         mine = gc[rank * 2 * B:(rank + 1) * 2 * B]
         c.check(c.lib.var_arm_encoder_bwd(c.handle, stream, ptr(flat), ptr(ga), ptr(mine[:B].contiguous()),
@@ -352,18 +423,24 @@ class VARTrainer:
 
     def _check(self, image, pos, neg):
         for t in (image, pos, neg):
-            if t is None or not t.is_cuda or not t.is_contiguous():
-                raise VarHipError("VARTrainer.step needs contiguous CUDA tensors (image, pos, neg)")
+            if t is None or t.device != self.dev or not t.is_contiguous():
+                raise VarHipError("VARTrainer.step needs contiguous tensors (image, pos, neg) on the trainer's device")
         if pos.dtype != torch.float32 or neg.dtype != torch.float32 or image.dtype not in (torch.uint8, torch.float32):
             raise VarHipError("image must be u8/f32 and MFCC f32")
 
 
-def train_representation(model, batches, epochs, lr=1e-4, weight_decay=1e-6, milestones=(10, 30, 50), gamma=0.2,
+def train_representation(model, batches, epochs, lr=1e-4, weight_decay=1e-6, milestones=None, gamma=0.2,
                          margin=1.0, save_dir=None, save_interval=10, start_ep=0, log=print):
     """The loop of VAR/pretext_VAR.py:44-91.  `batches()` yields (image, sound_positive, sound_negative, gt)
-    CUDA tensors for one epoch.  Returns the per-epoch average losses."""
+    CUDA tensors for one epoch -- every batch, including a short last one (the reference's DataLoader has
+    drop_last=False).  `milestones` defaults to the model's reference config: [10, 30, 50] for the Kuka model
+    (fourInARow/config.py:43-44), [20, 30] for the iTHOR model (Envs/ai2thor/config.py:47-48).
+    Returns the per-epoch average losses."""
     from .ithor import IthorTrainer, IthorVARPretextNet
-    trainer_cls = IthorTrainer if isinstance(model, IthorVARPretextNet) else VARTrainer
+    is_ithor = isinstance(model, IthorVARPretextNet)
+    if milestones is None:
+        milestones = (20, 30) if is_ithor else (10, 30, 50)
+    trainer_cls = IthorTrainer if is_ithor else VARTrainer
     tr = trainer_cls(model, lr=lr, weight_decay=weight_decay, margin=margin)
     model.train()
     loss_list = []
