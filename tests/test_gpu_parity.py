@@ -109,10 +109,15 @@ def test_fused_loss_grad_and_adam_vs_fixture(var_amd, golden_dir):
             ref = orc.flatten_params({k: fx[f'step{s + 1}.' + k] for k, _ in orc.PARAM_SPECS})
             got = m.flat_parameters().cpu().numpy()
             diff = np.abs(got - ref)
-            # Adam turns rounding-level gradient differences on near-zero gradients into O(lr) moves
+            # Adam's first update is lr * g / (|g| + 1e-8): where |g| >> 1e-8 it is +-lr whatever the rounding of g,
+            # and only entries whose gradient is itself of the order of eps can land elsewhere.  So: almost all of
+            # the arena within 2e-6, and after step 1 every entry beyond that is TRACED to a reference gradient
+            # below 1e-6 (the eps-dominated regime), not merely bounded by the distance Adam can travel.
             assert np.mean(diff < 2e-6) > 0.995
-            assert np.max(diff) < 1.05e-4 * (s + 1)
-            assert np.max(np.abs(got - p0)) < 1.05e-4 * (s + 1)
+            if s == 0:
+                g1 = orc.loss_grad(p0, fx['image0'], fx['pos0'], fx['neg0'])[1]
+                off = diff >= 2e-6
+                assert np.all(np.abs(g1[off]) < 1e-6), float(np.abs(g1[off]).max())
     # state_dict round trip keeps the reference checkpoint layout
     sd2 = m.state_dict()
     assert list(sd2.keys()) == [k for k, _ in orc.PARAM_SPECS]
@@ -132,22 +137,12 @@ def test_fused_grads_vs_oracle_random_batch(var_amd, golden_dir):
     m = make_model(var_amd, sd, 84)
     tr = var_amd.VARTrainer(m)
     tr.loss_and_grads(cuda(img), cuda(pos), cuda(neg))
-    loss_ref, g_ref, _ = orc.loss_grad(orc.flatten_params(sd), img, pos, neg)
+    from tests._gpu_helpers import assert_grads_match_or_traced, torch_loss_grad
+    net, loss_ref, g_ref, _, image_f32 = torch_loss_grad(sd, torch.from_numpy(img), torch.from_numpy(pos), torch.from_numpy(neg))
     assert abs(tr.loss.item() - loss_ref) < 1e-5
-    got = orc.unflatten_params(tr.grads.cpu().numpy())
-    ref = orc.unflatten_params(g_ref)
-    # A ReLU unit whose pre-activation is within fp32 rounding of zero (|x| ~ 1e-7; with ~1.5 M units in
-    # this batch there is usually one) is on or off depending on the summation order, and one such flip moves
-    # every entry of the filters below it by up to a few 1e-3 of the tensor's scale.  So: all tensors within
-    # 5e-3 in the L2 sense and 2e-2 elementwise, and at least 90 % of all entries within the fp32 tolerance.
-    close = total = 0
-    for k, _ in orc.PARAM_SPECS:
-        scale = np.max(np.abs(ref[k])) + 1e-30
-        assert np.linalg.norm(got[k] - ref[k]) / (np.linalg.norm(ref[k]) + 1e-30) < 5e-3, k
-        assert rel_err(got[k], ref[k]) < 2e-2, (k, rel_err(got[k], ref[k]))
-        close += int(np.sum(np.abs(got[k] - ref[k]) < 1e-3 * scale))
-        total += got[k].size
-    assert close > 0.9 * total
+    # every gradient tensor within 1e-3 of its scale -- unless a ReLU gate differs between the two forwards, which is
+    # only accepted (and then bounds the arena at 2e-2 in L2) when that unit's pre-activation is within 1e-5 of zero
+    assert_grads_match_or_traced(var_amd, tr, net, g_ref, image_f32, torch.from_numpy(pos), torch.from_numpy(neg), B)
 
 
 def test_edge_behaviours(var_amd, golden_dir):
@@ -303,13 +298,14 @@ def test_odd_batches_vs_oracle(var_amd, h, B):
     img = rng.integers(0, 256, size=(B, 3, h, h), dtype=np.uint8)
     pos = rng.standard_normal((B, 1, 100, 40)).astype(np.float32)
     neg = rng.standard_normal((B, 1, 100, 40)).astype(np.float32)
-    p0 = m.flat_parameters().cpu().numpy().copy()
+    sd0 = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
     tr.loss_and_grads(cuda(img), cuda(pos), cuda(neg))
-    l_ref, g_ref, _ = orc.loss_grad(p0, img, pos, neg)
-    g = tr.grads.cpu().numpy()
+    from tests._gpu_helpers import assert_grads_match_or_traced, torch_loss_grad
+    net, l_ref, g_ref, _, image_f32 = torch_loss_grad(sd0, torch.from_numpy(img), torch.from_numpy(pos), torch.from_numpy(neg), h)
     assert abs(tr.loss.item() - l_ref) < 1e-5
-    # L2 bound: a ReLU unit within rounding of zero may flip (see test_fused_grads_vs_oracle_random_batch)
-    assert np.linalg.norm(g - g_ref) / np.linalg.norm(g_ref) < 5e-3
+    assert_grads_match_or_traced(var_amd, tr, net, g_ref, image_f32, torch.from_numpy(pos), torch.from_numpy(neg), B)
+    l_c, g_c, _ = orc.loss_grad(orc.flatten_params(sd0), img, pos, neg)       # and the C oracle agrees with torch
+    assert abs(l_c - l_ref) < 1e-5 and np.linalg.norm(g_c - g_ref) / np.linalg.norm(g_ref) < 1e-3
 
 
 def test_replayed_training_learns_a_small_pool(var_amd):
