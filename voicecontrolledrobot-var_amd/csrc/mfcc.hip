@@ -4,175 +4,308 @@
 //   x/32768 -> reflect-padded frames (n_fft 512, hop 160) x periodic Hamming(400) centred in 512
 //   -> |rFFT|^2 -> 40 HTK-mel triangles -> log(. + 1e-6) -> orthonormal DCT-II -> (T, 40),
 //   T = 1 + N/160; rows beyond T are zero, rows beyond out_frames are dropped.
-// One wavefront per frame: the 512-point real FFT is a 256-point complex Stockham radix-4 FFT
-// (4 stages, exactly one radix-4 butterfly per lane per stage, ping-pong in LDS) plus the
-// even/odd split; a workgroup of 4 waves walks the frames of one clip.  PCM is read as
-// coalesced 128-byte rows straight from HBM/L2 (each sample is touched by 2.5 frames).
-// Tables (window, twiddles, mel triangles, DCT) are computed once on the host in double.
+//
+// Work unit = a TILE of 16 consecutive output frames of the flat (clip, frame) list, one 4-wave workgroup per tile
+// (persistent, two workgroups per CU):
+//   * FFT on the vector ALU, 16 LANES PER FRAME (4 frames per wave): the 512-point real FFT is a 256-point complex FFT of
+//     z[n] = x[2n] + i x[2n+1], factored 256 = 16 x 16 -- every lane runs a 16-point FFT on registers (two radix-4
+//     levels), multiplies by the W256 twiddles it keeps in registers, the 16 x 16 transpose goes once through a padded
+//     LDS tile, a second 16-point FFT, then the even/odd split to the 257 power bins.  Two LDS exchanges per frame instead
+//     of the four of a radix-4 Stockham FFT, a quarter of its wave-instructions.
+//   * mel (257 -> 40) and DCT (40 -> 40) on the MATRIX cores over the tile's 16 frames (v_mfma_f32_16x16x4_f32): the mel
+//     triangles of 16 consecutive filters only touch a band of bins (12 / 28 / 32 k-steps for the three filter tiles), the
+//     B operands (filter weights, DCT columns) are wave constants held in registers, the A operand is the power tile in
+//     LDS with a row pitch of 258 floats (conflict-free for the 16 x 4 operand read).
+// PCM is read as 4-byte sample pairs straight from HBM/L2 (each sample is touched by 3.2 frames); frames that overlap
+// either end of the clip (reflect padding) take a per-sample path.  Tables are computed once on the host in double.
 #include <math.h>
 
 #include <vector>
 
 #include "var_common.h"
 
+#ifndef MFCC_ABL
+#define MFCC_ABL 0
+#endif
 namespace {
 constexpr int NFFT = 512, WIN = 400, HOP = 160, NMEL = 40, NMFCC = 40, NFREQ = 257;
 constexpr int WOFF = (NFFT - WIN) / 2;   // 56
 
+// mel filter tiles: filters [16 t, 16 t + 16) read bins [kMelK0[t], kMelK0[t] + 4 kMelSteps[t])
+constexpr int kMelK0[3] = {0, 36, 132};
+constexpr int kMelSteps[3] = {12, 28, 32};            // multiples of 4: every wave takes the same number of k-steps of a tile
+constexpr int kMelSlots = (12 + 28 + 32) / 4;         // 18 B-operand registers per wave
+
 // table layout (floats)
-constexpr int TB_WIN = 0;                 // 400
+constexpr int TB_WIN = 0;                 // 400 (host-side only)
 constexpr int TB_TW256 = 400;             // 256 x (cos, sin) of -2 pi m / 256
 constexpr int TB_TW512 = TB_TW256 + 512;  // 256 x (cos, sin) of -2 pi k / 512
-constexpr int TB_DCT = TB_TW512 + 512;    // [n][k] 40 x 40
-constexpr int TB_MSTART = TB_DCT + 1600;  // 40 ints
-constexpr int TB_MCOUNT = TB_MSTART + 40;
-constexpr int TB_MOFF = TB_MCOUNT + 40;
-constexpr int TB_MW = TB_MOFF + 40;       // <= 640 weights (triangles back to back; host-side only)
-constexpr int MAXC = 34;                  // trip count of the mel loop (widest triangle: 33 bins)
-constexpr int TB_MWD = TB_MW + 640;       // dense [q][40]: weight of bin mstart[m] + q in filter m, 0 beyond its triangle
-constexpr int TB_WIN512 = TB_MWD + MAXC * 40;   // 512: Hamming(400) / 32768 centred in the frame, 0 outside
-constexpr int TB_TOTAL = TB_WIN512 + 512; // a multiple of 4
+constexpr int TB_WIN512 = TB_TW512 + 512; // 512: Hamming(400) / 32768 centred in the frame, 0 outside
+constexpr int TB_MELB = TB_WIN512 + 512;  // [wave 4][slot 18][lane 64]: B operand of the mel products
+constexpr int TB_DCTB = TB_MELB + 4 * kMelSlots * 64;   // [tile 3][step 10][lane 64]: B operand of the DCT products
+constexpr int TB_TOTAL = TB_DCTB + 3 * 10 * 64;          // a multiple of 4
 
-struct cplx { float x, y; };
-__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
-__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.x - b.x, a.y - b.y}; }
+// Complex numbers are float pairs in even-aligned register pairs so that the packed-f32 instructions of gfx950
+// (v_pk_add/mul/fma_f32: two f32 operations per lane per issue) carry the FFT; the swaps and sign flips of complex
+// arithmetic ride on the instructions' op_sel / neg modifiers (hipcc emits separate v_xor + v_mov for them).
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef f2 cplx;
 
-// Each wave owns its frames end to end and never synchronises with the other waves: all exchange
-// goes through the wave's private LDS region, where a wave's own DS operations execute in order,
-// so a compiler-level wave barrier is all that separates a butterfly stage from the next.
+// a * w  (w = (cos, sin) in a VGPR pair)
+__device__ __forceinline__ f2 cmul(f2 a, f2 w) {
+    f2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));                     // (a.x w.x, a.y w.x)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"              // (-a.y w.y + t.x, a.x w.y + t.y)
+        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+// a * (c + i s) with compile-time constants (the compiler keeps them in scalar registers)
+__device__ __forceinline__ f2 cmulc(f2 a, float c, float s) {
+    const f2 sw = {-a.y, a.x};
+    return __builtin_elementwise_fma(sw, f2{s, s}, a * f2{c, c});
+}
+// a + (-i) t = (a.x + t.y, a.y - t.x);  a - (-i) t = (a.x - t.y, a.y + t.x)
+__device__ __forceinline__ f2 add_mi(f2 a, f2 t) {
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(t));
+    return r;
+}
+__device__ __forceinline__ f2 sub_mi(f2 a, f2 t) {
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(t));
+    return r;
+}
+
+// 4-point DFT in place: (a, b, c, d) -> (X0, X1, X2, X3), forward transform (W4 = -i): 8 packed adds
+__device__ __forceinline__ void dft4(cplx& a, cplx& b, cplx& c, cplx& d) {
+    const cplx s0 = a + c, s1 = a - c, s2 = b + d, t = b - d;
+    a = s0 + s2; b = add_mi(s1, t); c = s0 - s2; d = sub_mi(s1, t);
+}
+
+// 16-point forward DFT on registers: v[n] -> v[k].  n = 4 na + q, k = r + 4 s:
+//   a[q][r] = W16^(q r) * DFT4_na(v[4 na + q])[r];   X[r + 4 s] = DFT4_q(a[q][r])[s]
+__device__ __forceinline__ void fft16(cplx (&v)[16]) {
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dft4(v[q], v[q + 4], v[q + 8], v[q + 12]);       // v[q + 4 r] = a[q][r] before twiddling
+    // W16^(q r), q, r in 1..3: exponents 1 2 3 / 2 4 6 / 3 6 9
+    v[1 + 4] = cmulc(v[1 + 4], C1, -S1);
+    v[1 + 8] = cmulc(v[1 + 8], H, -H);
+    v[1 + 12] = cmulc(v[1 + 12], S1, -C1);
+    v[2 + 4] = cmulc(v[2 + 4], H, -H);
+    v[2 + 8] = cplx{v[2 + 8].y, -v[2 + 8].x};                                    // * (-i)
+    v[2 + 12] = cmulc(v[2 + 12], -H, -H);
+    v[3 + 4] = cmulc(v[3 + 4], S1, -C1);
+    v[3 + 8] = cmulc(v[3 + 8], -H, -H);
+    v[3 + 12] = cmulc(v[3 + 12], -C1, S1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dft4(v[4 * r], v[4 * r + 1], v[4 * r + 2], v[4 * r + 3]);   // -> X[r + 4 s] at v[4 r + s]
+    // natural order: X[k] for k = r + 4 s sits at v[4 r + s]: transpose the 4 x 4 index (register renaming)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int s2 = r + 1; s2 < 4; ++s2) { const cplx t = v[4 * r + s2]; v[4 * r + s2] = v[4 * s2 + r]; v[4 * s2 + r] = t; }
+}
+
+// Waves own their four frames through the FFT: within a wave, DS operations execute in order, so a compiler-level
+// wave barrier is all that separates the two sides of an exchange through the wave's private LDS region.
 #define WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 
-constexpr int MW = 16;     // waves per workgroup (one clip per workgroup, frames dealt to waves)
+constexpr int FT = 16;                    // frames per tile
+constexpr int NTHR = 256;                 // 4 waves
+constexpr int TPITCH = 17 * 16;           // complex elements per frame of the transpose tile (row pitch 17)
+constexpr int PPITCH = 258;               // floats per frame of the power tile (== 2 mod 32)
+constexpr int LPITCH = 42;                // floats per frame of the log-mel tile (10 i mod 32 distinct for i < 16)
 
-__global__ void __launch_bounds__(MW * 64)
+// LDS carve-up (floats): 56 KB per workgroup; the register budget (244 VGPRs) sets two workgroups per CU
+constexpr int L_WIN = 0, L_TBUF = 512, L_PW = L_TBUF + 2 * FT * TPITCH;
+constexpr int L_PART = L_TBUF, L_LMEL = L_PW + FT * PPITCH + 8, L_LIVE = L_LMEL + FT * LPITCH;   // the partial sums alias the (then dead) transpose tile
+constexpr int L_TOTAL = L_LIVE + 2 * FT;
+constexpr int MFCC_LDS_BYTES = L_TOTAL * 4;
+
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+
+struct FrameRef { const int16_t* sig; int p0, N; bool live, interior; };
+
+__global__ void __launch_bounds__(NTHR, 2)
 mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const int* __restrict__ clip_index,
-            int pcm_stride, int out_frames, const float* __restrict__ tab, float* __restrict__ out) {
-    __shared__ float tabs[TB_TOTAL];                 // window, twiddles, DCT, mel triangles (15 KB)
-    __shared__ cplx bufA[MW][256];
-    __shared__ cplx bufB[MW][256];                   // after the FFT: power spectrum (264 floats) + log-mel (40)
-    const int clip = blockIdx.x;
+            int pcm_stride, int out_frames, int total_frames, const float* __restrict__ tab, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const float* win = lds + L_WIN;                 // window / 32768, zero outside its 400 taps
+    cplx* tbuf = (cplx*)(lds + L_TBUF);             // transpose tile; then the spectrum Z[k] (256 per frame)
+    float* pw = lds + L_PW;                         // power spectrum tile (A operand of the mel products), x 4
+    float* part = lds + L_PART;                     // mel partial sums of the four waves
+    float* lmel = lds + L_LMEL;                     // log-mel tile (A operand of the DCT products)
+    int* live_s = (int*)(lds + L_LIVE);             // [parity][frame]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int e = tid; e < TB_TOTAL / 4; e += MW * 64) ((float4*)tabs)[e] = ((const float4*)tab)[e];
-    const int N = lens[clip];
-    const int T = 1 + N / HOP;
-    const int16_t* sig = pcm + (size_t)(clip_index ? clip_index[clip] : clip) * pcm_stride;
-    const int* itab = (const int*)tabs;
-    const cplx* tw256 = (const cplx*)(tabs + TB_TW256);
-    const cplx* tw512 = (const cplx*)(tabs + TB_TW512);
-    float* xs = (float*)bufA[wave];
-    __syncthreads();
-    // mel filter of this lane (lanes >= 40 idle in that phase)
-    const int ml = lane < NMEL ? lane : 0;
-    const int mst = itab[TB_MSTART + ml];
-    float dct[NMEL];
-#pragma unroll
-    for (int n = 0; n < NMEL; ++n) dct[n] = tabs[TB_DCT + n * NMFCC + ml];
+    const int j = lane & 15, g = lane >> 4;
+    const int fi = 4 * wave + g;                                           // this lane group's frame within the tile
 
-    float* pw = (float*)bufB[wave];                  // the FFT result ends in bufA (4 stages), bufB is free then
-    float* lm = pw + 264;
-    for (int t = wave; t < out_frames; t += MW) {
-        // frames beyond T are MFCC-domain zero padding; N == 0 is the "empty" class (dataset.py:37-38)
-        const bool live = t < T && N > 0;
-        if (!live) {
-            if (lane < NMFCC) out[((size_t)clip * out_frames + t) * NMFCC + lane] = 0.f;
-            continue;
-        }
-        // 1. windowed frame -> LDS.  Frames whose 512 samples all lie inside the clip (all but two at either end)
-        //    take two samples per 4-byte load and the zero-extended window table: no index logic per sample.
-        const int p0 = t * HOP - NFFT / 2;
-        if (p0 >= 0 && p0 + NFFT <= N) {
+    for (int e = tid; e < FT * PPITCH + 8; e += NTHR) pw[e] = 0.f;          // pad column 257 and the slack stay zero
+    for (int e = tid; e < 512; e += NTHR) lds[L_WIN + e] = tab[TB_WIN512 + e];
+    // lane constants in registers: W256^(j k1), W512^(j + 16 m), mel / DCT B operands (the window taps stay in LDS:
+    // with them the kernel spills).  Measured: squeezing the kernel under 168 VGPRs for three workgroups per CU --
+    // constants re-read from the table per tile -- spills as well and runs at 65 us instead of 46.
+    cplx tw[16], tw5[16];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int n = lane + 64 * i;
-                const uint32_t two = *(const uint32_t*)(sig + p0 + 2 * n);        // p0 even, clip rows 4-byte aligned
-                const float2 w = *(const float2*)(tabs + TB_WIN512 + 2 * n);
-                float2 z;
-                z.x = (float)(int16_t)(two & 0xffff) * w.x;
-                z.y = (float)((int32_t)two >> 16) * w.y;
-                *(float2*)(xs + 2 * n) = z;
-            }
+    for (int k1 = 0; k1 < 16; ++k1) tw[k1] = ((const cplx*)(tab + TB_TW256))[(j * k1) & 255];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) tw5[m] = ((const cplx*)(tab + TB_TW512))[j + 16 * m];
+    float melb[kMelSlots], dctb[10];
+#pragma unroll
+    for (int s = 0; s < kMelSlots; ++s) melb[s] = tab[TB_MELB + (wave * kMelSlots + s) * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < 10; ++s) dctb[s] = tab[TB_DCTB + ((wave < 3 ? wave : 0) * 10 + s) * 64 + lane];
+    __syncthreads();
+
+    const int ntiles = (total_frames + FT - 1) / FT;
+    cplx* tb = tbuf + fi * TPITCH;
+    float* pf = pw + fi * PPITCH;
+
+    const float inv_of = 1.f / (float)out_frames;
+    auto frame_of = [&](int tile) {
+        FrameRef r;
+        const int f = tile * FT + fi;
+        const bool inb = tile < ntiles && f < total_frames;
+        // clip = f / out_frames through a float reciprocal (f < 2^23 frames is checked by the launcher) + one correction
+        int clip = (int)((float)f * inv_of), t = f - clip * out_frames;
+        if (t < 0) { --clip; t += out_frames; } else if (t >= out_frames) { ++clip; t -= out_frames; }
+        if (!inb) { clip = 0; t = 0; }
+        int N = lens[clip];
+        r.N = N < pcm_stride ? N : pcm_stride;
+        r.live = inb && r.N > 0 && t < 1 + r.N / HOP;
+        r.sig = pcm + (size_t)(clip_index ? clip_index[clip] : clip) * pcm_stride;
+        r.p0 = t * HOP - NFFT / 2;
+        r.interior = r.live && r.p0 >= 0 && r.p0 + NFFT <= r.N && !(pcm_stride & 1);
+        return r;
+    };
+    // sample pairs of the frame, one tile ahead: lane j takes z[16 n1 + j] = (x[32 n1 + 2 j], x[32 n1 + 2 j + 1]).
+    // Interior frames: one 4-byte load per pair.  Frames that overlap an end of the clip (reflect padding of the centred
+    // STFT; t = 0, 1 and the last four of a full clip): two 2-byte loads at reflected positions -- the window table is zero
+    // outside its 400 taps, so positions only have to be valid, not meaningful, there.
+    auto fetch = [&](const FrameRef& r, uint32_t (&two)[16]) {
+        if (__builtin_amdgcn_ballot_w64(r.live && !r.interior) == 0ull) {
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) two[n1] = r.live ? *(const uint32_t*)(r.sig + r.p0 + 32 * n1 + 2 * j) : 0u;
         } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int idx = lane + 64 * i;
-                float v = 0.f;
-                if (idx >= WOFF && idx < WOFF + WIN) {
-                    int pos = p0 + idx;
-                    if (pos < 0) pos = -pos;
-                    if (pos >= N) pos = 2 * (N - 1) - pos;
-                    pos = pos < 0 ? 0 : (pos >= N ? N - 1 : pos);
-                    v = (float)sig[pos] * tabs[TB_WIN512 + idx];
+            for (int n1 = 0; n1 < 16; ++n1) {
+                uint32_t pr = 0u;
+                if (r.live) {
+                    int a = r.p0 + 32 * n1 + 2 * j, b = a + 1;
+                    a = a < 0 ? -a : a; b = b < 0 ? -b : b;
+                    a = a >= r.N ? 2 * (r.N - 1) - a : a; b = b >= r.N ? 2 * (r.N - 1) - b : b;
+                    a = a < 0 ? 0 : (a >= r.N ? r.N - 1 : a); b = b < 0 ? 0 : (b >= r.N ? r.N - 1 : b);
+                    pr = (uint32_t)(uint16_t)r.sig[a] | ((uint32_t)(uint16_t)r.sig[b] << 16);
                 }
-                xs[idx] = v;
+                two[n1] = pr;
             }
         }
-        WAVE_SYNC();
-        // 2. 256-point complex FFT of z[n] = x[2n] + i x[2n+1]: Stockham radix-4, natural order out
-        cplx* src = bufA[wave];
-        cplx* dst = bufB[wave];
+    };
+
+    FrameRef fr = frame_of(blockIdx.x);
+    uint32_t two[16];
+    fetch(fr, two);
+    int par = 0;
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, par ^= FT) {
+        if (j == 0) live_s[par + fi] = fr.live ? 1 : 0;
+        cplx v[16];
+        // 1. windowed samples
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int Ns = 1 << (2 * s);
-            const int jm = lane & (Ns - 1);
-            const int m = jm * (64 / Ns);
-            cplx v0 = src[lane], v1 = src[lane + 64], v2 = src[lane + 128], v3 = src[lane + 192];
-            if (s > 0) {
-                v1 = cmul(v1, tw256[m]);
-                v2 = cmul(v2, tw256[(2 * m) & 255]);
-                v3 = cmul(v3, tw256[(3 * m) & 255]);
+        for (int n1 = 0; n1 < 16; ++n1)
+            v[n1] = f2{(float)(int16_t)(two[n1] & 0xffff), (float)((int32_t)two[n1] >> 16)} * *(const f2*)(win + 32 * n1 + 2 * j);
+        // the next tile's samples fly during the rest of this one
+        fr = frame_of(tile + gridDim.x);
+        fetch(fr, two);
+        // 2. 16-point FFT over n1 (this lane is n2 = j), twiddle W256^(n2 k1), transpose through LDS, FFT over n2
+#if MFCC_ABL != 2
+        fft16(v);
+#pragma unroll
+        for (int k1 = 1; k1 < 16; ++k1) v[k1] = cmul(v[k1], tw[k1]);
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) tb[k1 * 17 + j] = v[k1];
+        WAVE_SYNC();
+#pragma unroll
+        for (int n2 = 0; n2 < 16; ++n2) v[n2] = tb[j * 17 + n2];
+        WAVE_SYNC();
+        fft16(v);                                                   // v[k2] = Z[j + 16 k2]
+#endif
+        // 3. spectrum to LDS in natural order (the partner bin 256 - k lives in another lane)
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) tb[16 * k2 + j] = v[k2];
+        WAVE_SYNC();
+        // 4. even/odd split of the real transform, power x 4 (the 1/4 is folded into the mel weights): bins k = j + 16 m
+        //    2 X[k] = (Zk + conj Zm) + W512^k * (-i) (Zk - conj Zm),  m = 256 - k
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int k = j + 16 * m;
+            const cplx zk = v[m], zm = tb[(256 - k) & 255], w5 = tw5[m];
+            f2 sm, df, u, X;
+            asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(sm) : "v"(zk), "v"(zm));             // Zk + conj Zm
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(df) : "v"(zk), "v"(zm));             // Zk - conj Zm
+            // W * (-i) df = (df.y, -df.x) W.x + (df.x, df.y) W.y
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(u) : "v"(df), "v"(w5), "v"(sm));
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(X) : "v"(df), "v"(w5), "v"(u));
+            const f2 q = X * X;
+            pf[k] = q.x + q.y;
+        }
+        if (j == 0) { const float r = v[0].x - v[0].y; pf[256] = 4.f * r * r; }     // bin 256 = (Re Z0 - Im Z0)^2
+        __syncthreads();                                            // (1) power tile complete
+#if MFCC_ABL != 3
+        // 5. mel triangles on the matrix cores: D[frame][filter] over this wave's k-steps of each filter tile
+        f32x4m acc[3];
+#pragma unroll
+        for (int tl = 0; tl < 3; ++tl) acc[tl] = f32x4m{0.f, 0.f, 0.f, 0.f};
+        {
+            const float* pa = pw + (lane & 15) * PPITCH + (lane >> 4);
+            int slot = 0;
+#pragma unroll
+            for (int tl = 0; tl < 3; ++tl)
+#pragma unroll
+                for (int q = 0; q < kMelSteps[tl] / 4; ++q, ++slot)
+                    acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[kMelK0[tl] + 4 * (4 * q + wave)], melb[slot], acc[tl], 0, 0, 0);
+        }
+#pragma unroll
+        for (int tl = 0; tl < 3; ++tl)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[((wave * 3 + tl) * 4 + r) * 64 + lane] = acc[tl][r];
+        __syncthreads();                                            // (2) partial sums in place
+        // 6. fold the four partials in fixed order, log(. + 1e-6)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int r = tid >> 6, l2 = tid & 63;                  // (r, lane') of filter tile q
+            float s = part[((0 * 3 + q) * 4 + r) * 64 + l2];
+            s += part[((1 * 3 + q) * 4 + r) * 64 + l2];
+            s += part[((2 * 3 + q) * 4 + r) * 64 + l2];
+            s += part[((3 * 3 + q) * 4 + r) * 64 + l2];
+            const int frame = 4 * (l2 >> 4) + r, mel = 16 * q + (l2 & 15);
+            if (mel < NMEL) lmel[frame * LPITCH + mel] = __logf(s + 1e-6f);     // v_log_f32: 1 ulp, s + 1e-6 is never denormal
+        }
+#endif
+        __syncthreads();                                            // (3) log-mel tile complete
+        // 7. orthonormal DCT-II on the matrix cores (coefficient tile = wave, 10 k-steps) and store
+        if (wave < 3) {
+            f32x4m d = f32x4m{0.f, 0.f, 0.f, 0.f};
+            const float* la = lmel + (lane & 15) * LPITCH + (lane >> 4);
+#pragma unroll
+            for (int s = 0; s < 10; ++s) d = __builtin_amdgcn_mfma_f32_16x16x4f32(la[4 * s], dctb[s], d, 0, 0, 0);
+            const int coef = 16 * wave + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int frame = 4 * (lane >> 4) + r;
+                const int fo = tile * FT + frame;
+                if (coef < NMFCC && fo < total_frames) out[(size_t)fo * NMFCC + coef] = live_s[par + frame] ? d[r] : 0.f;
             }
-            const cplx a0 = cadd(v0, v2), a1 = csub(v0, v2), a2 = cadd(v1, v3);
-            const cplx d = csub(v1, v3);
-            const cplx a3 = {d.y, -d.x};                   // (v1 - v3) * (-i)
-            const int idx = (lane / Ns) * Ns * 4 + jm;
-            dst[idx] = cadd(a0, a2);
-            dst[idx + Ns] = cadd(a1, a3);
-            dst[idx + 2 * Ns] = csub(a0, a2);
-            dst[idx + 3 * Ns] = csub(a1, a3);
-            WAVE_SYNC();
-            cplx* tmp = src; src = dst; dst = tmp;
         }
-        // 3. split into the 257 bins of the real FFT, power
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = lane + 64 * i;
-            const cplx zk = src[k];
-            cplx zm = src[(256 - k) & 255];
-            zm.y = -zm.y;
-            const cplx xe = {0.5f * (zk.x + zm.x), 0.5f * (zk.y + zm.y)};
-            const cplx dd = csub(zk, zm);
-            const cplx xo = {0.5f * dd.y, -0.5f * dd.x};    // (zk - zm) / (2i)
-            const cplx X = cadd(xe, cmul(tw512[k], xo));
-            pw[k] = X.x * X.x + X.y * X.y;
-        }
-        // bin 256; bins 257..263 are read (with zero weight) by the mel loop and must be finite
-        if (lane < 8) { const cplx z0 = src[0]; const float r = z0.x - z0.y; pw[256 + lane] = lane ? 0.f : r * r; }
-        WAVE_SYNC();
-        // 4. mel triangles + log: fixed-trip loop over the dense weight table (zeros beyond a triangle; the
-        //    bins read there are finite: pw[257..263] is kept zero), addresses are base + immediates
-        {
-            float s = 0.f;
-#pragma unroll
-            for (int q = 0; q < MAXC; ++q) s += pw[mst + q] * tabs[TB_MWD + q * NMEL + ml];
-            if (lane < NMEL) lm[lane] = logf(s + 1e-6f);
-        }
-        WAVE_SYNC();
-        // 5. DCT-II (ortho) and store: this lane's column of the matrix is in registers
-        {
-            float s = 0.f;
-#pragma unroll
-            for (int n = 0; n < NMEL; ++n) s += lm[n] * dct[n];
-            if (lane < NMFCC) out[((size_t)clip * out_frames + t) * NMFCC + lane] = s;
-        }
-        WAVE_SYNC();
+        // no barrier here: the next tile touches tbuf (wave-private), pw only before its barrier 1 -- which every wave
+        // reaches after leaving step 5 of this tile --, part / lmel after its barriers 1 / 2, and the other half of live_s
     }
 }
 }  // namespace
 
 int mfcc_build_tables(var_ctx* c) {
     std::vector<float> tb(TB_TOTAL, 0.f);
-    int* it = (int*)tb.data();
     for (int i = 0; i < WIN; i++) tb[TB_WIN + i] = (float)(0.54 - 0.46 * cos(2.0 * M_PI * i / WIN));
     for (int m = 0; m < 256; m++) {
         tb[TB_TW256 + 2 * m] = (float)cos(-2.0 * M_PI * m / 256.0);
@@ -180,12 +313,7 @@ int mfcc_build_tables(var_ctx* c) {
         tb[TB_TW512 + 2 * m] = (float)cos(-2.0 * M_PI * m / 512.0);
         tb[TB_TW512 + 2 * m + 1] = (float)sin(-2.0 * M_PI * m / 512.0);
     }
-    for (int n = 0; n < NMEL; n++)
-        for (int k = 0; k < NMFCC; k++) {
-            double v = cos(M_PI / NMEL * (n + 0.5) * k) * sqrt(2.0 / NMEL);
-            if (k == 0) v *= 1.0 / sqrt(2.0);
-            tb[TB_DCT + n * NMFCC + k] = (float)v;
-        }
+    for (int i = 0; i < WIN; i++) tb[TB_WIN512 + WOFF + i] = tb[TB_WIN + i] * (1.f / 32768.f);   // exact: power of two
     // HTK mel triangles: torchaudio.functional.melscale_fbanks(257, 0, 8000, 40, 16000, None, 'htk')
     const double sr = 16000.0;
     const double m_min = 0.0, m_max = 2595.0 * log10(1.0 + (sr / 2.0) / 700.0);
@@ -194,43 +322,58 @@ int mfcc_build_tables(var_ctx* c) {
         const double m = m_min + (m_max - m_min) * i / (NMEL + 1);
         fpts[i] = 700.0 * (pow(10.0, m / 2595.0) - 1.0);
     }
-    int wo = 0;
-    for (int m = 0; m < NMEL; m++) {
-        int start = -1, count = 0;
+    std::vector<double> fb((size_t)NFREQ * NMEL, 0.0);
+    for (int m = 0; m < NMEL; m++)
         for (int k = 0; k < NFREQ; k++) {
             const double f = (sr / 2.0) * k / (NFREQ - 1);
             const double down = (f - fpts[m]) / (fpts[m + 1] - fpts[m]);
             const double up = (fpts[m + 2] - f) / (fpts[m + 2] - fpts[m + 1]);
             const double w = fmax(0.0, fmin(down, up));
-            if (w > 0.0) {
-                if (start < 0) start = k;
-                if (k != start + count) { VAR_SET_ERR(c, "mfcc tables: non-contiguous mel filter"); return VAR_ERR_ARG; }
-                if (wo + count >= 640) { VAR_SET_ERR(c, "mfcc tables: weight overflow"); return VAR_ERR_ARG; }
-                tb[TB_MW + wo + count] = (float)w;
-                count++;
+            fb[(size_t)k * NMEL + m] = w;
+            // every non-zero weight must fall inside the band its filter tile reads
+            const int tl = m / 16;
+            if (w > 0.0 && (k < kMelK0[tl] || k >= kMelK0[tl] + 4 * kMelSteps[tl])) {
+                VAR_SET_ERR(c, "mfcc tables: filter %d bin %d outside its band", m, k);
+                return VAR_ERR_ARG;
             }
         }
-        it[TB_MSTART + m] = start < 0 ? 0 : start;
-        it[TB_MCOUNT + m] = count;
-        it[TB_MOFF + m] = wo;
-        wo += count;
+    // B operands of v_mfma_f32_16x16x4_f32 (B[k = lane >> 4][col = lane & 15]), per wave and slot
+    for (int wave = 0; wave < 4; wave++) {
+        int slot = 0;
+        for (int tl = 0; tl < 3; tl++)
+            for (int q = 0; q < kMelSteps[tl] / 4; q++, slot++)
+                for (int lane = 0; lane < 64; lane++) {
+                    const int k = kMelK0[tl] + 4 * (4 * q + wave) + (lane >> 4), m = 16 * tl + (lane & 15);
+                    tb[TB_MELB + (wave * kMelSlots + slot) * 64 + lane] = (k < NFREQ && m < NMEL) ? 0.25f * (float)fb[(size_t)k * NMEL + m] : 0.f;   // the power tile holds 4 |X|^2
+                }
     }
-    for (int m = 0; m < NMEL; m++) {
-        if (it[TB_MCOUNT + m] > MAXC || it[TB_MSTART + m] + MAXC - 1 > 263) { VAR_SET_ERR(c, "mfcc tables: triangle too wide"); return VAR_ERR_ARG; }
-        for (int q = 0; q < it[TB_MCOUNT + m]; q++) tb[TB_MWD + q * NMEL + m] = tb[TB_MW + it[TB_MOFF + m] + q];
-    }
-    for (int i = 0; i < WIN; i++) tb[TB_WIN512 + WOFF + i] = tb[TB_WIN + i] * (1.f / 32768.f);   // exact: power of two
-    static_assert(TB_TOTAL % 4 == 0, "table is copied as float4");
+    for (int tl = 0; tl < 3; tl++)
+        for (int s = 0; s < 10; s++)
+            for (int lane = 0; lane < 64; lane++) {
+                const int n = 4 * s + (lane >> 4), k = 16 * tl + (lane & 15);
+                double v = 0.0;
+                if (k < NMFCC) {
+                    v = cos(M_PI / NMEL * (n + 0.5) * k) * sqrt(2.0 / NMEL);
+                    if (k == 0) v *= 1.0 / sqrt(2.0);
+                }
+                tb[TB_DCTB + (tl * 10 + s) * 64 + lane] = (float)v;
+            }
+    static_assert(TB_TOTAL % 4 == 0, "table size");
     VAR_HIP_CHECK(c, hipMalloc((void**)&c->mfcc_tab, sizeof(float) * TB_TOTAL));
     VAR_HIP_CHECK(c, hipMemcpy(c->mfcc_tab, tb.data(), sizeof(float) * TB_TOTAL, hipMemcpyHostToDevice));
+    VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)mfcc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MFCC_LDS_BYTES));
     return VAR_OK;
 }
 
 int launch_mfcc(var_ctx* c, hipStream_t s, const int16_t* pcm, const int* lens, const int* clip_index, int nclips,
                 int pcm_stride, int out_frames, float* out) {
     ProfScope prof(c, s, TAG_MFCC);
-    hipLaunchKernelGGL(mfcc_kernel, dim3(nclips), dim3(MW * 64), 0, s, pcm, lens, clip_index, pcm_stride, out_frames,
-                       c->mfcc_tab, out);
+    const long total = (long)nclips * out_frames;
+    if (total > (1L << 23)) { VAR_SET_ERR(c, "var_mfcc: %d clips x %d frames is too many", nclips, out_frames); return VAR_ERR_ARG; }
+    const int ntiles = (int)((total + FT - 1) / FT);
+    const int grid = ntiles < 512 ? ntiles : 512;              // persistent: two 70 KB workgroups per CU
+    hipLaunchKernelGGL(mfcc_kernel, dim3(grid), dim3(NTHR), MFCC_LDS_BYTES, s, pcm, lens, clip_index, pcm_stride, out_frames,
+                       (int)total, c->mfcc_tab, out);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }
