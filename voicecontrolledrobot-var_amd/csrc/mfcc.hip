@@ -118,31 +118,42 @@ constexpr int PPITCH = 258;               // floats per frame of the power tile 
 constexpr int LPITCH = 42;                // floats per frame of the log-mel tile (10 i mod 32 distinct for i < 16)
 
 // LDS carve-up (floats): 56 KB per workgroup; the register budget (244 VGPRs) sets two workgroups per CU
-constexpr int L_WIN = 0, L_TBUF = 512, L_PW = L_TBUF + 2 * FT * TPITCH;
-constexpr int L_PART = L_TBUF, L_LMEL = L_PW + FT * PPITCH + 8, L_LIVE = L_LMEL + FT * LPITCH;   // the partial sums alias the (then dead) transpose tile
-constexpr int L_TOTAL = L_LIVE + 2 * FT;
-constexpr int MFCC_LDS_BYTES = L_TOTAL * 4;
+constexpr int L_WIN = 0, L_TBUF = 512, L_TOTAL = L_TBUF + 2 * FT * TPITCH;
+constexpr int MFCC_LDS_BYTES = L_TOTAL * 4;     // dynamic part (36 KB); 31 KB more are static arrays of the kernel
 
 typedef float f32x4m __attribute__((ext_vector_type(4)));
 
 struct FrameRef { const int16_t* sig; int p0, N; bool live, interior; };
+struct FrameMeta { int clip, t, N, row; bool inb; };   // the two dependent index loads (lens, clip_index), one tile earlier
+
+PH_DECL();
+#ifdef VAR_PHASES
+extern "C" int var_debug_phases_mfcc(unsigned long long* out) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 __global__ void __launch_bounds__(NTHR, 2)
 mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const int* __restrict__ clip_index,
             int pcm_stride, int out_frames, int total_frames, const float* __restrict__ tab, float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // separate LDS objects, so that the compiler may move a wave's reads of one past its writes of another (with one
+    // array the 16 partner-bin reads of the split were each held behind the previous bin's power store)
+    extern __shared__ __attribute__((aligned(16))) float lds[];         // window table + transpose tile (dynamic part)
+    __shared__ __attribute__((aligned(16))) float pw[FT * PPITCH + 8];  // power spectrum tile x 4 (A operand of the mel products)
+    __shared__ __attribute__((aligned(16))) float part[4 * 3 * 4 * 64]; // mel partial sums of the four waves
+    __shared__ __attribute__((aligned(16))) float lmel[FT * LPITCH];    // log-mel tile (A operand of the DCT products)
+    __shared__ int live_s[2 * FT];                                      // [parity][frame]
     const float* win = lds + L_WIN;                 // window / 32768, zero outside its 400 taps
     cplx* tbuf = (cplx*)(lds + L_TBUF);             // transpose tile; then the spectrum Z[k] (256 per frame)
-    float* pw = lds + L_PW;                         // power spectrum tile (A operand of the mel products), x 4
-    float* part = lds + L_PART;                     // mel partial sums of the four waves
-    float* lmel = lds + L_LMEL;                     // log-mel tile (A operand of the DCT products)
-    int* live_s = (int*)(lds + L_LIVE);             // [parity][frame]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
     const int fi = 4 * wave + g;                                           // this lane group's frame within the tile
 
     for (int e = tid; e < FT * PPITCH + 8; e += NTHR) pw[e] = 0.f;          // pad column 257 and the slack stay zero
     for (int e = tid; e < 512; e += NTHR) lds[L_WIN + e] = tab[TB_WIN512 + e];
+    if (tid < 2 * FT) live_s[tid] = 0;
     // lane constants in registers: W256^(j k1), W512^(j + 16 m), mel / DCT B operands (the window taps stay in LDS:
     // with them the kernel spills).  Measured: squeezing the kernel under 168 VGPRs for three workgroups per CU --
     // constants re-read from the table per tile -- spills as well and runs at 65 us instead of 46.
@@ -163,19 +174,25 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
     float* pf = pw + fi * PPITCH;
 
     const float inv_of = 1.f / (float)out_frames;
-    auto frame_of = [&](int tile) {
-        FrameRef r;
+    auto meta_of = [&](int tile) {
+        FrameMeta m;
         const int f = tile * FT + fi;
-        const bool inb = tile < ntiles && f < total_frames;
+        m.inb = tile < ntiles && f < total_frames;
         // clip = f / out_frames through a float reciprocal (f < 2^23 frames is checked by the launcher) + one correction
         int clip = (int)((float)f * inv_of), t = f - clip * out_frames;
         if (t < 0) { --clip; t += out_frames; } else if (t >= out_frames) { ++clip; t -= out_frames; }
-        if (!inb) { clip = 0; t = 0; }
-        int N = lens[clip];
-        r.N = N < pcm_stride ? N : pcm_stride;
-        r.live = inb && r.N > 0 && t < 1 + r.N / HOP;
-        r.sig = pcm + (size_t)(clip_index ? clip_index[clip] : clip) * pcm_stride;
-        r.p0 = t * HOP - NFFT / 2;
+        if (!m.inb) { clip = 0; t = 0; }
+        m.clip = clip; m.t = t;
+        m.N = lens[clip];
+        m.row = clip_index ? clip_index[clip] : clip;
+        return m;
+    };
+    auto frame_of = [&](const FrameMeta& m) {
+        FrameRef r;
+        r.N = m.N < pcm_stride ? m.N : pcm_stride;
+        r.live = m.inb && r.N > 0 && m.t < 1 + r.N / HOP;
+        r.sig = pcm + (size_t)m.row * pcm_stride;
+        r.p0 = m.t * HOP - NFFT / 2;
         r.interior = r.live && r.p0 >= 0 && r.p0 + NFFT <= r.N && !(pcm_stride & 1);
         return r;
     };
@@ -188,49 +205,77 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
 #pragma unroll
             for (int n1 = 0; n1 < 16; ++n1) two[n1] = r.live ? *(const uint32_t*)(r.sig + r.p0 + 32 * n1 + 2 * j) : 0u;
         } else {
+            // all 32 loads first (branch-free: dead lanes read sample 0 of a valid row), then the packing -- written
+            // with a per-pair `if (live)` hipcc waits for every pair of loads before issuing the next
+            const int Nc = r.N > 0 ? r.N : 1;
+            uint16_t lo[16], hi[16];
 #pragma unroll
             for (int n1 = 0; n1 < 16; ++n1) {
-                uint32_t pr = 0u;
-                if (r.live) {
-                    int a = r.p0 + 32 * n1 + 2 * j, b = a + 1;
-                    a = a < 0 ? -a : a; b = b < 0 ? -b : b;
-                    a = a >= r.N ? 2 * (r.N - 1) - a : a; b = b >= r.N ? 2 * (r.N - 1) - b : b;
-                    a = a < 0 ? 0 : (a >= r.N ? r.N - 1 : a); b = b < 0 ? 0 : (b >= r.N ? r.N - 1 : b);
-                    pr = (uint32_t)(uint16_t)r.sig[a] | ((uint32_t)(uint16_t)r.sig[b] << 16);
-                }
-                two[n1] = pr;
+                int a = r.p0 + 32 * n1 + 2 * j, b = a + 1;
+                a = a < 0 ? -a : a; b = b < 0 ? -b : b;
+                a = a >= Nc ? 2 * (Nc - 1) - a : a; b = b >= Nc ? 2 * (Nc - 1) - b : b;
+                a = a < 0 ? 0 : (a >= Nc ? Nc - 1 : a); b = b < 0 ? 0 : (b >= Nc ? Nc - 1 : b);
+                a = r.live ? a : 0; b = r.live ? b : 0;
+                lo[n1] = (uint16_t)r.sig[a];
+                hi[n1] = (uint16_t)r.sig[b];
             }
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) two[n1] = r.live ? ((uint32_t)lo[n1] | ((uint32_t)hi[n1] << 16)) : 0u;
         }
     };
 
-    FrameRef fr = frame_of(blockIdx.x);
+    int tile = blockIdx.x;
+    FrameRef fr = frame_of(meta_of(tile));
     uint32_t two[16];
     fetch(fr, two);
+    FrameMeta mnext = meta_of(tile + gridDim.x);
     int par = 0;
+    // (measured: handing the tiles out through a device-wide atomic counter -- to balance the runs of dead tiles of
+    //  "empty" clips -- costs more than it balances: 3200 draws on one address take the kernel from 40 to 55 us)
 #pragma unroll 1
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, par ^= FT) {
+    for (; tile < ntiles; tile += gridDim.x, par ^= FT) {
+        PH(0);
         if (j == 0) live_s[par + fi] = fr.live ? 1 : 0;
+        // a tile without a single live frame (the "empty" class, dataset.py:37-38, covers whole clips; so does the
+        // zero padding of short clips) is all zeros: skip the transform.  The vote is workgroup-uniform.
+        if (__syncthreads_or(fr.live) == 0) {
+            for (int e = tid; e < FT * NMFCC; e += NTHR) {
+                const long o = (long)tile * FT * NMFCC + e;
+                if (o < (long)total_frames * NMFCC) out[o] = 0.f;
+            }
+            fr = frame_of(mnext);
+            fetch(fr, two);
+            mnext = meta_of(tile + 2 * gridDim.x);
+            continue;
+        }
+        PH(1);
         cplx v[16];
         // 1. windowed samples
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1)
             v[n1] = f2{(float)(int16_t)(two[n1] & 0xffff), (float)((int32_t)two[n1] >> 16)} * *(const f2*)(win + 32 * n1 + 2 * j);
-        // the next tile's samples fly during the rest of this one
-        fr = frame_of(tile + gridDim.x);
+        // the next tile's samples fly during the rest of this one (its clip row / length were fetched a tile earlier)
+        fr = frame_of(mnext);
         fetch(fr, two);
+        mnext = meta_of(tile + 2 * gridDim.x);
+        __builtin_amdgcn_sched_barrier(0);          // keep the loads HERE (hipcc otherwise sinks them towards their first use)
+        PH(2);
         // 2. 16-point FFT over n1 (this lane is n2 = j), twiddle W256^(n2 k1), transpose through LDS, FFT over n2
 #if MFCC_ABL != 2
         fft16(v);
 #pragma unroll
         for (int k1 = 1; k1 < 16; ++k1) v[k1] = cmul(v[k1], tw[k1]);
+        PH(3);
 #pragma unroll
         for (int k1 = 0; k1 < 16; ++k1) tb[k1 * 17 + j] = v[k1];
         WAVE_SYNC();
 #pragma unroll
         for (int n2 = 0; n2 < 16; ++n2) v[n2] = tb[j * 17 + n2];
         WAVE_SYNC();
+        PH(4);
         fft16(v);                                                   // v[k2] = Z[j + 16 k2]
 #endif
+        PH(5);
         // 3. spectrum to LDS in natural order (the partner bin 256 - k lives in another lane)
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) tb[16 * k2 + j] = v[k2];
@@ -251,7 +296,9 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
             pf[k] = q.x + q.y;
         }
         if (j == 0) { const float r = v[0].x - v[0].y; pf[256] = 4.f * r * r; }     // bin 256 = (Re Z0 - Im Z0)^2
+        PH(6);
         __syncthreads();                                            // (1) power tile complete
+        PH(7);
 #if MFCC_ABL != 3
         // 5. mel triangles on the matrix cores: D[frame][filter] over this wave's k-steps of each filter tile
         f32x4m acc[3];
@@ -270,7 +317,9 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
         for (int tl = 0; tl < 3; ++tl)
 #pragma unroll
             for (int r = 0; r < 4; ++r) part[((wave * 3 + tl) * 4 + r) * 64 + lane] = acc[tl][r];
+        PH(8);
         __syncthreads();                                            // (2) partial sums in place
+        PH(9);
         // 6. fold the four partials in fixed order, log(. + 1e-6)
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -283,7 +332,9 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
             if (mel < NMEL) lmel[frame * LPITCH + mel] = __logf(s + 1e-6f);     // v_log_f32: 1 ulp, s + 1e-6 is never denormal
         }
 #endif
+        PH(10);
         __syncthreads();                                            // (3) log-mel tile complete
+        PH(11);
         // 7. orthonormal DCT-II on the matrix cores (coefficient tile = wave, 10 k-steps) and store
         if (wave < 3) {
             f32x4m d = f32x4m{0.f, 0.f, 0.f, 0.f};
@@ -298,6 +349,7 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
                 if (coef < NMFCC && fo < total_frames) out[(size_t)fo * NMFCC + coef] = live_s[par + frame] ? d[r] : 0.f;
             }
         }
+        PH(12);
         // no barrier here: the next tile touches tbuf (wave-private), pw only before its barrier 1 -- which every wave
         // reaches after leaving step 5 of this tile --, part / lmel after its barriers 1 / 2, and the other half of live_s
     }

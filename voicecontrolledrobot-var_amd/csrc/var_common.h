@@ -191,6 +191,18 @@ struct ProfScope {
     }
 };
 
+// Phase timing inside a kernel (tuning builds only: -DVAR_PHASES): thread 0 of one workgroup accumulates the
+// shader-clock cycles between PH(i) marks into g_phase[i]; var_debug_phases() reads and clears them.
+#ifdef VAR_PHASES
+#define PH_DECL() static __device__ unsigned long long g_phase[32]
+#define PH_INIT(blk) unsigned long long ph_t = clock64(); const bool ph_on = (int)blockIdx.x == (blk) && threadIdx.x == 0
+#define PH(i) do { if (ph_on) { const unsigned long long t_ = clock64(); g_phase[i] += t_ - ph_t; ph_t = t_; } } while (0)
+#else
+#define PH_DECL()
+#define PH_INIT(blk)
+#define PH(i)
+#endif
+
 static inline int conv_out(int h) { return (h - 1) / 2 + 1; }   // 3x3 s2 p1
 
 extern "C" int retire_block(var_ctx* c, void* p);   // api.hip: keep a superseded device block alive until var_destroy
