@@ -208,8 +208,7 @@ def tag_flops(tag):
     (conv 1 + conv 2), tag 2 = conv 3 + 4 + 5 (+ image head, not counted), tags 7-9 = weight + data gradient of
     layers 2-4 in one grid, tag 11 = weight gradient of conv 2 + data gradient of conv 2 + weight gradient of conv 1.
     Halo recomputation inside the fused kernels is not counted."""
-    fused = not any(os.environ.get(k) for k in ("VAR_NO_HEAD", "VAR_NO_TAIL", "VAR_NO_MID", "VAR_NO_PAIR"))
-    if fused:
+    if True:
         if tag == 1:
             return LAYER_FLOPS[0] + LAYER_FLOPS[1]
         if tag == 2:
@@ -345,7 +344,7 @@ def main():
     ctx = Context.get(local_rank)
     ctx.ensure_plan(B, HW)
 
-    use_graph = not args.no_graph and not os.environ.get("VAR_SERIAL") and args.head == "triplet"
+    use_graph = not args.no_graph and args.head == "triplet"
     if args.head == "inbatch":
         args.no_roofline = True
     state = {"tab": None, "row": 0}

@@ -1,13 +1,12 @@
 #!/usr/bin/env python3
 """Per-kernel-family timings of one training step (B=256, 84x84) with every launch on ONE stream
-(VAR_SERIAL=1), measured with the library's own HIP-event hooks (var_profile_select/read).
-Usage: VAR_SERIAL=1 python tools/kbench.py [--batch 256] [--steps 20] [--tags 0,1,2]"""
+(var_set_streams(0)), measured with the library's own HIP-event hooks (var_profile_select/read).
+Usage: python tools/kbench.py [--batch 256] [--steps 20] [--tags 0,1,2]"""
 import argparse
 import os
 import sys
 import types
 
-os.environ.setdefault("VAR_SERIAL", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
@@ -27,6 +26,7 @@ model = var_amd.VARPretextNet(cfg).to("cuda")
 tr = var_amd.VARTrainer(model)
 pool = var_amd.SyntheticTripletPool(int(os.environ.get("KB_POOL", "2048")), hw=84, seed=0, clips_per_class=int(os.environ.get("KB_CPC", "32"))).freeze_pairs()
 ctx = Context.get(0)
+ctx.set_streams(0)
 
 
 def step():

@@ -32,8 +32,8 @@ int var_init(int device_id, var_ctx** out) {
     if (!c) return VAR_ERR_HIP;
     c->device = device_id;
     // Which parts of a step leave the caller's stream (bit 0: sound branch forward incl. MFCC, bit 1: sound
-    // branch backward, bit 2: image weight gradients, bit 3: slab folds, bit 4: with bit 0, the MFCC kernel stays on the caller's
-    // stream and only the sound CNN forks).  VAR_SERIAL=1 = none; VAR_STREAMS=<mask>.
+    // branch backward, bit 4: with bit 0, the MFCC kernel stays on the caller's stream and only the sound CNN
+    // forks); var_set_streams changes the plan (0 = everything on the caller's stream, for per-kernel timing).
     c->streams = default_streams();
     c->serial = c->streams == 0;
     c->pl = make_param_layout();
@@ -57,11 +57,6 @@ int var_init(int device_id, var_ctx** out) {
         return VAR_ERR_HIP;
     }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side3, hipStreamNonBlocking);
-    for (int i = 0; i < 5 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&c->ev_w[i], hipEventDisableTiming);
-    for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&c->ev_g[i], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_wjoin, hipEventDisableTiming);
     for (int i = 0; i < 2 && e == hipSuccess; i++) {
         e = hipEventCreateWithFlags(&c->ev_fork[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming);
@@ -98,12 +93,7 @@ int var_destroy(var_ctx* c) {
         if (c->ev_fork[i]) (void)hipEventDestroy(c->ev_fork[i]);
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
     }
-    for (int i = 0; i < 6; i++) if (c->ev_g[i]) (void)hipEventDestroy(c->ev_g[i]);
-    if (c->ev_wjoin) (void)hipEventDestroy(c->ev_wjoin);
     if (c->side) (void)hipStreamDestroy(c->side);
-    if (c->side2) (void)hipStreamDestroy(c->side2);
-    if (c->side3) (void)hipStreamDestroy(c->side3);
-    for (int i = 0; i < 5; i++) if (c->ev_w[i]) (void)hipEventDestroy(c->ev_w[i]);
     if (c->prof_ev) {
         for (int i = 0; i < 2 * kProfMaxPairs; i++) (void)hipEventDestroy(c->prof_ev[i]);
         delete[] c->prof_ev;
@@ -340,16 +330,13 @@ static int encoder_bwd(var_ctx* c, hipStream_t s, const float* params, float* gr
         VAR_HIP_CHECK(c, hipMemsetAsync(grads, 0, sizeof(float) * VAR_N_PARAMS, s));
     }
     const int snd_lo = c->saved_pos ? 0 : B, snd_hi = c->saved_neg ? 2 * B : B;
-    // streams: s = image head + dgrad/wgrad chain, side = sound head + sound CNN backward + loss value
-    // (side2 / side3 only with VAR_STREAMS bits 2 / 3)
+    // streams: s = image head + the image backward chain, side = sound head + sound CNN backward + loss value
     hipStream_t ss = (c->streams & 2) ? c->side : s;
-    hipStream_t sw = (c->streams & 4) ? c->side2 : s;
-    hipStream_t sr = (c->streams & 8) ? c->side3 : sw;
     // (same ordering rule as in the forward: the caller's chain first, then the side branch)
     if ((rc = fork_side(c, s, 1)) != VAR_OK) return rc;
     if (c->saved_image) {
         if ((rc = launch_heads_bwd(c, s, s, params, grads, B, true, 0, 0, fused, margin, inv_count)) != VAR_OK) return rc;
-        if ((rc = launch_img_bwd(c, s, sw, sr, params, grads, B)) != VAR_OK) return rc;
+        if ((rc = launch_img_bwd(c, s, params, grads, B)) != VAR_OK) return rc;
     }
     if ((rc = launch_heads_bwd(c, ss, ss, params, grads, B, false, snd_lo, snd_hi, fused, margin, inv_count)) != VAR_OK) return rc;
     if (fused && (rc = launch_triplet_loss(c, ss, params, B, margin, inv_count, loss_out)) != VAR_OK) return rc;
@@ -393,9 +380,9 @@ static int loss_grad_impl(var_ctx* c, hipStream_t s, const float* params, const 
     if ((rc = check_weights(c, params, who)) != VAR_OK) return rc;
     SET_DEVICE(c);
     // The training step proper (all three branches, no embedding output requested) takes the fused path: no finish
-    // and no triplet kernel on the caller's chain.  VAR_NO_FUSED_LOSS=1 (tuning aid) keeps the separate kernels.
-    static const bool allow_fused = !getenv("VAR_NO_FUSED_LOSS");
-    const bool fused = allow_fused && !feats_out && image && (mfcc_pos || (audio && audio->pcm)) && (mfcc_neg || (audio && audio->pcm));
+    // and no triplet kernel on the caller's chain.  (With feats_out the separate finish / triplet kernels run:
+    // tests/test_gpu_round2.py::test_config2_batch256_full_batch_parity covers both.)
+    const bool fused = !feats_out && image && (mfcc_pos || (audio && audio->pcm)) && (mfcc_neg || (audio && audio->pcm));
     if ((rc = encoder_fwd(c, s, params, image, image_is_u8, image_bstride, image_index, mfcc_pos, mfcc_neg, audio, B,
                           !fused)) != VAR_OK) return rc;
     if (fused) return encoder_bwd(c, s, params, grads, true, margin, inv_count, loss_out);
@@ -500,10 +487,10 @@ int var_mfcc(var_ctx* c, void* stream, const int16_t* pcm, const int* lens, cons
 }
 
 static const char* kTagNames[TAG_COUNT] = {
-    "img_conv_fwd_kernel[0]", "img_fwd_head_kernel[0+1]", "img_conv_fwd_kernel[2]", "img_conv_fwd_kernel[3]",
-    "img_conv_fwd_kernel[4]", "img_wgrad_kernel[0]", "img_wgrad_kernel[1]", "img_bwd_pair_kernel[wgrad2+dgrad2]",
-    "img_bwd_pair_kernel[wgrad3+dgrad3]", "img_bwd_pair_kernel[wgrad4+dgrad4]", "img_dgrad_kernel[0]", "img_bwd_last_kernel[wgrad1+dgrad1+wgrad0]",
-    "img_dgrad_kernel[2]", "img_dgrad_kernel[3]", "img_dgrad_kernel[4]", "img_wgrad_reduce_kernel",
+    "(unused)", "img_fwd_head_kernel[0+1]", "img_fwd_mid_kernel[2+3+4+head]", "(unused)",
+    "(unused)", "(unused)", "img_wgrad_kernel[1] (96x96 only)", "img_bwd_pair_kernel[wgrad2+dgrad2]",
+    "img_bwd_pair_kernel[wgrad3+dgrad3]", "img_bwd_pair_kernel[wgrad4+dgrad4]", "(unused)", "img_bwd_last_kernel[wgrad1+dgrad1+wgrad0]",
+    "(unused)", "(unused)", "(unused)", "img_wgrad_reduce_kernel",
     "snd_fwd_kernel", "snd_dgrad_kernel", "snd_wgrad_kernel", "snd_reduce_kernel", "heads_fwd_kernel",
     "heads_bwd_rows_kernel", "heads_bwd_gemm_kernel", "triplet_kernel", "adam_kernel", "pack_weights_kernel",
     "mfcc_kernel", "gg_kernel<ConvFwdP<11x5 s2>>", "gg_kernel<ConvDgradS2P<11x5 s2>>", "gg_kernel<ConvWgradP<11x5 s2>>"};
@@ -513,17 +500,12 @@ const char* var_profile_tag_name(int tag) { return (tag >= 0 && tag < TAG_COUNT)
 
 /* Record HIP events (on the launch stream) around every launch of kernel family `tag`
  * from now on (-1 = off).  Not for use under graph capture. */
-static int default_streams() {
-    int m = kDefaultStreams;
-    { const char* e = getenv("VAR_SERIAL"); if (e && e[0] == '1') m = 0; }
-    { const char* e = getenv("VAR_STREAMS"); if (e && e[0]) m = atoi(e) & 31; }
-    return m;
-}
+static int default_streams() { return kDefaultStreams; }
 
 int var_set_streams(var_ctx* c, int mask) {
     if (!c) return -1;
     const int old = c->streams;
-    c->streams = mask < 0 ? default_streams() : (mask & 31);
+    c->streams = mask < 0 ? default_streams() : (mask & 19);
     c->serial = c->streams == 0;
     return old;
 }

@@ -338,9 +338,7 @@ static int launch_tail(var_ctx* c, hipStream_t s, int B) {
         attr_set = true;
     }
     const int ntiles = (B * C::NB + C::NU - 1) / C::NU;
-    int gmax = kTailG;
-    if (const char* e = getenv("VAR_TAIL_G")) { if (atoi(e) > 0 && atoi(e) <= kTailG) gmax = atoi(e); }   // tuning aid
-    const int G = ntiles < gmax ? ntiles : gmax;
+    const int G = ntiles < kTailG ? ntiles : kTailG;
     c->wg_groups[0] = G;
     hipLaunchKernelGGL(img_bwd_tail_kernel<C>, dim3(G), dim3(C::NT), C::LDS_BYTES, s, c->gact[2],
                        c->wpack + c->kl.img_d[1], c->relu1, c->saved_image, c->saved_bstride, c->saved_index,

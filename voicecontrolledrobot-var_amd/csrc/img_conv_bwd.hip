@@ -367,20 +367,6 @@ __device__ __forceinline__ void img_dgrad16_body(const float* __restrict__ gy, c
     }
 }
 
-template <class C>
-__global__ void __launch_bounds__(C::NW * 64)
-img_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ wd, const float* __restrict__ x,
-                 float* __restrict__ gx, int B) {
-    img_dgrad_body<C>(gy, wd, x, gx, B, blockIdx.x);
-}
-
-template <class C>
-__global__ void __launch_bounds__(C::NW * 64)
-img_dgrad16_kernel(const float* __restrict__ gy, const float* __restrict__ wd, const float* __restrict__ x,
-                   float* __restrict__ gx, int B) {
-    img_dgrad16_body<C>(gy, wd, x, gx, B, blockIdx.x);
-}
-
 // ------------------------------------------------------------------------------------------
 // One launch for the two kernels of a layer that consume the same gy and do not depend on each other: the weight
 // gradient (persistent split-K workgroups, blocks [0, Gw * NCOMBO)) and the data gradient (one tile per workgroup,
@@ -402,52 +388,15 @@ img_bwd_pair_kernel(const void* __restrict__ wx, long wbstride, const float* __r
     }
 }
 
-template <class C>
-static int launch_dgrad16(var_ctx* c, hipStream_t s, const float* gy, const float* wd, const float* x, float* gx, int B,
-                          int layer) {
-    ProfScope prof(c, s, TAG_IMG_DGRAD0 + layer);
-    static bool attr_set = false;
-    if (!attr_set) {
-        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)img_dgrad16_kernel<C>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(img_dgrad16_kernel<C>, dim3(B * C::NB), dim3(C::NW * 64), C::LDS_BYTES, s, gy, wd, x, gx, B);
-    VAR_HIP_CHECK(c, hipGetLastError());
-    return VAR_OK;
-}
-
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-template <class C>
-static int launch_dgrad(var_ctx* c, hipStream_t s, const float* gy, const float* wd, const float* x, float* gx, int B,
-                        int layer) {
-    ProfScope prof(c, s, TAG_IMG_DGRAD0 + layer);
-    static bool attr_set = false;
-    if (!attr_set) {
-        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)img_dgrad_kernel<C>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-        attr_set = true;
-    }
-    const int units = B * C::NB;
-    hipLaunchKernelGGL(img_dgrad_kernel<C>, dim3((units + C::NU - 1) / C::NU), dim3(C::NW * 64), C::LDS_BYTES, s,
-                       gy, wd, x, gx, B);
-    VAR_HIP_CHECK(c, hipGetLastError());
-    return VAR_OK;
-}
-
 //                 CIN COUT  H  RI NU NW
-using D84_1 = DgCfg<32, 32, 42, 6, 2, 4>;
 using D84_2 = DgCfg<32, 64, 21, 22, 1, 4, 1>;     // 4 items x 3 slices          -> 12 waves
-using D84_3 = DgCfg<64, 64, 11, 12, 1, 4, 1>;     // 1 image, 4 items x 3 slices  -> 12 waves
 using D84_4 = DgCfg<64, 64, 6, 6, 3, 2, 2>;       // 3 images, 2 items x 6 slices -> 12 waves
 using G84_3 = Dg16Cfg<64, 64, 11, 12>;            // conv 4's data gradient on 16-wide tiles: 3 pair tiles x 4 channel tiles
 using G96_3 = Dg16Cfg<64, 64, 12, 12>;
-using D96_1 = DgCfg<32, 32, 48, 8, 1, 3>;
-using D96_2 = DgCfg<32, 64, 24, 8, 2, 3>;
 using D96_2p = DgCfg<32, 64, 24, 10, 2, 4, 1>;    // 12-wave form for the paired grid: 2 bands of 10 rows, 4 items x 3 slices
-using D96_3 = DgCfg<64, 64, 12, 12, 1, 4, 1>;
 using D96_4 = DgCfg<64, 64, 6, 6, 3, 2, 2>;
 
 // The last two kernels of the image backward in one grid: the weight gradient of conv 2 (blocks [0, Gw)) and the
@@ -475,14 +424,11 @@ static int launch_last(var_ctx* c, hipStream_t s, int B) {
         attr_set = true;
     }
     const int need = (B * WC::NB + WC::NU - 1) / WC::NU;
-    int gmax = img_wgrad_groups(1);
-    if (const char* e = getenv("VAR_WG_G1")) { if (atoi(e) > 0 && atoi(e) <= gmax) gmax = atoi(e); }   // tuning aid
+    const int gmax = img_wgrad_groups(1);
     const int Gw = need < gmax ? need : gmax;
     c->wg_groups[1] = Gw;
     const int ntiles = (B * TC::NB + TC::NU - 1) / TC::NU;
-    int tmax = kTailG;
-    if (const char* e = getenv("VAR_TAIL_G")) { if (atoi(e) > 0 && atoi(e) <= kTailG) tmax = atoi(e); }   // tuning aid
-    const int Gt = ntiles < tmax ? ntiles : tmax;
+    const int Gt = ntiles < kTailG ? ntiles : kTailG;
     c->wg_groups[0] = Gt;
     hipLaunchKernelGGL((img_bwd_last_kernel<WC, TC>), dim3(Gw + Gt), dim3(768), LDS_BYTES, s, c->act[1],
                        32L * c->hs[1] * c->hs[1], c->gact[2], c->slabs + img_slab_offset(1), Gw,
@@ -505,13 +451,7 @@ static int launch_pair(var_ctx* c, hipStream_t s, int layer, const void* wx, lon
         attr_set = true;
     }
     const int need = (B * WC::NB + WC::NU - 1) / WC::NU;
-    int gmax = img_wgrad_groups(layer);
-    {   // tuning aid: VAR_WG_G<layer>=n (never above the slab workspace)
-        char name[16];
-        snprintf(name, sizeof name, "VAR_WG_G%d", layer);
-        const char* e = getenv(name);
-        if (e && atoi(e) > 0 && atoi(e) <= gmax) gmax = atoi(e);
-    }
+    const int gmax = img_wgrad_groups(layer);
     const int Gw = need < gmax ? need : gmax;
     c->wg_groups[layer] = Gw;
     int nd;
@@ -522,82 +462,37 @@ static int launch_pair(var_ctx* c, hipStream_t s, int layer, const void* wx, lon
     return VAR_OK;
 }
 
-int launch_img_bwd(var_ctx* c, hipStream_t s, hipStream_t sw, hipStream_t sr, const float* params, float* grads, int B) {
+// The image backward on stream s: {wgrad l || dgrad l} in one grid for l = 4..2, {wgrad 1 || fused tail (dgrad 1 + wgrad 0)}
+// in one grid at 84 x 84 (two launches at 96 x 96, whose tail runs 9 waves), then ONE fold of all five layers' slabs.
+int launch_img_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads, int B) {
     const PackLayout& K = c->kl;
     int rc;
     const int H = c->H;
-    const long bs[6] = {c->saved_bstride, 32L * c->hs[1] * c->hs[1], 32L * c->hs[2] * c->hs[2],
-                        64L * c->hs[3] * c->hs[3], 64L * c->hs[4] * c->hs[4], 0};
+    const long bs[5] = {c->saved_bstride, 32L * c->hs[1] * c->hs[1], 32L * c->hs[2] * c->hs[2],
+                        64L * c->hs[3] * c->hs[3], 64L * c->hs[4] * c->hs[4]};
     const void* xin[5] = {c->saved_image, c->act[1], c->act[2], c->act[3], c->act[4]};
     if (H != 84 && H != 96) { VAR_SET_ERR(c, "unsupported image size %d (84 or 96)", H); return VAR_ERR_ARG; }
-    // dgrad chain on s; each weight-gradient kernel on sw as soon as its gy (gact[l+1]) exists
-    auto ready = [&](int l) -> int {
-        if (sw != s) { VAR_HIP_CHECK(c, hipEventRecord(c->ev_g[l], s)); VAR_HIP_CHECK(c, hipStreamWaitEvent(sw, c->ev_g[l], 0)); }
-        return VAR_OK;
-    };
-#define DG(A, Bc, l) (H == 84 ? launch_dgrad<A>(c, s, c->gact[l + 1], c->wpack + K.img_d[l], c->act[l], c->gact[l], B, l) \
-                              : launch_dgrad<Bc>(c, s, c->gact[l + 1], c->wpack + K.img_d[l], c->act[l], c->gact[l], B, l))
-    // VAR_NO_TAIL=1 (tuning aid): separate dgrad of conv 2 and wgrad of conv 1 through gact1 in HBM
-    static const bool fused_tail = !getenv("VAR_NO_TAIL");
-    if ((rc = ready(5)) != VAR_OK) return rc;
-    // With the folds on the same stream as the weight gradients (the default) all five layers are folded by ONE
-    // launch after the last weight-gradient kernel; on a stream of their own (sr != sw) each layer's fold is
-    // released by an event as soon as its slabs exist.
-    const bool fold_each = sr != sw;
-    // VAR_NO_PAIR=1 (tuning aid): weight and data gradient of a layer as two launches
-    static const bool allow_pair = !getenv("VAR_NO_PAIR");
-    const bool paired = allow_pair && sw == s && !fold_each;
-    // layers 2-4 at both sizes; the last grid (wgrad 1 + fused tail) at 84 x 84 only (the 96 tail runs 9 waves)
-    auto pair_ok = [&](int l) { return paired && l >= 2; };
-    for (int l = 4; l >= 0; --l) {
-        if (l == 0 && fused_tail) {
-            // layer 0's slabs were left by the tail kernel on s
-            if (sr != s) { VAR_HIP_CHECK(c, hipEventRecord(c->ev_g[0], s)); VAR_HIP_CHECK(c, hipStreamWaitEvent(sr, c->ev_g[0], 0)); }
-            if ((rc = launch_img_wgrad_reduce(c, sr, grads, 0, fold_each ? 0 : 4)) != VAR_OK) return rc;
-            break;
-        }
-        if (pair_ok(l)) {
-            const float* gyl = c->gact[l + 1];
-            const float* wdl = c->wpack + K.img_d[l];
-            if (H == 84) {
-                if (l == 4) rc = launch_pair<W84_4, D84_4, false>(c, s, 4, xin[4], bs[4], gyl, wdl, c->act[4], c->gact[4], B);
-                else if (l == 3) rc = launch_pair<W84_3, G84_3, true>(c, s, 3, xin[3], bs[3], gyl, wdl, c->act[3], c->gact[3], B);
-                else rc = launch_pair<W84_2, D84_2, false>(c, s, 2, xin[2], bs[2], gyl, wdl, c->act[2], c->gact[2], B);
-            } else {
-                if (l == 4) rc = launch_pair<W96_4, D96_4, false>(c, s, 4, xin[4], bs[4], gyl, wdl, c->act[4], c->gact[4], B);
-                else if (l == 3) rc = launch_pair<W96_3, G96_3, true>(c, s, 3, xin[3], bs[3], gyl, wdl, c->act[3], c->gact[3], B);
-                else rc = launch_pair<W96_2, D96_2p, false>(c, s, 2, xin[2], bs[2], gyl, wdl, c->act[2], c->gact[2], B);
-            }
-            if (rc != VAR_OK) return rc;
-            continue;
-        }
-        if (paired && H == 84 && l == 1 && fused_tail) {
-            rc = c->saved_u8 ? launch_last<W84_1, T84u>(c, s, B) : launch_last<W84_1, T84f>(c, s, B);
-            if (rc != VAR_OK) return rc;
-            continue;                                        // l = 0: the fold below
-        }
-        if ((rc = launch_img_wgrad(c, sw, l, xin[l], bs[l], l == 0 ? c->saved_u8 : 0, c->gact[l + 1], B)) != VAR_OK) return rc;
-        if (fold_each) {
-            VAR_HIP_CHECK(c, hipEventRecord(c->ev_w[l], sw)); VAR_HIP_CHECK(c, hipStreamWaitEvent(sr, c->ev_w[l], 0));
-            if ((rc = launch_img_wgrad_reduce(c, sr, grads, l, l)) != VAR_OK) return rc;
-        } else if (l == 0) {
-            if ((rc = launch_img_wgrad_reduce(c, sr, grads, 0, 4)) != VAR_OK) return rc;
-        }
-        if (l == 0) break;
-        switch (l) {
-            case 4: rc = DG(D84_4, D96_4, 4); break;
-            case 3: rc = getenv("VAR_NO_DG16") ? DG(D84_3, D96_3, 3)
-                       : (H == 84 ? launch_dgrad16<G84_3>(c, s, c->gact[4], c->wpack + K.img_d[3], c->act[3], c->gact[3], B, 3)
-                                  : launch_dgrad16<G96_3>(c, s, c->gact[4], c->wpack + K.img_d[3], c->act[3], c->gact[3], B, 3));
-                    break;
-            case 2: rc = DG(D84_2, D96_2, 2); break;
-            default: rc = fused_tail ? launch_img_bwd_tail(c, s, B) : DG(D84_1, D96_1, 1); break;
+    for (int l = 4; l >= 2; --l) {
+        const float* gyl = c->gact[l + 1];
+        const float* wdl = c->wpack + K.img_d[l];
+        if (H == 84) {
+            if (l == 4) rc = launch_pair<W84_4, D84_4, false>(c, s, 4, xin[4], bs[4], gyl, wdl, c->act[4], c->gact[4], B);
+            else if (l == 3) rc = launch_pair<W84_3, G84_3, true>(c, s, 3, xin[3], bs[3], gyl, wdl, c->act[3], c->gact[3], B);
+            else rc = launch_pair<W84_2, D84_2, false>(c, s, 2, xin[2], bs[2], gyl, wdl, c->act[2], c->gact[2], B);
+        } else {
+            if (l == 4) rc = launch_pair<W96_4, D96_4, false>(c, s, 4, xin[4], bs[4], gyl, wdl, c->act[4], c->gact[4], B);
+            else if (l == 3) rc = launch_pair<W96_3, G96_3, true>(c, s, 3, xin[3], bs[3], gyl, wdl, c->act[3], c->gact[3], B);
+            else rc = launch_pair<W96_2, D96_2p, false>(c, s, 2, xin[2], bs[2], gyl, wdl, c->act[2], c->gact[2], B);
         }
         if (rc != VAR_OK) return rc;
-        if (l > 1 || !fused_tail) { if ((rc = ready(l)) != VAR_OK) return rc; }
     }
-#undef DG
-    if (sr != s) { VAR_HIP_CHECK(c, hipEventRecord(c->ev_wjoin, sr)); VAR_HIP_CHECK(c, hipStreamWaitEvent(s, c->ev_wjoin, 0)); }
+    if (H == 84) {
+        rc = c->saved_u8 ? launch_last<W84_1, T84u>(c, s, B) : launch_last<W84_1, T84f>(c, s, B);
+    } else {
+        if ((rc = launch_img_wgrad1_96(c, s, xin[1], bs[1], c->gact[2], B)) != VAR_OK) return rc;
+        rc = launch_img_bwd_tail(c, s, B);
+    }
+    if (rc != VAR_OK) return rc;
     (void)params;
-    return VAR_OK;
+    return launch_img_wgrad_reduce(c, s, grads, 0, 4);
 }

@@ -17,13 +17,8 @@
 
 #include "img_stage.h"
 
-// WREG: the conv-2 filter slice of a wave (its filter row: 96 k x 32 n = 48 A operands) lives in REGISTERS instead of
-// LDS.  With one band per tile that brings the workgroup to 56 KB of LDS and 6 waves, so TWO workgroups share a CU and
-// one's epilogues / barrier waits overlap the other's matrix work (phase timing of the 12-wave form: 48 % of a tile's
-// cycles were conv-1 epilogue, barrier skew and the fold, with the matrix cores idle).
-template <int H1_, bool U8_, int R2_, int NU_, bool WREG_ = false>
+template <int H1_, bool U8_, int R2_, int NU_>
 struct HeadCfg {
-    static constexpr bool WREG = WREG_;
     static constexpr int H1 = H1_, W1 = H1_, R2 = R2_, NU = NU_;   // act1 plane (42 / 48); NU bands per tile
     static constexpr bool U8 = U8_;
     static constexpr int CH = 32;
@@ -45,13 +40,11 @@ struct HeadCfg {
     static constexpr int KS1 = 14;                           // k-steps of conv 1 (27 -> 28)
     static constexpr int IMS = 0;
     static constexpr int A1S = (NU * UNIT_I + 3) & ~3;
-    static constexpr int WDS = (A1S + NU * UNIT_1 + 3) & ~3; // conv-2 filter Wf[k][n], k = tap*CH + c (unless WREG)
-    static constexpr int LUT = WDS + (WREG ? 0 : 9 * CH * CH);   // x / 255.f
+    static constexpr int WDS = (A1S + NU * UNIT_1 + 3) & ~3; // conv-2 filter Wf[k][n], k = tap*CH + c
+    static constexpr int LUT = WDS + 9 * CH * CH;            // x / 255.f
     static constexpr int BIA = LUT + 256;                    // bias of conv 1 (32) and conv 2 (32)
     static constexpr int LDS_FLOATS = BIA + 64;
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
-    static constexpr int WG_PER_CU = LDS_BYTES <= 80 * 1024 ? 2 : 1;
-    static constexpr int WAVES_PER_EU = (WG_PER_CU * NW + 3) / 4;
     static_assert(HO2 % R2 == 0, "whole bands");
     static_assert(2 * NPB2 * 1024 <= NU * UNIT_1, "the fold scratch aliases the act1 tile");
     static_assert(NU <= 2, "at most two bands per tile");
@@ -67,7 +60,7 @@ extern "C" int var_debug_phases_head(unsigned long long* out) {
 #endif
 
 template <class C>
-__global__ void __launch_bounds__(C::NT, C::WAVES_PER_EU)
+__global__ void __launch_bounds__(C::NT)
 img_fwd_head_kernel(const void* __restrict__ image, long bstride, const int* __restrict__ bidx,
                     const float* __restrict__ wp1, const float* __restrict__ bias1,
                     const float* __restrict__ wp2, const float* __restrict__ bias2,
@@ -83,8 +76,7 @@ img_fwd_head_kernel(const void* __restrict__ image, long bstride, const int* __r
 
     PH_INIT(7);
     // ---- one-time: conv-2 filter and the u8 table into LDS, conv-1 filter into registers, pad columns ----
-    if constexpr (!C::WREG)
-        for (int e = tid; e < 9 * C::CH * C::CH / 4; e += NT) ((float4*)(lds + C::WDS))[e] = ((const float4*)wp2)[e];
+    for (int e = tid; e < 9 * C::CH * C::CH / 4; e += NT) ((float4*)(lds + C::WDS))[e] = ((const float4*)wp2)[e];
     if (tid < 256) lds[C::LUT + tid] = (float)tid / 255.f;
     if (tid < 32) { lds[C::BIA + tid] = bias1[tid]; lds[C::BIA + 32 + tid] = bias2[tid]; }
     lds_zero_cols<NT>(lds + C::IMS, C::NU * 3 * C::IRI, C::PWI, 0, 1, tid);
@@ -123,14 +115,6 @@ img_fwd_head_kernel(const void* __restrict__ image, long bstride, const int* __r
     const int oyl2 = q2 / C::WO2, ox2 = q2 - oyl2 * C::WO2;
     const int pixoff2 = C::A1S + u2 * C::UNIT_1 + (2 * oyl2 + ky) * C::PW1 + 2 * ox2 + half * C::PLANE_1;
     const int wl2 = C::WDS + ((ky * 3) * C::CH + half) * C::CH + l31;      // + (kx*CH + 2*c2)*CH
-    // WREG: A operands of this wave's filter row, k = (ky*3 + kx)*CH + 2 cp + half
-    float wreg[C::WREG ? 3 : 1][C::WREG ? C::CH / 2 : 1];
-    if constexpr (C::WREG) {
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-            for (int cp = 0; cp < C::CH / 2; ++cp) wreg[kx][cp] = wp2[(((ky * 3 + kx) * C::CH) + 2 * cp + half) * C::CH + l31];
-    }
 
     // The next tile's image band is fetched and stored by the waves that idle during the fold (ky > 0): their loads
     // fly during conv 2, their LDS stores happen while the ky = 0 waves run the epilogue.
@@ -241,7 +225,7 @@ img_fwd_head_kernel(const void* __restrict__ image, long bstride, const int* __r
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         bb[buf][u][kx] = lds[pixoff2 + 2 * (ch * UC + u) * C::PLANE_1 + kx];
-                        if constexpr (!C::WREG) wa[buf][u][kx] = lds[wl2 + (kx * C::CH + 2 * (ch * UC + u)) * C::CH];
+                        wa[buf][u][kx] = lds[wl2 + (kx * C::CH + 2 * (ch * UC + u)) * C::CH];
                     }
             };
             fetch(0, 0);
@@ -253,8 +237,7 @@ img_fwd_head_kernel(const void* __restrict__ image, long bstride, const int* __r
                 for (int u = 0; u < UC; ++u)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(C::WREG ? wreg[C::WREG ? kx : 0][C::WREG ? ch * UC + u : 0] : wa[ch & 1][u][kx],
-                                                                   bb[ch & 1][u][kx], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[ch & 1][u][kx], bb[ch & 1][u][kx], acc, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -288,9 +271,9 @@ img_fwd_head_kernel(const void* __restrict__ image, long bstride, const int* __r
 }
 
 //                    H1   U8   R2 NU
-// (measured, round 2: one band per tile with the filter rows in registers -- 56 KB, 6 waves, two workgroups per CU -- runs
-//  at 61 us instead of 52: twin workgroups start in lock-step and collide in the same phases; the 12-wave form with the
-//  filter in registers spills and runs at 57 us)
+// (measured, round 2: one band per tile with each wave's conv-2 filter row in registers -- 56 KB, 6 waves, two workgroups
+//  per CU -- runs at 61 us instead of 52: twin workgroups start in lock-step and collide in the same phases; the 12-wave
+//  form with the filter rows in registers spills and runs at 57 us)
 using H84u = HeadCfg<42, true, 3, 2>;      // 2 bands: 4 pixel blocks x 3 filter rows = 12 waves, 3 per SIMD
 using H84f = HeadCfg<42, false, 3, 2>;
 using H96u = HeadCfg<48, true, 4, 1>;      // 1 band: 3 pixel blocks x 3 filter rows = 9 waves
@@ -307,8 +290,7 @@ static int launch_head(var_ctx* c, hipStream_t s, const void* image, long bstrid
         attr_set = true;
     }
     const int ntiles = (B * C::NB + C::NU - 1) / C::NU;
-    const int gmax = 256 * C::WG_PER_CU;
-    const int G = ntiles < gmax ? ntiles : gmax;
+    const int G = ntiles < 256 ? ntiles : 256;
     const ParamLayout& L = c->pl;
     const PackLayout& K = c->kl;
     hipLaunchKernelGGL(img_fwd_head_kernel<C>, dim3(G), dim3(C::NT), C::LDS_BYTES, s, image, bstride, bidx,

@@ -342,13 +342,7 @@ static int launch_wgrad(var_ctx* c, hipStream_t s, const void* x, long bstride, 
         attr_set = true;
     }
     const int need = (B * C::NB + C::NU - 1) / C::NU;
-    int gmax = kWgG[layer];
-    {   // tuning aid: VAR_WG_G<layer>=n (never above the slab workspace)
-        char name[16];
-        snprintf(name, sizeof name, "VAR_WG_G%d", layer);
-        const char* e = getenv(name);
-        if (e && atoi(e) > 0 && atoi(e) <= kWgG[layer]) gmax = atoi(e);
-    }
+    const int gmax = kWgG[layer];
     const int G = need < gmax ? need : gmax;
     c->wg_groups[layer] = G;
     hipLaunchKernelGGL(img_wgrad_kernel<C>, dim3(G, C::NCOMBO), dim3(C::NT), C::LDS_BYTES, s, x, bstride, bidx, gy,
@@ -357,18 +351,10 @@ static int launch_wgrad(var_ctx* c, hipStream_t s, const void* x, long bstride, 
     return VAR_OK;
 }
 
-// weight gradient of image conv `layer` (0..4): x = that layer's input, gy = gact[layer+1]
-int launch_img_wgrad(var_ctx* c, hipStream_t s, int layer, const void* x, long bstride, int is_u8, const float* gy, int B) {
-    const int H = c->H;
-#define W2(A, Bc) (H == 84 ? launch_wgrad<A>(c, s, x, bstride, gy, B, layer) : launch_wgrad<Bc>(c, s, x, bstride, gy, B, layer))
-    switch (layer) {
-        case 0: return is_u8 ? W2(W84_0u, W96_0u) : W2(W84_0f, W96_0f);
-        case 1: return W2(W84_1, W96_1);
-        case 2: return W2(W84_2, W96_2);
-        case 3: return W2(W84_3, W96_3);
-        default: return W2(W84_4, W96_4);
-    }
-#undef W2
+// weight gradient of image conv 2 at 96 x 96 (the only stand-alone weight-gradient launch left: every other one
+// shares a grid with a data gradient, img_conv_bwd.hip): x = act1, gy = gact[2]
+int launch_img_wgrad1_96(var_ctx* c, hipStream_t s, const void* x, long bstride, const float* gy, int B) {
+    return launch_wgrad<W96_1>(c, s, x, bstride, gy, B, 1);
 }
 
 // fixed-order slab sums of layers [lo, hi] into the gradient arena

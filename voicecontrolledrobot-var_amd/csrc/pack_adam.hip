@@ -200,7 +200,6 @@ int launch_adam_dev(var_ctx* c, hipStream_t s, float* p, const float* g, float* 
     // few blocks (4 elements per thread): every block ends with one device-scope atomic on the same word
     int grid = (int)((n + 1023) / 1024);
     if (grid > 256) grid = 256;
-    if (const char* e = getenv("VAR_ADAM_GRID")) { if (atoi(e) > 0) grid = atoi(e); }    // tuning aid
     hipLaunchKernelGGL(adam_pack_dev_kernel, dim3(grid), dim3(256), 0, s, (const PackSeg*)c->pack_segs_dev, c->pack_nseg, p, g, m, v, n, lr_dev,
                        b1, b2, eps, wd, step_dev, c->done_ctr, repack ? c->wpack : nullptr, idx_table, row_ints, n_rows,
                        cursor, idx_row, ahead_from);

@@ -152,14 +152,9 @@ struct var_ctx {
     const float* saved_neg = nullptr;
     const int* saved_index = nullptr;     // optional image gather index of the saved forward
     // side stream for the sound branch (runs beside the image branch) and its fork/join events
-    bool serial = false;                  // VAR_SERIAL=1: everything on the caller's stream (for per-kernel profiling)
+    bool serial = false;                  // var_set_streams(0): everything on the caller's stream (per-kernel profiling)
     int streams = 0;              // bit mask, see var_init
     hipStream_t side = nullptr;
-    hipStream_t side2 = nullptr;          // VAR_STREAMS bit 2: weight-gradient kernels beside the dgrad chain (off by default)
-    hipEvent_t ev_g[6] = {nullptr};       // gact[l] ready (recorded on the dgrad stream)
-    hipEvent_t ev_wjoin = nullptr;
-    hipStream_t side3 = nullptr;          // VAR_STREAMS bit 3: slab folds on a stream of their own (off by default)
-    hipEvent_t ev_w[5] = {nullptr};       // wgrad of layer l done (recorded on side2)
     hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
     float* mfcc_buf = nullptr;            // (2*maxB, 100, 40) when the front-end runs inside the step
     float* mfcc_psf_tab = nullptr;        // tables of the python_speech_features front-end (mfcc_psf.hip), built on first use
@@ -214,7 +209,7 @@ int pack_table_upload(var_ctx* c);
 size_t img_slab_floats();
 int img_wgrad_groups(int layer);
 size_t img_slab_offset(int layer);
-int launch_img_wgrad(var_ctx* c, hipStream_t s, int layer, const void* x, long bstride, int is_u8, const float* gy, int B);
+int launch_img_wgrad1_96(var_ctx* c, hipStream_t s, const void* x, long bstride, const float* gy, int B);
 int launch_img_wgrad_reduce(var_ctx* c, hipStream_t s, float* grads, int lo, int hi);
 size_t snd_slab_floats();
 
@@ -226,8 +221,6 @@ int launch_img_fwd_head(var_ctx* c, hipStream_t s, const float* params, const vo
                         const int* image_index, int B);
 int launch_img_fwd_mid(var_ctx* c, hipStream_t s, const float* params, int B, bool with_head);
 // (launch_img_fwd also leaves c->relu1)
-int launch_img_fwd_conv2_pipe(var_ctx* c, hipStream_t s, const float* x, const float* wp, const float* bias,
-                              float* y, int B);
 // default: MFCC on the caller's stream, the sound CNN (forward and backward) beside the image CNN on one side
 // stream; image weight gradients and slab folds stay on the caller's stream.  Measured on MI355X (graph replay):
 // every cross-stream edge costs several us, and two GPU-filling persistent kernels side by side slow each other
@@ -235,7 +228,7 @@ int launch_img_fwd_conv2_pipe(var_ctx* c, hipStream_t s, const float* x, const f
 static constexpr int kDefaultStreams = 19;
 static constexpr int kTailG = 256;    // workgroups (= layer-0 slabs) of the fused backward tail
 int launch_img_bwd_tail(var_ctx* c, hipStream_t s, int B);
-int launch_img_bwd(var_ctx* c, hipStream_t s, hipStream_t sw, hipStream_t sr, const float* params, float* grads, int B);
+int launch_img_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads, int B);
 int launch_snd_fwd(var_ctx* c, hipStream_t s, const float* params, const float* pos, const float* neg, int B);
 int launch_snd_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads, int B);
 int launch_heads_fwd(var_ctx* c, hipStream_t s, hipStream_t ss, const float* params, int B, bool has_img, bool has_pos,
