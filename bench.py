@@ -23,11 +23,20 @@ import torch  # noqa: E402
 
 HW = 84
 BATCH = 256
-# 2*MAC per image of layer l's conv (fwd == wgrad == dgrad), H=84: Ho^2 * Cout * Cin * 9 * 2
-_HO = [42, 21, 11, 6, 3]
+# 2*MAC per image of layer l's conv (fwd == wgrad == dgrad): Ho^2 * Cout * Cin * 9 * 2
 _CH = [3, 32, 32, 64, 64, 64]
-LAYER_FLOPS = [2 * _HO[l] ** 2 * _CH[l + 1] * _CH[l] * 9 for l in range(5)]
-FLOPS_PER_TRIPLET = 58.407e6          # fwd+bwd, SURVEY.md section 8(d)
+
+
+def layer_flops(hw):
+    out, h = [], hw
+    for l in range(5):
+        h = (h - 1) // 2 + 1
+        out.append(2 * h * h * _CH[l + 1] * _CH[l] * 9)
+    return out
+
+
+LAYER_FLOPS = layer_flops(84)
+FLOPS_PER_TRIPLET = 58.407e6          # fwd+bwd @84, SURVEY.md section 8(d) (@96: 70.282e6)
 F32_MFMA_PEAK = 157.3                 # TFLOP/s, MI355X_MICROARCH.md "Peak FP32 (matrix)"
 
 
@@ -48,30 +57,53 @@ def host_cores():
     return min(n, 64)          # torch's intra-op pool does not scale past this on these small convs
 
 
-def cpu_baseline(seconds=10.0):
-    """The reference's step on the host cores: torch.nn CPU restatement (oracle/torch_oracle.py),
-    same shapes, MFCC precomputed (as VARFineTuneDataset does), tensors in RAM."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_run(batch, threads, seconds, min_steps):
     from oracle.torch_oracle import CPUTrainer
-    cores = host_cores()
-    torch.set_num_threads(cores)
+    torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(0)
-    img = torch.randint(0, 256, (BATCH, 3, HW, HW), dtype=torch.uint8, generator=g)
-    pos = torch.randn(BATCH, 1, 100, 40, generator=g) * 5
-    neg = torch.randn(BATCH, 1, 100, 40, generator=g) * 5
+    img = torch.randint(0, 256, (batch, 3, HW, HW), dtype=torch.uint8, generator=g)
+    pos = torch.randn(batch, 1, 100, 40, generator=g) * 5
+    neg = torch.randn(batch, 1, 100, 40, generator=g) * 5
     torch.manual_seed(453)
-    tr = CPUTrainer()
-    for _ in range(2):
-        tr.step(img, pos, neg)
+    tr = CPUTrainer(hw=HW)
+    tr.step(img, pos, neg)
     n, t0 = 0, time.perf_counter()
     while True:
         tr.step(img, pos, neg)
         n += 1
         dt = time.perf_counter() - t0
-        if dt >= seconds and n >= 5:
+        if dt >= seconds and n >= min_steps:
             break
+    return n, dt
+
+
+def cpu_baseline(seconds=8.0):
+    """The reference's step on the host cores: torch.nn CPU restatement (oracle/torch_oracle.py), same shapes, MFCC
+    precomputed (as VARFineTuneDataset does), tensors in RAM.  `value` = batch 256 on every core the process may use
+    (BASELINE configs[1]'s batch); `others` = batch 32 (configs[0], the reference's own CPU-runnable case) and a
+    one-thread figure, as BASELINE.md section 3 asks.  About 20 s in all."""
+    cores = host_cores()
+    n, dt = _cpu_run(BATCH, cores, seconds, 5)
+    n32, dt32 = _cpu_run(32, cores, 4.0, 10)
+    n1, dt1 = _cpu_run(BATCH, 1, 6.0, 1)
+    torch.set_num_threads(cores)
     return {"value": round(n * BATCH / dt, 1), "unit": "triplets/s", "cores": cores, "kind": "port",
-            "sample": f"{n} steps of batch {BATCH} (84x84 u8 images, precomputed f32 MFCC in RAM), "
-                      f"torch.nn CPU restatement of the reference step, {cores} threads, {dt:.1f} s"}
+            "cpu": cpu_model(),
+            "sample": f"{n} steps of batch {BATCH} ({HW}x{HW} u8 images, precomputed f32 MFCC in RAM), "
+                      f"torch.nn CPU restatement of the reference step, {cores} threads, {dt:.1f} s",
+            "others": {"batch32_all_threads": {"value": round(n32 * 32 / dt32, 1), "steps": n32, "seconds": round(dt32, 1)},
+                       "batch256_one_thread": {"value": round(n1 * BATCH / dt1, 1), "steps": n1, "seconds": round(dt1, 1)}}}
 
 
 # ---- BASELINE.json configs[3] shape on ONE model replica per GPU: the iTHOR model (fp32 here; config 4 names bf16) ----
@@ -208,25 +240,28 @@ def tag_flops(tag):
     (conv 1 + conv 2), tag 2 = conv 3 + 4 + 5 (+ image head, not counted), tags 7-9 = weight + data gradient of
     layers 2-4 in one grid, tag 11 = weight gradient of conv 2 + data gradient of conv 2 + weight gradient of conv 1.
     Halo recomputation inside the fused kernels is not counted."""
-    if True:
-        if tag == 1:
-            return LAYER_FLOPS[0] + LAYER_FLOPS[1]
-        if tag == 2:
-            return LAYER_FLOPS[2] + LAYER_FLOPS[3] + LAYER_FLOPS[4]
-        if tag in (7, 8, 9):
-            return 2 * LAYER_FLOPS[tag - 5]
-        if tag == 11:
-            return 2 * LAYER_FLOPS[1] + LAYER_FLOPS[0]
+    if tag == 1:
+        return LAYER_FLOPS[0] + LAYER_FLOPS[1]
+    if tag == 2:
+        return LAYER_FLOPS[2] + LAYER_FLOPS[3] + LAYER_FLOPS[4]
+    if tag in (7, 8, 9):
+        return 2 * LAYER_FLOPS[tag - 5]
+    if tag == 11:                             # 84: wgrad 1 + tail in one grid; 96: the tail alone (wgrad 1 = tag 6)
+        return (2 if HW == 84 else 1) * LAYER_FLOPS[1] + LAYER_FLOPS[0]
     return LAYER_FLOPS[tag % 5]
 
 
 def pmc_traffic(tag_name, hw):
-    """HBM bytes per launch of the dominant kernel, from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE
-    WRITE_SIZE in its own run, gfx950 correction: FETCH_SIZE x 2, see profiles/r01_pmc_hbm_traffic.json).
+    """HBM bytes per launch of the dominant kernel, from the committed PMC pass of THIS round's kernels (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction: FETCH_SIZE x 2; tools/pmc_traffic.sh ->
+    profiles/r02_pmc_hbm_traffic.json; batch 256, 84 x 84 only).
     PMC counters cannot be collected from inside this process, so this is the figure of that pass
     (same workload, same kernel); None when the file or the kernel is not in it."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_hbm_traffic.json")
+    if hw != 84:
+        return None
     want = {"img_fwd_head_kernel[0+1]": "img_fwd_head_kernel<HeadCfg<%d," % (hw // 2),
+            "img_fwd_mid_kernel[2+3+4+head]": "img_fwd_mid_kernel<",
             "img_bwd_last_kernel[wgrad1+dgrad1+wgrad0]": "img_bwd_last_kernel<",
             "img_bwd_pair_kernel[wgrad2+dgrad2]": "img_bwd_pair_kernel<WgCfg<32, 64,",
             "img_bwd_pair_kernel[wgrad3+dgrad3]": "img_bwd_pair_kernel<WgCfg<64, 64, %d," % (11 if hw == 84 else 12)}.get(tag_name)
@@ -237,6 +272,26 @@ def pmc_traffic(tag_name, hw):
     for name, row in table.items():
         if want in name:
             return int(row["hbm_bytes_fetch_x2_plus_write"])
+    return None
+
+
+def algorithmic_bytes(tag, B, hw):
+    """Bytes a launch of the kernel family MUST move: inputs read once, outputs written once."""
+    h = [hw]
+    for _ in range(5):
+        h.append((h[-1] - 1) // 2 + 1)
+    act = [B * _CH[l] * h[l] * h[l] * 4 for l in range(6)]     # act[0] as f32; the u8 image is act[0] / 4
+    img = act[0] // 4
+    bits = B * h[1] * h[1] * 4
+    if tag == 1:
+        return img + act[1] + act[2] + bits
+    if tag == 2:
+        return act[2] + act[3] + act[4] + act[5]
+    if tag in (7, 8, 9):                      # wgrad l (x, gy) || dgrad l (gy, mask x, gx)
+        l = tag - 5
+        return 2 * act[l + 1] + 3 * act[l]
+    if tag == 11:                             # wgrad 1 (act1, gact2) || tail (gact2, bits, image)
+        return act[1] + 2 * act[2] + bits + img
     return None
 
 
@@ -286,14 +341,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
+    ap.add_argument("--serial", action="store_true",
+                    help="kuka workload: every kernel on ONE stream (var_set_streams(0)) -- per-kernel profiling runs")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="ithor workload only: operand precision of the products (bf16 = BASELINE config 4's; accumulation fp32)")
     ap.add_argument("--hw", type=int, choices=(84, 96), default=84,
-                    help="kuka workload: image side; 84 = BASELINE's metric (default), 96 = the reference's default img_dim "
-                         "(no roofline leg: the FLOP table below is for 84)")
+                    help="kuka workload: image side; 84 = BASELINE's metric (default), 96 = the reference's default img_dim")
     ap.add_argument("--head", choices=("triplet", "inbatch"), default="triplet",
                     help="kuka workload: the reference's triplet loss (default, BASELINE's metric) or the in-batch-negatives "
-                         "contrastive head of configs[2] (extension; eager launches, MFCC features precomputed)")
+                         "contrastive head of configs[2] (extension; replayed step with the MFCC front-end inside)")
     ap.add_argument("--workload", choices=("kuka", "ithor"), default="kuka",
                     help="kuka = BASELINE.json's metric (default); ithor = the reference's second pretext model")
     ap.add_argument("--pool", type=int, default=4096,
@@ -331,10 +387,10 @@ def main():
     import var_amd
     from var_amd._lib import Context
 
-    global HW, FLOPS_PER_TRIPLET
+    global HW, FLOPS_PER_TRIPLET, LAYER_FLOPS
     if args.hw != 84:
         HW, FLOPS_PER_TRIPLET = args.hw, 70.282e6             # SURVEY.md section 8(d), Kuka @96
-        args.no_roofline = True
+        LAYER_FLOPS = layer_flops(args.hw)
     B = args.batch
     cfg = types.SimpleNamespace(img_dim=(3, HW, HW), sound_dim=(1, 100, 40), representationDim=3)
     torch.manual_seed(453)                                     # pretextEnvSeed; identical weights on every rank
@@ -343,8 +399,10 @@ def main():
     pool = var_amd.SyntheticTripletPool(args.pool, hw=HW, seed=rank, clips_per_class=64, device=dev).freeze_pairs()
     ctx = Context.get(local_rank)
     ctx.ensure_plan(B, HW)
+    if args.serial:
+        ctx.set_streams(0)
 
-    use_graph = not args.no_graph and args.head == "triplet"
+    use_graph = not args.no_graph
     if args.head == "inbatch":
         args.no_roofline = True
     state = {"tab": None, "row": 0}
@@ -409,8 +467,12 @@ def main():
         # the captured step walks a device-resident table of shuffled epochs by itself (no host copy per step);
         # the host installs the next epochs' table when this one is used up
         trows = 256
-        replay, load_table = tr.capture_epoch_steps(pool.images, pool.clips, B, pool.index_table(B, trows)[:trows].contiguous(),
-                                                    global_batch=B * world)
+        if args.head == "inbatch":
+            replay, load_table = tr.capture_inbatch_epoch_steps(pool.images, pool.clips, B,
+                                                                pool.index_table(B, trows)[:trows].contiguous(), tau=0.1)
+        else:
+            replay, load_table = tr.capture_epoch_steps(pool.images, pool.clips, B, pool.index_table(B, trows)[:trows].contiguous(),
+                                                        global_batch=B * world)
         gstate = {"left": trows}
 
         def step():
@@ -463,7 +525,9 @@ def main():
             ach = flops / (us * 1e-6) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": names[dom_tag], "achieved": round(ach, 2),
                                "peak": F32_MFMA_PEAK, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK, 4),
-                               "traffic": pmc_traffic(names[dom_tag], HW), "avg_us": round(us, 2), "launches": iso_n,
+                               "traffic": pmc_traffic(names[dom_tag], HW) if B == 256 else None,
+                               "algorithmic_bytes": algorithmic_bytes(dom_tag, B, HW),
+                               "avg_us": round(us, 2), "launches": iso_n,
                                "with_side_stream_us": round(1e3 * roof_ms / roof_n, 2),
                                "flops_per_launch": flops}
         if not args.no_cpu_baseline and world == 1:

@@ -35,8 +35,8 @@ class KukaNetCPU(nn.Module):
 
 
 class CPUTrainer:
-    def __init__(self, state_dict=None, lr=1e-4, weight_decay=1e-6, margin=1.0):
-        self.model = KukaNetCPU()
+    def __init__(self, state_dict=None, lr=1e-4, weight_decay=1e-6, margin=1.0, hw=84):
+        self.model = KukaNetCPU(hw)
         if state_dict is not None:
             self.model.load_state_dict({k: torch.as_tensor(v) for k, v in state_dict.items()})
         self.model.train()

@@ -314,3 +314,26 @@ def test_inbatch_head_at_config3_size(var_amd):
     assert abs(loss.item() - rl.item()) < 1e-5 * max(1.0, abs(rl.item()))
     np.testing.assert_allclose(ga.cpu().numpy(), ta.grad.numpy(), atol=1e-7, rtol=2e-4)
     np.testing.assert_allclose(gc.cpu().numpy(), tc.grad.numpy(), atol=1e-7, rtol=2e-4)
+
+
+def test_replayed_inbatch_step_equals_eager(var_amd, golden_dir):
+    """The replayed in-batch-negatives step (bench.py --head inbatch: gather, MFCC, encoder, head, backward, Adam and the
+    row fetch in ONE graph) against eager step_inbatch calls on the same rows."""
+    sd = load(golden_dir, "kuka_weights.npz")
+    B = 32
+    pool = var_amd.SyntheticTripletPool(128, hw=84, seed=41, clips_per_class=4).freeze_pairs()
+    table = pool.index_table(B, 3, drop_last=True)[:3].contiguous()
+    mb = make_model(var_amd, sd)
+    tb = var_amd.VARTrainer(mb, lr=1e-3)
+    replay, _ = tb.capture_inbatch_epoch_steps(pool.images, pool.clips, B, table, tau=0.1)
+    losses_b = [float(replay().item()) for _ in range(4)]
+    ma = make_model(var_amd, sd)
+    ta = var_amd.VARTrainer(ma, lr=1e-3)
+    losses_a = []
+    for s in range(4):
+        r = table[s % 3]
+        f = var_amd.mfcc(pool.clips, r[3 * B:], out_frames=100, clip_index=r[B:3 * B])
+        losses_a.append(float(ta.step_inbatch(pool.images[r[:B].long()].contiguous(), f[:B].contiguous(), f[B:].contiguous(),
+                                              tau=0.1).item()))
+    assert np.allclose(losses_a, losses_b, rtol=0, atol=1e-5), (losses_a, losses_b)
+    assert float((ma.flat_parameters() - mb.flat_parameters()).abs().max()) < 1e-4

@@ -133,3 +133,24 @@ def test_two_level_clip_draw_and_load_num(tmp_path):
     sub = var_amd.TripletPool.from_pickles(paths, *args, device="cpu", load_num=2)
     assert sub.n_items == 6 and len(set(sub.images[:, 0, 0, 0].tolist())) == 2
     assert var_amd.TripletPool.from_pickles(paths, *args, device="cpu", load_num='all').n_items == 15
+
+
+def test_replayed_inbatch_step_equals_eager_step_inbatch():
+    """capture_inbatch_epoch_steps (gather + MFCC + encoder + in-batch head + backward + Adam + row fetch as a replayed
+    step) walks the index table like eager step_inbatch calls on the same rows fed the same features."""
+    torch.manual_seed(3)
+    ma, mb = var_amd.VARPretextNet(_cfg()), var_amd.VARPretextNet(_cfg())
+    mb.load_state_dict(ma.state_dict())
+    ta = var_amd.VARTrainer(ma, lr=1e-3, _ctx=OracleContext())
+    tb = var_amd.VARTrainer(mb, lr=1e-3, _ctx=OracleContext())
+    pool = _pool(12)
+    B = 4
+    table = pool.index_table(B, 3, drop_last=True)
+    replay, _ = tb.capture_inbatch_epoch_steps(pool.images, pool.clips, B, table, tau=0.1)
+    for s in range(4):                                             # the 4th replay wraps to row 0
+        r = table[s % 3]
+        want = float(ta.step_inbatch(pool.images[r[:B].long()].contiguous(), _features(pool, r[B:2 * B], r[3 * B:4 * B]),
+                                     _features(pool, r[2 * B:3 * B], r[4 * B:]), tau=0.1).item())
+        got = float(replay().item())
+        assert abs(got - want) < 1e-6, (s, got, want)
+    assert float((ma.flat_parameters() - mb.flat_parameters()).abs().max()) < 2e-5      # 4 Adam steps of lr 1e-3

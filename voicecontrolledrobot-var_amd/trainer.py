@@ -414,6 +414,94 @@ class VARTrainer:
         self.adam()
         return self.loss
 
+    def capture_inbatch_epoch_steps(self, images, pcm, batch, table, tau=0.1):
+        """step_inbatch as a replayed step over the HBM-resident dataset (BASELINE configs[2]): per step the captured
+        graphs gather the images of the current index row, run the MFCC front-end, the encoder forward, the
+        in-batch-negatives head, the encoder backward and Adam + row fetch.  With one rank everything is ONE graph; with
+        several the three collectives (all-gather of the candidates, all-reduce of the candidate gradients, all-reduce
+        of the parameter gradients) stay eager between four graphs.  Returns (replay, load_table) like
+        capture_epoch_steps; `table` rows are [image_index | clip_index (2B) | lens (2B)], equal shards."""
+        B = batch
+        rows, row_ints = int(table.shape[0]), int(table.shape[1])
+        if row_ints != 5 * B or table.dtype != torch.int32 or table.device != self.dev or not table.is_contiguous():
+            raise VarHipError("index table must be a contiguous int32 (rows, 5*batch) tensor on the trainer's device")
+        c, dev, world, rank, rccl = self.ctx, self.dev, self.world, self.rank, self.rccl
+        flat = self.model.flat_parameters()
+        c.ensure_plan(B, self.hw)
+        self._g_table = torch.empty_like(table)
+        self._g_cursor = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._g_idx = torch.zeros(row_ints, dtype=torch.int32, device=dev)
+        self._device_scalars(B)
+        idx64 = torch.zeros(B, dtype=torch.int64, device=dev)
+        img = torch.zeros((B,) + tuple(images.shape[1:]), dtype=images.dtype, device=dev)
+        feats = torch.zeros((2 * B, 1, 100, 40), dtype=torch.float32, device=dev)
+        emb = torch.zeros((3, B, 3), dtype=torch.float32, device=dev)            # [image | pos | neg]
+        cand = torch.zeros((world * 2 * B, 3), dtype=torch.float32, device=dev) if world > 1 else emb[1:].reshape(2 * B, 3)
+        target = (torch.arange(B, dtype=torch.int32, device=dev) + rank * 2 * B).contiguous()
+        loss1 = torch.zeros(1, dtype=torch.float32, device=dev)
+        ga, gc = torch.zeros((B, 3), dtype=torch.float32, device=dev), torch.zeros_like(cand)
+        scratch = torch.zeros(2 * B, dtype=torch.float32, device=dev)
+        mine = gc[rank * 2 * B:(rank + 1) * 2 * B]
+        clip_idx, lens = self._g_idx[B:3 * B], self._g_idx[3 * B:5 * B]
+        self._keep_inbatch = (idx64, img, feats, emb, cand, target, loss1, ga, gc, scratch)
+
+        def body_fwd():
+            self._bind()
+            idx64.copy_(self._g_idx[:B])
+            torch.index_select(images, 0, idx64, out=img)
+            c.check(c.lib.var_mfcc(c.handle, c.stream(), ptr(pcm), ptr(lens), ptr(clip_idx), 2 * B, pcm.stride(0), 100,
+                                   ptr(feats)), "var_mfcc")
+            c.check(c.lib.var_arm_encoder_fwd(c.handle, c.stream(), ptr(flat), ptr(img), int(img.dtype == torch.uint8),
+                                              img.stride(0), ptr(feats), ptr(feats[B:]), B, self.hw, ptr(emb[0]), ptr(emb[1]),
+                                              ptr(emb[2]), None, None, 1), "var_arm_encoder_fwd")
+
+        def body_loss():
+            c.check(c.lib.var_inbatch_loss_fwd_bwd(c.handle, c.stream(), ptr(emb[0]), ptr(cand), ptr(target), B, cand.shape[0],
+                                                   float(tau), 1.0 / (B * world), ptr(scratch), ptr(loss1), ptr(ga), ptr(gc)),
+                    "var_inbatch_loss_fwd_bwd")
+
+        def body_bwd():
+            self._bind()
+            c.check(c.lib.var_arm_encoder_bwd(c.handle, c.stream(), ptr(flat), ptr(ga), ptr(mine[:B]), ptr(mine[B:]),
+                                              ptr(self.gbuf)), "var_arm_encoder_bwd")
+            self.gbuf[N_PARAMS:].copy_(loss1)
+
+        adam = self._body_adam(self._g_table, rows, row_ints, 0)
+        body_fwd()                                                  # warm-up outside capture (torch's lazy initialisations)
+        if world > 1:
+            g_fwd, g_loss, g_bwd, g_adam = c.capture([[body_fwd], [body_loss], [body_bwd], [adam]])
+        else:
+            (g_all,) = c.capture([[body_fwd, body_loss, body_bwd, adam]])
+
+        def load_table(t):
+            assert t.shape == self._g_table.shape
+            self._g_table.copy_(t, non_blocking=True)
+            self._g_idx.copy_(t[0], non_blocking=True)
+            self._g_cursor.zero_()
+
+        def replay():
+            if world == 1:
+                g_all()
+            else:
+                g_fwd()
+                local = emb[1:].reshape(2 * B, 3)
+                if rccl is not None:
+                    cand.copy_(rccl.allgather(local.reshape(-1)).view(-1, 3))
+                else:
+                    torch.distributed.all_gather_into_tensor(cand, local, group=self.pg)
+                g_loss()
+                if rccl is not None:
+                    rccl.allreduce(gc.view(-1))
+                else:
+                    torch.distributed.all_reduce(gc, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+                g_bwd()
+                self.allreduce()
+                g_adam()
+            self.step_count += 1
+            return self.loss
+        load_table(table)
+        return replay, load_table
+
     def step_from_pcm(self, image, pcm, lens, global_batch=None):
         """Same without gathering: image (B,3,H,H), pcm int16 (2B, n) = [pos | neg], lens (2B) (0 = empty)."""
         B = image.shape[0]
