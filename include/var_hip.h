@@ -182,6 +182,14 @@ int var_adam_step_graph(var_ctx* ctx, void* stream, float* params, const float* 
 int var_mfcc(var_ctx* ctx, void* stream, const int16_t* pcm, const int* lens, const int* clip_index,
              int nclips, int pcm_stride, int out_frames, float* out);
 
+/* The same front-end with the STFT parameters of the dataset a clip comes from (Envs/audioLoader.py:23-31, param_dict:
+ * nFFT / int(windowLenTime * fs) / int(windowStepTime * fs)): 512 / 400 / 160 for GoogleCommand, FSC, ESC50, Spatial,
+ * Synthetic -- var_mfcc's kernel -- and 1024 / 800 / 640 for NSynth and UrbanSound, or any power-of-two n_fft in
+ * 64..2048 with win_length <= n_fft; T = 1 + len / hop_length frames.  The first call for a new configuration builds
+ * its tables (it allocates: make it once outside graph capture). */
+int var_mfcc_ex(var_ctx* ctx, void* stream, const int16_t* pcm, const int* lens, const int* clip_index,
+                int nclips, int pcm_stride, int out_frames, int n_fft, int win_length, int hop_length, float* out);
+
 /* iTHOR model ------------------------------------------------------------------------------
  * The second VARPretextNet of the reference (models/pretext/ai2thor_pretext_model.py:5-58, config 4 of
  * BASELINE.json): stride-1 3x3 convolutions with 2x2 max pools on the image, three wide stride-2 convolutions

@@ -41,23 +41,29 @@ N_FREQ = N_FFT // 2 + 1
 LOG_OFFSET = 1e-6
 
 
+# per-dataset STFT parameters of Envs/audioLoader.py:23-31 at 16 kHz: (n_fft, win_length, hop_length)
+DATASET_STFT = {"GoogleCommand": (512, 400, 160), "ESC50": (512, 400, 160), "FSC": (512, 400, 160),
+                "Spatial": (512, 400, 160), "Synthetic": (512, 400, 160),
+                "NSynth": (1024, 800, 640), "UrbanSound": (1024, 800, 640)}
+
+
 def hamming_periodic(n=WIN, dtype=np.float64):
     # torch.hamming_window(n, periodic=True): 0.54 - 0.46 cos(2 pi i / n)
     i = np.arange(n, dtype=np.float64)
     return (0.54 - 0.46 * np.cos(2.0 * np.pi * i / n)).astype(dtype)
 
 
-def padded_window(dtype=np.float64):
-    """The 400-tap window centred in a 512-sample FFT frame (torch.stft semantics)."""
-    w = np.zeros(N_FFT, dtype=dtype)
-    left = (N_FFT - WIN) // 2
-    w[left:left + WIN] = hamming_periodic(WIN, dtype)
+def padded_window(dtype=np.float64, n_fft=N_FFT, win=WIN):
+    """The win-tap window centred in an n_fft-sample FFT frame (torch.stft semantics)."""
+    w = np.zeros(n_fft, dtype=dtype)
+    left = (n_fft - win) // 2
+    w[left:left + win] = hamming_periodic(win, dtype)
     return w
 
 
-def mel_filterbank(sample_rate=16000, dtype=np.float64):
-    """torchaudio.functional.melscale_fbanks(257, 0, sr/2, 40, sr, norm=None, 'htk') -> (257, 40)."""
-    all_freqs = np.linspace(0.0, sample_rate // 2, N_FREQ)
+def mel_filterbank(sample_rate=16000, dtype=np.float64, n_fft=N_FFT):
+    """torchaudio.functional.melscale_fbanks(n_fft/2+1, 0, sr/2, 40, sr, norm=None, 'htk') -> (n_freq, 40)."""
+    all_freqs = np.linspace(0.0, sample_rate // 2, n_fft // 2 + 1)
     m_min = 2595.0 * np.log10(1.0 + 0.0 / 700.0)
     m_max = 2595.0 * np.log10(1.0 + (sample_rate / 2.0) / 700.0)
     m_pts = np.linspace(m_min, m_max, N_MELS + 2)
@@ -80,34 +86,35 @@ def dct_matrix(dtype=np.float64):
     return dct.T.astype(dtype)
 
 
-def frames_reflect(x):
-    """center=True / pad_mode='reflect' framing: (T, 512) windows of the padded signal."""
+def frames_reflect(x, n_fft=N_FFT, hop=HOP):
+    """center=True / pad_mode='reflect' framing: (T, n_fft) windows of the padded signal."""
     n = x.shape[0]
-    pad = N_FFT // 2
+    pad = n_fft // 2
     xp = np.pad(x, (pad, pad), mode="reflect")
-    t = 1 + n // HOP
-    idx = np.arange(N_FFT)[None, :] + HOP * np.arange(t)[:, None]
+    t = 1 + n // hop
+    idx = np.arange(n_fft)[None, :] + hop * np.arange(t)[:, None]
     return xp[idx]
 
 
-def power_spectrogram(x, dtype=np.float64):
-    """(T, 257) power spectrogram of a float waveform."""
-    fr = frames_reflect(x.astype(dtype)) * padded_window(dtype)[None, :]
-    spec = np.fft.rfft(fr.astype(np.float64), n=N_FFT, axis=1)
+def power_spectrogram(x, dtype=np.float64, n_fft=N_FFT, win=WIN, hop=HOP):
+    """(T, n_fft/2+1) power spectrogram of a float waveform."""
+    fr = frames_reflect(x.astype(dtype), n_fft, hop) * padded_window(dtype, n_fft, win)[None, :]
+    spec = np.fft.rfft(fr.astype(np.float64), n=n_fft, axis=1)
     return (spec.real ** 2 + spec.imag ** 2).astype(dtype)
 
 
-def mfcc_torchaudio(pcm, sample_rate=16000, dtype=np.float64):
-    """int16 (or float) waveform -> (T, 40) MFCC, T = 1 + N//160.
+def mfcc_torchaudio(pcm, sample_rate=16000, dtype=np.float64, n_fft=N_FFT, win=WIN, hop=HOP):
+    """int16 (or float) waveform -> (T, 40) MFCC, T = 1 + N//hop.
 
-    Follows Envs/audioLoader.py:150-157 (int16 -> /32768 float32 first)."""
+    Follows Envs/audioLoader.py:150-157 (int16 -> /32768 float32 first); (n_fft, win, hop) = the dataset's entry of
+    audioLoader.param_dict (:23-31): 512/400/160 (GoogleCommand, FSC, ESC50 ...) or 1024/800/640 (NSynth, UrbanSound)."""
     pcm = np.asarray(pcm)
     if pcm.dtype == np.int16:
         x = (pcm / 32768.0).astype(np.float32)
     else:
         x = pcm.astype(np.float32)
-    p = power_spectrogram(x, dtype)
-    mel = p @ mel_filterbank(sample_rate, dtype)
+    p = power_spectrogram(x, dtype, n_fft, win, hop)
+    mel = p @ mel_filterbank(sample_rate, dtype, n_fft)
     logmel = np.log(mel + dtype(LOG_OFFSET))
     return (logmel @ dct_matrix(dtype)).astype(dtype)
 

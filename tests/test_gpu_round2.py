@@ -337,3 +337,34 @@ def test_replayed_inbatch_step_equals_eager(var_amd, golden_dir):
                                               tau=0.1).item()))
     assert np.allclose(losses_a, losses_b, rtol=0, atol=1e-5), (losses_a, losses_b)
     assert float((ma.flat_parameters() - mb.flat_parameters()).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("dataset", ["NSynth", "UrbanSound", "GoogleCommand"])
+def test_mfcc_with_the_dataset_stft_parameters(var_amd, dataset):
+    """Envs/audioLoader.py:23-31: NSynth / UrbanSound clips use n_fft 1024, a 50 ms window and a 40 ms step (26 frames per
+    second of audio); GoogleCommand 512 / 25 ms / 10 ms.  var_mfcc_ex against the numpy oracle with the same parameters,
+    incl. a short clip, an odd length and the "empty" class; odd row strides take the per-sample path."""
+    n_fft, win, hop = mfcc_np.DATASET_STFT[dataset]
+    clips = mfcc_np.synth_clips(5, seed=33)
+    lens = np.array([16000, 9001, 700, 0, 16000], dtype=np.int32)
+    frames = 1 + 16000 // hop
+    out = var_amd.mfcc(cuda(clips), cuda(lens), frames + 3, dataset=dataset).cpu().numpy()
+    assert out.shape == (5, 1, frames + 3, 40)
+    for i in range(5):
+        if lens[i] == 0:
+            assert np.all(out[i] == 0)
+            continue
+        ref = mfcc_np.mfcc_torchaudio(clips[i, :lens[i]], n_fft=n_fft, win=win, hop=hop)
+        T = ref.shape[0]
+        assert T == 1 + lens[i] // hop
+        assert np.max(np.abs(out[i, 0, :T] - ref)) < 2e-3, (i, np.max(np.abs(out[i, 0, :T] - ref)))
+        assert np.all(out[i, 0, T:] == 0)                          # MFCC-domain zero padding (audioLoader.py:245-250)
+    # odd row stride: rows are only 2-byte aligned
+    odd = np.zeros((3, 16001), np.int16)
+    odd[:, :16000] = clips[:3]
+    got = var_amd.mfcc(cuda(odd), cuda(np.array([16000, 16000, 12345], np.int32)), 100, dataset=dataset).cpu().numpy()
+    for i, n in enumerate((16000, 16000, 12345)):
+        ref = mfcc_np.process_sound_feat(mfcc_np.mfcc_torchaudio(odd[i, :n], n_fft=n_fft, win=win, hop=hop))
+        assert np.max(np.abs(got[i] - ref)) < 2e-3
+    with pytest.raises(var_amd.VarHipError):
+        var_amd.mfcc(cuda(clips), cuda(lens), 100, n_fft=1000)

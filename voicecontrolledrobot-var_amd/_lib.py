@@ -51,6 +51,7 @@ _SIGNATURES = {
     "var_adam_step_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _f, _f, _f, _f, _vp]),
     "var_adam_step_graph": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _f, _f, _f, _f, _vp, _vp, _i, _i, _vp, _vp, _i]),
     "var_mfcc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "var_mfcc_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "var_arm_loss_grad_pcm": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
     "var_arm_loss_grad_gather": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
     "var_inbatch_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),

@@ -79,6 +79,7 @@ int var_destroy(var_ctx* c) {
     CHECK_CTX(c);
     (void)hipSetDevice(c->device);
     comm_free(c);
+    mfcc_any_forget(c);
     ithor_free(c);
     armnet_free(c);
     if (c->ws) (void)hipFree(c->ws);
@@ -484,6 +485,20 @@ int var_mfcc(var_ctx* c, void* stream, const int16_t* pcm, const int* lens, cons
     }
     SET_DEVICE(c);
     return launch_mfcc(c, (hipStream_t)stream, pcm, lens, clip_index, nclips, pcm_stride, out_frames, out);
+}
+
+int var_mfcc_ex(var_ctx* c, void* stream, const int16_t* pcm, const int* lens, const int* clip_index, int nclips,
+                int pcm_stride, int out_frames, int n_fft, int win_length, int hop_length, float* out) {
+    CHECK_CTX(c);
+    if (!pcm || !lens || !out || nclips <= 0 || pcm_stride <= 0 || out_frames <= 0) {
+        VAR_SET_ERR(c, "var_mfcc_ex: bad argument");
+        return VAR_ERR_ARG;
+    }
+    SET_DEVICE(c);
+    if (n_fft == 512 && win_length == 400 && hop_length == 160)
+        return launch_mfcc(c, (hipStream_t)stream, pcm, lens, clip_index, nclips, pcm_stride, out_frames, out);
+    return launch_mfcc_any(c, (hipStream_t)stream, pcm, lens, clip_index, nclips, pcm_stride, out_frames, n_fft, win_length,
+                           hop_length, out);
 }
 
 static const char* kTagNames[TAG_COUNT] = {

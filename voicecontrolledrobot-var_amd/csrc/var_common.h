@@ -202,6 +202,9 @@ static inline int conv_out(int h) { return (h - 1) / 2 + 1; }   // 3x3 s2 p1
 
 extern "C" int retire_block(var_ctx* c, void* p);   // api.hip: keep a superseded device block alive until var_destroy
 int mfcc_build_tables(var_ctx* c);
+int launch_mfcc_any(var_ctx* c, hipStream_t s, const int16_t* pcm, const int* lens, const int* clip_index, int nclips,
+                    int pcm_stride, int out_frames, int n_fft, int win, int hop, float* out);
+void mfcc_any_forget(var_ctx* c);
 void ithor_free(var_ctx* c);
 void armnet_free(var_ctx* c);
 void comm_free(var_ctx* c);

@@ -27,9 +27,20 @@ def triplet_margin_loss(anchor, positive, negative, margin=1.0, inv_count=None, 
     return loss, ga, gp, gn
 
 
-def mfcc(pcm, lens=None, out_frames=100, clip_index=None):
+# STFT parameters per dataset at 16 kHz (Envs/audioLoader.py:23-31): (n_fft, win_length, hop_length)
+DATASET_STFT = {"GoogleCommand": (512, 400, 160), "ESC50": (512, 400, 160), "FSC": (512, 400, 160),
+                "Spatial": (512, 400, 160), "Synthetic": (512, 400, 160),
+                "NSynth": (1024, 800, 640), "UrbanSound": (1024, 800, 640)}
+
+
+def mfcc(pcm, lens=None, out_frames=100, clip_index=None, n_fft=512, win_length=400, hop_length=160, dataset=None):
     """int16 PCM (nclips, nsamples) on the GPU -> (nclips, 1, out_frames, 40) f32 MFCC:
-    Envs/audioLoader.py:147-157 (torchaudio branch) + :241-252 (truncate / zero-pad)."""
+    Envs/audioLoader.py:147-157 (torchaudio branch) + :241-252 (truncate / zero-pad).  `dataset` selects the STFT
+    parameters the reference uses for clips of that dataset (audioLoader.param_dict); default = GoogleCommand's."""
+    if dataset is not None:
+        if dataset not in DATASET_STFT:
+            raise VarHipError(f"unknown dataset {dataset!r}: one of {sorted(DATASET_STFT)}")
+        n_fft, win_length, hop_length = DATASET_STFT[dataset]
     _require_cuda(pcm)
     if pcm.dtype != torch.int16 or pcm.dim() != 2:
         raise VarHipError("mfcc expects an int16 (nclips, nsamples) tensor")
@@ -43,8 +54,8 @@ def mfcc(pcm, lens=None, out_frames=100, clip_index=None):
     lens = lens.to(device=pcm.device, dtype=torch.int32).contiguous()
     out = torch.empty((n, 1, out_frames, 40), dtype=torch.float32, device=pcm.device)
     ctx = Context.get(pcm.device.index)
-    ctx.check(ctx.lib.var_mfcc(ctx.handle, current_stream_handle(), ptr(pcm), ptr(lens), ptr(clip_index), n, stride,
-                               int(out_frames), ptr(out)), "var_mfcc")
+    ctx.check(ctx.lib.var_mfcc_ex(ctx.handle, current_stream_handle(), ptr(pcm), ptr(lens), ptr(clip_index), n, stride,
+                                  int(out_frames), int(n_fft), int(win_length), int(hop_length), ptr(out)), "var_mfcc_ex")
     return out
 
 
