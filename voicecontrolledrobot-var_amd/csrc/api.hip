@@ -256,6 +256,14 @@ static int join_side(var_ctx* c, hipStream_t s, int i) {
     return VAR_OK;
 }
 
+// up to five (dst, src, n) segments copied by ONE launch: the encoder outputs of var_arm_encoder_fwd (five
+// hipMemcpyAsync calls cost more host time than the B = 8 forward's kernels)
+struct CopySegs { float* dst[5]; const float* src[5]; int n[5]; int count; };
+__global__ void __launch_bounds__(256) copy_out_kernel(CopySegs S) {
+    for (int k = 0; k < S.count; ++k)
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < S.n[k]; e += gridDim.x * 256) S.dst[k][e] = S.src[k][e];
+}
+
 static int encoder_fwd(var_ctx* c, hipStream_t s, const float* params, const void* image, int is_u8,
                        long bstride, const int* image_index, const float* pos, const float* neg,
                        const AudioIn* audio, int B, bool finish = true) {
@@ -265,24 +273,27 @@ static int encoder_fwd(var_ctx* c, hipStream_t s, const float* params, const voi
         neg = c->mfcc_buf + (size_t)B * VAR_MFCC_FRAMES * VAR_MFCC_COEFFS;
     }
     const bool snd = pos || neg;
-    hipStream_t ss = (c->streams & 1) ? c->side : s;
+    // small batches (the RL stage's 8 envs) stay on the caller's stream: every kernel is a few us there and a
+    // fork / join pair costs more than the overlap gives
+    const bool fork_ok = (c->streams & 1) && B > 32;
+    hipStream_t ss = fork_ok ? c->side : s;
     // Launch ORDER matters under graph replay: the chain that is enqueued first after a fork keeps the hardware
     // queue of its predecessor, the other branch pays a cross-queue hand-over (5-10 us).  So the caller's stream
     // (MFCC -> image CNN -> image head) is enqueued first and the sound branch, which has slack, afterwards.
-    const bool mfcc_main = (c->streams & 16) != 0 || !(c->streams & 1);
+    const bool mfcc_main = (c->streams & 16) != 0 || !fork_ok;
     bool forked = false;
     if (snd && audio && audio->pcm) {
         if (!mfcc_main) { if ((rc = fork_side(c, s, 0)) != VAR_OK) return rc; forked = true; }
         if ((rc = launch_mfcc(c, mfcc_main ? s : ss, audio->pcm, audio->lens, audio->clip_index, 2 * B, audio->pcm_stride,
                               VAR_MFCC_FRAMES, c->mfcc_buf)) != VAR_OK) return rc;
     }
-    if (snd && !forked && (rc = fork_side(c, s, 0)) != VAR_OK) return rc;     // the side stream starts after the caller's prior work
+    if (snd && fork_ok && !forked && (rc = fork_side(c, s, 0)) != VAR_OK) return rc;     // the side stream starts after the caller's prior work
     if (image && (rc = launch_img_fwd(c, s, params, image, is_u8, bstride, image_index, B)) != VAR_OK) return rc;
     if (image && (rc = launch_heads_fwd(c, s, s, params, B, true, false, false, finish)) != VAR_OK) return rc;
     if (snd) {
         if ((rc = launch_snd_fwd(c, ss, params, pos, neg, B)) != VAR_OK) return rc;
         if ((rc = launch_heads_fwd(c, ss, ss, params, B, false, pos != nullptr, neg != nullptr, finish)) != VAR_OK) return rc;
-        if ((rc = join_side(c, s, 0)) != VAR_OK) return rc;
+        if (fork_ok && (rc = join_side(c, s, 0)) != VAR_OK) return rc;
     }
     c->saved_B = B;
     c->saved_gen = ++c->fwd_gen;
@@ -309,14 +320,18 @@ int var_arm_encoder_fwd(var_ctx* c, void* stream, const float* params, const voi
     hipStream_t s = (hipStream_t)stream;
     if ((rc = encoder_fwd(c, s, params, image, image_is_u8, image_bstride, nullptr, mfcc_pos, mfcc_neg, nullptr, B)) != VAR_OK) return rc;
     if (!save_for_bwd) c->saved_B = 0;
-    const size_t e = sizeof(float) * 3 * (size_t)B;
-    if (image && image_feat) VAR_HIP_CHECK(c, hipMemcpyAsync(image_feat, c->emb, e, hipMemcpyDeviceToDevice, s));
-    if (mfcc_pos && pos_feat) VAR_HIP_CHECK(c, hipMemcpyAsync(pos_feat, c->emb + 3 * B, e, hipMemcpyDeviceToDevice, s));
-    if (mfcc_neg && neg_feat) VAR_HIP_CHECK(c, hipMemcpyAsync(neg_feat, c->emb + 6 * B, e, hipMemcpyDeviceToDevice, s));
-    if (image && image_raw)
-        VAR_HIP_CHECK(c, hipMemcpyAsync(image_raw, c->act[5], sizeof(float) * kImgFeat * (size_t)B, hipMemcpyDeviceToDevice, s));
-    if (mfcc_pos && pos_raw)
-        VAR_HIP_CHECK(c, hipMemcpyAsync(pos_raw, c->sact[4], sizeof(float) * kSndFeat * (size_t)B, hipMemcpyDeviceToDevice, s));
+    CopySegs S{};
+    auto seg = [&](float* dst, const float* src, int n) { S.dst[S.count] = dst; S.src[S.count] = src; S.n[S.count] = n; S.count++; };
+    if (image && image_feat) seg(image_feat, c->emb, 3 * B);
+    if (mfcc_pos && pos_feat) seg(pos_feat, c->emb + 3 * B, 3 * B);
+    if (mfcc_neg && neg_feat) seg(neg_feat, c->emb + 6 * B, 3 * B);
+    if (image && image_raw) seg(image_raw, c->act[5], kImgFeat * B);
+    if (mfcc_pos && pos_raw) seg(pos_raw, c->sact[4], kSndFeat * B);
+    if (S.count) {
+        const int grid = (kImgFeat * B + 255) / 256;
+        hipLaunchKernelGGL(copy_out_kernel, dim3(grid < 1024 ? grid : 1024), dim3(256), 0, s, S);
+        VAR_HIP_CHECK(c, hipGetLastError());
+    }
     return VAR_OK;
 }
 

@@ -18,37 +18,44 @@ def _conv_out(h):
     return (h - 1) // 2 + 1
 
 
+def _encoder_forward(module, need_grad, image, pos, neg):
+    """var_arm_encoder_fwd on this model's packed weights; returns (outs, B, generation of the saved forward)."""
+    flat = module._flat
+    dev = flat.device
+    c = Context.get(dev.index)
+    ref = image if image is not None else (pos if pos is not None else neg)
+    B = ref.shape[0]
+    H = module.config.img_dim[1]
+    c.ensure_plan(B, H)
+    stream = current_stream_handle()
+    module.hip_weights(c)                  # this model's packed image: bound, re-packed only if the parameters changed
+    mk = lambda n: torch.empty((B, n), dtype=torch.float32, device=dev)
+    image_feat = mk(3) if image is not None else None
+    image_raw = mk(576) if image is not None else None
+    pos_feat = mk(3) if pos is not None else None
+    pos_raw = mk(160) if pos is not None else None
+    neg_feat = mk(3) if neg is not None else None
+    is_u8 = image is not None and image.dtype == torch.uint8
+    bstride = 0 if image is None else image.stride(0)
+    c.check(c.lib.var_arm_encoder_fwd(c.handle, stream, ptr(flat), ptr(image), int(is_u8), bstride,
+                                      ptr(pos), ptr(neg), B, H, ptr(image_feat), ptr(pos_feat),
+                                      ptr(neg_feat), ptr(image_raw), ptr(pos_raw), int(need_grad)),
+            "var_arm_encoder_fwd")
+    gen = c.lib.var_saved_generation(c.handle) if need_grad else 0
+    return (image_feat, pos_feat, neg_feat, image_raw, pos_raw), B, gen
+
+
 class _EncoderFn(torch.autograd.Function):
     """forward/backward of the whole encoder through the C ABI (var_arm_encoder_fwd/_bwd)."""
 
     @staticmethod
     def forward(ctx, module, need_grad, image, pos, neg, *params):
-        flat = module._flat
-        dev = flat.device
-        c = Context.get(dev.index)
-        ref = image if image is not None else (pos if pos is not None else neg)
-        B = ref.shape[0]
-        H = module.config.img_dim[1]
-        c.ensure_plan(B, H)
-        stream = current_stream_handle()
-        module.hip_weights(c)                  # this model's packed image: bound, re-packed only if the parameters changed
-        mk = lambda n: torch.empty((B, n), dtype=torch.float32, device=dev)
-        image_feat = mk(3) if image is not None else None
-        image_raw = mk(576) if image is not None else None
-        pos_feat = mk(3) if pos is not None else None
-        pos_raw = mk(160) if pos is not None else None
-        neg_feat = mk(3) if neg is not None else None
-        is_u8 = image is not None and image.dtype == torch.uint8
-        bstride = 0 if image is None else image.stride(0)
-        c.check(c.lib.var_arm_encoder_fwd(c.handle, stream, ptr(flat), ptr(image), int(is_u8), bstride,
-                                          ptr(pos), ptr(neg), B, H, ptr(image_feat), ptr(pos_feat),
-                                          ptr(neg_feat), ptr(image_raw), ptr(pos_raw), int(need_grad)),
-                "var_arm_encoder_fwd")
+        outs, B, gen = _encoder_forward(module, need_grad, image, pos, neg)
+        dev = module._flat.device
         ctx.module = module
         ctx.keep = (image, pos, neg)          # the C side re-reads the inputs in backward
         ctx.B = B
-        ctx.gen = c.lib.var_saved_generation(c.handle) if need_grad else 0
-        outs = (image_feat, pos_feat, neg_feat, image_raw, pos_raw)
+        ctx.gen = gen
         ctx.present = [o is not None for o in outs]
         dummy = torch.zeros(0, device=dev)
         res = tuple(o if o is not None else dummy for o in outs)
@@ -125,8 +132,14 @@ class VARPretextNet(nn.Module):
 
     # ---- flat parameter arena (what the C ABI reads; also the all-reduce / Adam buffer) ----
     def _named_in_order(self):
-        d = dict(self.named_parameters())
-        return [d[k] for k, _ in PARAM_SPECS]
+        """The 26 parameters in state_dict() order (cached: nn.Module keeps the Parameter objects across .to() /
+        load_state_dict; the cache is checked against the module dict cheaply and rebuilt if a layer was replaced)."""
+        pl = self.__dict__.get("_plist")
+        if pl is None or pl[0] is not self.imgBranch[0].weight or pl[-1] is not self.soundTriplet[2].bias:
+            d = dict(self.named_parameters())
+            pl = [d[k] for k, _ in PARAM_SPECS]
+            self.__dict__["_plist"] = pl
+        return pl
 
     def _flatten_params(self):
         params = self._named_in_order()
@@ -167,6 +180,7 @@ class VARPretextNet(nn.Module):
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
+        self.__dict__["_plist"] = None
         self._flatten_params()
         return r
 
@@ -204,7 +218,10 @@ class VARPretextNet(nn.Module):
         if image is not None or pos is not None or neg is not None:
             params = self._named_in_order()
             need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-            outs = _EncoderFn.apply(self, need_grad, image, pos, neg, *params)
+            if need_grad:
+                outs = _EncoderFn.apply(self, True, image, pos, neg, *params)
+            else:                                         # inference: no autograd node, no 26-parameter argument list
+                outs = _encoder_forward(self, False, image, pos, neg)[0]
             if image is not None:
                 image_feat, image_feat_raw = outs[0], outs[3]
             if pos is not None:
