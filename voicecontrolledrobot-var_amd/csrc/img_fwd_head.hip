@@ -272,8 +272,8 @@ img_fwd_head_kernel(const void* __restrict__ image, long bstride, const int* __r
 
 //                    H1   U8   R2 NU
 // (measured, round 2: one band per tile with each wave's conv-2 filter row in registers -- 56 KB, 6 waves, two workgroups
-//  per CU -- runs at 61 us instead of 52: twin workgroups start in lock-step and collide in the same phases; the 12-wave
-//  form with the filter rows in registers spills and runs at 57 us)
+//  per CU -- runs at 61 us instead of 52, and starting the second workgroup of each CU later only adds the delay: the
+//  per-tile fixed costs double with half-size tiles; the 12-wave form with the filter rows in registers spills, 57 us)
 using H84u = HeadCfg<42, true, 3, 2>;      // 2 bands: 4 pixel blocks x 3 filter rows = 12 waves, 3 per SIMD
 using H84f = HeadCfg<42, false, 3, 2>;
 using H96u = HeadCfg<48, true, 4, 1>;      // 1 band: 3 pixel blocks x 3 filter rows = 9 waves
