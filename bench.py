@@ -352,6 +352,10 @@ def main():
                          "contrastive head of configs[2] (extension; replayed step with the MFCC front-end inside)")
     ap.add_argument("--workload", choices=("kuka", "ithor"), default="kuka",
                     help="kuka = BASELINE.json's metric (default); ithor = the reference's second pretext model")
+    ap.add_argument("--rehearse-one-device", action="store_true",
+                    help="multi-rank REHEARSAL on a box with one GPU: every rank uses cuda:0 and the ranks exchange through "
+                         "gloo (RCCL refuses two ranks on one device).  Exercises the N > 1 code path end to end; the "
+                         "number it prints is not a scaling measurement and is labelled as such.")
     ap.add_argument("--pool", type=int, default=4096,
                     help="kuka workload: triplets in the HBM-resident synthetic pool (16384 = 1.4 GB > the 256 MB Infinity Cache)")
     args = ap.parse_args()
@@ -369,14 +373,19 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     n_dev = torch.cuda.device_count()                          # counting devices does not initialise HIP
-    if n_dev < world or local_rank >= n_dev:
+    if args.rehearse_one_device:
+        local_rank = 0
+    if n_dev < 1 or (not args.rehearse_one_device and (n_dev < world or local_rank >= n_dev)):
         sys.stderr.write(f"bench.py: --gpus {world} needs {world} visible devices, found {n_dev} "
                          f"(rank {rank}, local rank {local_rank})\n")
         raise SystemExit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or "RANK" in os.environ:
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if args.rehearse_one_device:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=dev)
     args.n_ranks_seen = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
 
     if args.workload == "ithor":
@@ -505,6 +514,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "n_ranks_seen": args.n_ranks_seen,
+            **({"rehearsal": "all ranks on ONE device, gloo exchange: code-path check, not a scaling number"}
+               if args.rehearse_one_device else {}),
             "config": {"workload": "Kuka+GoogleCommand pretext step, batch 256 per GPU on MI355X, fp32: "
                                    f"u8 {HW}x{HW} image + 2 int16 1 s clips per triplet resident in HBM -> MFCC -> "
                                    "fwd + triplet loss + bwd + Adam (BASELINE.json configs[1])",
