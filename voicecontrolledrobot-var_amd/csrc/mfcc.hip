@@ -224,6 +224,7 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
         }
     };
 
+    PH_INIT(5);
     int tile = blockIdx.x;
     FrameRef fr = frame_of(meta_of(tile));
     uint32_t two[16];
