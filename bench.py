@@ -88,6 +88,32 @@ def _cpu_run(batch, threads, seconds, min_steps):
     return n, dt
 
 
+def parity_vs_cpu(var_amd, model, pool, batch=64):
+    """max |delta| of the three embeddings and of the loss between the HIP path and the CPU restatement of the reference
+    on the same (image, audio) triplets (BASELINE.md section 3's last bullet; north_star: within 1e-3 fp32).  The MFCC
+    features come from the HIP front-end for both sides (its own parity vs the numpy oracle is tests/test_gpu_parity.py's)."""
+    from oracle.torch_oracle import KukaNetCPU
+    row = pool.epoch_index_table(batch)[0]
+    img = pool.images[row[:batch].long()].contiguous()
+    feats = var_amd.mfcc(pool.clips, row[3 * batch:], out_frames=100, clip_index=row[batch:3 * batch])
+    pos, neg = feats[:batch].contiguous(), feats[batch:].contiguous()
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        d = model(img, pos, neg)
+    model.train(was_training)
+    net = KukaNetCPU(HW)
+    net.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    with torch.no_grad():
+        a, p, n = net((img.cpu() / 255.).float(), pos.cpu(), neg.cpu())
+        crit = torch.nn.TripletMarginLoss(margin=1.0, p=2)
+        l_cpu = float(crit(a, p, n))
+        l_hip = float(crit(d["image_feat"].cpu(), d["sound_feat_positive"].cpu(), d["sound_feat_negative"].cpu()))
+    diff = max(float((d["image_feat"].cpu() - a).abs().max()), float((d["sound_feat_positive"].cpu() - p).abs().max()),
+               float((d["sound_feat_negative"].cpu() - n).abs().max()))
+    return {"batch": batch, "max_abs_embedding_diff": diff, "loss_diff": abs(l_hip - l_cpu), "tolerance": 1e-3}
+
+
 def cpu_baseline(seconds=8.0):
     """The reference's step on the host cores: torch.nn CPU restatement (oracle/torch_oracle.py), same shapes, MFCC
     precomputed (as VARFineTuneDataset does), tensors in RAM.  `value` = batch 256 on every core the process may use
@@ -543,6 +569,7 @@ def main():
                                "flops_per_launch": flops}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
+            out["parity_vs_cpu"] = parity_vs_cpu(var_amd, model, pool)
         emit(json.dumps(out))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
