@@ -218,6 +218,17 @@ struct MidCfg {
     static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU: the whole LDS");
 };
 
+PH_DECL();
+}  // namespace
+#ifdef VAR_PHASES
+extern "C" int var_debug_phases_mid(unsigned long long* out) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
+namespace {
+
 template <class C, int H2>
 __global__ void __launch_bounds__(MID_NT)
 img_fwd_mid_kernel(const float* __restrict__ x2, const float* __restrict__ w3, const float* __restrict__ b3,
@@ -229,27 +240,36 @@ img_fwd_mid_kernel(const float* __restrict__ x2, const float* __restrict__ w3, c
     const int tid = threadIdx.x, b = blockIdx.x;
     float* ra = lds;
     float* rb = lds + C::A;
+    PH_INIT(9);
     if (tid < 64) { lds[C::BIA + tid] = b3[tid]; lds[C::BIA + 64 + tid] = b4[tid]; lds[C::BIA + 128 + tid] = b5[tid]; }
     // region B = conv 4's input tile: zero it once (pads stay zero, data cells are written by conv 3's epilogue)
     lds_zero<MID_NT>(rb, C::Bsz, tid);
     // conv 3 input: the image's act2 planes, padding materialised
     lds_zero_cols<MID_NT>(ra, 32 * C::T2::IR, C::T2::PW, 0, 1, tid);
     lds_zero_cols<MID_NT>(ra, 32 * C::T2::IR, C::T2::PW, H2 + 1, C::T2::PW - H2 - 1, tid);
+    PH(0);
     stage_x_band<32, H2, H2, C::T2::IR, C::T2::PW, C::T2::PLANE, false, MID_NT>(ra, x2 + (size_t)b * 32 * H2 * H2, -1, true, tid);
+    PH(1);
     __syncthreads();
+    PH(2);
     mid_layer<32, 64, H2, 4, 3, 1, C::T3::PLANE, C::T3::PW, C::NPB3>(ra, ra, rb, w3, lds + C::BIA, y3 + (size_t)b * 64 * C::H3 * C::H3, tid);
+    PH(3);
     // region A is dead (conv 3's fold has been read): it becomes conv 5's input tile
     __syncthreads();
     lds_zero<MID_NT>(ra, (C::X4 + 3) & ~3, tid);
     __syncthreads();
+    PH(4);
     mid_layer16<64, 64, C::H3, 12, 1, C::T4::PLANE, C::T4::PW>(rb, rb, ra, w4, lds + C::BIA + 64, y4 + (size_t)b * 64 * C::H4 * C::H4, tid);
+    PH(5);
     __syncthreads();
+    PH(6);
     mid_layer16<64, 64, C::H4, 4, 3, 1, 1>(ra, rb, nullptr, w5, lds + C::BIA + 128, y5 + (size_t)b * 64 * C::H5 * C::H5, tid,
                                           lds + C::A5S);
     // ---- image head of this image (imgTriplet, arm_pretext_model.py:46-50): hidden = relu(W0 a5 + b0) on the VALU
     //      (one row: nothing for the matrix cores), 768 threads = 128 hidden units x 6 K slices of 96, folded in
     //      fixed order; then this image's partial of the 128 -> 3 layer in the (row, 4, 4) layout the finish / rows
     //      kernels read (block 0 carries the whole dot product, blocks 1..3 are zero).
+    PH(7);
     if (hw0t) {
         static_assert(C::H5 * C::H5 * 64 == kImgFeat && MID_NT == 6 * kHid, "head phase shape");
         __syncthreads();
@@ -283,6 +303,7 @@ img_fwd_mid_kernel(const float* __restrict__ x2, const float* __restrict__ w3, c
             part[(size_t)b * 16 + e] = 0.f;
         }
     }
+    PH(8);
 }
 }  // namespace
 
