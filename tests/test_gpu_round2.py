@@ -368,3 +368,26 @@ def test_mfcc_with_the_dataset_stft_parameters(var_amd, dataset):
         assert np.max(np.abs(got[i] - ref)) < 2e-3
     with pytest.raises(var_amd.VarHipError):
         var_amd.mfcc(cuda(clips), cuda(lens), 100, n_fft=1000)
+
+
+def test_pool_training_loop_on_the_gpu(var_amd, tmp_path):
+    """train_representation_from_pool at the reference's default shape -- 300 triplets, batch 128 (128 / 128 / 44), per-epoch
+    MultiStepLR -- learns (the triplet loss of a memorisable pool falls), and its legacy .pt loads into a fresh model that
+    reproduces the trained embeddings."""
+    torch.manual_seed(453)
+    model = var_amd.VARPretextNet(cfg()).to("cuda")
+    pool = var_amd.SyntheticTripletPool(300, hw=84, seed=7, clips_per_class=2, empty_frac=0.1).freeze_pairs()
+    out = var_amd.train_representation_from_pool(model, pool, 12, 128, lr=1e-3, milestones=(8,), gamma=0.2,
+                                                 save_dir=str(tmp_path), save_interval=5, log=lambda *a: None)
+    assert len(out) == 12 and np.all(np.isfinite(out))
+    assert out[-1] < out[0] - 0.1, out
+    assert sorted(p.name for p in tmp_path.iterdir()) == ['11.pt', '4.pt', '9.pt', 'progress.csv']
+    fresh = var_amd.VARPretextNet(cfg()).to("cuda")
+    fresh.load_state_dict(torch.load(tmp_path / '11.pt', weights_only=True))
+    row = pool.epoch_index_table(64)[0]
+    img = pool.images[row[:64].long()].contiguous()
+    f = var_amd.mfcc(pool.clips, row[3 * 64:5 * 64], 100, row[64:3 * 64])
+    with torch.no_grad():
+        a = model(img, f[:64].contiguous(), None)
+        b = fresh(img, f[:64].contiguous(), None)
+    assert torch.equal(a['image_feat'], b['image_feat']) and torch.equal(a['sound_feat_positive'], b['sound_feat_positive'])

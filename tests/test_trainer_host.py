@@ -154,3 +154,43 @@ def test_replayed_inbatch_step_equals_eager_step_inbatch():
         got = float(replay().item())
         assert abs(got - want) < 1e-6, (s, got, want)
     assert float((ma.flat_parameters() - mb.flat_parameters()).abs().max()) < 2e-5      # 4 Adam steps of lr 1e-3
+
+
+def test_pool_training_loop_equals_the_reference_loop(tmp_path):
+    """train_representation_from_pool (shuffled epoch tables, ragged last batch, per-epoch MultiStepLR, device-side loss
+    accumulation, legacy .pt + progress.csv) against the reference's loop restated on the CPU over the same epoch
+    tables: per-epoch average losses and final weights."""
+    import csv
+    torch.manual_seed(21)
+    model = var_amd.VARPretextNet(_cfg())
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    pool = _pool(14, seed=5)
+    pool_ref = _pool(14, seed=5)                                   # same draws: the reference loop's tables
+    B, epochs, milestones = 4, 3, (1, 2)
+    out = var_amd.train_representation_from_pool(model, pool, epochs, B, lr=1e-3, milestones=milestones, gamma=0.5,
+                                                 save_dir=str(tmp_path), save_interval=2, log=lambda *a: None,
+                                                 _ctx=OracleContext())
+    ref = CPUTrainer(state_dict=sd, lr=1e-3)
+    want = []
+    spe, bt = pool_ref.steps_per_epoch(B), pool_ref.tail_batch(B)
+    assert (spe, bt) == (4, 2)
+    for ep in range(epochs):
+        for g in ref.opt.param_groups:
+            g['lr'] = var_amd.multistep_lr(1e-3, milestones, 0.5, ep)
+        table = pool_ref.epoch_index_table(B)
+        losses = []
+        for row in range(spe):
+            Bs = bt if row == spe - 1 else B
+            r = table[row]
+            losses.append(ref.step(pool_ref.images[r[:Bs].long()], _features(pool_ref, r[Bs:2 * Bs], r[3 * Bs:4 * Bs]),
+                                   _features(pool_ref, r[2 * Bs:3 * Bs], r[4 * Bs:5 * Bs])))
+        want.append(sum(losses) / len(losses))
+    np.testing.assert_allclose(out, want, atol=3e-6)
+    flat_ref = torch.cat([ref.model.state_dict()[k].reshape(-1) for k, _ in var_amd.PARAM_SPECS])
+    assert float((model.flat_parameters() - flat_ref).abs().max()) < 3e-5
+    assert sorted(p.name for p in tmp_path.iterdir()) == ['1.pt', '2.pt', 'progress.csv']
+    with open(tmp_path / 'progress.csv') as f:
+        rows = list(csv.reader(f))
+    assert rows[0] == ['avg_loss'] and len(rows) == 1 + epochs
+    loaded = torch.load(tmp_path / '2.pt', weights_only=True)
+    assert list(loaded.keys()) == [k for k, _ in var_amd.PARAM_SPECS]

@@ -13,7 +13,7 @@ from .model import VARPretextNet  # noqa: F401
 from .ithor import IthorTrainer, IthorVARPretextNet, project_representation  # noqa: F401
 from .actor_critic import ArmNetPolicy  # noqa: F401
 from .comm import RcclComm  # noqa: F401
-from .trainer import VARTrainer, train_representation, multistep_lr  # noqa: F401
+from .trainer import VARTrainer, train_representation, train_representation_from_pool, multistep_lr  # noqa: F401
 from .data import SyntheticTripletPool, TripletPool, choose_negative_id, load_wav_clips, process_sound_feat  # noqa: F401
 from .ops import inbatch_contrastive_loss, mfcc, mfcc_psf, triplet_margin_loss  # noqa: F401
 from .reward import IntrinsicReward, ReturnNormalizer, RunningMeanStd  # noqa: F401

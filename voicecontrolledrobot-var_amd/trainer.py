@@ -555,3 +555,52 @@ def train_representation(model, batches, epochs, lr=1e-4, weight_decay=1e-6, mil
                 w.writerow([v])
     model.eval()
     return loss_list
+
+
+def train_representation_from_pool(model, pool, epochs, batch, lr=1e-4, weight_decay=1e-6, milestones=(10, 30, 50),
+                                   gamma=0.2, margin=1.0, save_dir=None, save_interval=10, start_ep=0, log=print,
+                                   drop_last=False, _ctx=None):
+    """The loop of VAR/pretext_VAR.py:44-91 over a TripletPool resident in HBM (u8 images, int16 clips, frozen pairs =
+    VARFineTuneDataset, dataset.py:94-133): every epoch is a freshly shuffled index table (DataLoader(shuffle=True),
+    drop_last=False incl. the short last batch) walked by the replayed step -- gather, MFCC front-end, forward, triplet
+    loss, backward, Adam in one graph launch per step; MultiStepLR per epoch (utils.py:42-46); average loss per epoch =
+    sum of the step losses / number of steps (:82), accumulated on the device (no per-step host sync); legacy-format
+    checkpoints every `save_interval` epochs and at the end (:75-80), progress.csv (:87-91).  Kuka model."""
+    tr = VARTrainer(model, lr=lr, weight_decay=weight_decay, margin=margin, _ctx=_ctx)
+    if getattr(pool, "clip_tab", None) is None:
+        pool.freeze_pairs()
+    model.train()
+    spe, bt = pool.steps_per_epoch(batch, drop_last), pool.tail_batch(batch, drop_last)
+    if spe < 1:
+        raise VarHipError(f"the pool holds {pool.n_items} triplets: no step of batch {batch} with drop_last={drop_last}")
+    replay = load_table = None
+    loss_list = []
+    acc = torch.zeros(1, dtype=torch.float32, device=tr.dev)
+    for ep in range(epochs):
+        tr.set_lr(multistep_lr(lr, milestones, gamma, ep))
+        table = pool.epoch_index_table(batch, drop_last)
+        if replay is None:
+            replay, load_table = tr.capture_epoch_steps(pool.images, pool.clips, batch, table, steps_per_epoch=spe,
+                                                        tail_batch=bt)
+        else:
+            load_table(table)
+        acc.zero_()
+        for _ in range(spe):
+            acc += replay()
+        avg = float(acc.item()) / spe
+        loss_list.append(avg)
+        log('average loss', avg)
+        if save_dir and ((ep + 1) % save_interval == 0 or ep + 1 == epochs):
+            os.makedirs(save_dir, exist_ok=True)
+            fname = os.path.join(save_dir, str(start_ep + ep) + '.pt')
+            torch.save(model.state_dict(), fname, _use_new_zipfile_serialization=False)
+            log('Model saved to ' + fname)
+    if save_dir:
+        os.makedirs(save_dir, exist_ok=True)
+        with open(os.path.join(save_dir, 'progress.csv'), 'w', newline='') as f:
+            w = csv.writer(f)
+            w.writerow(['avg_loss'])
+            for v in loss_list:
+                w.writerow([v])
+    model.eval()
+    return loss_list
