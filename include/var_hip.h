@@ -279,8 +279,8 @@ int var_mfcc_psf(var_ctx* ctx, void* stream, const int16_t* pcm, const int* lens
  * kernel family (tag in [0, var_profile_tag_count()), -1 = off); var_profile_read returns the
  * summed durations and the launch count since the select (it synchronises on the events).
  * var_set_streams: which parts of a step leave the caller's stream (bit 0: sound CNN forward, bit 1: sound
- * CNN backward, bit 2: image weight gradients, bit 3: slab folds, bit 4: with bit 0, MFCC stays on the caller's
- * stream); -1 restores the default / VAR_STREAMS.  0 times every kernel alone on one stream.  Returns the old mask.
+ * CNN backward, bit 4: with bit 0, MFCC stays on the caller's stream); -1 restores the default (19).  0 puts every
+ * kernel on the caller's stream (per-kernel timing).  Returns the old mask.
  * var_debug_buffer: address/length of a named workspace buffer ("act1".."act5", "gact1"..,
  * "sact1".."sact4", "gsact1".., "emb", "gemb", "wpack") for layer-wise parity tests. */
 int var_profile_tag_count(void);
