@@ -367,6 +367,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
+    ap.add_argument("--streams", type=int, default=None,
+                    help="kuka workload: stream plan mask of var_set_streams (bit 0 sound forward, bit 1 sound backward on the "
+                         "side stream, bit 4 MFCC stays on the caller's stream; default 3)")
     ap.add_argument("--serial", action="store_true",
                     help="kuka workload: every kernel on ONE stream (var_set_streams(0)) -- per-kernel profiling runs")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
@@ -436,6 +439,8 @@ def main():
     ctx.ensure_plan(B, HW)
     if args.serial:
         ctx.set_streams(0)
+    if args.streams is not None:
+        ctx.set_streams(args.streams)
 
     use_graph = not args.no_graph
     if args.head == "inbatch":

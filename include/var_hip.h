@@ -126,7 +126,7 @@ int var_arm_loss_grad(var_ctx* ctx, void* stream, const float* params,
 
 /* The same with the data-loader work of dataset.py:64-89 / Envs/audioLoader.py:147-157 folded in:
  * the batch is gathered by index from a dataset resident in HBM and the MFCC front-end runs
- * inside the step (by default on the caller's stream, in front of the image CNN; see var_set_streams).
+ * inside the step (by default with the rest of the sound branch on the library's side stream; see var_set_streams).
  *   image        dataset images (N,C>=3,H,H) u8|f32; sample b uses row image_index[b] (NULL: row b)
  *   pcm          dataset clips, rows of pcm_stride int16 samples; clip_index (2B) = [pos | neg] rows
  *                (NULL: rows 0..2B-1); lens (2B) valid samples per clip, 0 = the "empty" class whose
@@ -279,7 +279,7 @@ int var_mfcc_psf(var_ctx* ctx, void* stream, const int16_t* pcm, const int* lens
  * kernel family (tag in [0, var_profile_tag_count()), -1 = off); var_profile_read returns the
  * summed durations and the launch count since the select (it synchronises on the events).
  * var_set_streams: which parts of a step leave the caller's stream (bit 0: sound CNN forward, bit 1: sound
- * CNN backward, bit 4: with bit 0, MFCC stays on the caller's stream); -1 restores the default (19).  0 puts every
+ * CNN backward, bit 4: with bit 0, MFCC stays on the caller's stream); -1 restores the default (3).  0 puts every
  * kernel on the caller's stream (per-kernel timing).  Returns the old mask.
  * var_debug_buffer: address/length of a named workspace buffer ("act1".."act5", "gact1"..,
  * "sact1".."sact4", "gsact1".., "emb", "gemb", "wpack") for layer-wise parity tests. */

@@ -224,11 +224,12 @@ int launch_img_fwd_head(var_ctx* c, hipStream_t s, const float* params, const vo
                         const int* image_index, int B);
 int launch_img_fwd_mid(var_ctx* c, hipStream_t s, const float* params, int B, bool with_head);
 // (launch_img_fwd also leaves c->relu1)
-// default: MFCC on the caller's stream, the sound CNN (forward and backward) beside the image CNN on one side
-// stream; image weight gradients and slab folds stay on the caller's stream.  Measured on MI355X (graph replay):
+// default: the whole sound branch -- MFCC front-end, sound CNN and sound head, forward and backward -- beside the image
+// CNN on one side stream.  (Round 1 kept the 61-us MFCC on the caller's stream, mask 19; with round 2's 43-us kernel the
+// image chain starting at once and the front-end on the side stream is 4-5 us per step faster: 0.346 vs 0.351 ms.)  Measured on MI355X (graph replay):
 // every cross-stream edge costs several us, and two GPU-filling persistent kernels side by side slow each other
 // down more than the overlap gains -- only the small sound kernels are worth forking.
-static constexpr int kDefaultStreams = 19;
+static constexpr int kDefaultStreams = 3;
 static constexpr int kTailG = 256;    // workgroups (= layer-0 slabs) of the fused backward tail
 int launch_img_bwd_tail(var_ctx* c, hipStream_t s, int B);
 int launch_img_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads, int B);
