@@ -391,3 +391,29 @@ def test_pool_training_loop_on_the_gpu(var_amd, tmp_path):
         a = model(img, f[:64].contiguous(), None)
         b = fresh(img, f[:64].contiguous(), None)
     assert torch.equal(a['image_feat'], b['image_feat']) and torch.equal(a['sound_feat_positive'], b['sound_feat_positive'])
+
+
+def test_trainer_notices_parameters_changed_behind_its_back(var_amd, golden_dir):
+    """load_state_dict between steps (what a fine-tune run does) without an explicit tr.pack(): the next eager step and
+    the next replay re-pack the weight image by themselves (torch's version counters) and use the NEW weights."""
+    sd1, sd2 = load(golden_dir, "kuka_weights.npz"), load(golden_dir, "kuka_weights2.npz")
+    fx2 = load(golden_dir, "kuka_h84_w2.npz")
+    m = make_model(var_amd, sd1)
+    tr = var_amd.VARTrainer(m, lr=0.0)
+    args = (cuda(fx2['image']), cuda(fx2['sound_positive']), cuda(fx2['sound_negative']))
+    tr.loss_and_grads(*args)
+    assert abs(tr.loss.item() - float(fx2['loss'])) > 1e-4          # weights 1 on fixture 2: some other loss
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd2.items()})
+    tr.loss_and_grads(*args)
+    assert abs(tr.loss.item() - float(fx2['loss'])) < 1e-5          # weights 2 without tr.pack()
+    # the same through a replayed step
+    pool = var_amd.SyntheticTripletPool(32, hw=84, seed=2, clips_per_class=2).freeze_pairs()
+    table = pool.index_table(16, 2, drop_last=True)[:2].contiguous()
+    replay, load_table = tr.capture_epoch_steps(pool.images, pool.clips, 16, table)
+    l2 = float(replay().item())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd1.items()})
+    load_table(table)
+    l1 = float(replay().item())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd2.items()})
+    load_table(table)
+    assert abs(float(replay().item()) - l2) < 1e-6 and abs(l1 - l2) > 1e-5

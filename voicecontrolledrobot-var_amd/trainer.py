@@ -74,7 +74,10 @@ class VARTrainer:
         self.weights = self.model.hip_weights(self.ctx, force=True)
 
     def _bind(self):
-        self.weights.bind()
+        """Bind this model's packed weight image for the next C-ABI calls -- and re-pack it first if the parameters
+        were changed behind the trainer's back (load_state_dict, an external optimiser: torch's version counters tell).
+        The trainer's own Adam keeps the image current by itself."""
+        self.weights = self.model.hip_weights(self.ctx)
 
     @property
     def grads(self):
@@ -198,6 +201,7 @@ class VARTrainer:
             (g_grad,), g_adam = self.ctx.capture([[grad, adam]]), None
 
         def replay(idx_row):
+            self._bind()
             self._g_idx.copy_(idx_row, non_blocking=True)
             g_grad()
             if g_adam is not None:
@@ -256,6 +260,7 @@ class VARTrainer:
                 state["row"] = 0
 
             def replay():
+                self._bind()
                 graphs[1 if is_tail(state["row"]) else 0]()
                 state["row"] = (state["row"] + 1) % rows
                 self.step_count += 1
@@ -311,6 +316,7 @@ class VARTrainer:
 
         def replay():
             row = state["row"]
+            self._bind()
             g_grad[1 if is_tail(row) else 0]()
             work = self.allreduce(async_op=True)
             g_front[1 if is_tail((row + 1) % rows) else 0]()   # MFCC of the next step while the collective is in flight
@@ -480,6 +486,7 @@ class VARTrainer:
             self._g_cursor.zero_()
 
         def replay():
+            self._bind()
             if world == 1:
                 g_all()
             else:
