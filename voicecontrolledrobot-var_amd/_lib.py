@@ -142,7 +142,8 @@ class Context:
         with torch.cuda.stream(side):
             for bodies in groups:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side):
+                # thread-local capture: the RCCL watchdog thread of torch.distributed may query events meanwhile
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                     for body in bodies:
                         body()
                 graphs.append(g)

@@ -324,7 +324,7 @@ class IthorTrainer:
         with torch.cuda.stream(side):
             for bodies in ((body_grad,), (body_adam,)) if collective else ((body_grad, body_adam),):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side):
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                     for b in bodies:
                         b()
                 graphs.append(g)

@@ -120,7 +120,7 @@ class IntrinsicReward:
             for with_goal in (True, False):
                 body(with_goal)                                  # warm-up outside capture (lazy kernel attributes)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side):
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                     body(with_goal)
                 self._graphs[with_goal] = g
         torch.cuda.current_stream().wait_stream(side)
