@@ -24,9 +24,6 @@
 
 #include "var_common.h"
 
-#ifndef MFCC_ABL
-#define MFCC_ABL 0
-#endif
 namespace {
 constexpr int NFFT = 512, WIN = 400, HOP = 160, NMEL = 40, NMFCC = 40, NFREQ = 257;
 constexpr int WOFF = (NFFT - WIN) / 2;   // 56
@@ -262,7 +259,6 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
         __builtin_amdgcn_sched_barrier(0);          // keep the loads HERE (hipcc otherwise sinks them towards their first use)
         PH(2);
         // 2. 16-point FFT over n1 (this lane is n2 = j), twiddle W256^(n2 k1), transpose through LDS, FFT over n2
-#if MFCC_ABL != 2
         fft16(v);
 #pragma unroll
         for (int k1 = 1; k1 < 16; ++k1) v[k1] = cmul(v[k1], tw[k1]);
@@ -275,7 +271,6 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
         WAVE_SYNC();
         PH(4);
         fft16(v);                                                   // v[k2] = Z[j + 16 k2]
-#endif
         PH(5);
         // 3. spectrum to LDS in natural order (the partner bin 256 - k lives in another lane)
 #pragma unroll
@@ -300,7 +295,6 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
         PH(6);
         __syncthreads();                                            // (1) power tile complete
         PH(7);
-#if MFCC_ABL != 3
         // 5. mel triangles on the matrix cores: D[frame][filter] over this wave's k-steps of each filter tile
         f32x4m acc[3];
 #pragma unroll
@@ -332,7 +326,6 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
             const int frame = 4 * (l2 >> 4) + r, mel = 16 * q + (l2 & 15);
             if (mel < NMEL) lmel[frame * LPITCH + mel] = __logf(s + 1e-6f);     // v_log_f32: 1 ulp, s + 1e-6 is never denormal
         }
-#endif
         PH(10);
         __syncthreads();                                            // (3) log-mel tile complete
         PH(11);
