@@ -571,13 +571,16 @@ int var_profile_read(var_ctx* c, float* total_ms, int* count) {
 }
 
 /* Testing hook: address and length (floats) of a workspace buffer, by name
- * ("act1".."act5", "gact1".."gact5", "sact1".."sact4", "gsact1".."gsact4", "emb", "gemb", "wpack"). */
+ * ("act1".."act5", "gact1".."gact5", "sact1".."sact4", "gsact1".."gsact4", "emb", "gemb", "wpack";
+ * iTHOR workspace: "ithor_s1".."ithor_s3", "ithor_gs1".."ithor_gs3": sound conv outputs / their gradients, sized for
+ * the planned batch). */
 int var_debug_buffer(var_ctx* c, const char* name, void** ptr, long* nfloats) {
     CHECK_CTX(c);
     if (!name || !ptr || !nfloats) return VAR_ERR_ARG;
     const size_t B = c->maxB;
     *ptr = nullptr; *nfloats = 0;
     if (!strcmp(name, "wpack")) { *ptr = c->wpack; *nfloats = c->kl.total; return VAR_OK; }
+    if (!strncmp(name, "ithor_", 6)) return ithor_debug_buffer(c, name + 6, ptr, nfloats);
     if (!c->ws) { VAR_SET_ERR(c, "var_debug_buffer: no plan"); return VAR_ERR_PLAN; }
     for (int l = 1; l <= 5; l++) {
         char a[16], g[16];

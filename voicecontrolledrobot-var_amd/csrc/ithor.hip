@@ -7,6 +7,7 @@
 // layers, the GRU's input and recurrent products and their gradients) is an instance of the f32-MFMA
 // gather-GEMM of gg.h; this file adds the element-wise kernels (max pool, GRU gates, ReLU masks, bias sums,
 // normalise) and the host-side schedule.  Parameters are used in place in their state_dict() layouts.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -55,6 +56,7 @@ struct ithor_state {
     float *GI = nullptr, *GH = nullptr, *Hb = nullptr, *R = nullptr, *Z = nullptr, *Nn = nullptr, *GHN = nullptr;
     float *DGI = nullptr, *DGH = nullptr, *DH = nullptr, *DHP = nullptr;
     float *slab = nullptr, *bslab = nullptr;              // split-K partial sums / bias-sum partials
+    void* bfws = nullptr;                                 // bf16 images / packed filters of the staged sound kernels (snd_bf16.hip)
     int gh_split = 1, dh_split = 1;
     bool bf16 = false;
     float *sraw = nullptr, *gsraw = nullptr;              // (clips,1024)
@@ -462,7 +464,8 @@ static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* imag
         }
         {
             ProfScope prof(c, s, TAG_ITHOR_S2_FWD);
-            RUN((conv_fwd<GS2, false, false>(c, s, snd_dims(2, nclips), st->s[1], P + L.sw[1], P + L.sb[1], st->s[2])));
+            if (st->bf16) RUN(snd2_bf16_fwd(c, s, st->s[1], P + L.sw[1], P + L.sb[1], st->s[2], nclips, st->bfws));
+            else RUN((conv_fwd<GS2, false, false>(c, s, snd_dims(2, nclips), st->s[1], P + L.sw[1], P + L.sb[1], st->s[2])));
         }
         RUN((conv_fwd<GS3, false, true>(c, s, snd_dims(3, nclips), st->s[2], P + L.sw[2], P + L.sb[2], st->s[3])));
         const int rows = nclips * kSeq;
@@ -651,6 +654,21 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
     return VAR_OK;
 }
 
+int ithor_debug_buffer(var_ctx* c, const char* name, void** ptr, long* nfloats) {
+    ithor_state* st = ith(c);
+    if (!st) { VAR_SET_ERR(c, "var_debug_buffer: no iTHOR plan"); return VAR_ERR_PLAN; }
+    const long C2 = 2L * st->maxB;
+    const long ssz[4] = {0, C2 * 64 * 300 * 20, C2 * 64 * 150 * 13, C2 * kSeq * kGin};
+    for (int l = 1; l <= 3; ++l) {
+        char a[8], g[8];
+        snprintf(a, sizeof a, "s%d", l); snprintf(g, sizeof g, "gs%d", l);
+        if (!strcmp(name, a)) { *ptr = st->s[l]; *nfloats = ssz[l]; return VAR_OK; }
+        if (!strcmp(name, g)) { *ptr = st->gs[l]; *nfloats = ssz[l]; return VAR_OK; }
+    }
+    VAR_SET_ERR(c, "var_debug_buffer: unknown iTHOR buffer '%s'", name);
+    return VAR_ERR_ARG;
+}
+
 // ---- C ABI ------------------------------------------------------------------------------------------------------
 #define CHECK_CTX(c) do { if (!(c)) return VAR_ERR_ARG; } while (0)
 
@@ -706,6 +724,7 @@ int var_ithor_plan(var_ctx* c, int max_batch, int img_hw) {
     const long ohi = take(B * 128), oghi = take(B * 128), ohs1 = take(C2 * 128), oghs1 = take(C2 * 128);
     const long ohs2 = take(C2 * 64), oghs2 = take(C2 * 64);
     const long oraw = take(9 * B), ograw = take(9 * B), oemb = take(9 * B), ogemb = take(9 * B), oloss = take(64);
+    const long obf = take((snd_bf16_workspace_bytes((int)C2) + 3) / 4);
     VAR_HIP_CHECK(c, hipMalloc((void**)&st->ws, (size_t)total * sizeof(float)));
     float* w = (float*)st->ws;
     for (int l = 1; l <= 6; ++l) { st->a[l] = w + oa[l]; st->ga[l] = w + oga[l]; }
@@ -717,6 +736,7 @@ int var_ithor_plan(var_ctx* c, int max_batch, int img_hw) {
     st->sraw = w + osraw; st->gsraw = w + ogsraw;
     st->hid_i = w + ohi; st->ghid_i = w + oghi; st->hid_s1 = w + ohs1; st->ghid_s1 = w + oghs1;
     st->hid_s2 = w + ohs2; st->ghid_s2 = w + oghs2;
+    st->bfws = w + obf;
     st->raw = w + oraw; st->graw = w + ograw; st->emb = w + oemb; st->gemb = w + ogemb; st->loss = w + oloss;
     return VAR_OK;
 }

@@ -250,3 +250,8 @@ int launch_adam_dev(var_ctx* c, hipStream_t s, float* p, const float* g, float* 
                     const int* idx_table, int row_ints, int n_rows, int* cursor, int* idx_row, int ahead_from);
 int launch_mfcc(var_ctx* c, hipStream_t s, const int16_t* pcm, const int* lens, const int* clip_index, int nclips,
                 int pcm_stride, int out_frames, float* out);
+
+// snd_bf16.hip: the iTHOR model's 11x5 sound convolution in its bf16 mode (patch staged in LDS, 32x32x16 bf16 MFMA)
+long snd_bf16_workspace_bytes(int nclips);
+int snd2_bf16_fwd(var_ctx* c, hipStream_t s, const float* x, const float* w, const float* bias, float* y, int nclips, void* ws);
+int ithor_debug_buffer(var_ctx* c, const char* name, void** ptr, long* nfloats);
