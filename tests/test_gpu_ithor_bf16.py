@@ -52,3 +52,34 @@ def test_conv2_forward_bf16_kernel_vs_float64_on_rounded_operands(var_amd, B):
     err = float((s2.double() - ref).abs().max())
     assert err < 2e-5 * max(scale, 1.0), (err, scale)
     assert float((s2 > 0).float().mean()) > 0.05                       # not trivially all-zero
+
+
+def _after_backward(var_amd, B, seed):
+    torch.manual_seed(5)
+    m = var_amd.IthorVARPretextNet(cfg(96)).to("cuda").set_precision("bf16")
+    pos, neg = sounds(B, seed)
+    img = torch.randint(0, 256, (B, 3, 96, 96), dtype=torch.uint8, generator=torch.Generator().manual_seed(seed)).cuda()
+    tr = var_amd.IthorTrainer(m)
+    tr.loss_and_grads(img, pos, neg)
+    from var_amd._lib import Context
+    ctx = Context.get(0)
+    n = 2 * B
+    buf = {k: ctx.debug_buffer("ithor_" + k).cpu() for k in ("s1", "s2", "gs1", "gs2")}
+    shapes = {"s1": (n, 64, 300, 20), "gs1": (n, 64, 300, 20), "s2": (n, 64, 150, 13), "gs2": (n, 64, 150, 13)}
+    buf = {k: v[:int(np.prod(shapes[k]))].view(shapes[k]) for k, v in buf.items()}
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    wk = [k for k, v in sd.items() if tuple(v.shape) == (64, 64, 11, 5)][0]
+    return m, tr, buf, sd[wk], wk
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_conv2_data_gradient_bf16_kernel_vs_float64_on_rounded_operands(var_amd, B):
+    m, tr, buf, w, _ = _after_backward(var_amd, B, 21 + B)
+    gy = buf["gs2"]
+    assert float(gy.abs().max()) > 0
+    ref = torch.nn.functional.conv_transpose2d(bf16_round(gy), bf16_round(w), stride=2, padding=(5, 5), output_padding=(1, 1))
+    ref = ref * (bf16_round(buf["s1"]) > 0)
+    assert ref.shape == buf["gs1"].shape
+    scale = float(ref.abs().max())
+    err = float((buf["gs1"].double() - ref).abs().max())
+    assert err < 2e-5 * scale, (err, scale)

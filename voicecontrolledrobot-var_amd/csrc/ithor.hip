@@ -464,7 +464,7 @@ static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* imag
         }
         {
             ProfScope prof(c, s, TAG_ITHOR_S2_FWD);
-            if (st->bf16) RUN(snd2_bf16_fwd(c, s, st->s[1], P + L.sw[1], P + L.sb[1], st->s[2], nclips, st->bfws));
+            if (st->bf16) RUN(snd2_bf16_fwd(c, s, st->s[1], P + L.sw[1], P + L.sb[1], st->s[2], nclips, 2 * st->maxB, st->bfws));
             else RUN((conv_fwd<GS2, false, false>(c, s, snd_dims(2, nclips), st->s[1], P + L.sw[1], P + L.sb[1], st->s[2])));
         }
         RUN((conv_fwd<GS3, false, true>(c, s, snd_dims(3, nclips), st->s[2], P + L.sw[2], P + L.sb[2], st->s[3])));
@@ -637,7 +637,8 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             RUN(chan_sum(c, s, st->gs[2], G + L.sb[1], nclips, 64, 150 * 13));
             {
                 ProfScope prof(c, s, TAG_ITHOR_S2_DGRAD);
-                RUN((conv_dgrad<GS2, false>(c, s, d, st->gs[2], P + L.sw[1], st->gs[1], st->s[1])));
+                if (st->bf16) RUN(snd2_bf16_dgrad(c, s, st->gs[2], P + L.sw[1], st->gs[1], nclips, 2 * st->maxB, st->bfws));
+                else RUN((conv_dgrad<GS2, false>(c, s, d, st->gs[2], P + L.sw[1], st->gs[1], st->s[1])));
             }
         }
         {

@@ -23,6 +23,13 @@
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+// 16 bytes per lane at (wave-uniform byte offset) + (lane offset) of a buffer: scalar base + one offset register instead of
+// a 64-bit address pair per load (hipcc otherwise keeps one pair per 4 KB of a table alive across the whole kernel)
+__device__ __forceinline__ u32x4_t wload(__amdgpu_buffer_rsrc_t r, int lane_off, int byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, byte_off, 0);
+}
 
 namespace {
 
@@ -56,6 +63,30 @@ __global__ void __launch_bounds__(256) to_c8_kernel(const float* __restrict__ x,
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = bf16_bits(src[(long)j * HW]);
     y[i] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+}
+
+// the same for a 64-channel map, one thread per pixel, plus the sign masks the data-gradient kernel's store wants:
+// mask[(n*HW + pix)*2 + h] bit 16 cb + 4 g + j = x[n][32 cb + 8 g + 4 h + j][pix] > 0 (as bf16)
+__global__ void __launch_bounds__(256) to_c8_mask_kernel(const float* __restrict__ x, uint4* __restrict__ y,
+                                                         unsigned* __restrict__ mask, long total, int HW) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int pix = (int)(i % HW);
+    const long n = i / HW;
+    const float* src = x + n * 64 * HW + pix;
+    unsigned mk[2] = {0u, 0u};
+#pragma unroll
+    for (int pl = 0; pl < 8; ++pl) {
+        unsigned v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = bf16_bits(src[(long)(8 * pl + j) * HW]);
+            if (v[j] - 1u < 0x7fffu) mk[j >> 2] |= 1u << (16 * (pl >> 2) + 4 * (pl & 3) + (j & 3));
+        }
+        y[(n * 8 + pl) * HW + pix] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+    }
+    mask[2 * i] = mk[0];
+    mask[2 * i + 1] = mk[1];
 }
 
 // OIHW fp32 (64,64,11,5) -> fragment order [q][tap][cb][lane][8]: lane (r, h) of block cb holds
@@ -99,7 +130,8 @@ __global__ void __launch_bounds__(256) snd2_fwd_kernel(const uint4* __restrict__
         const uint4* src = x8 + ((long)clip * 8 + 2 * q) * (HI * WI);
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
-            const int e = tid + 256 * k;
+            int e = tid + 256 * k;
+            asm volatile("" : "+v"(e));                     // (loop-invariant otherwise: hipcc would keep all of it live)
             const int hh = e >= nrows * WI ? 1 : 0, e2 = e - hh * nrows * WI;
             const int i = e2 / WI, yy = y0 + i;
             const bool ok = e2 < nrows * WI && (unsigned)yy < (unsigned)HI;
@@ -111,7 +143,8 @@ __global__ void __launch_bounds__(256) snd2_fwd_kernel(const uint4* __restrict__
         const int nrows = 2 * kRows[t] + 9;
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
-            const int e = tid + 256 * k;
+            int e = tid + 256 * k;
+            asm volatile("" : "+v"(e));
             const int hh = e >= nrows * WI ? 1 : 0, e2 = e - hh * nrows * WI;
             const int i = e2 / WI, c5 = e2 - i * WI + 5;
             if (e2 < nrows * WI)
@@ -120,6 +153,7 @@ __global__ void __launch_bounds__(256) snd2_fwd_kernel(const uint4* __restrict__
     };
     static_assert(2 * NR * WI <= NST * 256, "staging registers");
 
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, NQ * NTAP * 2048, 0x00020000);
     int tile = blockIdx.x;
     if (tile < ntiles) { stage_load(tile, 0); stage_store(tile, 0); }
     __syncthreads();
@@ -142,14 +176,14 @@ __global__ void __launch_bounds__(256) snd2_fwd_kernel(const uint4* __restrict__
             __builtin_amdgcn_sched_barrier(0);
 
             const unsigned char* img = lds + buf * BUFB;
-            const uint4* wq = wp + (long)q * NTAP * 128 + lane;
+            const int wq0 = q * NTAP * 2048;
             // software pipeline, pinned with sched_barriers (left alone, hipcc sinks every load to its use and waits
             // for it there): filter fragments one filter ROW ahead, pixel fragments one TAP ahead
-            uint4 wrow[2][KW][2];
+            u32x4_t wrow[2][KW][2];
             bf16x8_t a[2][4];
             auto toff = [](int tap) { const int ky = tap / KW, kx = tap - ky * KW; return ky * SUBP + (kx & 1) * PARB + (kx >> 1) * SLOT; };
 #pragma unroll
-            for (int kx = 0; kx < KW; ++kx) { wrow[0][kx][0] = wq[kx * 128]; wrow[0][kx][1] = wq[kx * 128 + 64]; }
+            for (int kx = 0; kx < KW; ++kx) { wrow[0][kx][0] = wload(wr, lane * 16, wq0 + kx * 2048); wrow[0][kx][1] = wload(wr, lane * 16, wq0 + kx * 2048 + 1024); }
 #pragma unroll
             for (int m = 0; m < 4; ++m) a[0][m] = *(const bf16x8_t*)(img + abase[m] + toff(0));
             __builtin_amdgcn_sched_barrier(0);
@@ -159,8 +193,8 @@ __global__ void __launch_bounds__(256) snd2_fwd_kernel(const uint4* __restrict__
                 if (ky + 1 < KH) {
 #pragma unroll
                     for (int kx = 0; kx < KW; ++kx) {
-                        wrow[cur ^ 1][kx][0] = wq[((ky + 1) * KW + kx) * 128];
-                        wrow[cur ^ 1][kx][1] = wq[((ky + 1) * KW + kx) * 128 + 64];
+                        wrow[cur ^ 1][kx][0] = wload(wr, lane * 16, wq0 + ((ky + 1) * KW + kx) * 2048);
+                        wrow[cur ^ 1][kx][1] = wload(wr, lane * 16, wq0 + ((ky + 1) * KW + kx) * 2048 + 1024);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -206,18 +240,179 @@ __global__ void __launch_bounds__(256) snd2_fwd_kernel(const uint4* __restrict__
     }
 }
 
-}  // namespace
+// ---- data gradient ---------------------------------------------------------------------------------------------
+// dx[ci][iy][ix] = sum_{co,ky,kx} gy[co][(iy+5-ky)/2][(ix+5-kx)/2] W[co][ci][ky][kx] over the taps of matching parity:
+// the four pixel-parity classes (a, b) = (iy & 1, ix & 1) are four stride-1 correlations of the gy map with
+// (5|6) x (2|3) taps, dy = (a+5-ky)/2 in -2..3, dx = (b+5-kx)/2 in 1..3 -- the column never leaves the map, rows outside
+// it are staged as zeros.  Tile: one clip x 25 rows u x 10 columns v (250 pixel slots = 8 MFMA column blocks); wave
+// (wm, cb) owns 4 column blocks and one 32-channel row block for BOTH column parities b: a pixel pair (2v, 2v+1) ends
+// up in one lane, so the store is 8 bytes per lane and 80 contiguous bytes per map row (4-byte stores at an 8-byte
+// stride, one parity at a time, made this kernel 4x slower than its arithmetic).  The two row parities a are two passes
+// over the same gy patch (30 rows, all 64 channels: 8 planes of 16-byte slots, 55 KB, double-buffered).  A filter row's
+// five taps read three distinct pixel fragments (dx = 3 | 2, 2 | 1, 1).  The ReLU mask of the layer below comes as one
+// 32-bit word per (pixel, lane half), laid out by the forward's conversion kernel in this epilogue's register order.
+constexpr int DG_ROWS = 25, DG_TILES = 6, DG_PR = DG_ROWS + 5, DG_PLB = (DG_PR + 3) * SUBP, DG_BUFB = 8 * DG_PLB;
+constexpr int DG_LDSB = 2 * DG_BUFB;
+constexpr int WI2 = WI / 2;
 
-// workspace (bytes) of the bf16 kernels for up to `nclips` clips: [x8 | wp]
-long snd_bf16_workspace_bytes(int nclips) {
-    return (long)nclips * CI * HI * WI * 2 + (long)NQ * NTAP * 2 * 64 * 16 + 256;
+// OIHW fp32 -> [q][tap][cb][lane][8]: lane (r, h) of block cb holds W[co = 16 q + 8 h + j][ci = 32 cb + r][tap]
+__global__ void __launch_bounds__(256) pack_w2t_kernel(const float* __restrict__ w, uint4* __restrict__ wp) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= NQ * NTAP * 2 * 64) return;
+    const int lane = i & 63, cb = (i >> 6) & 1, qt = i >> 7, tap = qt % NTAP, q = qt / NTAP;
+    const int ci = 32 * cb + (lane & 31), co0 = 16 * q + 8 * (lane >> 5);
+    unsigned v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = bf16_bits(w[((long)(co0 + j) * CI + ci) * NTAP + tap]);
+    wp[i] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
 }
 
-int snd2_bf16_fwd(var_ctx* c, hipStream_t s, const float* x, const float* w, const float* bias, float* y, int nclips, void* ws) {
+template <int A>
+__device__ __forceinline__ void dgrad_pass(const unsigned char* __restrict__ img, const int (&abase)[4], __amdgpu_buffer_rsrc_t wq,
+                                           int wlane, const unsigned* __restrict__ mask, int mshift, float* __restrict__ dxo,
+                                           int u0, int wm, int p31, int h) {
+    constexpr int NKY = A ? 6 : 5, NROW = NQ * NKY;
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][b][r] = 0.f;
+    // row R = (q, i): ky = 2 i + 1 - A
+    auto wofs = [](int R, int kx) { const int q = R / NKY, i = R - q * NKY; return (q * NTAP + (2 * i + 1 - A) * KW + kx) * 2048; };
+    auto aofs = [](int R, int d) {              // pixel fragment set d: dx = 3 - d
+        const int q = R / NKY, i = R - q * NKY, ky = 2 * i + 1 - A;
+        return 2 * q * DG_PLB + ((A + 5 - ky) / 2 + 2) * SUBP + (3 - d) * SLOT;
+    };
+    u32x4_t wrow[3][KW];
+    bf16x8_t a[2][3][4];
+#pragma unroll
+    for (int R = 0; R < 2; ++R)
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) wrow[R][kx] = wload(wq, wlane, wofs(R, kx));
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a[0][d][m] = *(const bf16x8_t*)(img + abase[m] + aofs(0, d));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int R = 0; R < NROW; ++R) {
+        const int ac = R & 1;
+        if (R + 2 < NROW) {
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) wrow[(R + 2) % 3][kx] = wload(wq, wlane, wofs(R + 2, kx));
+        }
+        if (R + 1 < NROW) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) a[ac ^ 1][d][m] = *(const bf16x8_t*)(img + abase[m] + aofs(R + 1, d));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+            const int b = (kx + 1) & 1, d = (kx + 1) >> 1;            // kx 0 | 1 2 | 3 4 -> dx 3 | 2 2 | 1 1
+            const bf16x8_t w = __builtin_bit_cast(bf16x8_t, wrow[R % 3][kx]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a[ac][d][m], acc[m][b], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // masked store: this lane's pixel pair (iy, 2v | 2v+1), channels 8 g + 4 h + j of its 32-channel block = register
+    // 4 g + j = bit 16 cb + 4 g + j of the pixel's mask word (dxo points at the block)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int P = 128 * wm + 32 * m + p31, ul = P / WI2, v = P - ul * WI2;
+        if (P < DG_ROWS * WI2) {
+            const int pix = (2 * (u0 + ul) + A) * WI + 2 * v;
+            const unsigned m0 = mask[2 * pix + h] >> mshift, m1 = mask[2 * pix + 2 + h] >> mshift;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = (r & 3) + 8 * (r >> 2) + 4 * h;
+                float2 o;
+                o.x = (m0 >> r) & 1u ? acc[m][0][r] : 0.f;
+                o.y = (m1 >> r) & 1u ? acc[m][1][r] : 0.f;
+                *(float2*)(dxo + (long)ci * (HI * WI) + pix) = o;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) snd2_dgrad_kernel(const uint4* __restrict__ gy8, const uint4* __restrict__ wp,
+                                                         const unsigned* __restrict__ mask, float* __restrict__ dx, int nclips) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p31 = lane & 31;
+    const int wm = wave & 1, cb = wave >> 1;
+    const int ntiles = nclips * DG_TILES;
+    int abase[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int P = 128 * wm + 32 * m + p31, ul = P / WI2, v = P - ul * WI2;
+        abase[m] = h * DG_PLB + ul * SUBP + v * SLOT;
+    }
+    constexpr int NSL = 8 * DG_PR * WO, NST = (NSL + 255) / 256;          // 3120 slots, 13 per thread
+    uint4 sreg[NST];
+    auto stage_load = [&](int tile) {
+        const int clip = tile / DG_TILES, t = tile - clip * DG_TILES, oy0 = DG_ROWS * t - 2;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            int e = tid + 256 * k;
+            asm volatile("" : "+v"(e));                     // keep the slots' index arithmetic out of the registers
+            const int pl = e / (DG_PR * WO), e2 = e - pl * (DG_PR * WO), oy = oy0 + e2 / WO;
+            const bool ok = e < NSL && (unsigned)oy < (unsigned)HO;
+            sreg[k] = ok ? gy8[((long)clip * 8 + pl) * (HO * WO) + oy0 * WO + e2] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            int e = tid + 256 * k;
+            asm volatile("" : "+v"(e));
+            const int pl = e / (DG_PR * WO), e2 = e - pl * (DG_PR * WO);
+            if (e < NSL) *(uint4*)(lds + buf * DG_BUFB + pl * DG_PLB + e2 * SLOT) = sreg[k];
+        }
+    };
+    // (rows DG_PR .. DG_PR+2 of a plane are only read by the unused pixel slots 250..255)
+    for (int i = tid; i < DG_LDSB / 16; i += 256) ((uint4*)lds)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    int tile = blockIdx.x;
+    if (tile < ntiles) { stage_load(tile); stage_store(0); }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t wq = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, NQ * NTAP * 2048, 0x00020000);
+    const int wlane = cb * 1024 + lane * 16;
+    int buf = 0;
+    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        const int clip = tile / DG_TILES, t = tile - clip * DG_TILES, u0 = DG_ROWS * t;
+        const unsigned* mk = mask + (long)clip * (HI * WI) * 2;
+        float* dxo = dx + ((long)clip * CI + 32 * cb) * (HI * WI);
+        const int ntile = tile + (int)gridDim.x;
+        const unsigned char* img = lds + buf * DG_BUFB;
+        dgrad_pass<0>(img, abase, wq, wlane, mk, 16 * cb, dxo, u0, wm, p31, h);
+        if (ntile < ntiles) stage_load(ntile);
+        __builtin_amdgcn_sched_barrier(0);
+        dgrad_pass<1>(img, abase, wq, wlane, mk, 16 * cb, dxo, u0, wm, p31, h);
+        if (ntile < ntiles) stage_store(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+// workspace (bytes) of the bf16 kernels for up to `nclips` clips: [x8 | gy8 | mask | wp | wpt]
+static inline long x8_bytes(int nclips) { return ((long)nclips * CI * HI * WI * 2 + 255) & ~255L; }
+static inline long gy8_bytes(int nclips) { return ((long)nclips * CO * HO * WO * 2 + 255) & ~255L; }
+constexpr long kWpBytes = (long)NQ * NTAP * 2 * 64 * 16;
+static inline long mask_bytes(int nclips) { return ((long)nclips * HI * WI * 8 + 255) & ~255L; }
+long snd_bf16_workspace_bytes(int nclips) { return x8_bytes(nclips) + gy8_bytes(nclips) + mask_bytes(nclips) + 2 * kWpBytes + 256; }
+
+int snd2_bf16_fwd(var_ctx* c, hipStream_t s, const float* x, const float* w, const float* bias, float* y, int nclips,
+                  int maxclips, void* ws) {
     uint4* x8 = (uint4*)ws;
-    uint4* wp = (uint4*)((char*)ws + (((long)nclips * CI * HI * WI * 2 + 255) & ~255L));
-    const long total = (long)nclips * 8 * HI * WI;
-    hipLaunchKernelGGL(to_c8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, x8, total, 8, HI * WI);
+    unsigned* mask = (unsigned*)((char*)ws + x8_bytes(maxclips) + gy8_bytes(maxclips));
+    uint4* wp = (uint4*)((char*)ws + x8_bytes(maxclips) + gy8_bytes(maxclips) + mask_bytes(maxclips));
+    const long total = (long)nclips * HI * WI;
+    hipLaunchKernelGGL(to_c8_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, x8, mask, total, HI * WI);
     VAR_HIP_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(pack_w2_kernel, dim3((NQ * NTAP * 128 + 255) / 256), dim3(256), 0, s, w, wp);
     VAR_HIP_CHECK(c, hipGetLastError());
@@ -228,6 +423,27 @@ int snd2_bf16_fwd(var_ctx* c, hipStream_t s, const float* x, const float* w, con
     }
     const int ntiles = nclips * TILES;
     hipLaunchKernelGGL(snd2_fwd_kernel, dim3(ntiles < 256 ? ntiles : 256), dim3(256), LDSB, s, x8, wp, bias, y, nclips);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}
+
+// dx (fp32 NCHW, masked by the sign of the forward's bf16 image of x, still in the workspace) from gy (fp32 NCHW)
+int snd2_bf16_dgrad(var_ctx* c, hipStream_t s, const float* gy, const float* w, float* dx, int nclips, int maxclips, void* ws) {
+    uint4* gy8 = (uint4*)((char*)ws + x8_bytes(maxclips));
+    const unsigned* mask = (const unsigned*)((char*)ws + x8_bytes(maxclips) + gy8_bytes(maxclips));
+    uint4* wpt = (uint4*)((char*)ws + x8_bytes(maxclips) + gy8_bytes(maxclips) + mask_bytes(maxclips) + kWpBytes);
+    const long total = (long)nclips * 8 * HO * WO;
+    hipLaunchKernelGGL(to_c8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, gy, gy8, total, 8, HO * WO);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(pack_w2t_kernel, dim3((NQ * NTAP * 128 + 255) / 256), dim3(256), 0, s, w, wpt);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    static bool attr = false;
+    if (!attr) {
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd2_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DG_LDSB));
+        attr = true;
+    }
+    const int ntiles = nclips * DG_TILES;
+    hipLaunchKernelGGL(snd2_dgrad_kernel, dim3(ntiles < 256 ? ntiles : 256), dim3(256), DG_LDSB, s, gy8, wpt, mask, dx, nclips);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }

@@ -253,5 +253,7 @@ int launch_mfcc(var_ctx* c, hipStream_t s, const int16_t* pcm, const int* lens, 
 
 // snd_bf16.hip: the iTHOR model's 11x5 sound convolution in its bf16 mode (patch staged in LDS, 32x32x16 bf16 MFMA)
 long snd_bf16_workspace_bytes(int nclips);
-int snd2_bf16_fwd(var_ctx* c, hipStream_t s, const float* x, const float* w, const float* bias, float* y, int nclips, void* ws);
+int snd2_bf16_fwd(var_ctx* c, hipStream_t s, const float* x, const float* w, const float* bias, float* y, int nclips,
+                  int maxclips, void* ws);
+int snd2_bf16_dgrad(var_ctx* c, hipStream_t s, const float* gy, const float* w, float* dx, int nclips, int maxclips, void* ws);
 int ithor_debug_buffer(var_ctx* c, const char* name, void** ptr, long* nfloats);
