@@ -83,3 +83,19 @@ def test_conv2_data_gradient_bf16_kernel_vs_float64_on_rounded_operands(var_amd,
     scale = float(ref.abs().max())
     err = float((buf["gs1"].double() - ref).abs().max())
     assert err < 2e-5 * scale, (err, scale)
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_conv2_weight_gradient_bf16_kernel_vs_float64_on_rounded_operands(var_amd, B):
+    m, tr, buf, w, wk = _after_backward(var_amd, B, 31 + B)
+    g = tr.grads.cpu()
+    o = 0
+    for k, p in m.named_parameters():
+        if k == wk:
+            got = g[o:o + p.numel()].view(p.shape)
+        o += p.numel()
+    ref = torch.nn.grad.conv2d_weight(bf16_round(buf["s1"]), (64, 64, 11, 5), bf16_round(buf["gs2"]), stride=2, padding=(5, 5))
+    scale = float(ref.abs().max())
+    assert scale > 0
+    err = float((got.double() - ref).abs().max())
+    assert err < 1e-4 * scale, (err, scale)

@@ -630,14 +630,16 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
         }
         {
             const ConvDims d = snd_dims(2, nclips);
+            if (st->bf16) RUN(snd2_bf16_prepare_gy(c, s, st->gs[2], nclips, 2 * st->maxB, st->bfws));
             {
                 ProfScope prof(c, s, TAG_ITHOR_S2_WGRAD);
-                RUN((conv_wgrad<GS2, false, false>(c, s, d, st->s[1], st->gs[2], G + L.sw[1])));
+                if (st->bf16) RUN(snd2_bf16_wgrad(c, s, G + L.sw[1], st->slab, nclips, 2 * st->maxB, st->bfws));
+                else RUN((conv_wgrad<GS2, false, false>(c, s, d, st->s[1], st->gs[2], G + L.sw[1])));
             }
             RUN(chan_sum(c, s, st->gs[2], G + L.sb[1], nclips, 64, 150 * 13));
             {
                 ProfScope prof(c, s, TAG_ITHOR_S2_DGRAD);
-                if (st->bf16) RUN(snd2_bf16_dgrad(c, s, st->gs[2], P + L.sw[1], st->gs[1], nclips, 2 * st->maxB, st->bfws));
+                if (st->bf16) RUN(snd2_bf16_dgrad(c, s, P + L.sw[1], st->gs[1], nclips, 2 * st->maxB, st->bfws));
                 else RUN((conv_dgrad<GS2, false>(c, s, d, st->gs[2], P + L.sw[1], st->gs[1], st->s[1])));
             }
         }

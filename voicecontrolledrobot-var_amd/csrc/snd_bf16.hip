@@ -397,6 +397,162 @@ __global__ void __launch_bounds__(256) snd2_dgrad_kernel(const uint4* __restrict
     }
 }
 
+// ---- weight gradient -------------------------------------------------------------------------------------------
+// dW[co][ci][ky][kx] = sum_{n,oy,ox} gy[n][co][oy][ox] x[n][ci][2oy-5+ky][2ox-5+kx]: the MFMA's k index is the PIXEL,
+// so both operands are read from their channel-innermost LDS images with the transposing ds_read_b64_tr_b16 (4 pixels
+// x 16 channels per 16-lane group; each lane supplies its own row address, so the stride-2 walk through the x patch and
+// the 13-pixel rows cost nothing).  A workgroup owns one 32-channel block of ci and one half of the 55 taps for a group of
+// clips; wave w owns 7 taps and both 32-row blocks of co: 14 accumulators (224 registers) that live across all the
+// clips of the group and are written once, to the group's slab (tap, co, ci); a fold adds the slabs in fixed order.
+// Tile = 12 output rows (156 pixels = 10 k-steps of 16): x patch 33 rows x 4 planes (parity-split as in the forward),
+// gy 8 planes, double-buffered (2 x 74 KB), the next tile staged two slots per thread and k-step.
+constexpr int WG_TR = 12, WG_TILES = 13, WG_XR = 2 * WG_TR + 9, WG_KS = 10;
+constexpr int WG_XPARB = WG_XR * SUBP, WG_XPL = 2 * WG_XPARB + 160;       // plane pitches = 64 mod 256: the four planes a
+constexpr int WG_GPL = WG_KS * 256 + 64;                                  // half-wave reads fall on disjoint banks
+constexpr int WG_XB = 4 * WG_XPL, WG_BUFB = WG_XB + 8 * WG_GPL, WG_LDSB = 2 * WG_BUFB;
+static_assert(WG_XPL % 256 == 64 && WG_GPL % 256 == 64 && WG_LDSB <= 160 * 1024, "wgrad LDS");
+constexpr int WG_TAPS = 7;                                                // per wave
+
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8_t tr_read2(const unsigned char* p0, const unsigned char* p1) {
+    const bf16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)p0);
+    const bf16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)p1);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ void __launch_bounds__(256) snd2_wgrad_kernel(const uint4* __restrict__ x8, const uint4* __restrict__ gy8,
+                                                         float* __restrict__ slab, int nclips, int per_group) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int g16 = (lane >> 4) & 1, qp = (lane & 15) >> 2, p = lane & 3;
+    const int cib = blockIdx.x & 1, th = (blockIdx.x >> 1) & 1, grp = blockIdx.x >> 2;
+    const int clip_lo = grp * per_group, clip_hi = min(nclips, clip_lo + per_group);
+    const int ntiles = (clip_hi - clip_lo) * WG_TILES;
+
+    for (int i = tid; i < WG_LDSB / 16; i += 256) ((uint4*)lds)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+
+    // this wave's taps (the 55th slot of the last wave repeats tap 54 and is not stored)
+    int tapoff[WG_TAPS];
+#pragma unroll
+    for (int i = 0; i < WG_TAPS; ++i) {
+        const int t = min(th * 28 + WG_TAPS * wave + i, NTAP - 1), ky = t / KW, kx = t - ky * KW;
+        tapoff[i] = (kx & 1) * WG_XPARB + ky * SUBP + (kx >> 1) * SLOT;
+    }
+    // per lane: plane / half-slot of its 4 channels, and the patch offset of its pixel in each (k-step, read)
+    const int xbase = (2 * g16 + (p >> 1)) * WG_XPL + 8 * (p & 1);
+    const int gbase = WG_XB + (2 * g16 + (p >> 1)) * WG_GPL + (8 * h + qp) * SLOT + 8 * (p & 1);
+    int pixoff[WG_KS][2];
+#pragma unroll
+    for (int ks = 0; ks < WG_KS; ++ks)
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            const int P = 16 * ks + 8 * h + 4 * rd + qp, oyl = P / WO, ox = P - oyl * WO;
+            pixoff[ks][rd] = xbase + oyl * 2 * SUBP + ox * SLOT;
+        }
+
+    // staging: 4 x planes x 33 rows x 20 slots, then 8 gy planes x 156 slots; 2 slots per thread and k-step
+    constexpr int NXS = 4 * WG_XR * WI, NGS = 8 * WG_TR * WO, NSL = NXS + NGS;
+    static_assert(NSL <= 2 * WG_KS * 256, "staging slots");
+    auto slot_load = [&](int tile, int k) -> uint4 {
+        const int clip = clip_lo + tile / WG_TILES, t = tile % WG_TILES, oy0 = WG_TR * t;
+        int e = tid + 256 * k;
+        asm volatile("" : "+v"(e));
+        if (e < NXS) {
+            const int pl = e / (WG_XR * WI), e2 = e - pl * (WG_XR * WI), y0 = 2 * oy0 - 5, yy = y0 + e2 / WI;
+            return (unsigned)yy < (unsigned)HI ? x8[((long)clip * 8 + 4 * cib + pl) * (HI * WI) + y0 * WI + e2] : make_uint4(0, 0, 0, 0);
+        }
+        const int f = e - NXS, pl = f / (WG_TR * WO), e2 = f - pl * (WG_TR * WO), oy = oy0 + e2 / WO;
+        return (f < NGS && oy < HO) ? gy8[((long)clip * 8 + pl) * (HO * WO) + oy0 * WO + e2] : make_uint4(0, 0, 0, 0);
+    };
+    auto slot_store = [&](int buf, int k, uint4 v) {
+        int e = tid + 256 * k;
+        asm volatile("" : "+v"(e));
+        unsigned char* base = lds + buf * WG_BUFB;
+        if (e < NXS) {
+            const int pl = e / (WG_XR * WI), e2 = e - pl * (WG_XR * WI), i = e2 / WI, c5 = e2 - i * WI + 5;
+            *(uint4*)(base + pl * WG_XPL + (c5 & 1) * WG_XPARB + i * SUBP + (c5 >> 1) * SLOT) = v;
+        } else if (e - NXS < NGS) {
+            const int f = e - NXS, pl = f / (WG_TR * WO), e2 = f - pl * (WG_TR * WO);
+            *(uint4*)(base + WG_XB + pl * WG_GPL + e2 * SLOT) = v;
+        }
+    };
+
+    f32x16_t acc[WG_TAPS][2];
+#pragma unroll
+    for (int i = 0; i < WG_TAPS; ++i)
+#pragma unroll
+        for (int cob = 0; cob < 2; ++cob)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][cob][r] = 0.f;
+
+    if (ntiles > 0) {
+#pragma unroll 1
+        for (int k = 0; k < 2 * WG_KS; ++k) slot_store(0, k, slot_load(0, k));
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int buf = tile & 1;
+        const unsigned char* img = lds + buf * WG_BUFB;
+        const bool have = tile + 1 < ntiles;
+        uint4 st[2][2];
+        bf16x8_t a[2][2], b[2][WG_TAPS];
+        auto frags = [&](int ks, int set) {
+#pragma unroll
+            for (int cob = 0; cob < 2; ++cob)
+                a[set][cob] = tr_read2(img + gbase + cob * 4 * WG_GPL + ks * 256, img + gbase + cob * 4 * WG_GPL + ks * 256 + 64);
+#pragma unroll
+            for (int i = 0; i < WG_TAPS; ++i) b[set][i] = tr_read2(img + pixoff[ks][0] + tapoff[i], img + pixoff[ks][1] + tapoff[i]);
+        };
+        frags(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < WG_KS; ++ks) {
+            const int set = ks & 1;
+            if (have) { st[set][0] = slot_load(tile + 1, 2 * ks); st[set][1] = slot_load(tile + 1, 2 * ks + 1); }
+            if (ks + 1 < WG_KS) frags(ks + 1, set ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < WG_TAPS; ++i) {
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[set][0], b[set][i], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[set][1], b[set][i], acc[i][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (have && ks > 0) { slot_store(buf ^ 1, 2 * ks - 2, st[set ^ 1][0]); slot_store(buf ^ 1, 2 * ks - 1, st[set ^ 1][1]); }
+        }
+        if (have) { slot_store(buf ^ 1, 2 * WG_KS - 2, st[(WG_KS - 1) & 1][0]); slot_store(buf ^ 1, 2 * WG_KS - 1, st[(WG_KS - 1) & 1][1]); }
+        __syncthreads();
+    }
+
+    // slab[grp][tap][co][ci]: lanes walk ci
+    float* out = slab + (long)grp * NTAP * CO * CI + 32 * cib + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < WG_TAPS; ++i) {
+        const int t = th * 28 + WG_TAPS * wave + i;
+        if (t < NTAP && (th == 1 || t < 28)) {
+#pragma unroll
+            for (int cob = 0; cob < 2; ++cob)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = 32 * cob + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    out[((long)t * CO + co) * CI] = acc[i][cob][r];
+                }
+        }
+    }
+}
+
+// dW (OIHW) += sum over the groups' slabs (tap, co, ci), in group order
+__global__ void __launch_bounds__(256) snd2_wgrad_fold_kernel(const float* __restrict__ slab, float* __restrict__ dw, int ngroups) {
+    const int i = blockIdx.x * 256 + threadIdx.x;              // (tap, co, ci)
+    if (i >= NTAP * CO * CI) return;
+    float a = 0.f;
+    for (int g = 0; g < ngroups; ++g) a += slab[(long)g * NTAP * CO * CI + i];
+    const int ci = i & 63, co = (i >> 6) & 63, t = i >> 12;
+    dw[((long)co * CI + ci) * NTAP + t] += a;
+}
+
 }  // namespace
 
 // workspace (bytes) of the bf16 kernels for up to `nclips` clips: [x8 | gy8 | mask | wp | wpt]
@@ -427,14 +583,11 @@ int snd2_bf16_fwd(var_ctx* c, hipStream_t s, const float* x, const float* w, con
     return VAR_OK;
 }
 
-// dx (fp32 NCHW, masked by the sign of the forward's bf16 image of x, still in the workspace) from gy (fp32 NCHW)
-int snd2_bf16_dgrad(var_ctx* c, hipStream_t s, const float* gy, const float* w, float* dx, int nclips, int maxclips, void* ws) {
+// dx (fp32 NCHW, masked by the sign of the forward's bf16 image of x) from the prepared gy image
+int snd2_bf16_dgrad(var_ctx* c, hipStream_t s, const float* w, float* dx, int nclips, int maxclips, void* ws) {
     uint4* gy8 = (uint4*)((char*)ws + x8_bytes(maxclips));
     const unsigned* mask = (const unsigned*)((char*)ws + x8_bytes(maxclips) + gy8_bytes(maxclips));
     uint4* wpt = (uint4*)((char*)ws + x8_bytes(maxclips) + gy8_bytes(maxclips) + mask_bytes(maxclips) + kWpBytes);
-    const long total = (long)nclips * 8 * HO * WO;
-    hipLaunchKernelGGL(to_c8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, gy, gy8, total, 8, HO * WO);
-    VAR_HIP_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(pack_w2t_kernel, dim3((NQ * NTAP * 128 + 255) / 256), dim3(256), 0, s, w, wpt);
     VAR_HIP_CHECK(c, hipGetLastError());
     static bool attr = false;
@@ -444,6 +597,36 @@ int snd2_bf16_dgrad(var_ctx* c, hipStream_t s, const float* gy, const float* w, 
     }
     const int ntiles = nclips * DG_TILES;
     hipLaunchKernelGGL(snd2_dgrad_kernel, dim3(ntiles < 256 ? ntiles : 256), dim3(256), DG_LDSB, s, gy8, wpt, mask, dx, nclips);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}
+
+// gy (fp32 NCHW, already masked) -> its bf16 C8 image in the workspace: once per backward, before the two kernels that read it
+int snd2_bf16_prepare_gy(var_ctx* c, hipStream_t s, const float* gy, int nclips, int maxclips, void* ws) {
+    uint4* gy8 = (uint4*)((char*)ws + x8_bytes(maxclips));
+    const long total = (long)nclips * 8 * HO * WO;
+    hipLaunchKernelGGL(to_c8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, gy, gy8, total, 8, HO * WO);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}
+
+// dW += the weight gradient from the forward's bf16 image of x and the prepared gy image; `slab` holds
+// snd2_bf16_wgrad_groups(nclips) * 55*64*64 floats
+int snd2_bf16_wgrad_groups(int nclips) { return nclips < 64 ? nclips : 64; }
+int snd2_bf16_wgrad(var_ctx* c, hipStream_t s, float* dw, float* slab, int nclips, int maxclips, void* ws) {
+    const uint4* x8 = (const uint4*)ws;
+    const uint4* gy8 = (const uint4*)((char*)ws + x8_bytes(maxclips));
+    static bool attr = false;
+    if (!attr) {
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd2_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDSB));
+        attr = true;
+    }
+    int groups = snd2_bf16_wgrad_groups(nclips);
+    const int per = (nclips + groups - 1) / groups;
+    groups = (nclips + per - 1) / per;
+    hipLaunchKernelGGL(snd2_wgrad_kernel, dim3(4 * groups), dim3(256), WG_LDSB, s, x8, gy8, slab, nclips, per);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(snd2_wgrad_fold_kernel, dim3((NTAP * CO * CI + 255) / 256), dim3(256), 0, s, slab, dw, groups);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }
