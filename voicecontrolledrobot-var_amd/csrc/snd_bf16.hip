@@ -400,15 +400,19 @@ __global__ void __launch_bounds__(256) snd2_dgrad_kernel(const uint4* __restrict
 // ---- weight gradient -------------------------------------------------------------------------------------------
 // dW[co][ci][ky][kx] = sum_{n,oy,ox} gy[n][co][oy][ox] x[n][ci][2oy-5+ky][2ox-5+kx]: the MFMA's k index is the PIXEL,
 // so both operands are read from their channel-innermost LDS images with the transposing ds_read_b64_tr_b16 (4 pixels
-// x 16 channels per 16-lane group; each lane supplies its own row address, so the stride-2 walk through the x patch and
-// the 13-pixel rows cost nothing).  A workgroup owns one 32-channel block of ci and one half of the 55 taps for a group of
-// clips; wave w owns 7 taps and both 32-row blocks of co: 14 accumulators (224 registers) that live across all the
-// clips of the group and are written once, to the group's slab (tap, co, ci); a fold adds the slabs in fixed order.
-// Tile = 12 output rows (156 pixels = 10 k-steps of 16): x patch 33 rows x 4 planes (parity-split as in the forward),
-// gy 8 planes, double-buffered (2 x 74 KB), the next tile staged two slots per thread and k-step.
-constexpr int WG_TR = 12, WG_TILES = 13, WG_XR = 2 * WG_TR + 9, WG_KS = 10;
+// x 16 channels per 16-lane group; each lane supplies its own row address, so the stride-2 walk through the x patch
+// costs nothing).  A workgroup owns one 32-channel block of ci and one half of the 55 taps for a group of clips; wave w
+// owns 7 taps and both 32-row blocks of co: 14 accumulators (224 registers) that live across all the clips of the
+// group and are written once, to the group's slab (tap, co, ci); a fold adds the slabs in fixed order.
+// Tile = 12 output rows; a k-step is ONE output row (13 pixels + 3 slots whose gy is zero): 19 % of the matrix work is
+// padding, but every operand address is a per-lane constant plus an immediate (with 16 consecutive pixels per k-step
+// the row/column split of each pixel cost more instruction issue than the matrix instructions themselves -- one wave
+// per SIMD hides nothing).  x patch 33 rows x 4 planes (parity-split as in the forward), gy 8 planes x 12 rows x 16
+// slots, double-buffered (2 x 79 KB); every thread stages 20 fixed slots per tile, one pair per k-step, loaded a whole
+// tile before they are stored.
+constexpr int WG_TR = 12, WG_TILES = 13, WG_XR = 2 * WG_TR + 9, WG_KS = WG_TR;
 constexpr int WG_XPARB = WG_XR * SUBP, WG_XPL = 2 * WG_XPARB + 160;       // plane pitches = 64 mod 256: the four planes a
-constexpr int WG_GPL = WG_KS * 256 + 64;                                  // half-wave reads fall on disjoint banks
+constexpr int WG_GPL = WG_TR * 256 + 64;                                  // half-wave reads fall on disjoint banks
 constexpr int WG_XB = 4 * WG_XPL, WG_BUFB = WG_XB + 8 * WG_GPL, WG_LDSB = 2 * WG_BUFB;
 static_assert(WG_XPL % 256 == 64 && WG_GPL % 256 == 64 && WG_LDSB <= 160 * 1024, "wgrad LDS");
 constexpr int WG_TAPS = 7;                                                // per wave
@@ -432,49 +436,43 @@ __global__ void __launch_bounds__(256) snd2_wgrad_kernel(const uint4* __restrict
     for (int i = tid; i < WG_LDSB / 16; i += 256) ((uint4*)lds)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
 
-    // this wave's taps (the 55th slot of the last wave repeats tap 54 and is not stored)
-    int tapoff[WG_TAPS];
+    // per lane: plane / half-slot of its 4 channels and its pixel (8 h + qp [+ 4]) of a row; plus this wave's taps
+    // (the 55th slot of the last wave repeats tap 54 and is not stored)
+    const int xlane = (2 * g16 + (p >> 1)) * WG_XPL + 8 * (p & 1) + (8 * h + qp) * SLOT;
+    const int glane = WG_XB + (2 * g16 + (p >> 1)) * WG_GPL + 8 * (p & 1) + (8 * h + qp) * SLOT;
+    int tapbase[WG_TAPS];
 #pragma unroll
     for (int i = 0; i < WG_TAPS; ++i) {
         const int t = min(th * 28 + WG_TAPS * wave + i, NTAP - 1), ky = t / KW, kx = t - ky * KW;
-        tapoff[i] = (kx & 1) * WG_XPARB + ky * SUBP + (kx >> 1) * SLOT;
+        tapbase[i] = xlane + (kx & 1) * WG_XPARB + ky * SUBP + (kx >> 1) * SLOT;
     }
-    // per lane: plane / half-slot of its 4 channels, and the patch offset of its pixel in each (k-step, read)
-    const int xbase = (2 * g16 + (p >> 1)) * WG_XPL + 8 * (p & 1);
-    const int gbase = WG_XB + (2 * g16 + (p >> 1)) * WG_GPL + (8 * h + qp) * SLOT + 8 * (p & 1);
-    int pixoff[WG_KS][2];
-#pragma unroll
-    for (int ks = 0; ks < WG_KS; ++ks)
-#pragma unroll
-        for (int rd = 0; rd < 2; ++rd) {
-            const int P = 16 * ks + 8 * h + 4 * rd + qp, oyl = P / WO, ox = P - oyl * WO;
-            pixoff[ks][rd] = xbase + oyl * 2 * SUBP + ox * SLOT;
-        }
 
-    // staging: 4 x planes x 33 rows x 20 slots, then 8 gy planes x 156 slots; 2 slots per thread and k-step
-    constexpr int NXS = 4 * WG_XR * WI, NGS = 8 * WG_TR * WO, NSL = NXS + NGS;
-    static_assert(NSL <= 2 * WG_KS * 256, "staging slots");
+    // staging, fixed slots per thread: x = 4 planes x 3 passes of 12 rows x 20 columns (threads 0..239), gy = 8 planes x
+    // 156 pixels (threads 0..155)
+    const int xr = tid / WI, xc = tid - xr * WI, xc5 = xc + 5;
+    const bool xthr = tid < 12 * WI, gthr = tid < WG_TR * WO;
+    const int xdst = (xc5 & 1) * WG_XPARB + xr * SUBP + (xc5 >> 1) * SLOT;
+    const int grow = tid / WO, gdst = WG_XB + (grow * 16 + (tid - grow * WO)) * SLOT;
+    constexpr int NPAIR = 10;                            // 12 x slots + 8 gy slots per thread
+    static_assert(NPAIR <= WG_KS, "one slot pair per k-step");
     auto slot_load = [&](int tile, int k) -> uint4 {
         const int clip = clip_lo + tile / WG_TILES, t = tile % WG_TILES, oy0 = WG_TR * t;
-        int e = tid + 256 * k;
-        asm volatile("" : "+v"(e));
-        if (e < NXS) {
-            const int pl = e / (WG_XR * WI), e2 = e - pl * (WG_XR * WI), y0 = 2 * oy0 - 5, yy = y0 + e2 / WI;
-            return (unsigned)yy < (unsigned)HI ? x8[((long)clip * 8 + 4 * cib + pl) * (HI * WI) + y0 * WI + e2] : make_uint4(0, 0, 0, 0);
+        if (k < 12) {
+            const int pl = k / 3, i = xr + 12 * (k % 3), yy = 2 * oy0 - 5 + i;
+            const bool ok = xthr && i < WG_XR && (unsigned)yy < (unsigned)HI;
+            return ok ? x8[((long)clip * 8 + 4 * cib + pl) * (HI * WI) + yy * WI + xc] : make_uint4(0, 0, 0, 0);
         }
-        const int f = e - NXS, pl = f / (WG_TR * WO), e2 = f - pl * (WG_TR * WO), oy = oy0 + e2 / WO;
-        return (f < NGS && oy < HO) ? gy8[((long)clip * 8 + pl) * (HO * WO) + oy0 * WO + e2] : make_uint4(0, 0, 0, 0);
+        const int pl = k - 12;
+        const bool ok = gthr && oy0 + grow < HO;
+        return ok ? gy8[((long)clip * 8 + pl) * (HO * WO) + oy0 * WO + tid] : make_uint4(0, 0, 0, 0);
     };
     auto slot_store = [&](int buf, int k, uint4 v) {
-        int e = tid + 256 * k;
-        asm volatile("" : "+v"(e));
         unsigned char* base = lds + buf * WG_BUFB;
-        if (e < NXS) {
-            const int pl = e / (WG_XR * WI), e2 = e - pl * (WG_XR * WI), i = e2 / WI, c5 = e2 - i * WI + 5;
-            *(uint4*)(base + pl * WG_XPL + (c5 & 1) * WG_XPARB + i * SUBP + (c5 >> 1) * SLOT) = v;
-        } else if (e - NXS < NGS) {
-            const int f = e - NXS, pl = f / (WG_TR * WO), e2 = f - pl * (WG_TR * WO);
-            *(uint4*)(base + WG_XB + pl * WG_GPL + e2 * SLOT) = v;
+        if (k < 12) {
+            const int pl = k / 3, i = xr + 12 * (k % 3);
+            if (xthr && i < WG_XR) *(uint4*)(base + pl * WG_XPL + xdst + 12 * (k % 3) * SUBP) = v;
+        } else if (gthr) {
+            *(uint4*)(base + (k - 12) * WG_GPL + gdst) = v;
         }
     };
 
@@ -486,9 +484,16 @@ __global__ void __launch_bounds__(256) snd2_wgrad_kernel(const uint4* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][cob][r] = 0.f;
 
+    // Slot pair j of tile T+1 is stored (into the other buffer) at k-step j of tile T and its registers are re-loaded at
+    // once with the pair of tile T+2: every load has a whole tile to land.
+    uint4 st[NPAIR][2];
     if (ntiles > 0) {
-#pragma unroll 1
-        for (int k = 0; k < 2 * WG_KS; ++k) slot_store(0, k, slot_load(0, k));
+#pragma unroll
+        for (int k = 0; k < 2 * NPAIR; ++k) slot_store(0, k, slot_load(0, k));
+    }
+    if (ntiles > 1) {
+#pragma unroll
+        for (int j = 0; j < NPAIR; ++j) { st[j][0] = slot_load(1, 2 * j); st[j][1] = slot_load(1, 2 * j + 1); }
     }
     __syncthreads();
 
@@ -496,33 +501,39 @@ __global__ void __launch_bounds__(256) snd2_wgrad_kernel(const uint4* __restrict
     for (int tile = 0; tile < ntiles; ++tile) {
         const int buf = tile & 1;
         const unsigned char* img = lds + buf * WG_BUFB;
-        const bool have = tile + 1 < ntiles;
-        uint4 st[2][2];
+        const bool have1 = tile + 1 < ntiles, have2 = tile + 2 < ntiles;
         bf16x8_t a[2][2], b[2][WG_TAPS];
-        auto frags = [&](int ks, int set) {
-#pragma unroll
-            for (int cob = 0; cob < 2; ++cob)
-                a[set][cob] = tr_read2(img + gbase + cob * 4 * WG_GPL + ks * 256, img + gbase + cob * 4 * WG_GPL + ks * 256 + 64);
-#pragma unroll
-            for (int i = 0; i < WG_TAPS; ++i) b[set][i] = tr_read2(img + pixoff[ks][0] + tapoff[i], img + pixoff[ks][1] + tapoff[i]);
+        // fragment f of k-step ks (= output row ks: x rows 2 ks + ky): f = 0, 1: gy for the two co blocks; 2 + i: x for tap i
+        auto frag = [&](int ks, int set, int f) {
+            if (f < 2) a[set][f] = tr_read2(img + glane + f * 4 * WG_GPL + ks * 256, img + glane + f * 4 * WG_GPL + ks * 256 + 64);
+            else b[set][f - 2] = tr_read2(img + tapbase[f - 2] + ks * 2 * SUBP, img + tapbase[f - 2] + ks * 2 * SUBP + 64);
         };
-        frags(0, 0);
+#pragma unroll
+        for (int f = 0; f < 9; ++f) frag(0, 0, f);
         __builtin_amdgcn_sched_barrier(0);
+        // One wave per SIMD: whatever is not issued in the shadow of a matrix instruction is paid in full, and hipcc
+        // neither interleaves the transposed reads by itself nor under sched_group_barrier -- so the order is pinned by
+        // hand: per pair of matrix instructions one or two fragments of the next k-step, the staging behind the last ones.
 #pragma unroll
         for (int ks = 0; ks < WG_KS; ++ks) {
             const int set = ks & 1;
-            if (have) { st[set][0] = slot_load(tile + 1, 2 * ks); st[set][1] = slot_load(tile + 1, 2 * ks + 1); }
-            if (ks + 1 < WG_KS) frags(ks + 1, set ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < WG_TAPS; ++i) {
+                if (ks + 1 < WG_KS) {
+                    if (i < 2) { frag(ks + 1, set ^ 1, 2 * i); frag(ks + 1, set ^ 1, 2 * i + 1); }
+                    else frag(ks + 1, set ^ 1, i + 2);
+                }
+                if (ks < NPAIR && i >= WG_TAPS - 2) {
+                    const int q = i - (WG_TAPS - 2);
+                    if (have1) slot_store(buf ^ 1, 2 * ks + q, st[ks][q]);
+                    if (have2) st[ks][q] = slot_load(tile + 2, 2 * ks + q);
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[set][0], b[set][i], acc[i][0], 0, 0, 0);
                 acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[set][1], b[set][i], acc[i][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            if (have && ks > 0) { slot_store(buf ^ 1, 2 * ks - 2, st[set ^ 1][0]); slot_store(buf ^ 1, 2 * ks - 1, st[set ^ 1][1]); }
         }
-        if (have) { slot_store(buf ^ 1, 2 * WG_KS - 2, st[(WG_KS - 1) & 1][0]); slot_store(buf ^ 1, 2 * WG_KS - 1, st[(WG_KS - 1) & 1][1]); }
         __syncthreads();
     }
 
