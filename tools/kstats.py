@@ -7,6 +7,7 @@ rows = list(csv.DictReader(open(f)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 for r in rows[:int(sys.argv[3]) if len(sys.argv) > 3 else 30]:
     n = re.sub(r"\s+", " ", r["Name"])
+    n = n.replace("(anonymous namespace)::", "")
     n = re.sub(r"\(.*", "", n)[:90]
     print(f"{float(r['TotalDurationNs']) / steps / 1e3:9.1f} us/step {int(r['Calls']) / steps:7.1f} calls {float(r['AverageNs']) / 1e3:9.1f} us  {n}")
 print(f"{tot / steps / 1e6:.3f} ms/step in kernels")

@@ -56,6 +56,7 @@ struct ithor_state {
     float *GI = nullptr, *GH = nullptr, *Hb = nullptr, *R = nullptr, *Z = nullptr, *Nn = nullptr, *GHN = nullptr;
     float *DGI = nullptr, *DGH = nullptr, *DH = nullptr, *DHP = nullptr;
     float *slab = nullptr, *bslab = nullptr;              // split-K partial sums / bias-sum partials
+    void* gruws = nullptr;                                // W_hh in MFMA fragment order (gru_bf16.hip)
     void* bfws = nullptr;                                 // bf16 images / packed filters of the staged sound kernels (snd_bf16.hip)
     int gh_split = 1, dh_split = 1;
     bool bf16 = false;
@@ -480,7 +481,13 @@ static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* imag
             RUN(gg(c, s, p, 2));
         }
         for (int d = 0; d < 2; ++d) VAR_HIP_CHECK(c, hipMemsetAsync(st->Hb + d * dirH, 0, sizeof(float) * nclips * kGh, s));
+        if (st->bf16) RUN(gru_bf16_pack(c, s, P + L.w_hh[0], dirP, st->gruws));
         for (int step = 0; step < kSeq; ++step) {
+            if (st->bf16) {      // product + gates in one launch (gru_bf16.hip)
+                RUN(gru_bf16_step_fwd(c, s, st->GI, st->Hb, P + L.b_hh[0], dirP, st->R, st->Z, st->Nn, st->GHN, nclips, step, dirGI,
+                                      dirH, dirS, save ? 1 : 0, st->gruws));
+                continue;
+            }
             // split over K into partial slabs of GH that the gate kernel adds in fixed order
             DenseP<true, true, 2> p{};
             p.M = kG3; p.N = nclips; p.K = kGh;
@@ -572,6 +579,11 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
         IT_CHECK(c);
         const int dh_split = rec_split(4 * ((nclips + 63) / 64) * 2, kG3 / GG_KC, 8);
         for (int step = kSeq - 1; step >= 0; --step) {
+            if (st->bf16) {      // dh = DH + dgh(step+1) W_hh, then the step's gate derivatives, in one launch
+                RUN(gru_bf16_step_bwd(c, s, st->DH, st->Hb, st->R, st->Z, st->Nn, st->GHN, st->DGI, st->DGH, nclips, step,
+                                      step == kSeq - 1 ? 0 : 1, dirGI, dirH, dirS, dirDGH, st->gruws));
+                continue;
+            }
             hipLaunchKernelGGL(gru_gate_bwd_kernel, dim3((nclips * kGh + 255) / 256, 2), dim3(256), 0, s, st->DH, st->DHP,
                                step == kSeq - 1 ? 0 : dh_split,
                                st->Hb + (long)step * nclips * kGh, st->R, st->Z, st->Nn, st->GHN, st->DGI, st->DGH, nclips, step,
@@ -727,7 +739,7 @@ int var_ithor_plan(var_ctx* c, int max_batch, int img_hw) {
     const long ohi = take(B * 128), oghi = take(B * 128), ohs1 = take(C2 * 128), oghs1 = take(C2 * 128);
     const long ohs2 = take(C2 * 64), oghs2 = take(C2 * 64);
     const long oraw = take(9 * B), ograw = take(9 * B), oemb = take(9 * B), ogemb = take(9 * B), oloss = take(64);
-    const long obf = take((snd_bf16_workspace_bytes((int)C2) + 3) / 4);
+    const long obf = take((snd_bf16_workspace_bytes((int)C2) + 3) / 4), ogru = take((gru_bf16_workspace_bytes() + 3) / 4);
     VAR_HIP_CHECK(c, hipMalloc((void**)&st->ws, (size_t)total * sizeof(float)));
     float* w = (float*)st->ws;
     for (int l = 1; l <= 6; ++l) { st->a[l] = w + oa[l]; st->ga[l] = w + oga[l]; }
@@ -739,7 +751,7 @@ int var_ithor_plan(var_ctx* c, int max_batch, int img_hw) {
     st->sraw = w + osraw; st->gsraw = w + ogsraw;
     st->hid_i = w + ohi; st->ghid_i = w + oghi; st->hid_s1 = w + ohs1; st->ghid_s1 = w + oghs1;
     st->hid_s2 = w + ohs2; st->ghid_s2 = w + oghs2;
-    st->bfws = w + obf;
+    st->bfws = w + obf; st->gruws = w + ogru;
     st->raw = w + oraw; st->graw = w + ograw; st->emb = w + oemb; st->gemb = w + ogemb; st->loss = w + oloss;
     return VAR_OK;
 }
