@@ -37,7 +37,10 @@ __device__ __forceinline__ bf16x8_t to_bf16x8(const float4 a, const float4 b) {
 __device__ __forceinline__ u32x4_t wload(__amdgpu_buffer_rsrc_t r, int lane_off, int byte_off) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, byte_off, 0);
 }
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// gate non-linearities on the hardware exp / rcp (v_exp_f32, v_rcp_f32: ~1 ulp each; the libm forms were a quarter of the
+// step kernel); tanh(x) = 1 - 2 / (1 + e^{2x}) saturates correctly at both ends (e^{2x} -> 0 | inf)
+__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
 
 // W_hh (dir stride dirP floats; [1536][512]) -> both fragment tables
 __global__ void __launch_bounds__(256) gru_pack_kernel(const float* __restrict__ w_hh, long dirP, uint4* __restrict__ wf,
@@ -61,201 +64,200 @@ __global__ void __launch_bounds__(256) gru_pack_kernel(const float* __restrict__
 }
 
 // ---- forward step ----------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) gru_step_fwd_kernel(const float* __restrict__ GI, float* __restrict__ Hb, const uint4* __restrict__ wf,
-                                                           const float* __restrict__ b_hh, long dirP, float* __restrict__ R,
-                                                           float* __restrict__ Z, float* __restrict__ Nn, float* __restrict__ GHN,
-                                                           int nclips, int step, long dirGI, long dirH, long dirS, int save) {
-    __shared__ float red[2][3][16][64];                  // the upper K half's accumulators
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, cbk = wave & 1, kh = wave >> 1;
+// 512 threads: wave = (32-clip block cbk, quarter of K kq), every operand load of the wave in flight at once.  The state
+// is read as its bf16 copy H16 (written by the previous step next to the fp32 state).  The four K quarters meet in LDS;
+// the gate phase re-maps the tile so that 8 consecutive lanes hold the 32 hidden units of ONE clip (128-byte rows of
+// gi / r / z / n / h) instead of one clip per lane.
+constexpr int RS = 66;                                  // LDS row stride of a 64-lane accumulator row
+
+__global__ void __launch_bounds__(512) gru_step_fwd_kernel(const float* __restrict__ GI, float* __restrict__ Hb, uint2* __restrict__ H16,
+                                                           const uint4* __restrict__ wf, const float* __restrict__ b_hh, long dirP,
+                                                           float* __restrict__ R, float* __restrict__ Z, float* __restrict__ Nn,
+                                                           float* __restrict__ GHN, int nclips, int step, long dirGI, long dirH,
+                                                           long dirS, int save) {
+    extern __shared__ float red[];                       // [cbk 2][kq 4][gate 3][r 16][RS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, cbk = wave & 1, kq = wave >> 1;
     const int js = blockIdx.x, cs = blockIdx.y, dir = blockIdx.z;
-    const int clip = 64 * cs + 32 * cbk + (lane & 31);
-    const bool live = clip < nclips;
-    const float* hprev = Hb + dir * dirH + (long)step * nclips * GH + (long)(live ? clip : 0) * GH;
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, (int)kWfBytes, 0x00020000);
-    const int wbase = ((dir * NJS + js) * 32 + 16 * kh) * 3 * 1024;
-    f32x16_t acc[3];
+    // the gate phase's operands first (thread = (clip_l = tid / 8, hidden quad jq = tid % 8)): their HBM latency runs
+    // under the product
+    const int jq = tid & 7, cl = tid >> 3, clip = 64 * cs + cl, clipc = min(clip, nclips - 1);
+    const int t = dir ? SEQ - 1 - step : step, j = 32 * js + 4 * jq;
+    const float* gi = GI + dir * dirGI + ((long)clipc * SEQ + t) * G3 + j;
+    const float* bh = b_hh + dir * dirP + j;
+    const float* hprev = Hb + dir * dirH + (long)step * nclips * GH + (long)clipc * GH + j;
+    const float4 gr = *(const float4*)gi, gz = *(const float4*)(gi + GH), gn = *(const float4*)(gi + 2 * GH);
+    const float4 br = *(const float4*)bh, bz = *(const float4*)(bh + GH), bn = *(const float4*)(bh + 2 * GH);
+    const float4 hp = *(const float4*)hprev;
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const int clip = min(64 * cs + 32 * cbk + (lane & 31), nclips - 1);
+        const uint4* hsrc = (const uint4*)(H16 + (((long)(step & 1) * 2 + dir) * nclips + clip) * (GH / 4)) + 16 * kq + h;
+        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, (int)kWfBytes, 0x00020000);
+        const int wbase = ((dir * NJS + js) * 32 + 8 * kq) * 3 * 1024;
+        u32x4_t a[8][3];
+        uint4 b[8];
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
+        for (int i = 0; i < 8; ++i) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
-    constexpr int CH = 4;                                // k-steps per chunk, two chunks in flight
-    u32x4_t a[2][CH][3];
-    float4 b[2][CH][2];
-    auto load = [&](int c, int set) {
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const int ks = CH * c + i;
-#pragma unroll
-            for (int g = 0; g < 3; ++g) a[set][i][g] = wload(wr, lane * 16, wbase + (ks * 3 + g) * 1024);
-            const float4* src = (const float4*)(hprev + 16 * (16 * kh + ks) + 8 * h);
-            b[set][i][0] = src[0]; b[set][i][1] = src[1];
+            for (int g = 0; g < 3; ++g) a[i][g] = wload(wr, lane * 16, wbase + (i * 3 + g) * 1024);
+            b[i] = hsrc[2 * i];
         }
-    };
-    load(0, 0);
-#pragma unroll
-    for (int c = 0; c < 16 / CH; ++c) {
-        const int set = c & 1;
-        if (c + 1 < 16 / CH) load(c + 1, set ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const bf16x8_t bv = to_bf16x8(b[set][i][0], b[set][i][1]);
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[set][i][g]), bv, acc[g], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (kh == 1) {
+        f32x16_t acc[3];
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[cbk][g][r][lane] = acc[g][r];
+            for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[i][g]), __builtin_bit_cast(bf16x8_t, b[i]),
+                                                                 acc[g], 0, 0, 0);
+        float* dst = red + ((cbk * 4 + kq) * 3) * 16 * RS + lane;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(g * 16 + r) * RS] = acc[g][r];
     }
     __syncthreads();
-    if (kh == 1 || !live) return;
+    // gate phase: thread = (clip_l = tid / 8, hidden quad jq = tid % 8): units 32 js + 4 jq + 0..3, which the accumulators hold
+    // in rows 4 (jq / 2) + e of lanes (clip_l % 32) + 32 (jq % 2)
+    if (clip >= nclips) return;
+    float gh[3][4];
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[g][r] += red[cbk][g][r][lane];
-    // gates on the accumulator layout: register quad q holds hidden units 32 js + 8 q + 4 h + 0..3 of this lane's clip
-    const int t = dir ? SEQ - 1 - step : step;
-    const float* gi = GI + dir * dirGI + ((long)clip * SEQ + t) * G3;
-    const float* bh = b_hh + dir * dirP;
-    float* hnext = Hb + dir * dirH + (long)(step + 1) * nclips * GH + (long)clip * GH;
-    const long so = dir * dirS + (long)step * nclips * GH + (long)clip * GH;
+        for (int e = 0; e < 4; ++e) {
+            float v = 0.f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int j = 32 * js + 8 * q + 4 * h;
-        const float4 gr = *(const float4*)(gi + j), gz = *(const float4*)(gi + GH + j), gn = *(const float4*)(gi + 2 * GH + j);
-        const float4 br = *(const float4*)(bh + j), bz = *(const float4*)(bh + GH + j), bn = *(const float4*)(bh + 2 * GH + j);
-        const float4 hp = *(const float4*)(hprev + j);
-        float4 o, rr, zz, nn, gg;
-#define GRU_LANE(c, e)                                                         \
-        {                                                                      \
-            const float r_ = sigmoidf_(gr.c + (acc[0][4 * q + e] + br.c));     \
-            const float z_ = sigmoidf_(gz.c + (acc[1][4 * q + e] + bz.c));     \
-            const float ghn_ = acc[2][4 * q + e] + bn.c;                       \
-            const float n_ = tanhf(gn.c + r_ * ghn_);                          \
-            o.c = (1.f - z_) * n_ + z_ * hp.c;                                 \
-            rr.c = r_; zz.c = z_; nn.c = n_; gg.c = ghn_;                      \
+            for (int q = 0; q < 4; ++q) v += red[((((cl >> 5) * 4 + q) * 3 + g) * 16 + 4 * (jq >> 1) + e) * RS + (cl & 31) + 32 * (jq & 1)];
+            gh[g][e] = v;
         }
-        GRU_LANE(x, 0) GRU_LANE(y, 1) GRU_LANE(z, 2) GRU_LANE(w, 3)
-#undef GRU_LANE
-        *(float4*)(hnext + j) = o;
-        if (save) {
-            *(float4*)(R + so + j) = rr; *(float4*)(Z + so + j) = zz; *(float4*)(Nn + so + j) = nn; *(float4*)(GHN + so + j) = gg;
-        }
+    float* hnext = Hb + dir * dirH + (long)(step + 1) * nclips * GH + (long)clip * GH + j;
+    const long so = dir * dirS + (long)step * nclips * GH + (long)clip * GH + j;
+    float4 o, rr, zz, nn, gg;
+#define GRU_LANE(c, e)                                                     \
+    {                                                                      \
+        const float r_ = sigmoidf_(gr.c + (gh[0][e] + br.c));              \
+        const float z_ = sigmoidf_(gz.c + (gh[1][e] + bz.c));              \
+        const float ghn_ = gh[2][e] + bn.c;                                \
+        const float n_ = tanhf_(gn.c + r_ * ghn_);                          \
+        o.c = (1.f - z_) * n_ + z_ * hp.c;                                 \
+        rr.c = r_; zz.c = z_; nn.c = n_; gg.c = ghn_;                      \
     }
+    GRU_LANE(x, 0) GRU_LANE(y, 1) GRU_LANE(z, 2) GRU_LANE(w, 3)
+#undef GRU_LANE
+    *(float4*)hnext = o;
+    H16[(((long)((step + 1) & 1) * 2 + dir) * nclips + clip) * (GH / 4) + 8 * js + jq] = make_uint2(pack2(o.x, o.y), pack2(o.z, o.w));
+    if (save) { *(float4*)(R + so) = rr; *(float4*)(Z + so) = zz; *(float4*)(Nn + so) = nn; *(float4*)(GHN + so) = gg; }
 }
 
 // ---- backward step ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) gru_step_bwd_kernel(float* __restrict__ DH, const float* __restrict__ Hb, const uint4* __restrict__ wb,
-                                                           const float* __restrict__ R, const float* __restrict__ Z,
+__global__ void __launch_bounds__(512) gru_step_bwd_kernel(float* __restrict__ DH, const float* __restrict__ Hb, const uint4* __restrict__ wb,
+                                                           uint2* __restrict__ DG16, const float* __restrict__ R, const float* __restrict__ Z,
                                                            const float* __restrict__ Nn, const float* __restrict__ GHN,
                                                            float* __restrict__ DGI, float* __restrict__ DGH, int nclips, int step,
                                                            int has_next, long dirGI, long dirH, long dirS, long dirDGH) {
-    __shared__ float red[2][16][64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, cbk = wave & 1, kh = wave >> 1;
+    extern __shared__ float red[];                       // [cbk 2][kq 4][r 16][RS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, cbk = wave & 1, kq = wave >> 1;
     const int js = blockIdx.x, cs = blockIdx.y, dir = blockIdx.z;
-    const int clip = 64 * cs + 32 * cbk + (lane & 31);
-    const bool live = clip < nclips;
-    f32x16_t acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int jq = tid & 7, cl = tid >> 3, clip = 64 * cs + cl, clipc = min(clip, nclips - 1);
+    const int t = dir ? SEQ - 1 - step : step, j = 32 * js + 4 * jq;
+    const long so = dir * dirS + (long)step * nclips * GH + (long)clipc * GH + j;
+    const float* hprev = Hb + dir * dirH + (long)step * nclips * GH + (long)clipc * GH + j;
+    float* dh = DH + (long)dir * nclips * GH + (long)clipc * GH + j;
+    const float4 r4 = *(const float4*)(R + so), z4 = *(const float4*)(Z + so), n4 = *(const float4*)(Nn + so);
+    const float4 g4 = *(const float4*)(GHN + so), hp = *(const float4*)hprev, d4 = *(const float4*)dh;
+    __builtin_amdgcn_sched_barrier(0);
     if (has_next) {                                      // uniform
-        const float* dgn = DGH + dir * dirDGH + ((long)(step + 1) * nclips + (live ? clip : 0)) * G3;
+        const int clip = min(64 * cs + 32 * cbk + (lane & 31), nclips - 1);
+        const uint4* gsrc = (const uint4*)(DG16 + (((long)((step + 1) & 1) * 2 + dir) * nclips + clip) * (G3 / 4)) + 48 * kq + h;
         const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, (int)kWbBytes, 0x00020000);
-        const int wbase = ((dir * NJS + js) * 96 + 48 * kh) * 1024;
-        constexpr int CH = 8;
-        u32x4_t a[2][CH];
-        float4 b[2][CH][2];
-        auto load = [&](int c, int set) {
+        const int wbase = ((dir * NJS + js) * 96 + 24 * kq) * 1024;
+        u32x4_t a[24];
+        uint4 b[24];
 #pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                const int ks = CH * c + i;
-                a[set][i] = wload(wr, lane * 16, wbase + ks * 1024);
-                const float4* src = (const float4*)(dgn + 16 * (48 * kh + ks) + 8 * h);
-                b[set][i][0] = src[0]; b[set][i][1] = src[1];
-            }
-        };
-        load(0, 0);
+        for (int i = 0; i < 24; ++i) { a[i] = wload(wr, lane * 16, wbase + i * 1024); b[i] = gsrc[2 * i]; }
+        f32x16_t acc;
 #pragma unroll
-        for (int c = 0; c < 48 / CH; ++c) {
-            const int set = c & 1;
-            if (c + 1 < 48 / CH) load(c + 1, set ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-            for (int i = 0; i < CH; ++i)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[set][i]),
-                                                              to_bf16x8(b[set][i][0], b[set][i][1]), acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (kh == 1) {
+        for (int i = 0; i < 24; ++i)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[i]), __builtin_bit_cast(bf16x8_t, b[i]), acc, 0, 0, 0);
+        float* dst = red + (cbk * 4 + kq) * 16 * RS + lane;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[cbk][r][lane] = acc[r];
-        }
+        for (int r = 0; r < 16; ++r) dst[r * RS] = acc[r];
         __syncthreads();
-        if (kh == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] += red[cbk][r][lane];
-        }
     }
-    if (kh == 1 || !live) return;
-    const int t = dir ? SEQ - 1 - step : step;
-    const long so = dir * dirS + (long)step * nclips * GH + (long)clip * GH;
-    const float* hprev = Hb + dir * dirH + (long)step * nclips * GH + (long)clip * GH;
-    float* dh = DH + (long)dir * nclips * GH + (long)clip * GH;
-    float* dgi = DGI + dir * dirGI + ((long)clip * SEQ + t) * G3;
-    float* dgh = DGH + dir * dirDGH + ((long)step * nclips + clip) * G3;
+    if (clip >= nclips) return;
+    float dp[4] = {0.f, 0.f, 0.f, 0.f};
+    if (has_next) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int j = 32 * js + 8 * q + 4 * h;
-        const float4 r4 = *(const float4*)(R + so + j), z4 = *(const float4*)(Z + so + j), n4 = *(const float4*)(Nn + so + j);
-        const float4 g4 = *(const float4*)(GHN + so + j), hp = *(const float4*)(hprev + j), d4 = *(const float4*)(dh + j);
-        float4 dr, dz, dn, dnr, dd;
-#define GRU_LANE(c, e)                                                         \
-        {                                                                      \
-            const float dh_ = d4.c + acc[4 * q + e];                           \
-            const float dn_ = dh_ * (1.f - z4.c) * (1.f - n4.c * n4.c);        \
-            dz.c = dh_ * (hp.c - n4.c) * z4.c * (1.f - z4.c);                  \
-            dr.c = dn_ * g4.c * r4.c * (1.f - r4.c);                           \
-            dn.c = dn_; dnr.c = dn_ * r4.c; dd.c = dh_ * z4.c;                 \
-        }
-        GRU_LANE(x, 0) GRU_LANE(y, 1) GRU_LANE(z, 2) GRU_LANE(w, 3)
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dp[e] += red[(((cl >> 5) * 4 + q) * 16 + 4 * (jq >> 1) + e) * RS + (cl & 31) + 32 * (jq & 1)];
+    }
+    float* dgi = DGI + dir * dirGI + ((long)clip * SEQ + t) * G3 + j;
+    float* dgh = DGH + dir * dirDGH + ((long)step * nclips + clip) * G3 + j;
+    float4 dr, dz, dn, dnr, dd;
+#define GRU_LANE(c, e)                                                     \
+    {                                                                      \
+        const float dh_ = d4.c + dp[e];                                    \
+        const float dn_ = dh_ * (1.f - z4.c) * (1.f - n4.c * n4.c);        \
+        dz.c = dh_ * (hp.c - n4.c) * z4.c * (1.f - z4.c);                  \
+        dr.c = dn_ * g4.c * r4.c * (1.f - r4.c);                           \
+        dn.c = dn_; dnr.c = dn_ * r4.c; dd.c = dh_ * z4.c;                 \
+    }
+    GRU_LANE(x, 0) GRU_LANE(y, 1) GRU_LANE(z, 2) GRU_LANE(w, 3)
 #undef GRU_LANE
-        *(float4*)(dgi + j) = dr; *(float4*)(dgi + GH + j) = dz; *(float4*)(dgi + 2 * GH + j) = dn;
-        *(float4*)(dgh + j) = dr; *(float4*)(dgh + GH + j) = dz; *(float4*)(dgh + 2 * GH + j) = dnr;
-        *(float4*)(dh + j) = dd;
-    }
+    *(float4*)dgi = dr; *(float4*)(dgi + GH) = dz; *(float4*)(dgi + 2 * GH) = dn;
+    *(float4*)dgh = dr; *(float4*)(dgh + GH) = dz; *(float4*)(dgh + 2 * GH) = dnr;
+    *(float4*)dh = dd;
+    uint2* g16 = DG16 + (((long)(step & 1) * 2 + dir) * nclips + clip) * (G3 / 4) + 8 * js + jq;
+    g16[0] = make_uint2(pack2(dr.x, dr.y), pack2(dr.z, dr.w));
+    g16[GH / 4] = make_uint2(pack2(dz.x, dz.y), pack2(dz.z, dz.w));
+    g16[2 * GH / 4] = make_uint2(pack2(dnr.x, dnr.y), pack2(dnr.z, dnr.w));
 }
 
 }  // namespace
 
-long gru_bf16_workspace_bytes() { return kWfBytes + kWbBytes; }
+// workspace: [Wf | Wb | H16 (2 x dir x clips x 512 bf16) | DG16 (2 x dir x clips x 1536 bf16)]
+static inline long h16_bytes(int maxclips) { return 2L * 2 * maxclips * GH * 2; }
+static inline long dg16_bytes(int maxclips) { return 2L * 2 * maxclips * G3 * 2; }
+long gru_bf16_workspace_bytes(int maxclips) { return kWfBytes + kWbBytes + h16_bytes(maxclips) + dg16_bytes(maxclips); }
+constexpr int kFwdLds = 2 * 4 * 3 * 16 * RS * 4, kBwdLds = 2 * 4 * 16 * RS * 4;
 
-int gru_bf16_pack(var_ctx* c, hipStream_t s, const float* w_hh, long dirP, void* ws) {
+// once per forward: both fragment tables of W_hh, and the zero initial state's bf16 copy
+int gru_bf16_pack(var_ctx* c, hipStream_t s, const float* w_hh, long dirP, int nclips, void* ws) {
     uint4* wf = (uint4*)ws;
     uint4* wb = (uint4*)((char*)ws + kWfBytes);
     const int n = (int)((kWfBytes + kWbBytes) / 16);
     hipLaunchKernelGGL(gru_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w_hh, dirP, wf, wb);
     VAR_HIP_CHECK(c, hipGetLastError());
+    VAR_HIP_CHECK(c, hipMemsetAsync((char*)ws + kWfBytes + kWbBytes, 0, 2L * nclips * GH * 2, s));   // H16 parity 0, both directions
+    static bool attr = false;
+    if (!attr) {
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)gru_step_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds));
+        attr = true;
+    }
     return VAR_OK;
 }
 
 int gru_bf16_step_fwd(var_ctx* c, hipStream_t s, const float* GI, float* Hb, const float* b_hh, long dirP, float* R, float* Z,
-                      float* Nn, float* GHN, int nclips, int step, long dirGI, long dirH, long dirS, int save, void* ws) {
-    hipLaunchKernelGGL(gru_step_fwd_kernel, dim3(NJS, (nclips + 63) / 64, 2), dim3(256), 0, s, GI, Hb, (const uint4*)ws, b_hh, dirP, R,
-                       Z, Nn, GHN, nclips, step, dirGI, dirH, dirS, save);
+                      float* Nn, float* GHN, int nclips, int maxclips, int step, long dirGI, long dirH, long dirS, int save, void* ws) {
+    uint2* h16 = (uint2*)((char*)ws + kWfBytes + kWbBytes);
+    hipLaunchKernelGGL(gru_step_fwd_kernel, dim3(NJS, (nclips + 63) / 64, 2), dim3(512), kFwdLds, s, GI, Hb, h16, (const uint4*)ws, b_hh,
+                       dirP, R, Z, Nn, GHN, nclips, step, dirGI, dirH, dirS, save);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }
 
 int gru_bf16_step_bwd(var_ctx* c, hipStream_t s, float* DH, const float* Hb, const float* R, const float* Z, const float* Nn,
-                      const float* GHN, float* DGI, float* DGH, int nclips, int step, int has_next, long dirGI, long dirH,
-                      long dirS, long dirDGH, void* ws) {
-    hipLaunchKernelGGL(gru_step_bwd_kernel, dim3(NJS, (nclips + 63) / 64, 2), dim3(256), 0, s, DH, Hb,
-                       (const uint4*)((const char*)ws + kWfBytes), R, Z, Nn, GHN, DGI, DGH, nclips, step, has_next, dirGI, dirH,
+                      const float* GHN, float* DGI, float* DGH, int nclips, int maxclips, int step, int has_next, long dirGI,
+                      long dirH, long dirS, long dirDGH, void* ws) {
+    uint2* dg16 = (uint2*)((char*)ws + kWfBytes + kWbBytes + h16_bytes(maxclips));
+    hipLaunchKernelGGL(gru_step_bwd_kernel, dim3(NJS, (nclips + 63) / 64, 2), dim3(512), kBwdLds, s, DH, Hb,
+                       (const uint4*)((const char*)ws + kWfBytes), dg16, R, Z, Nn, GHN, DGI, DGH, nclips, step, has_next, dirGI, dirH,
                        dirS, dirDGH);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;

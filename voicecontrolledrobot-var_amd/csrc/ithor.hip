@@ -481,11 +481,11 @@ static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* imag
             RUN(gg(c, s, p, 2));
         }
         for (int d = 0; d < 2; ++d) VAR_HIP_CHECK(c, hipMemsetAsync(st->Hb + d * dirH, 0, sizeof(float) * nclips * kGh, s));
-        if (st->bf16) RUN(gru_bf16_pack(c, s, P + L.w_hh[0], dirP, st->gruws));
+        if (st->bf16) RUN(gru_bf16_pack(c, s, P + L.w_hh[0], dirP, nclips, st->gruws));
         for (int step = 0; step < kSeq; ++step) {
             if (st->bf16) {      // product + gates in one launch (gru_bf16.hip)
-                RUN(gru_bf16_step_fwd(c, s, st->GI, st->Hb, P + L.b_hh[0], dirP, st->R, st->Z, st->Nn, st->GHN, nclips, step, dirGI,
-                                      dirH, dirS, save ? 1 : 0, st->gruws));
+                RUN(gru_bf16_step_fwd(c, s, st->GI, st->Hb, P + L.b_hh[0], dirP, st->R, st->Z, st->Nn, st->GHN, nclips, 2 * st->maxB, step,
+                                      dirGI, dirH, dirS, save ? 1 : 0, st->gruws));
                 continue;
             }
             // split over K into partial slabs of GH that the gate kernel adds in fixed order
@@ -580,7 +580,7 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
         const int dh_split = rec_split(4 * ((nclips + 63) / 64) * 2, kG3 / GG_KC, 8);
         for (int step = kSeq - 1; step >= 0; --step) {
             if (st->bf16) {      // dh = DH + dgh(step+1) W_hh, then the step's gate derivatives, in one launch
-                RUN(gru_bf16_step_bwd(c, s, st->DH, st->Hb, st->R, st->Z, st->Nn, st->GHN, st->DGI, st->DGH, nclips, step,
+                RUN(gru_bf16_step_bwd(c, s, st->DH, st->Hb, st->R, st->Z, st->Nn, st->GHN, st->DGI, st->DGH, nclips, 2 * st->maxB, step,
                                       step == kSeq - 1 ? 0 : 1, dirGI, dirH, dirS, dirDGH, st->gruws));
                 continue;
             }
@@ -739,7 +739,7 @@ int var_ithor_plan(var_ctx* c, int max_batch, int img_hw) {
     const long ohi = take(B * 128), oghi = take(B * 128), ohs1 = take(C2 * 128), oghs1 = take(C2 * 128);
     const long ohs2 = take(C2 * 64), oghs2 = take(C2 * 64);
     const long oraw = take(9 * B), ograw = take(9 * B), oemb = take(9 * B), ogemb = take(9 * B), oloss = take(64);
-    const long obf = take((snd_bf16_workspace_bytes((int)C2) + 3) / 4), ogru = take((gru_bf16_workspace_bytes() + 3) / 4);
+    const long obf = take((snd_bf16_workspace_bytes((int)C2) + 3) / 4), ogru = take((gru_bf16_workspace_bytes((int)C2) + 3) / 4);
     VAR_HIP_CHECK(c, hipMalloc((void**)&st->ws, (size_t)total * sizeof(float)));
     float* w = (float*)st->ws;
     for (int l = 1; l <= 6; ++l) { st->a[l] = w + oa[l]; st->ga[l] = w + oga[l]; }

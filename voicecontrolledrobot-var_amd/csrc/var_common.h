@@ -262,10 +262,10 @@ int snd2_bf16_wgrad(var_ctx* c, hipStream_t s, float* dw, float* slab, int nclip
 int ithor_debug_buffer(var_ctx* c, const char* name, void** ptr, long* nfloats);
 
 // gru_bf16.hip: one launch per GRU time step and pass (recurrent product on bf16 MFMA + gate arithmetic), bf16 mode
-long gru_bf16_workspace_bytes();
-int gru_bf16_pack(var_ctx* c, hipStream_t s, const float* w_hh, long dirP, void* ws);
+long gru_bf16_workspace_bytes(int maxclips);
+int gru_bf16_pack(var_ctx* c, hipStream_t s, const float* w_hh, long dirP, int nclips, void* ws);
 int gru_bf16_step_fwd(var_ctx* c, hipStream_t s, const float* GI, float* Hb, const float* b_hh, long dirP, float* R, float* Z,
-                      float* Nn, float* GHN, int nclips, int step, long dirGI, long dirH, long dirS, int save, void* ws);
+                      float* Nn, float* GHN, int nclips, int maxclips, int step, long dirGI, long dirH, long dirS, int save, void* ws);
 int gru_bf16_step_bwd(var_ctx* c, hipStream_t s, float* DH, const float* Hb, const float* R, const float* Z, const float* Nn,
-                      const float* GHN, float* DGI, float* DGH, int nclips, int step, int has_next, long dirGI, long dirH,
-                      long dirS, long dirDGH, void* ws);
+                      const float* GHN, float* DGI, float* DGH, int nclips, int maxclips, int step, int has_next, long dirGI,
+                      long dirH, long dirS, long dirDGH, void* ws);
