@@ -282,13 +282,20 @@ int var_mfcc_psf(var_ctx* ctx, void* stream, const int16_t* pcm, const int* lens
  * CNN backward, bit 4: with bit 0, MFCC stays on the caller's stream); -1 restores the default (3).  0 puts every
  * kernel on the caller's stream (per-kernel timing).  Returns the old mask.
  * var_debug_buffer: address/length of a named workspace buffer ("act1".."act5", "gact1"..,
- * "sact1".."sact4", "gsact1".., "emb", "gemb", "wpack") for layer-wise parity tests. */
+ * "sact1".."sact4", "gsact1".., "emb", "gemb", "wpack"; "ithor_s1".."ithor_s3", "ithor_gs1".."ithor_gs3") for
+ * layer-wise parity tests.
+ * var_debug_ithor_dense: one dense product of the iTHOR model's bf16 mode through the kernel its schedule would pick,
+ * C[m + n*M] (+= when `add`) = sum_k A(m,k) B(k,n), A(m,k) = a[m*K + k] if a_kfast else a[k*M + m], B likewise with
+ * b[n*K + k] | b[k*N + n]; nsplit > 1 writes split-K slabs C + s*M*N instead (device pointers, fp32).  Returns 1 when
+ * the staged bf16 kernel (dense_bf16.h) ran, 0 when the shapes fell back to the gather-GEMM, < 0 on error. */
 int var_profile_tag_count(void);
 const char* var_profile_tag_name(int tag);
 int var_profile_select(var_ctx* ctx, int tag);
 int var_profile_read(var_ctx* ctx, float* total_ms, int* count);
 int var_set_streams(var_ctx* ctx, int mask);
 int var_debug_buffer(var_ctx* ctx, const char* name, void** ptr, long* nfloats);
+int var_debug_ithor_dense(var_ctx* ctx, void* stream, int a_kfast, int b_kfast, const float* a, const float* b,
+                          float* c, int M, int N, int K, int nsplit, int add);
 
 #ifdef __cplusplus
 }

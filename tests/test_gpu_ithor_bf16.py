@@ -162,3 +162,36 @@ def test_gru_and_sound_gradients_bf16_close_to_fp32(var_amd):
     assert max(v for k, v in worst.items() if k.startswith("rnn.")) < 0.02, worst
     assert max(v for k, v in worst.items() if k.startswith("soundTriplet.")) < 0.06, worst
     assert max(v for k, v in worst.items() if k.startswith("cnn.")) < 0.15, worst
+
+
+@pytest.mark.parametrize("akf,bkf", [(1, 1), (0, 1), (0, 0), (1, 0)])
+@pytest.mark.parametrize("M,N,K,nsplit,add", [(128, 128, 32, 1, 0), (448, 200, 96, 1, 0), (1536, 292, 448, 1, 0),
+                                              (448, 1536, 1472, 4, 0), (512, 1536, 2336, 8, 0), (132, 68, 64, 1, 1)])
+def test_dense_bf16_kernel_vs_float64_on_rounded_operands(var_amd, akf, bkf, M, N, K, nsplit, add):
+    """dense_bf16.h through var_debug_ithor_dense: all four operand layouts (K-contiguous -> ds_read_b128 image,
+    index-contiguous -> transposed reads), ragged M / N, split-K slabs and the accumulate mode."""
+    import ctypes
+    from var_amd._lib import Context
+    m = var_amd.IthorVARPretextNet(cfg(96)).to("cuda").set_precision("bf16")
+    ctx = Context.get(0)
+    m._ensure_plan(ctx, 2)
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + akf * 2 + bkf)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(K, N, generator=g)
+    a_dev = (A if akf else A.T).contiguous().cuda()
+    b_dev = (B.T if bkf else B).contiguous().cuda()
+    ns = max(nsplit, 1)
+    out = torch.full((ns, N, M), 0.5 if add else float("nan"), device="cuda")
+    rc = ctx.lib.var_debug_ithor_dense(ctx.handle, None, akf, bkf, a_dev.data_ptr(), b_dev.data_ptr(), out.data_ptr(), M, N, K,
+                                       nsplit, add)
+    torch.cuda.synchronize()
+    assert rc == 1, rc                                           # the staged kernel ran, not the fallback
+    ref = (bf16_round(A) @ bf16_round(B)).T                      # (N, M): C[m + n*M]
+    got = out.double().cpu()
+    if nsplit > 1:
+        got = got.sum(0)                                         # trimmed splits write zeros
+    else:
+        got = got[0] - (0.5 if add else 0.0)
+    assert torch.isfinite(got).all()
+    err = float((got - ref).abs().max())
+    assert err < 2e-5 * float(ref.abs().max()) * max(1.0, (K / 512) ** 0.5), err

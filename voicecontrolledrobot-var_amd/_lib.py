@@ -77,6 +77,7 @@ _SIGNATURES = {
     "var_set_streams": (_i, [_vp, _i]),
     "var_profile_read": (_i, [_vp, ctypes.POINTER(_f), ctypes.POINTER(_i)]),
     "var_debug_buffer": (_i, [_vp, ctypes.c_char_p, ctypes.POINTER(_vp), ctypes.POINTER(_l)]),
+    "var_debug_ithor_dense": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())

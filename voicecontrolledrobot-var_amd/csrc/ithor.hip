@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include "gg.h"
+#include "dense_bf16.h"
 
 // ---- geometry ------------------------------------------------------------------------------------------------
 static constexpr int kICh[7] = {3, 32, 32, 64, 64, 128, 128};
@@ -89,6 +90,13 @@ void ithor_free(var_ctx* c) {
 template <int KC, class P>
 static int gg(var_ctx* c, hipStream_t s, const P& p, int batches) {
     return ith(c)->bf16 ? gg_launch<P, KC, true>(c, s, p, batches) : gg_launch<P, KC, false>(c, s, p, batches);
+}
+// dense products: in bf16 mode the LDS-staged kernel of dense_bf16.h where its alignment conditions hold
+template <bool AK, bool BK, int MODE>
+static int gg(var_ctx* c, hipStream_t s, const DenseP<AK, BK, MODE>& p, int batches = 1) {
+    if (ith(c)->bf16 && dense16::eligible(p)) return dense16::launch(c, s, p, batches);
+    return ith(c)->bf16 ? gg_launch<DenseP<AK, BK, MODE>, GG_KC, true>(c, s, p, batches)
+                        : gg_launch<DenseP<AK, BK, MODE>, GG_KC, false>(c, s, p, batches);
 }
 
 // ---- element-wise kernels ---------------------------------------------------------------------------------------
@@ -684,6 +692,30 @@ int ithor_debug_buffer(var_ctx* c, const char* name, void** ptr, long* nfloats) 
     return VAR_ERR_ARG;
 }
 
+template <bool AK, bool BK>
+static int debug_dense(var_ctx* c, hipStream_t s, const float* a, const float* b, float* out, int M, int N, int K, int nsplit, int add) {
+    const long sam = AK ? K : 1, sak = AK ? 1 : M, sbk = BK ? 1 : N, sbn = BK ? K : 1;
+    if (nsplit > 1) {
+        DenseP<AK, BK, 2> p{};
+        p.M = M; p.N = N; p.K = K; p.nsplit = eff_split(K, nsplit);
+        p.A = a; p.sam = sam; p.sak = sak; p.Bm = b; p.sbk = sbk; p.sbn = sbn; p.C = out; p.scm = 1; p.scn = M; p.sC = (long)M * N;
+        const int r = gg(c, s, p);
+        return r != VAR_OK ? r : (dense16::eligible(p) ? 1 : 0);
+    }
+    if (add) {
+        DenseP<AK, BK, 1> p{};
+        p.M = M; p.N = N; p.K = K; p.nsplit = 1;
+        p.A = a; p.sam = sam; p.sak = sak; p.Bm = b; p.sbk = sbk; p.sbn = sbn; p.C = out; p.scm = 1; p.scn = M;
+        const int r = gg(c, s, p);
+        return r != VAR_OK ? r : (dense16::eligible(p) ? 1 : 0);
+    }
+    DenseP<AK, BK, 0> p{};
+    p.M = M; p.N = N; p.K = K; p.nsplit = 1;
+    p.A = a; p.sam = sam; p.sak = sak; p.Bm = b; p.sbk = sbk; p.sbn = sbn; p.C = out; p.scm = 1; p.scn = M;
+    const int r = gg(c, s, p);
+    return r != VAR_OK ? r : (dense16::eligible(p) ? 1 : 0);
+}
+
 // ---- C ABI ------------------------------------------------------------------------------------------------------
 #define CHECK_CTX(c) do { if (!(c)) return VAR_ERR_ARG; } while (0)
 
@@ -804,6 +836,18 @@ int var_ithor_encoder_fwd(var_ctx* c, void* stream, const float* params, const v
     if (snd_neg) RUN(copy_out(c, s, st->emb + 3 * mB + 3L * off, neg_feat, 3L * B));
     if (!save_for_bwd) st->B = 0;              // the recurrent states were not kept: no backward from this forward
     return VAR_OK;
+}
+
+int var_debug_ithor_dense(var_ctx* c, void* stream, int a_kfast, int b_kfast, const float* a, const float* b, float* out, int M,
+                          int N, int K, int nsplit, int add) {
+    CHECK_CTX(c);
+    if (!ith(c) || !ith(c)->bf16) { VAR_SET_ERR(c, "var_debug_ithor_dense: var_ithor_plan + var_ithor_set_bf16(1) first"); return VAR_ERR_PLAN; }
+    if (!a || !b || !out || M < 1 || N < 1 || K < 1) return VAR_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (a_kfast) return b_kfast ? debug_dense<true, true>(c, s, a, b, out, M, N, K, nsplit, add)
+                                : debug_dense<true, false>(c, s, a, b, out, M, N, K, nsplit, add);
+    return b_kfast ? debug_dense<false, true>(c, s, a, b, out, M, N, K, nsplit, add)
+                   : debug_dense<false, false>(c, s, a, b, out, M, N, K, nsplit, add);
 }
 
 int var_ithor_saved_generation(var_ctx* c) {
