@@ -83,6 +83,14 @@ def test_conv2_data_gradient_bf16_kernel_vs_float64_on_rounded_operands(var_amd,
     scale = float(ref.abs().max())
     err = float((buf["gs1"].double() - ref).abs().max())
     assert err < 2e-5 * scale, (err, scale)
+    # conv 1's bias gradient comes out of the same kernel's store: the channel sums of what it wrote
+    g, o = tr.grads.cpu().double(), 0
+    for k, p in m.named_parameters():
+        if k == "cnn.0.bias":
+            got = g[o:o + p.numel()]
+        o += p.numel()
+    want = buf["gs1"].double().sum((0, 2, 3))
+    assert float((got - want).abs().max()) < 1e-5 * float(want.abs().max() + buf["gs1"].abs().double().sum((0, 2, 3)).max() * 1e-2)
 
 
 @pytest.mark.parametrize("B", [1, 3])

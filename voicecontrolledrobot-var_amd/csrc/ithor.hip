@@ -184,8 +184,18 @@ __global__ void __launch_bounds__(256) col_sum_kernel(const float* __restrict__ 
     const int per = (rows + gridDim.y - 1) / gridDim.y;
     const int lo = blockIdx.y * per, hi = min(rows, lo + per);
     float acc = 0.f;
-    if (col < cols)
-        for (int r = lo + ty; r < hi; r += 4) acc += g[(long)r * cols + col];
+    if (col < cols) {
+        // eight independent loads in flight per thread (one at a time, the 230 MB gate-gradient maps took 150 us each),
+        // added in a fixed order
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int r = lo + ty;
+        for (; r + 28 < hi; r += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += g[(long)(r + 4 * u) * cols + col];
+        }
+        for (; r < hi; r += 4) a[0] += g[(long)r * cols + col];
+        acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
     __shared__ float red[4][64];
     red[ty][threadIdx.x & 63] = acc;
     __syncthreads();
@@ -659,7 +669,11 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             RUN(chan_sum(c, s, st->gs[2], G + L.sb[1], nclips, 64, 150 * 13));
             {
                 ProfScope prof(c, s, TAG_ITHOR_S2_DGRAD);
-                if (st->bf16) RUN(snd2_bf16_dgrad(c, s, P + L.sw[1], st->gs[1], nclips, 2 * st->maxB, st->bfws));
+                if (st->bf16) {     // (its store also yields the channel sums of gs[1]: conv 1's bias gradient)
+                    int nparts = 0;
+                    RUN(snd2_bf16_dgrad(c, s, P + L.sw[1], st->gs[1], st->bslab, &nparts, nclips, 2 * st->maxB, st->bfws));
+                    RUN(slab_reduce(c, s, G + L.sb[0], st->bslab, 64, nparts, 64));
+                }
                 else RUN((conv_dgrad<GS2, false>(c, s, d, st->gs[2], P + L.sw[1], st->gs[1], st->s[1])));
             }
         }
@@ -671,7 +685,7 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
                 RUN((conv_wgrad<GS1, false, false>(c, s, snd_dims(1, B), src, st->gs[1] + (long)off * 64 * 300 * 20, G + L.sw[0])));
                 off += B;
             }
-            RUN(chan_sum(c, s, st->gs[1], G + L.sb[0], nclips, 64, 300 * 20));
+            if (!st->bf16) RUN(chan_sum(c, s, st->gs[1], G + L.sb[0], nclips, 64, 300 * 20));
         }
     }
     return VAR_OK;

@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(256) pack_w2t_kernel(const float* __restrict__
 template <int A>
 __device__ __forceinline__ void dgrad_pass(const unsigned char* __restrict__ img, const int (&abase)[4], __amdgpu_buffer_rsrc_t wq,
                                            int wlane, const unsigned* __restrict__ mask, int mshift, float* __restrict__ dxo,
-                                           int u0, int wm, int p31, int h) {
+                                           int u0, int wm, int p31, int h, float (&bsum)[16]) {
     constexpr int NKY = A ? 6 : 5, NROW = NQ * NKY;
     f32x16_t acc[4][2];
 #pragma unroll
@@ -334,16 +334,21 @@ __device__ __forceinline__ void dgrad_pass(const unsigned char* __restrict__ img
                 o.x = (m0 >> r) & 1u ? acc[m][0][r] : 0.f;
                 o.y = (m1 >> r) & 1u ? acc[m][1][r] : 0.f;
                 *(float2*)(dxo + (long)ci * (HI * WI) + pix) = o;
+                bsum[r] += o.x + o.y;                     // the bias gradient of the layer below: channel sums of dx
             }
         }
     }
 }
 
 __global__ void __launch_bounds__(256) snd2_dgrad_kernel(const uint4* __restrict__ gy8, const uint4* __restrict__ wp,
-                                                         const unsigned* __restrict__ mask, float* __restrict__ dx, int nclips) {
+                                                         const unsigned* __restrict__ mask, float* __restrict__ dx,
+                                                         float* __restrict__ bias_part, int nclips) {
     extern __shared__ __align__(16) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p31 = lane & 31;
     const int wm = wave & 1, cb = wave >> 1;
+    float bsum[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bsum[r] = 0.f;
     const int ntiles = nclips * DG_TILES;
     int abase[4];
 #pragma unroll
@@ -388,13 +393,24 @@ __global__ void __launch_bounds__(256) snd2_dgrad_kernel(const uint4* __restrict
         float* dxo = dx + ((long)clip * CI + 32 * cb) * (HI * WI);
         const int ntile = tile + (int)gridDim.x;
         const unsigned char* img = lds + buf * DG_BUFB;
-        dgrad_pass<0>(img, abase, wq, wlane, mk, 16 * cb, dxo, u0, wm, p31, h);
+        dgrad_pass<0>(img, abase, wq, wlane, mk, 16 * cb, dxo, u0, wm, p31, h, bsum);
         if (ntile < ntiles) stage_load(ntile);
         __builtin_amdgcn_sched_barrier(0);
-        dgrad_pass<1>(img, abase, wq, wlane, mk, 16 * cb, dxo, u0, wm, p31, h);
+        dgrad_pass<1>(img, abase, wq, wlane, mk, 16 * cb, dxo, u0, wm, p31, h, bsum);
         if (ntile < ntiles) stage_store(buf ^ 1);
         __syncthreads();
     }
+    // this workgroup's channel sums (fixed order: butterfly over the 32 pixel lanes, then the two pixel-half waves)
+    float* red = (float*)lds;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = bsum[r];
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) v += __shfl_xor(v, d);
+        if (p31 == 0) red[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = v;
+    }
+    __syncthreads();
+    if (tid < 64) bias_part[blockIdx.x * 64 + tid] = red[(2 * (tid >> 5)) * 32 + (tid & 31)] + red[(2 * (tid >> 5) + 1) * 32 + (tid & 31)];
 }
 
 // ---- weight gradient -------------------------------------------------------------------------------------------
@@ -595,7 +611,9 @@ int snd2_bf16_fwd(var_ctx* c, hipStream_t s, const float* x, const float* w, con
 }
 
 // dx (fp32 NCHW, masked by the sign of the forward's bf16 image of x) from the prepared gy image
-int snd2_bf16_dgrad(var_ctx* c, hipStream_t s, const float* w, float* dx, int nclips, int maxclips, void* ws) {
+// bias_part: gridDim x 64 partial channel sums of dx (the bias gradient of the layer below); returns the grid size in *nparts
+int snd2_bf16_dgrad(var_ctx* c, hipStream_t s, const float* w, float* dx, float* bias_part, int* nparts, int nclips, int maxclips,
+                    void* ws) {
     uint4* gy8 = (uint4*)((char*)ws + x8_bytes(maxclips));
     const unsigned* mask = (const unsigned*)((char*)ws + x8_bytes(maxclips) + gy8_bytes(maxclips));
     uint4* wpt = (uint4*)((char*)ws + x8_bytes(maxclips) + gy8_bytes(maxclips) + mask_bytes(maxclips) + kWpBytes);
@@ -607,7 +625,8 @@ int snd2_bf16_dgrad(var_ctx* c, hipStream_t s, const float* w, float* dx, int nc
         attr = true;
     }
     const int ntiles = nclips * DG_TILES;
-    hipLaunchKernelGGL(snd2_dgrad_kernel, dim3(ntiles < 256 ? ntiles : 256), dim3(256), DG_LDSB, s, gy8, wpt, mask, dx, nclips);
+    *nparts = ntiles < 256 ? ntiles : 256;
+    hipLaunchKernelGGL(snd2_dgrad_kernel, dim3(*nparts), dim3(256), DG_LDSB, s, gy8, wpt, mask, dx, bias_part, nclips);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }

@@ -256,7 +256,8 @@ long snd_bf16_workspace_bytes(int nclips);
 int snd2_bf16_fwd(var_ctx* c, hipStream_t s, const float* x, const float* w, const float* bias, float* y, int nclips,
                   int maxclips, void* ws);
 int snd2_bf16_prepare_gy(var_ctx* c, hipStream_t s, const float* gy, int nclips, int maxclips, void* ws);
-int snd2_bf16_dgrad(var_ctx* c, hipStream_t s, const float* w, float* dx, int nclips, int maxclips, void* ws);
+int snd2_bf16_dgrad(var_ctx* c, hipStream_t s, const float* w, float* dx, float* bias_part, int* nparts, int nclips, int maxclips,
+                    void* ws);
 int snd2_bf16_wgrad_groups(int nclips);
 int snd2_bf16_wgrad(var_ctx* c, hipStream_t s, float* dw, float* slab, int nclips, int maxclips, void* ws);
 int ithor_debug_buffer(var_ctx* c, const char* name, void** ptr, long* nfloats);
