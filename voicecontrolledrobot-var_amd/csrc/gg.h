@@ -475,6 +475,7 @@ struct DenseP {
     float* C; long scm, scn, zC, sC;
     const float* bias; long zbias;
     int relu;
+    int a16, b16;            // dense_bf16.h only: A / Bm point at a bf16 copy of the operand (same element strides)
     struct CM { long off; int m; };
     __device__ int k_extent(int) const { return K; }
     __device__ SepM a_m(int m, int z) const { return SepM{(unsigned)(z * zA + m * sam) * 4u, m < M ? SEP_OK : 0u}; }

@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(512) gru_step_fwd_kernel(const float* __restri
     __builtin_amdgcn_sched_barrier(0);
     {
         const int clip = min(64 * cs + 32 * cbk + (lane & 31), nclips - 1);
-        const uint4* hsrc = (const uint4*)(H16 + (((long)(step & 1) * 2 + dir) * nclips + clip) * (GH / 4)) + 16 * kq + h;
+        const uint4* hsrc = (const uint4*)(H16 + (((long)dir * (SEQ + 1) + step) * nclips + clip) * (GH / 4)) + 16 * kq + h;
         const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, (int)kWfBytes, 0x00020000);
         const int wbase = ((dir * NJS + js) * 32 + 8 * kq) * 3 * 1024;
         u32x4_t a[8][3];
@@ -148,13 +148,14 @@ __global__ void __launch_bounds__(512) gru_step_fwd_kernel(const float* __restri
     GRU_LANE(x, 0) GRU_LANE(y, 1) GRU_LANE(z, 2) GRU_LANE(w, 3)
 #undef GRU_LANE
     *(float4*)hnext = o;
-    H16[(((long)((step + 1) & 1) * 2 + dir) * nclips + clip) * (GH / 4) + 8 * js + jq] = make_uint2(pack2(o.x, o.y), pack2(o.z, o.w));
+    H16[(((long)dir * (SEQ + 1) + step + 1) * nclips + clip) * (GH / 4) + 8 * js + jq] = make_uint2(pack2(o.x, o.y), pack2(o.z, o.w));
     if (save) { *(float4*)(R + so) = rr; *(float4*)(Z + so) = zz; *(float4*)(Nn + so) = nn; *(float4*)(GHN + so) = gg; }
 }
 
 // ---- backward step ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(512) gru_step_bwd_kernel(float* __restrict__ DH, const float* __restrict__ Hb, const uint4* __restrict__ wb,
-                                                           uint2* __restrict__ DG16, const float* __restrict__ R, const float* __restrict__ Z,
+                                                           uint2* __restrict__ DG16, uint2* __restrict__ DGI16, const float* __restrict__ R,
+                                                           const float* __restrict__ Z,
                                                            const float* __restrict__ Nn, const float* __restrict__ GHN,
                                                            float* __restrict__ DGI, float* __restrict__ DGH, int nclips, int step,
                                                            int has_next, long dirGI, long dirH, long dirS, long dirDGH) {
@@ -171,7 +172,7 @@ __global__ void __launch_bounds__(512) gru_step_bwd_kernel(float* __restrict__ D
     __builtin_amdgcn_sched_barrier(0);
     if (has_next) {                                      // uniform
         const int clip = min(64 * cs + 32 * cbk + (lane & 31), nclips - 1);
-        const uint4* gsrc = (const uint4*)(DG16 + (((long)((step + 1) & 1) * 2 + dir) * nclips + clip) * (G3 / 4)) + 48 * kq + h;
+        const uint4* gsrc = (const uint4*)(DG16 + (((long)dir * SEQ + step + 1) * nclips + clip) * (G3 / 4)) + 48 * kq + h;
         const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, (int)kWbBytes, 0x00020000);
         const int wbase = ((dir * NJS + js) * 96 + 24 * kq) * 1024;
         u32x4_t a[24];
@@ -213,19 +214,42 @@ __global__ void __launch_bounds__(512) gru_step_bwd_kernel(float* __restrict__ D
     *(float4*)dgi = dr; *(float4*)(dgi + GH) = dz; *(float4*)(dgi + 2 * GH) = dn;
     *(float4*)dgh = dr; *(float4*)(dgh + GH) = dz; *(float4*)(dgh + 2 * GH) = dnr;
     *(float4*)dh = dd;
-    uint2* g16 = DG16 + (((long)(step & 1) * 2 + dir) * nclips + clip) * (G3 / 4) + 8 * js + jq;
-    g16[0] = make_uint2(pack2(dr.x, dr.y), pack2(dr.z, dr.w));
-    g16[GH / 4] = make_uint2(pack2(dz.x, dz.y), pack2(dz.z, dz.w));
-    g16[2 * GH / 4] = make_uint2(pack2(dnr.x, dnr.y), pack2(dnr.z, dnr.w));
+    // bf16 copies of both gate-gradient rows: the next step's product reads DG16, the dW / dX products read both
+    uint2* g16 = DG16 + (((long)dir * SEQ + step) * nclips + clip) * (G3 / 4) + 8 * js + jq;
+    uint2* i16 = DGI16 + ((long)dir * SEQ * nclips + (long)clip * SEQ + t) * (G3 / 4) + 8 * js + jq;
+    const uint2 pr = make_uint2(pack2(dr.x, dr.y), pack2(dr.z, dr.w)), pz = make_uint2(pack2(dz.x, dz.y), pack2(dz.z, dz.w));
+    g16[0] = pr; g16[GH / 4] = pz; g16[2 * GH / 4] = make_uint2(pack2(dnr.x, dnr.y), pack2(dnr.z, dnr.w));
+    i16[0] = pr; i16[GH / 4] = pz; i16[2 * GH / 4] = make_uint2(pack2(dn.x, dn.y), pack2(dn.z, dn.w));
+}
+
+// fp32 -> bf16, 8 elements per thread (n % 8 == 0)
+__global__ void __launch_bounds__(256) to_bf16_kernel(const float4* __restrict__ x, uint4* __restrict__ y, long n8) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const float4 a = x[2 * i], b = x[2 * i + 1];
+    y[i] = make_uint4(pack2(a.x, a.y), pack2(a.z, a.w), pack2(b.x, b.y), pack2(b.z, b.w));
 }
 
 }  // namespace
 
-// workspace: [Wf | Wb | H16 (2 x dir x clips x 512 bf16) | DG16 (2 x dir x clips x 1536 bf16)]
-static inline long h16_bytes(int maxclips) { return 2L * 2 * maxclips * GH * 2; }
-static inline long dg16_bytes(int maxclips) { return 2L * 2 * maxclips * G3 * 2; }
-long gru_bf16_workspace_bytes(int maxclips) { return kWfBytes + kWbBytes + h16_bytes(maxclips) + dg16_bytes(maxclips); }
+// workspace: [Wf | Wb | H16 (dir, step 0..73, clip, 512) | DGH16 (dir, step, clip, 1536) | DGI16 (dir, clip*73+t, 1536) | X16 (clip*73+t, 448)], bf16
+static inline long h16_bytes(int mc) { return 2L * (SEQ + 1) * mc * GH * 2; }
+static inline long dg16_bytes(int mc) { return 2L * SEQ * mc * G3 * 2; }
+static inline long x16_bytes(int mc) { return (long)SEQ * mc * 448 * 2; }
+long gru_bf16_workspace_bytes(int mc) { return kWfBytes + kWbBytes + h16_bytes(mc) + 2 * dg16_bytes(mc) + x16_bytes(mc) + 256; }
+void* gru_bf16_h16(void* ws) { return (char*)ws + kWfBytes + kWbBytes; }
+void* gru_bf16_dgh16(void* ws, int mc) { return (char*)gru_bf16_h16(ws) + h16_bytes(mc); }
+void* gru_bf16_dgi16(void* ws, int mc) { return (char*)gru_bf16_dgh16(ws, mc) + dg16_bytes(mc); }
+void* gru_bf16_x16(void* ws, int mc) { return (char*)gru_bf16_dgi16(ws, mc) + dg16_bytes(mc); }
 constexpr int kFwdLds = 2 * 4 * 3 * 16 * RS * 4, kBwdLds = 2 * 4 * 16 * RS * 4;
+
+// the GRU's input sequence (fp32, n floats, n % 8 == 0) as bf16 for the dense products
+int gru_bf16_convert_x(var_ctx* c, hipStream_t s, const float* x, long n, int maxclips, void* ws) {
+    hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, s, (const float4*)x,
+                       (uint4*)gru_bf16_x16(ws, maxclips), n / 8);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}
 
 // once per forward: both fragment tables of W_hh, and the zero initial state's bf16 copy
 int gru_bf16_pack(var_ctx* c, hipStream_t s, const float* w_hh, long dirP, int nclips, void* ws) {
@@ -234,7 +258,8 @@ int gru_bf16_pack(var_ctx* c, hipStream_t s, const float* w_hh, long dirP, int n
     const int n = (int)((kWfBytes + kWbBytes) / 16);
     hipLaunchKernelGGL(gru_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w_hh, dirP, wf, wb);
     VAR_HIP_CHECK(c, hipGetLastError());
-    VAR_HIP_CHECK(c, hipMemsetAsync((char*)ws + kWfBytes + kWbBytes, 0, 2L * nclips * GH * 2, s));   // H16 parity 0, both directions
+    for (int d = 0; d < 2; ++d)                          // H16 [dir][step 0]
+        VAR_HIP_CHECK(c, hipMemsetAsync((char*)gru_bf16_h16(ws) + (long)d * (SEQ + 1) * nclips * GH * 2, 0, (long)nclips * GH * 2, s));
     static bool attr = false;
     if (!attr) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)gru_step_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds));
@@ -245,9 +270,8 @@ int gru_bf16_pack(var_ctx* c, hipStream_t s, const float* w_hh, long dirP, int n
 
 int gru_bf16_step_fwd(var_ctx* c, hipStream_t s, const float* GI, float* Hb, const float* b_hh, long dirP, float* R, float* Z,
                       float* Nn, float* GHN, int nclips, int maxclips, int step, long dirGI, long dirH, long dirS, int save, void* ws) {
-    uint2* h16 = (uint2*)((char*)ws + kWfBytes + kWbBytes);
-    hipLaunchKernelGGL(gru_step_fwd_kernel, dim3(NJS, (nclips + 63) / 64, 2), dim3(512), kFwdLds, s, GI, Hb, h16, (const uint4*)ws, b_hh,
-                       dirP, R, Z, Nn, GHN, nclips, step, dirGI, dirH, dirS, save);
+    hipLaunchKernelGGL(gru_step_fwd_kernel, dim3(NJS, (nclips + 63) / 64, 2), dim3(512), kFwdLds, s, GI, Hb, (uint2*)gru_bf16_h16(ws),
+                       (const uint4*)ws, b_hh, dirP, R, Z, Nn, GHN, nclips, step, dirGI, dirH, dirS, save);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }
@@ -255,10 +279,9 @@ int gru_bf16_step_fwd(var_ctx* c, hipStream_t s, const float* GI, float* Hb, con
 int gru_bf16_step_bwd(var_ctx* c, hipStream_t s, float* DH, const float* Hb, const float* R, const float* Z, const float* Nn,
                       const float* GHN, float* DGI, float* DGH, int nclips, int maxclips, int step, int has_next, long dirGI,
                       long dirH, long dirS, long dirDGH, void* ws) {
-    uint2* dg16 = (uint2*)((char*)ws + kWfBytes + kWbBytes + h16_bytes(maxclips));
     hipLaunchKernelGGL(gru_step_bwd_kernel, dim3(NJS, (nclips + 63) / 64, 2), dim3(512), kBwdLds, s, DH, Hb,
-                       (const uint4*)((const char*)ws + kWfBytes), dg16, R, Z, Nn, GHN, DGI, DGH, nclips, step, has_next, dirGI, dirH,
-                       dirS, dirDGH);
+                       (const uint4*)((const char*)ws + kWfBytes), (uint2*)gru_bf16_dgh16(ws, maxclips),
+                       (uint2*)gru_bf16_dgi16(ws, maxclips), R, Z, Nn, GHN, DGI, DGH, nclips, step, has_next, dirGI, dirH, dirS, dirDGH);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }

@@ -91,6 +91,16 @@ template <int KC, class P>
 static int gg(var_ctx* c, hipStream_t s, const P& p, int batches) {
     return ith(c)->bf16 ? gg_launch<P, KC, true>(c, s, p, batches) : gg_launch<P, KC, false>(c, s, p, batches);
 }
+// bf16 mode: operand copies (written by the GRU step kernels / gru_bf16_convert_x) instead of the fp32 arrays, where the
+// staged kernel takes the resulting shape -- the big products are bound by their operand traffic
+template <class P>
+static void use_bf16_copies(var_ctx* c, P& p, const void* a16, const void* b16) {
+    if (!ith(c)->bf16) return;
+    P q = p;
+    if (a16) { q.A = (const float*)a16; q.a16 = 1; }
+    if (b16) { q.Bm = (const float*)b16; q.b16 = 1; }
+    if (dense16::eligible(q)) p = q;
+}
 // dense products: in bf16 mode the LDS-staged kernel of dense_bf16.h where its alignment conditions hold
 template <bool AK, bool BK, int MODE>
 static int gg(var_ctx* c, hipStream_t s, const DenseP<AK, BK, MODE>& p, int batches = 1) {
@@ -496,6 +506,10 @@ static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* imag
             p.A = P + L.w_ih[0]; p.sam = kGin; p.sak = 1; p.zA = dirP;
             p.Bm = st->s[3]; p.sbk = 1; p.sbn = kGin; p.zB = 0;
             p.C = st->GI; p.scm = 1; p.scn = kG3; p.zC = dirGI; p.bias = P + L.b_ih[0]; p.zbias = dirP;
+            if (st->bf16) {
+                RUN(gru_bf16_convert_x(c, s, st->s[3], (long)rows * kGin, 2 * st->maxB, st->gruws));
+                use_bf16_copies(c, p, nullptr, gru_bf16_x16(st->gruws, 2 * st->maxB));
+            }
             RUN(gg(c, s, p, 2));
         }
         for (int d = 0; d < 2; ++d) VAR_HIP_CHECK(c, hipMemsetAsync(st->Hb + d * dirH, 0, sizeof(float) * nclips * kGh, s));
@@ -624,6 +638,12 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             p.A = st->Hb; p.sam = 1; p.sak = kGh; p.zA = dirH;
             p.Bm = st->DGH; p.sbk = kG3; p.sbn = 1; p.zB = dirDGH;
             p.C = st->slab; p.scm = 1; p.scn = kGh; p.zC = one; p.sC = 2 * one;
+            {
+                auto q = p;
+                q.zA = (long)(kSeq + 1) * nclips * kGh;
+                use_bf16_copies(c, q, gru_bf16_h16(st->gruws), gru_bf16_dgh16(st->gruws, 2 * st->maxB));
+                if (q.a16) p = q;
+            }
             RUN(gg(c, s, p, 2));
             for (int d = 0; d < 2; ++d) RUN(slab_reduce(c, s, G + L.w_hh[d], st->slab + d * one, (int)one, p.nsplit, 2 * one));
             // dW_ih[dir][g][i] = sum_{clip,t} DGI[dir][clip,t][g] * X[clip,t][i]
@@ -632,6 +652,8 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             p.A = st->s[3]; p.sam = 1; p.sak = kGin; p.zA = 0;
             p.Bm = st->DGI; p.sbk = kG3; p.sbn = 1; p.zB = dirGI;
             p.C = st->slab; p.scm = 1; p.scn = kGin; p.zC = onei; p.sC = 2 * onei;
+            p.a16 = p.b16 = 0;
+            use_bf16_copies(c, p, gru_bf16_x16(st->gruws, 2 * st->maxB), gru_bf16_dgi16(st->gruws, 2 * st->maxB));
             RUN(gg(c, s, p, 2));
             for (int d = 0; d < 2; ++d) RUN(slab_reduce(c, s, G + L.w_ih[d], st->slab + d * onei, (int)onei, p.nsplit, 2 * onei));
         }
@@ -644,11 +666,13 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             p.M = kGin; p.N = rows; p.K = kG3; p.nsplit = 1;
             p.A = P + L.w_ih[0]; p.sam = 1; p.sak = kGin; p.Bm = st->DGI; p.sbk = 1; p.sbn = kG3;
             p.C = st->gs[3]; p.scm = 1; p.scn = kGin;
+            use_bf16_copies(c, p, nullptr, gru_bf16_dgi16(st->gruws, 2 * st->maxB));
             RUN(gg(c, s, p));
             DenseP<false, true, 1> q{};
             q.M = kGin; q.N = rows; q.K = kG3; q.nsplit = 1;
             q.A = P + L.w_ih[1]; q.sam = 1; q.sak = kGin; q.Bm = st->DGI + dirGI; q.sbk = 1; q.sbn = kG3;
             q.C = st->gs[3]; q.scm = 1; q.scn = kGin;
+            use_bf16_copies(c, q, nullptr, (const unsigned short*)gru_bf16_dgi16(st->gruws, 2 * st->maxB) + dirGI);
             RUN(gg(c, s, q));
         }
         RUN(relu_mask(c, s, st->gs[3], st->s[3], (long)rows * kGin));

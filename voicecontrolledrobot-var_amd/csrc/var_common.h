@@ -264,6 +264,11 @@ int ithor_debug_buffer(var_ctx* c, const char* name, void** ptr, long* nfloats);
 
 // gru_bf16.hip: one launch per GRU time step and pass (recurrent product on bf16 MFMA + gate arithmetic), bf16 mode
 long gru_bf16_workspace_bytes(int maxclips);
+void* gru_bf16_h16(void* ws);                 // bf16 copies: states (dir, step 0..73, clip, 512)
+void* gru_bf16_dgh16(void* ws, int maxclips); //   gate gradients wrt gh (dir, step, clip, 1536)
+void* gru_bf16_dgi16(void* ws, int maxclips); //   gate gradients wrt gi (dir, clip*73+t, 1536)
+void* gru_bf16_x16(void* ws, int maxclips);   //   the input sequence (clip*73+t, 448)
+int gru_bf16_convert_x(var_ctx* c, hipStream_t s, const float* x, long n, int maxclips, void* ws);
 int gru_bf16_pack(var_ctx* c, hipStream_t s, const float* w_hh, long dirP, int nclips, void* ws);
 int gru_bf16_step_fwd(var_ctx* c, hipStream_t s, const float* GI, float* Hb, const float* b_hh, long dirP, float* R, float* Z,
                       float* Nn, float* GHN, int nclips, int maxclips, int step, long dirGI, long dirH, long dirS, int save, void* ws);
