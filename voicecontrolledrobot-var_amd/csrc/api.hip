@@ -523,7 +523,7 @@ static const char* kTagNames[TAG_COUNT] = {
     "(unused)", "(unused)", "(unused)", "img_wgrad_reduce_kernel",
     "snd_fwd_kernel", "snd_dgrad_kernel", "snd_wgrad_kernel", "snd_reduce_kernel", "heads_fwd_kernel",
     "heads_bwd_rows_kernel", "heads_bwd_gemm_kernel", "triplet_kernel", "adam_kernel", "pack_weights_kernel",
-    "mfcc_kernel", "gg_kernel<ConvFwdP<11x5 s2>>", "gg_kernel<ConvDgradS2P<11x5 s2>>", "gg_kernel<ConvWgradP<11x5 s2>>"};
+    "mfcc_kernel", "ithor conv 11x5 s2 forward", "ithor conv 11x5 s2 data gradient", "ithor conv 11x5 s2 weight gradient"};
 
 int var_profile_tag_count(void) { return TAG_COUNT; }
 const char* var_profile_tag_name(int tag) { return (tag >= 0 && tag < TAG_COUNT) ? kTagNames[tag] : ""; }

@@ -491,10 +491,11 @@ static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* imag
                                              st->s[1] + (long)off * 64 * 300 * 20)));
             off += B;
         }
-        {
+        if (st->bf16) {      // (times its main kernel under the same tag itself)
+            RUN(snd2_bf16_fwd(c, s, st->s[1], P + L.sw[1], P + L.sb[1], st->s[2], nclips, 2 * st->maxB, st->bfws));
+        } else {
             ProfScope prof(c, s, TAG_ITHOR_S2_FWD);
-            if (st->bf16) RUN(snd2_bf16_fwd(c, s, st->s[1], P + L.sw[1], P + L.sb[1], st->s[2], nclips, 2 * st->maxB, st->bfws));
-            else RUN((conv_fwd<GS2, false, false>(c, s, snd_dims(2, nclips), st->s[1], P + L.sw[1], P + L.sb[1], st->s[2])));
+            RUN((conv_fwd<GS2, false, false>(c, s, snd_dims(2, nclips), st->s[1], P + L.sw[1], P + L.sb[1], st->s[2])));
         }
         RUN((conv_fwd<GS3, false, true>(c, s, snd_dims(3, nclips), st->s[2], P + L.sw[2], P + L.sb[2], st->s[3])));
         const int rows = nclips * kSeq;
@@ -685,20 +686,20 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
         {
             const ConvDims d = snd_dims(2, nclips);
             if (st->bf16) RUN(snd2_bf16_prepare_gy(c, s, st->gs[2], nclips, 2 * st->maxB, st->bfws));
-            {
+            if (st->bf16) {
+                RUN(snd2_bf16_wgrad(c, s, G + L.sw[1], st->slab, nclips, 2 * st->maxB, st->bfws));
+            } else {
                 ProfScope prof(c, s, TAG_ITHOR_S2_WGRAD);
-                if (st->bf16) RUN(snd2_bf16_wgrad(c, s, G + L.sw[1], st->slab, nclips, 2 * st->maxB, st->bfws));
-                else RUN((conv_wgrad<GS2, false, false>(c, s, d, st->s[1], st->gs[2], G + L.sw[1])));
+                RUN((conv_wgrad<GS2, false, false>(c, s, d, st->s[1], st->gs[2], G + L.sw[1])));
             }
             RUN(chan_sum(c, s, st->gs[2], G + L.sb[1], nclips, 64, 150 * 13));
-            {
+            if (st->bf16) {     // (its store also yields the channel sums of gs[1]: conv 1's bias gradient)
+                int nparts = 0;
+                RUN(snd2_bf16_dgrad(c, s, P + L.sw[1], st->gs[1], st->bslab, &nparts, nclips, 2 * st->maxB, st->bfws));
+                RUN(slab_reduce(c, s, G + L.sb[0], st->bslab, 64, nparts, 64));
+            } else {
                 ProfScope prof(c, s, TAG_ITHOR_S2_DGRAD);
-                if (st->bf16) {     // (its store also yields the channel sums of gs[1]: conv 1's bias gradient)
-                    int nparts = 0;
-                    RUN(snd2_bf16_dgrad(c, s, P + L.sw[1], st->gs[1], st->bslab, &nparts, nclips, 2 * st->maxB, st->bfws));
-                    RUN(slab_reduce(c, s, G + L.sb[0], st->bslab, 64, nparts, 64));
-                }
-                else RUN((conv_dgrad<GS2, false>(c, s, d, st->gs[2], P + L.sw[1], st->gs[1], st->s[1])));
+                RUN((conv_dgrad<GS2, false>(c, s, d, st->gs[2], P + L.sw[1], st->gs[1], st->s[1])));
             }
         }
         {

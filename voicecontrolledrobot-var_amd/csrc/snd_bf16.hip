@@ -605,6 +605,7 @@ int snd2_bf16_fwd(var_ctx* c, hipStream_t s, const float* x, const float* w, con
         attr = true;
     }
     const int ntiles = nclips * TILES;
+    ProfScope prof(c, s, TAG_ITHOR_S2_FWD);
     hipLaunchKernelGGL(snd2_fwd_kernel, dim3(ntiles < 256 ? ntiles : 256), dim3(256), LDSB, s, x8, wp, bias, y, nclips);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
@@ -626,6 +627,7 @@ int snd2_bf16_dgrad(var_ctx* c, hipStream_t s, const float* w, float* dx, float*
     }
     const int ntiles = nclips * DG_TILES;
     *nparts = ntiles < 256 ? ntiles : 256;
+    ProfScope prof(c, s, TAG_ITHOR_S2_DGRAD);
     hipLaunchKernelGGL(snd2_dgrad_kernel, dim3(*nparts), dim3(256), DG_LDSB, s, gy8, wpt, mask, dx, bias_part, nclips);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
@@ -654,7 +656,10 @@ int snd2_bf16_wgrad(var_ctx* c, hipStream_t s, float* dw, float* slab, int nclip
     int groups = snd2_bf16_wgrad_groups(nclips);
     const int per = (nclips + groups - 1) / groups;
     groups = (nclips + per - 1) / per;
-    hipLaunchKernelGGL(snd2_wgrad_kernel, dim3(4 * groups), dim3(256), WG_LDSB, s, x8, gy8, slab, nclips, per);
+    {
+        ProfScope prof(c, s, TAG_ITHOR_S2_WGRAD);
+        hipLaunchKernelGGL(snd2_wgrad_kernel, dim3(4 * groups), dim3(256), WG_LDSB, s, x8, gy8, slab, nclips, per);
+    }
     VAR_HIP_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(snd2_wgrad_fold_kernel, dim3((NTAP * CO * CI + 255) / 256), dim3(256), 0, s, slab, dw, groups);
     VAR_HIP_CHECK(c, hipGetLastError());
