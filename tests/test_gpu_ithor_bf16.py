@@ -203,3 +203,27 @@ def test_dense_bf16_kernel_vs_float64_on_rounded_operands(var_amd, akf, bkf, M, 
     assert torch.isfinite(got).all()
     err = float((got - ref).abs().max())
     assert err < 2e-5 * float(ref.abs().max()) * max(1.0, (K / 512) ** 0.5), err
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_conv3_forward_bf16_kernel_vs_float64_on_rounded_operands(var_amd, B):
+    """The 7x3 stride-2 convolution through the geometry-templated staged kernel, reading conv 2's own C8 bf16 image
+    (written by conv 2's store) and writing the GRU's (clip, 73, 448) sequence."""
+    torch.manual_seed(5)
+    m = var_amd.IthorVARPretextNet(cfg(96)).to("cuda").set_precision("bf16")
+    pos, neg = sounds(B, 41 + B)
+    with torch.no_grad():
+        m(None, pos, neg)
+    from var_amd._lib import Context
+    ctx = Context.get(0)
+    n = 2 * B
+    s2 = ctx.debug_buffer("ithor_s2")[:n * 64 * 150 * 13].view(n, 64, 150, 13).cpu()
+    s3 = ctx.debug_buffer("ithor_s3")[:n * 73 * 448].view(n, 73, 64, 7).permute(0, 2, 1, 3).cpu()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    wk = [k for k, v in sd.items() if tuple(v.shape) == (64, 64, 7, 3)][0]
+    ref = torch.relu(torch.nn.functional.conv2d(bf16_round(s2), bf16_round(sd[wk]), sd[wk.replace("weight", "bias")].double(),
+                                                stride=2, padding=(1, 1)))
+    assert ref.shape == s3.shape
+    scale = float(ref.abs().max())
+    err = float((s3.double() - ref).abs().max())
+    assert scale > 0.05 and err < 2e-5 * max(scale, 1.0), (err, scale)

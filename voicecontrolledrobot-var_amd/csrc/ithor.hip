@@ -497,7 +497,8 @@ static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* imag
             ProfScope prof(c, s, TAG_ITHOR_S2_FWD);
             RUN((conv_fwd<GS2, false, false>(c, s, snd_dims(2, nclips), st->s[1], P + L.sw[1], P + L.sb[1], st->s[2])));
         }
-        RUN((conv_fwd<GS3, false, true>(c, s, snd_dims(3, nclips), st->s[2], P + L.sw[2], P + L.sb[2], st->s[3])));
+        if (st->bf16) RUN(snd3_bf16_fwd(c, s, P + L.sw[2], P + L.sb[2], st->s[3], nclips, 2 * st->maxB, st->bfws));
+        else RUN((conv_fwd<GS3, false, true>(c, s, snd_dims(3, nclips), st->s[2], P + L.sw[2], P + L.sb[2], st->s[3])));
         const int rows = nclips * kSeq;
         const long dirP = L.w_ih[1] - L.w_ih[0];
         const long dirGI = (long)rows * kG3, dirH = (long)(kSeq + 1) * nclips * kGh, dirS = (long)kSeq * nclips * kGh;

@@ -37,15 +37,6 @@ constexpr int CI = 64, CO = 64, HI = 300, WI = 20, HO = 150, WO = 13, KH = 11, K
 constexpr int NQ = 4;                         // quarters of 16 input channels
 constexpr int SLOT = 16;                      // bytes: 8 bf16 channels of one pixel
 constexpr int SUBP = 13 * SLOT;               // 208: sub-row pitch (10 data slots + 3 zero slots shared with the next row)
-constexpr int NR = 85;                        // patch rows of a 38-row tile
-constexpr int PARB = (NR + 6) * SUBP;         // one column-parity image (+ rows that only unused pixel slots touch)
-constexpr int PLANEB = 2 * PARB;              // one k-half
-constexpr int BUFB = 2 * PLANEB;              // one quarter
-constexpr int LDSB = 2 * BUFB + 8 * SUBP;
-static_assert(LDSB <= 160 * 1024, "LDS");
-constexpr int TILES = 4;
-__device__ __constant__ int kRow0[TILES] = {0, 38, 76, 113};
-__device__ __constant__ int kRows[TILES] = {38, 38, 37, 37};
 
 __device__ __forceinline__ unsigned bf16_bits(float x) {          // round to nearest even (no NaNs in this model)
     const unsigned u = __float_as_uint(x);
@@ -89,27 +80,61 @@ __global__ void __launch_bounds__(256) to_c8_mask_kernel(const float* __restrict
     mask[2 * i + 1] = mk[1];
 }
 
-// OIHW fp32 (64,64,11,5) -> fragment order [q][tap][cb][lane][8]: lane (r, h) of block cb holds
-// W[co = 32 cb + r][ci = 16 q + 8 h + j][tap], j = 0..7
-__global__ void __launch_bounds__(256) pack_w2_kernel(const float* __restrict__ w, uint4* __restrict__ wp) {
+// ---- forward --------------------------------------------------------------------------------------------------
+// One kernel for the model's two 64 -> 64 stride-2 sound convolutions: the geometry is a type.
+struct Geo2 {            // conv 2: 11x5, pad 5, (300,20) -> (150,13); 4 tiles of 38|38|37|37 output rows per clip
+    static constexpr int HI = 300, WI = 20, HO = 150, WO = 13, KH = 11, KW = 5, PH = 5, PW = 5, NSLOT = 13, TILES = 4, TROWS = 38;
+    static constexpr bool SEQ = false;
+    __device__ static int row0(int t) { return t < 2 ? 38 * t : 76 + 37 * (t - 2); }
+    __device__ static int rows(int t) { return t < 2 ? 38 : 37; }
+};
+struct Geo3 {            // conv 3: 7x3, pad 1, (150,13) -> (73,7) = 511 pixels: one tile per clip; stored as the GRU's sequence
+    static constexpr int HI = 150, WI = 13, HO = 73, WO = 7, KH = 7, KW = 3, PH = 1, PW = 1, NSLOT = 7, TILES = 1, TROWS = 73;
+    static constexpr bool SEQ = true;
+    __device__ static int row0(int) { return 0; }
+    __device__ static int rows(int) { return 73; }
+};
+template <class G>
+struct FwdLayout {
+    static constexpr int NTAP = G::KH * G::KW;
+    static constexpr int SUBP = G::NSLOT * SLOT;                  // sub-row pitch: data slots + zero slots shared with the next row
+    static constexpr int NR = 2 * G::TROWS + G::KH - 2;           // patch rows of the largest tile
+    static constexpr int PARB = (NR + 6) * SUBP;                  // one column-parity image (+ rows only unused pixel slots touch)
+    static constexpr int PLANEB = 2 * PARB, BUFB = 2 * PLANEB, LDSB = 2 * BUFB + 8 * SUBP;
+    static constexpr int NST = (2 * NR * G::WI + 255) / 256;      // staging slots per thread and quarter
+    static_assert(LDSB <= 160 * 1024, "LDS");
+    static_assert(G::TROWS * G::WO <= 512, "16 MFMA column blocks per tile");
+    // the zero slots: column c sits at parity (c + PW) & 1, slot (c + PW) >> 1; a tap reads slot ox + (kx >> 1) <= NSLOT + 1
+    static_assert((G::WO - 1) + ((G::KW - 1) >> 1) <= G::NSLOT + 1, "padding slots");
+};
+
+// OIHW fp32 (64,64,KH,KW) -> fragment order [q][tap][cb][lane][8]: lane (r, h) of block cb holds
+// W[co = 32 cb + r][ci = 16 q + 8 h + j][tap] (forward), or, T, W[co = 16 q + 8 h + j][ci = 32 cb + r][tap] (data gradient)
+template <bool T>
+__global__ void __launch_bounds__(256) pack_w_kernel(const float* __restrict__ w, uint4* __restrict__ wp, int ntap) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= NQ * NTAP * 2 * 64) return;
-    const int lane = i & 63, cb = (i >> 6) & 1, qt = i >> 7, tap = qt % NTAP, q = qt / NTAP;
-    const int co = 32 * cb + (lane & 31), ci0 = 16 * q + 8 * (lane >> 5);
+    if (i >= NQ * ntap * 2 * 64) return;
+    const int lane = i & 63, cb = (i >> 6) & 1, qt = i >> 7, tap = qt % ntap, q = qt / ntap;
+    const int r = 32 * cb + (lane & 31), k0 = 16 * q + 8 * (lane >> 5);
     unsigned v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = bf16_bits(w[((long)co * CI + ci0 + j) * NTAP + tap]);
+    for (int j = 0; j < 8; ++j) v[j] = bf16_bits(T ? w[((long)(k0 + j) * CI + r) * ntap + tap] : w[((long)r * CI + k0 + j) * ntap + tap]);
     wp[i] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
 }
 
-// ---- forward --------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) snd2_fwd_kernel(const uint4* __restrict__ x8, const uint4* __restrict__ wp,
-                                                       const float* __restrict__ bias, float* __restrict__ y, int nclips) {
+// y: bias + ReLU, fp32 NCHW or (SEQ) the (clip, oy, co*WO + ox) sequence; y8 / ymask (optional): the same values as the next
+// layer's C8 bf16 image and the sign words its data-gradient kernel stores through (to_c8_mask_kernel's layouts)
+template <class G>
+__global__ void __launch_bounds__(256) snd_fwd_kernel(const uint4* __restrict__ x8, const uint4* __restrict__ wp,
+                                                      const float* __restrict__ bias, float* __restrict__ y, uint2* __restrict__ y8,
+                                                      unsigned* __restrict__ ymask, int nclips) {
+    using L = FwdLayout<G>;
+    constexpr int WO = G::WO, KH = G::KH, KW = G::KW, NTAP = L::NTAP, SUBP = L::SUBP, PARB = L::PARB, PLANEB = L::PLANEB, BUFB = L::BUFB;
     extern __shared__ __align__(16) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p31 = lane & 31;
-    const int ntiles = nclips * TILES;
+    const int ntiles = nclips * G::TILES;
 
-    for (int i = tid; i < LDSB / 16; i += 256) ((uint4*)lds)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < L::LDSB / 16; i += 256) ((uint4*)lds)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
 
     // this lane's four pixel slots: byte offset of (input row 2 oyl, slot ox) in its k-half's images
@@ -120,38 +145,37 @@ __global__ void __launch_bounds__(256) snd2_fwd_kernel(const uint4* __restrict__
         abase[m] = h * PLANEB + oyl * 2 * SUBP + ox * SLOT;
     }
 
-    // staging: a quarter of a tile's patch = 2 planes x nrows x 20 slots, 14 slots per thread through registers.
-    // Column c of the map sits at parity (c + 5) & 1, slot (c + 5) >> 1 of its sub-row.
-    constexpr int NST = 14;
+    // staging: a quarter of a tile's patch = 2 planes x nrows x WI slots through registers.
+    // Column c of the map sits at parity (c + PW) & 1, slot (c + PW) >> 1 of its sub-row.
+    constexpr int NST = L::NST;
     uint4 sreg[NST];
     auto stage_load = [&](int tile, int q) {
-        const int clip = tile >> 2, t = tile & 3;
-        const int y0 = 2 * kRow0[t] - 5, nrows = 2 * kRows[t] + 9;
-        const uint4* src = x8 + ((long)clip * 8 + 2 * q) * (HI * WI);
+        const int clip = tile / G::TILES, t = tile - clip * G::TILES;
+        const int y0 = 2 * G::row0(t) - G::PH, nrows = 2 * G::rows(t) + KH - 2;
+        const uint4* src = x8 + ((long)clip * 8 + 2 * q) * (G::HI * G::WI);
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
             int e = tid + 256 * k;
             asm volatile("" : "+v"(e));                     // (loop-invariant otherwise: hipcc would keep all of it live)
-            const int hh = e >= nrows * WI ? 1 : 0, e2 = e - hh * nrows * WI;
-            const int i = e2 / WI, yy = y0 + i;
-            const bool ok = e2 < nrows * WI && (unsigned)yy < (unsigned)HI;
-            sreg[k] = ok ? src[(long)hh * (HI * WI) + (long)y0 * WI + e2] : make_uint4(0, 0, 0, 0);
+            const int hh = e >= nrows * G::WI ? 1 : 0, e2 = e - hh * nrows * G::WI;
+            const int i = e2 / G::WI, yy = y0 + i;
+            const bool ok = e2 < nrows * G::WI && (unsigned)yy < (unsigned)G::HI;
+            sreg[k] = ok ? src[(long)hh * (G::HI * G::WI) + (long)y0 * G::WI + e2] : make_uint4(0, 0, 0, 0);
         }
     };
     auto stage_store = [&](int tile, int buf) {
-        const int t = tile & 3;
-        const int nrows = 2 * kRows[t] + 9;
+        const int t = tile % G::TILES;
+        const int nrows = 2 * G::rows(t) + KH - 2;
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
             int e = tid + 256 * k;
             asm volatile("" : "+v"(e));
-            const int hh = e >= nrows * WI ? 1 : 0, e2 = e - hh * nrows * WI;
-            const int i = e2 / WI, c5 = e2 - i * WI + 5;
-            if (e2 < nrows * WI)
+            const int hh = e >= nrows * G::WI ? 1 : 0, e2 = e - hh * nrows * G::WI;
+            const int i = e2 / G::WI, c5 = e2 - i * G::WI + G::PW;
+            if (e2 < nrows * G::WI)
                 *(uint4*)(lds + buf * BUFB + hh * PLANEB + (c5 & 1) * PARB + i * SUBP + (c5 >> 1) * SLOT) = sreg[k];
         }
     };
-    static_assert(2 * NR * WI <= NST * 256, "staging registers");
 
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, NQ * NTAP * 2048, 0x00020000);
     int tile = blockIdx.x;
@@ -220,21 +244,37 @@ __global__ void __launch_bounds__(256) snd2_fwd_kernel(const uint4* __restrict__
             __syncthreads();
         }
 
-        // bias + ReLU, fp32 NCHW: lanes walk the pixels (128 contiguous bytes per channel and block)
-        const int clip = tile >> 2, t = tile & 3;
-        const int npx = kRows[t] * WO;
-        float* yo = y + (long)clip * CO * (HO * WO) + kRow0[t] * WO;
+        // bias + ReLU; lanes walk the pixels (NCHW: 128 contiguous bytes per channel and block)
+        const int clip = tile / G::TILES, t = tile - clip * G::TILES;
+        const int npx = G::rows(t) * WO, pix0 = G::row0(t) * WO;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int P = 128 * wave + 32 * m + p31;
             if (P < npx) {
+                unsigned mk = 0u;
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int co = 32 * cb + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        yo[(long)co * (HO * WO) + P] = fmaxf(acc[m][cb][r] + bias[co], 0.f);
+                    for (int g = 0; g < 4; ++g) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int co = 32 * cb + 8 * g + 4 * h + e;
+                            v[e] = fmaxf(acc[m][cb][4 * g + e] + bias[co], 0.f);
+                            if (G::SEQ) {
+                                const int oyl = P / WO, ox = P - oyl * WO;
+                                y[((long)clip * G::HO + oyl) * (CO * WO) + co * WO + ox] = v[e];
+                            } else {
+                                y[((long)clip * CO + co) * (G::HO * WO) + pix0 + P] = v[e];
+                            }
+                        }
+                        if (y8) {       // plane 4 cb + g, this lane's half (4 h .. 4 h + 3) of the pixel's 16-byte slot
+                            const unsigned b0 = bf16_bits(v[0]), b1 = bf16_bits(v[1]), b2 = bf16_bits(v[2]), b3 = bf16_bits(v[3]);
+                            y8[(((long)clip * 8 + 4 * cb + g) * (G::HO * WO) + pix0 + P) * 2 + h] = make_uint2(b0 | (b1 << 16), b2 | (b3 << 16));
+                            mk |= ((b0 ? 1u : 0u) | (b1 ? 2u : 0u) | (b2 ? 4u : 0u) | (b3 ? 8u : 0u)) << (16 * cb + 4 * g);
+                        }
                     }
+                if (y8) ymask[((long)clip * (G::HO * WO) + pix0 + P) * 2 + h] = mk;
             }
         }
     }
@@ -254,18 +294,6 @@ __global__ void __launch_bounds__(256) snd2_fwd_kernel(const uint4* __restrict__
 constexpr int DG_ROWS = 25, DG_TILES = 6, DG_PR = DG_ROWS + 5, DG_PLB = (DG_PR + 3) * SUBP, DG_BUFB = 8 * DG_PLB;
 constexpr int DG_LDSB = 2 * DG_BUFB;
 constexpr int WI2 = WI / 2;
-
-// OIHW fp32 -> [q][tap][cb][lane][8]: lane (r, h) of block cb holds W[co = 16 q + 8 h + j][ci = 32 cb + r][tap]
-__global__ void __launch_bounds__(256) pack_w2t_kernel(const float* __restrict__ w, uint4* __restrict__ wp) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= NQ * NTAP * 2 * 64) return;
-    const int lane = i & 63, cb = (i >> 6) & 1, qt = i >> 7, tap = qt % NTAP, q = qt / NTAP;
-    const int ci = 32 * cb + (lane & 31), co0 = 16 * q + 8 * (lane >> 5);
-    unsigned v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = bf16_bits(w[((long)(co0 + j) * CI + ci) * NTAP + tap]);
-    wp[i] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
-}
 
 template <int A>
 __device__ __forceinline__ void dgrad_pass(const unsigned char* __restrict__ img, const int (&abase)[4], __amdgpu_buffer_rsrc_t wq,
@@ -582,31 +610,64 @@ __global__ void __launch_bounds__(256) snd2_wgrad_fold_kernel(const float* __res
 
 }  // namespace
 
-// workspace (bytes) of the bf16 kernels for up to `nclips` clips: [x8 | gy8 | mask | wp | wpt]
-static inline long x8_bytes(int nclips) { return ((long)nclips * CI * HI * WI * 2 + 255) & ~255L; }
-static inline long gy8_bytes(int nclips) { return ((long)nclips * CO * HO * WO * 2 + 255) & ~255L; }
-constexpr long kWpBytes = (long)NQ * NTAP * 2 * 64 * 16;
-static inline long mask_bytes(int nclips) { return ((long)nclips * HI * WI * 8 + 255) & ~255L; }
-long snd_bf16_workspace_bytes(int nclips) { return x8_bytes(nclips) + gy8_bytes(nclips) + mask_bytes(nclips) + 2 * kWpBytes + 256; }
+// workspace of the bf16 sound kernels for up to mc clips (byte offsets, 256-aligned):
+//   x8    conv 1's output as C8 bf16 (mc, 8, 300*20) + m1: its sign words      (written by to_c8_mask_kernel)
+//   y8    conv 2's output as C8 bf16 (mc, 8, 150*13) + m2: its sign words      (written by conv 2's forward)
+//   gy8   gradient wrt conv 2's output, C8 bf16; g38: gradient wrt conv 3's output (mc, 8, 73*7), C8 bf16
+//   wp2 / wpt2 / wp3 / wpt3: fragment-ordered filters (forward / data gradient)
+struct BfWs { long x8, m1, y8, m2, gy8, g38, wp2, wpt2, wp3, wpt3, total; };
+constexpr long kWp2Bytes = (long)NQ * 55 * 2 * 64 * 16, kWp3Bytes = (long)NQ * 21 * 2 * 64 * 16;
+static BfWs bf_ws(int mc) {
+    BfWs w{};
+    long o = 0;
+    auto take = [&](long n) { const long at = o; o += (n + 255) & ~255L; return at; };
+    w.x8 = take((long)mc * CI * 300 * 20 * 2); w.m1 = take((long)mc * 300 * 20 * 8);
+    w.y8 = take((long)mc * CI * 150 * 13 * 2); w.m2 = take((long)mc * 150 * 13 * 8);
+    w.gy8 = take((long)mc * CO * 150 * 13 * 2); w.g38 = take((long)mc * CO * 73 * 7 * 2);
+    w.wp2 = take(kWp2Bytes); w.wpt2 = take(kWp2Bytes); w.wp3 = take(kWp3Bytes); w.wpt3 = take(kWp3Bytes);
+    w.total = o;
+    return w;
+}
+long snd_bf16_workspace_bytes(int nclips) { return bf_ws(nclips).total; }
+template <class T> static T* at(void* ws, long off) { return (T*)((char*)ws + off); }
 
+// conv 2 forward: y (fp32 NCHW) from x (fp32 NCHW, converted here); also leaves y's C8 image + sign words for conv 3
 int snd2_bf16_fwd(var_ctx* c, hipStream_t s, const float* x, const float* w, const float* bias, float* y, int nclips,
                   int maxclips, void* ws) {
-    uint4* x8 = (uint4*)ws;
-    unsigned* mask = (unsigned*)((char*)ws + x8_bytes(maxclips) + gy8_bytes(maxclips));
-    uint4* wp = (uint4*)((char*)ws + x8_bytes(maxclips) + gy8_bytes(maxclips) + mask_bytes(maxclips));
+    const BfWs o = bf_ws(maxclips);
+    using L = FwdLayout<Geo2>;
     const long total = (long)nclips * HI * WI;
-    hipLaunchKernelGGL(to_c8_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, x8, mask, total, HI * WI);
+    hipLaunchKernelGGL(to_c8_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, at<uint4>(ws, o.x8),
+                       at<unsigned>(ws, o.m1), total, HI * WI);
     VAR_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(pack_w2_kernel, dim3((NQ * NTAP * 128 + 255) / 256), dim3(256), 0, s, w, wp);
+    hipLaunchKernelGGL(pack_w_kernel<false>, dim3((NQ * L::NTAP * 128 + 255) / 256), dim3(256), 0, s, w, at<uint4>(ws, o.wp2), L::NTAP);
     VAR_HIP_CHECK(c, hipGetLastError());
     static bool attr = false;
     if (!attr) {
-        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd2_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd_fwd_kernel<Geo2>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDSB));
         attr = true;
     }
-    const int ntiles = nclips * TILES;
+    const int ntiles = nclips * Geo2::TILES;
     ProfScope prof(c, s, TAG_ITHOR_S2_FWD);
-    hipLaunchKernelGGL(snd2_fwd_kernel, dim3(ntiles < 256 ? ntiles : 256), dim3(256), LDSB, s, x8, wp, bias, y, nclips);
+    hipLaunchKernelGGL(snd_fwd_kernel<Geo2>, dim3(ntiles < 256 ? ntiles : 256), dim3(256), L::LDSB, s, at<uint4>(ws, o.x8),
+                       at<uint4>(ws, o.wp2), bias, y, at<uint2>(ws, o.y8), at<unsigned>(ws, o.m2), nclips);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}
+
+// conv 3 forward: the GRU's input sequence y (clip, 73, 448), fp32, from conv 2's C8 image in the workspace
+int snd3_bf16_fwd(var_ctx* c, hipStream_t s, const float* w, const float* bias, float* y, int nclips, int maxclips, void* ws) {
+    const BfWs o = bf_ws(maxclips);
+    using L = FwdLayout<Geo3>;
+    hipLaunchKernelGGL(pack_w_kernel<false>, dim3((NQ * L::NTAP * 128 + 255) / 256), dim3(256), 0, s, w, at<uint4>(ws, o.wp3), L::NTAP);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    static bool attr = false;
+    if (!attr) {
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd_fwd_kernel<Geo3>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDSB));
+        attr = true;
+    }
+    hipLaunchKernelGGL(snd_fwd_kernel<Geo3>, dim3(nclips < 256 ? nclips : 256), dim3(256), L::LDSB, s, at<uint4>(ws, o.y8),
+                       at<uint4>(ws, o.wp3), bias, y, (uint2*)nullptr, (unsigned*)nullptr, nclips);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }
@@ -615,10 +676,11 @@ int snd2_bf16_fwd(var_ctx* c, hipStream_t s, const float* x, const float* w, con
 // bias_part: gridDim x 64 partial channel sums of dx (the bias gradient of the layer below); returns the grid size in *nparts
 int snd2_bf16_dgrad(var_ctx* c, hipStream_t s, const float* w, float* dx, float* bias_part, int* nparts, int nclips, int maxclips,
                     void* ws) {
-    uint4* gy8 = (uint4*)((char*)ws + x8_bytes(maxclips));
-    const unsigned* mask = (const unsigned*)((char*)ws + x8_bytes(maxclips) + gy8_bytes(maxclips));
-    uint4* wpt = (uint4*)((char*)ws + x8_bytes(maxclips) + gy8_bytes(maxclips) + mask_bytes(maxclips) + kWpBytes);
-    hipLaunchKernelGGL(pack_w2t_kernel, dim3((NQ * NTAP * 128 + 255) / 256), dim3(256), 0, s, w, wpt);
+    const BfWs o = bf_ws(maxclips);
+    uint4* gy8 = at<uint4>(ws, o.gy8);
+    const unsigned* mask = at<unsigned>(ws, o.m1);
+    uint4* wpt = at<uint4>(ws, o.wpt2);
+    hipLaunchKernelGGL(pack_w_kernel<true>, dim3((NQ * NTAP * 128 + 255) / 256), dim3(256), 0, s, w, wpt, NTAP);
     VAR_HIP_CHECK(c, hipGetLastError());
     static bool attr = false;
     if (!attr) {
@@ -635,7 +697,7 @@ int snd2_bf16_dgrad(var_ctx* c, hipStream_t s, const float* w, float* dx, float*
 
 // gy (fp32 NCHW, already masked) -> its bf16 C8 image in the workspace: once per backward, before the two kernels that read it
 int snd2_bf16_prepare_gy(var_ctx* c, hipStream_t s, const float* gy, int nclips, int maxclips, void* ws) {
-    uint4* gy8 = (uint4*)((char*)ws + x8_bytes(maxclips));
+    uint4* gy8 = at<uint4>(ws, bf_ws(maxclips).gy8);
     const long total = (long)nclips * 8 * HO * WO;
     hipLaunchKernelGGL(to_c8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, gy, gy8, total, 8, HO * WO);
     VAR_HIP_CHECK(c, hipGetLastError());
@@ -646,8 +708,8 @@ int snd2_bf16_prepare_gy(var_ctx* c, hipStream_t s, const float* gy, int nclips,
 // snd2_bf16_wgrad_groups(nclips) * 55*64*64 floats
 int snd2_bf16_wgrad_groups(int nclips) { return nclips < 64 ? nclips : 64; }
 int snd2_bf16_wgrad(var_ctx* c, hipStream_t s, float* dw, float* slab, int nclips, int maxclips, void* ws) {
-    const uint4* x8 = (const uint4*)ws;
-    const uint4* gy8 = (const uint4*)((char*)ws + x8_bytes(maxclips));
+    const uint4* x8 = at<uint4>(ws, bf_ws(maxclips).x8);
+    const uint4* gy8 = at<uint4>(ws, bf_ws(maxclips).gy8);
     static bool attr = false;
     if (!attr) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd2_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDSB));
