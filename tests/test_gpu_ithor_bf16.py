@@ -227,3 +227,29 @@ def test_conv3_forward_bf16_kernel_vs_float64_on_rounded_operands(var_amd, B):
     scale = float(ref.abs().max())
     err = float((s3.double() - ref).abs().max())
     assert scale > 0.05 and err < 2e-5 * max(scale, 1.0), (err, scale)
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_conv3_data_gradient_bf16_kernel_vs_float64_on_rounded_operands(var_amd, B):
+    """conv 3's staged data-gradient kernel: gs2 against the transposed convolution of the bf16-rounded operands, masked by
+    conv 2's sign words; its by-products: conv 2's bias gradient (channel sums of gs2) and -- checked through conv 2's own
+    gradient tests above -- the C8 image of gs2."""
+    m, tr, buf, _, _ = _after_backward(var_amd, B, 51 + B)
+    from var_amd._lib import Context
+    n = 2 * B
+    gs3 = Context.get(0).debug_buffer("ithor_gs3")[:n * 73 * 448].view(n, 73, 64, 7).permute(0, 2, 1, 3).cpu()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    wk = [k for k, v in sd.items() if tuple(v.shape) == (64, 64, 7, 3)][0]
+    ref = torch.nn.functional.conv_transpose2d(bf16_round(gs3), bf16_round(sd[wk]), stride=2, padding=(1, 1), output_padding=(1, 0))
+    ref = ref * (bf16_round(buf["s2"]) > 0)
+    assert ref.shape == buf["gs2"].shape
+    scale = float(ref.abs().max())
+    err = float((buf["gs2"].double() - ref).abs().max())
+    assert scale > 0 and err < 2e-5 * scale, (err, scale)
+    g, o = tr.grads.cpu().double(), 0
+    for k, p in m.named_parameters():
+        if k == wk.replace("weight", "bias").replace("cnn.4", "cnn.2"):
+            got = g[o:o + p.numel()]
+        o += p.numel()
+    want = buf["gs2"].double().sum((0, 2, 3))
+    assert float((got - want).abs().max()) < 1e-5 * float(buf["gs2"].abs().double().sum((0, 2, 3)).max())

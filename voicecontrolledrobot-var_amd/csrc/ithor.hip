@@ -682,18 +682,24 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             const ConvDims d = snd_dims(3, nclips);
             RUN((conv_wgrad<GS3, false, true>(c, s, d, st->s[2], st->gs[3], G + L.sw[2])));
             RUN(chan_sum(c, s, st->gs[3], G + L.sb[2], nclips * kSeq, 64, 7));
-            RUN((conv_dgrad<GS3, true>(c, s, d, st->gs[3], P + L.sw[2], st->gs[2], st->s[2])));
+            if (st->bf16) {     // (also leaves gs[2]'s C8 image for conv 2's kernels and the channel sums of gs[2] = conv 2's bias gradient)
+                int nparts = 0;
+                RUN(snd3_bf16_dgrad(c, s, st->gs[3], P + L.sw[2], st->gs[2], st->bslab, &nparts, nclips, 2 * st->maxB, st->bfws));
+                RUN(slab_reduce(c, s, G + L.sb[1], st->bslab, 64, nparts, 64));
+            } else {
+                RUN((conv_dgrad<GS3, true>(c, s, d, st->gs[3], P + L.sw[2], st->gs[2], st->s[2])));
+            }
         }
         {
             const ConvDims d = snd_dims(2, nclips);
-            if (st->bf16) RUN(snd2_bf16_prepare_gy(c, s, st->gs[2], nclips, 2 * st->maxB, st->bfws));
+
             if (st->bf16) {
                 RUN(snd2_bf16_wgrad(c, s, G + L.sw[1], st->slab, nclips, 2 * st->maxB, st->bfws));
             } else {
                 ProfScope prof(c, s, TAG_ITHOR_S2_WGRAD);
                 RUN((conv_wgrad<GS2, false, false>(c, s, d, st->s[1], st->gs[2], G + L.sw[1])));
             }
-            RUN(chan_sum(c, s, st->gs[2], G + L.sb[1], nclips, 64, 150 * 13));
+            if (!st->bf16) RUN(chan_sum(c, s, st->gs[2], G + L.sb[1], nclips, 64, 150 * 13));
             if (st->bf16) {     // (its store also yields the channel sums of gs[1]: conv 1's bias gradient)
                 int nparts = 0;
                 RUN(snd2_bf16_dgrad(c, s, P + L.sw[1], st->gs[1], st->bslab, &nparts, nclips, 2 * st->maxB, st->bfws));

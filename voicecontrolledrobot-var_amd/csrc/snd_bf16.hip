@@ -281,48 +281,66 @@ __global__ void __launch_bounds__(256) snd_fwd_kernel(const uint4* __restrict__ 
 }
 
 // ---- data gradient ---------------------------------------------------------------------------------------------
-// dx[ci][iy][ix] = sum_{co,ky,kx} gy[co][(iy+5-ky)/2][(ix+5-kx)/2] W[co][ci][ky][kx] over the taps of matching parity:
-// the four pixel-parity classes (a, b) = (iy & 1, ix & 1) are four stride-1 correlations of the gy map with
-// (5|6) x (2|3) taps, dy = (a+5-ky)/2 in -2..3, dx = (b+5-kx)/2 in 1..3 -- the column never leaves the map, rows outside
-// it are staged as zeros.  Tile: one clip x 25 rows u x 10 columns v (250 pixel slots = 8 MFMA column blocks); wave
-// (wm, cb) owns 4 column blocks and one 32-channel row block for BOTH column parities b: a pixel pair (2v, 2v+1) ends
-// up in one lane, so the store is 8 bytes per lane and 80 contiguous bytes per map row (4-byte stores at an 8-byte
-// stride, one parity at a time, made this kernel 4x slower than its arithmetic).  The two row parities a are two passes
-// over the same gy patch (30 rows, all 64 channels: 8 planes of 16-byte slots, 55 KB, double-buffered).  A filter row's
-// five taps read three distinct pixel fragments (dx = 3 | 2, 2 | 1, 1).  The ReLU mask of the layer below comes as one
-// 32-bit word per (pixel, lane half), laid out by the forward's conversion kernel in this epilogue's register order.
-constexpr int DG_ROWS = 25, DG_TILES = 6, DG_PR = DG_ROWS + 5, DG_PLB = (DG_PR + 3) * SUBP, DG_BUFB = 8 * DG_PLB;
-constexpr int DG_LDSB = 2 * DG_BUFB;
-constexpr int WI2 = WI / 2;
+// dx[ci][iy][ix] = sum_{co,ky,kx} gy[co][(iy+PH-ky)/2][(ix+PW-kx)/2] W[co][ci][ky][kx] over the taps of matching parity:
+// the four pixel-parity classes (a, b) = (iy & 1, ix & 1) are four stride-1 correlations of the gy map, dy = (a+PH-ky)/2,
+// dx = (b+PW-kx)/2 -- rows outside the map are staged as zeros, the column never leaves the map (+ one zero slot).
+// Tile: one clip x ROWS rows u x V column pairs v; wave (wm, cb) owns MB column blocks and one 32-channel row block for
+// BOTH column parities b: a pixel pair (2v, 2v+1) ends up in one lane, so a map row is stored as 8 contiguous bytes per
+// lane (4-byte stores at an 8-byte stride, one parity at a time, made the first version 4x slower than its arithmetic).
+// The two row parities a are two passes over the same gy patch (all 64 channels: 8 planes of 16-byte slots,
+// double-buffered).  A filter row's taps read (KW+1)/2 distinct pixel fragments.  The ReLU mask of the layer below
+// comes as one 32-bit word per (pixel, lane half) in this epilogue's register order (written by the forward / the
+// conversion kernel); the store also yields the channel sums of dx (the bias gradient of the layer below) and, on
+// request, dx as the C8 bf16 image the layer below's own gradient kernels read.
+struct DGeo2 {           // conv 2: dx (300,20) from gy (150,13); 6 tiles of 25 rows u
+    static constexpr int HI = 300, WI = 20, HO = 150, WO = 13, KH = 11, KW = 5, PH = 5, PW = 5;
+    static constexpr int ROWS = 25, TILES = 6, MB = 4, NSLOT = 13;
+};
+struct DGeo3 {           // conv 3: dx (150,13) from gy (73,7); 3 tiles of 25 rows u; the 7th pixel pair of a row is half empty
+    static constexpr int HI = 150, WI = 13, HO = 73, WO = 7, KH = 7, KW = 3, PH = 1, PW = 1;
+    static constexpr int ROWS = 25, TILES = 3, MB = 3, NSLOT = 8;
+};
+template <class G>
+struct DgLayout {
+    static constexpr int NTAP = G::KH * G::KW, V = (G::WI + 1) / 2, NSET = (G::KW + 1) / 2, DXMAX = (1 + G::PW) / 2;
+    static constexpr int DYMIN = (G::PH - (G::KH - 2)) / 2;       // a = 0, the last odd ky (exact: PH and KH are odd): -2 for both layers
+    static constexpr int DYMAX = (1 + G::PH) / 2;
+    static constexpr int PR = G::ROWS + DYMAX - DYMIN, SUBP = G::NSLOT * SLOT, PLB = (PR + 3) * SUBP, BUFB = 8 * PLB, LDSB = 2 * BUFB;
+    static constexpr int NSL = 8 * PR * G::WO, NST = (NSL + 255) / 256;
+    static_assert(G::PH % 2 == 1 && G::PW % 2 == 1 && DYMIN == -2, "tap parities");
+    static_assert(2 * 32 * G::MB >= G::ROWS * V && G::ROWS * G::TILES * 2 >= G::HI, "tile");
+    static_assert((V - 1) + DXMAX < G::NSLOT + (G::NSLOT > G::WO ? 0 : 1) || G::NSLOT > G::WO, "zero slot");
+};
 
-template <int A>
-__device__ __forceinline__ void dgrad_pass(const unsigned char* __restrict__ img, const int (&abase)[4], __amdgpu_buffer_rsrc_t wq,
-                                           int wlane, const unsigned* __restrict__ mask, int mshift, float* __restrict__ dxo,
-                                           int u0, int wm, int p31, int h, float (&bsum)[16]) {
-    constexpr int NKY = A ? 6 : 5, NROW = NQ * NKY;
-    f32x16_t acc[4][2];
+template <class G, int A>
+__device__ __forceinline__ void dgrad_pass(const unsigned char* __restrict__ img, const int (&abase)[G::MB], __amdgpu_buffer_rsrc_t wq,
+                                           int wlane, const unsigned* __restrict__ mask, int cb, float* __restrict__ dxo,
+                                           uint2* __restrict__ dx8, int u0, int wm, int p31, int h, float (&bsum)[16]) {
+    using L = DgLayout<G>;
+    constexpr int KW = G::KW, MB = G::MB, NSET = L::NSET, NKY = A ? (G::KH + 1) / 2 : G::KH / 2, NROW = NQ * NKY;
+    f32x16_t acc[MB][2];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][b][r] = 0.f;
     // row R = (q, i): ky = 2 i + 1 - A
-    auto wofs = [](int R, int kx) { const int q = R / NKY, i = R - q * NKY; return (q * NTAP + (2 * i + 1 - A) * KW + kx) * 2048; };
-    auto aofs = [](int R, int d) {              // pixel fragment set d: dx = 3 - d
+    auto wofs = [](int R, int kx) { const int q = R / NKY, i = R - q * NKY; return (q * L::NTAP + (2 * i + 1 - A) * KW + kx) * 2048; };
+    auto aofs = [](int R, int d) {              // pixel fragment set d: dx = DXMAX - d
         const int q = R / NKY, i = R - q * NKY, ky = 2 * i + 1 - A;
-        return 2 * q * DG_PLB + ((A + 5 - ky) / 2 + 2) * SUBP + (3 - d) * SLOT;
+        return 2 * q * L::PLB + ((A + G::PH - ky) / 2 - L::DYMIN) * L::SUBP + (L::DXMAX - d) * SLOT;
     };
     u32x4_t wrow[3][KW];
-    bf16x8_t a[2][3][4];
+    bf16x8_t a[2][NSET][MB];
 #pragma unroll
     for (int R = 0; R < 2; ++R)
 #pragma unroll
         for (int kx = 0; kx < KW; ++kx) wrow[R][kx] = wload(wq, wlane, wofs(R, kx));
 #pragma unroll
-    for (int d = 0; d < 3; ++d)
+    for (int d = 0; d < NSET; ++d)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) a[0][d][m] = *(const bf16x8_t*)(img + abase[m] + aofs(0, d));
+        for (int m = 0; m < MB; ++m) a[0][d][m] = *(const bf16x8_t*)(img + abase[m] + aofs(0, d));
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int R = 0; R < NROW; ++R) {
@@ -333,68 +351,83 @@ __device__ __forceinline__ void dgrad_pass(const unsigned char* __restrict__ img
         }
         if (R + 1 < NROW) {
 #pragma unroll
-            for (int d = 0; d < 3; ++d)
+            for (int d = 0; d < NSET; ++d)
 #pragma unroll
-                for (int m = 0; m < 4; ++m) a[ac ^ 1][d][m] = *(const bf16x8_t*)(img + abase[m] + aofs(R + 1, d));
+                for (int m = 0; m < MB; ++m) a[ac ^ 1][d][m] = *(const bf16x8_t*)(img + abase[m] + aofs(R + 1, d));
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kx = 0; kx < KW; ++kx) {
-            const int b = (kx + 1) & 1, d = (kx + 1) >> 1;            // kx 0 | 1 2 | 3 4 -> dx 3 | 2 2 | 1 1
+            const int b = (kx + 1) & 1, d = (kx + 1) >> 1;            // kx 0 | 1 2 | 3 4 -> dx DXMAX | DXMAX-1 (x2) | DXMAX-2 (x2)
             const bf16x8_t w = __builtin_bit_cast(bf16x8_t, wrow[R % 3][kx]);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a[ac][d][m], acc[m][b], 0, 0, 0);
+            for (int m = 0; m < MB; ++m) acc[m][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a[ac][d][m], acc[m][b], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    // masked store: this lane's pixel pair (iy, 2v | 2v+1), channels 8 g + 4 h + j of its 32-channel block = register
-    // 4 g + j = bit 16 cb + 4 g + j of the pixel's mask word (dxo points at the block)
+    // masked store: this lane's pixel pair (iy, 2v | 2v+1), channels 32 cb + 8 g + 4 h + e = register 4 g + e = bit
+    // 16 cb + 4 g + e of the pixel's mask word (dxo points at the clip)
+    constexpr bool EVEN = G::WI % 2 == 0;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int P = 128 * wm + 32 * m + p31, ul = P / WI2, v = P - ul * WI2;
-        if (P < DG_ROWS * WI2) {
-            const int pix = (2 * (u0 + ul) + A) * WI + 2 * v;
-            const unsigned m0 = mask[2 * pix + h] >> mshift, m1 = mask[2 * pix + 2 + h] >> mshift;
+    for (int m = 0; m < MB; ++m) {
+        const int P = 32 * MB * wm + 32 * m + p31, ul = P / L::V, v = P - ul * L::V, iy = 2 * (u0 + ul) + A;
+        if (P < G::ROWS * L::V && iy < G::HI) {
+            const int pix = iy * G::WI + 2 * v;
+            const bool two = EVEN || 2 * v + 1 < G::WI;
+            const unsigned m0 = mask[2 * pix + h] >> (16 * cb), m1 = two ? mask[2 * pix + 2 + h] >> (16 * cb) : 0u;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ci = (r & 3) + 8 * (r >> 2) + 4 * h;
-                float2 o;
-                o.x = (m0 >> r) & 1u ? acc[m][0][r] : 0.f;
-                o.y = (m1 >> r) & 1u ? acc[m][1][r] : 0.f;
-                *(float2*)(dxo + (long)ci * (HI * WI) + pix) = o;
-                bsum[r] += o.x + o.y;                     // the bias gradient of the layer below: channel sums of dx
+            for (int g = 0; g < 4; ++g) {
+                float2 o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    o[e].x = (m0 >> r) & 1u ? acc[m][0][r] : 0.f;
+                    o[e].y = (m1 >> r) & 1u ? acc[m][1][r] : 0.f;
+                    float* q = dxo + (long)(32 * cb + 8 * g + 4 * h + e) * (G::HI * G::WI) + pix;
+                    if (EVEN) *(float2*)q = o[e];
+                    else { q[0] = o[e].x; if (two) q[1] = o[e].y; }
+                    bsum[r] += o[e].x + o[e].y;           // the bias gradient of the layer below: channel sums of dx
+                }
+                if (dx8) {      // plane 4 cb + g of the C8 image, this lane's half of the two pixels' slots
+                    uint2* q8 = dx8 + ((long)(4 * cb + g) * (G::HI * G::WI) + pix) * 2 + h;
+                    q8[0] = make_uint2(bf16_bits(o[0].x) | (bf16_bits(o[1].x) << 16), bf16_bits(o[2].x) | (bf16_bits(o[3].x) << 16));
+                    if (two) q8[2] = make_uint2(bf16_bits(o[0].y) | (bf16_bits(o[1].y) << 16), bf16_bits(o[2].y) | (bf16_bits(o[3].y) << 16));
+                }
             }
         }
     }
 }
 
-__global__ void __launch_bounds__(256) snd2_dgrad_kernel(const uint4* __restrict__ gy8, const uint4* __restrict__ wp,
-                                                         const unsigned* __restrict__ mask, float* __restrict__ dx,
-                                                         float* __restrict__ bias_part, int nclips) {
+template <class G>
+__global__ void __launch_bounds__(256) snd_dgrad_kernel(const uint4* __restrict__ gy8, const uint4* __restrict__ wp,
+                                                        const unsigned* __restrict__ mask, float* __restrict__ dx, uint2* __restrict__ dx8,
+                                                        float* __restrict__ bias_part, int nclips) {
+    using L = DgLayout<G>;
+    constexpr int MB = G::MB;
     extern __shared__ __align__(16) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p31 = lane & 31;
     const int wm = wave & 1, cb = wave >> 1;
     float bsum[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) bsum[r] = 0.f;
-    const int ntiles = nclips * DG_TILES;
-    int abase[4];
+    const int ntiles = nclips * G::TILES;
+    int abase[MB];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int P = 128 * wm + 32 * m + p31, ul = P / WI2, v = P - ul * WI2;
-        abase[m] = h * DG_PLB + ul * SUBP + v * SLOT;
+    for (int m = 0; m < MB; ++m) {
+        const int P = 32 * MB * wm + 32 * m + p31, ul = P / L::V, v = P - ul * L::V;
+        abase[m] = h * L::PLB + ul * L::SUBP + v * SLOT;
     }
-    constexpr int NSL = 8 * DG_PR * WO, NST = (NSL + 255) / 256;          // 3120 slots, 13 per thread
+    constexpr int NSL = L::NSL, NST = L::NST;
     uint4 sreg[NST];
     auto stage_load = [&](int tile) {
-        const int clip = tile / DG_TILES, t = tile - clip * DG_TILES, oy0 = DG_ROWS * t - 2;
+        const int clip = tile / G::TILES, t = tile - clip * G::TILES, oy0 = G::ROWS * t + L::DYMIN;
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
             int e = tid + 256 * k;
             asm volatile("" : "+v"(e));                     // keep the slots' index arithmetic out of the registers
-            const int pl = e / (DG_PR * WO), e2 = e - pl * (DG_PR * WO), oy = oy0 + e2 / WO;
-            const bool ok = e < NSL && (unsigned)oy < (unsigned)HO;
-            sreg[k] = ok ? gy8[((long)clip * 8 + pl) * (HO * WO) + oy0 * WO + e2] : make_uint4(0, 0, 0, 0);
+            const int pl = e / (L::PR * G::WO), e2 = e - pl * (L::PR * G::WO), oy = oy0 + e2 / G::WO;
+            const bool ok = e < NSL && (unsigned)oy < (unsigned)G::HO;
+            sreg[k] = ok ? gy8[((long)clip * 8 + pl) * (G::HO * G::WO) + oy0 * G::WO + e2] : make_uint4(0, 0, 0, 0);
         }
     };
     auto stage_store = [&](int buf) {
@@ -402,29 +435,30 @@ __global__ void __launch_bounds__(256) snd2_dgrad_kernel(const uint4* __restrict
         for (int k = 0; k < NST; ++k) {
             int e = tid + 256 * k;
             asm volatile("" : "+v"(e));
-            const int pl = e / (DG_PR * WO), e2 = e - pl * (DG_PR * WO);
-            if (e < NSL) *(uint4*)(lds + buf * DG_BUFB + pl * DG_PLB + e2 * SLOT) = sreg[k];
+            const int pl = e / (L::PR * G::WO), e2 = e - pl * (L::PR * G::WO), i = e2 / G::WO;
+            if (e < NSL) *(uint4*)(lds + buf * L::BUFB + pl * L::PLB + i * L::SUBP + (e2 - i * G::WO) * SLOT) = sreg[k];
         }
     };
-    // (rows DG_PR .. DG_PR+2 of a plane are only read by the unused pixel slots 250..255)
-    for (int i = tid; i < DG_LDSB / 16; i += 256) ((uint4*)lds)[i] = make_uint4(0, 0, 0, 0);
+    // (rows past the patch and the slots past a row's WO pixels are only read by unused pixel slots / as the zero column)
+    for (int i = tid; i < L::LDSB / 16; i += 256) ((uint4*)lds)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     int tile = blockIdx.x;
     if (tile < ntiles) { stage_load(tile); stage_store(0); }
     __syncthreads();
-    const __amdgpu_buffer_rsrc_t wq = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, NQ * NTAP * 2048, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wq = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, NQ * L::NTAP * 2048, 0x00020000);
     const int wlane = cb * 1024 + lane * 16;
     int buf = 0;
     for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
-        const int clip = tile / DG_TILES, t = tile - clip * DG_TILES, u0 = DG_ROWS * t;
-        const unsigned* mk = mask + (long)clip * (HI * WI) * 2;
-        float* dxo = dx + ((long)clip * CI + 32 * cb) * (HI * WI);
+        const int clip = tile / G::TILES, t = tile - clip * G::TILES, u0 = G::ROWS * t;
+        const unsigned* mk = mask + (long)clip * (G::HI * G::WI) * 2;
+        float* dxo = dx + (long)clip * CI * (G::HI * G::WI);
+        uint2* dx8o = dx8 ? dx8 + (long)clip * 8 * (G::HI * G::WI) * 2 : nullptr;
         const int ntile = tile + (int)gridDim.x;
-        const unsigned char* img = lds + buf * DG_BUFB;
-        dgrad_pass<0>(img, abase, wq, wlane, mk, 16 * cb, dxo, u0, wm, p31, h, bsum);
+        const unsigned char* img = lds + buf * L::BUFB;
+        dgrad_pass<G, 0>(img, abase, wq, wlane, mk, cb, dxo, dx8o, u0, wm, p31, h, bsum);
         if (ntile < ntiles) stage_load(ntile);
         __builtin_amdgcn_sched_barrier(0);
-        dgrad_pass<1>(img, abase, wq, wlane, mk, 16 * cb, dxo, u0, wm, p31, h, bsum);
+        dgrad_pass<G, 1>(img, abase, wq, wlane, mk, cb, dxo, dx8o, u0, wm, p31, h, bsum);
         if (ntile < ntiles) stage_store(buf ^ 1);
         __syncthreads();
     }
@@ -439,6 +473,19 @@ __global__ void __launch_bounds__(256) snd2_dgrad_kernel(const uint4* __restrict
     }
     __syncthreads();
     if (tid < 64) bias_part[blockIdx.x * 64 + tid] = red[(2 * (tid >> 5)) * 32 + (tid & 31)] + red[(2 * (tid >> 5) + 1) * 32 + (tid & 31)];
+}
+
+// gradient wrt conv 3's output: the (clip, oy, co*7 + ox) sequence, fp32 -> C8 bf16 (clip, 8, 73*7)
+__global__ void __launch_bounds__(256) seq_to_c8_kernel(const float* __restrict__ g, uint4* __restrict__ y, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;              // (clip*8 + plane) * 511 + pix
+    if (i >= total) return;
+    const int pix = (int)(i % 511), oy = pix / 7, ox = pix - oy * 7;
+    const long pl = i / 511, clip = pl >> 3;
+    const float* src = g + (clip * 73 + oy) * 448 + (pl & 7) * 56 + ox;
+    unsigned v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = bf16_bits(src[7 * j]);
+    y[i] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
 }
 
 // ---- weight gradient -------------------------------------------------------------------------------------------
@@ -672,27 +719,44 @@ int snd3_bf16_fwd(var_ctx* c, hipStream_t s, const float* w, const float* bias, 
     return VAR_OK;
 }
 
-// dx (fp32 NCHW, masked by the sign of the forward's bf16 image of x) from the prepared gy image
-// bias_part: gridDim x 64 partial channel sums of dx (the bias gradient of the layer below); returns the grid size in *nparts
-int snd2_bf16_dgrad(var_ctx* c, hipStream_t s, const float* w, float* dx, float* bias_part, int* nparts, int nclips, int maxclips,
-                    void* ws) {
-    const BfWs o = bf_ws(maxclips);
-    uint4* gy8 = at<uint4>(ws, o.gy8);
-    const unsigned* mask = at<unsigned>(ws, o.m1);
-    uint4* wpt = at<uint4>(ws, o.wpt2);
-    hipLaunchKernelGGL(pack_w_kernel<true>, dim3((NQ * NTAP * 128 + 255) / 256), dim3(256), 0, s, w, wpt, NTAP);
+template <class G>
+static int dgrad_launch(var_ctx* c, hipStream_t s, const float* w, const uint4* gy8, uint4* wpt, const unsigned* mask, float* dx,
+                        uint2* dx8, float* bias_part, int* nparts, int nclips, int tag) {
+    using L = DgLayout<G>;
+    hipLaunchKernelGGL(pack_w_kernel<true>, dim3((NQ * L::NTAP * 128 + 255) / 256), dim3(256), 0, s, w, wpt, L::NTAP);
     VAR_HIP_CHECK(c, hipGetLastError());
     static bool attr = false;
     if (!attr) {
-        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd2_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DG_LDSB));
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd_dgrad_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDSB));
         attr = true;
     }
-    const int ntiles = nclips * DG_TILES;
+    const int ntiles = nclips * G::TILES;
     *nparts = ntiles < 256 ? ntiles : 256;
-    ProfScope prof(c, s, TAG_ITHOR_S2_DGRAD);
-    hipLaunchKernelGGL(snd2_dgrad_kernel, dim3(*nparts), dim3(256), DG_LDSB, s, gy8, wpt, mask, dx, bias_part, nclips);
+    ProfScope prof(c, s, tag);
+    hipLaunchKernelGGL(snd_dgrad_kernel<G>, dim3(*nparts), dim3(256), L::LDSB, s, gy8, wpt, mask, dx, dx8, bias_part, nclips);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
+}
+
+// conv 2: dx (fp32 NCHW, masked by conv 1's sign words) from the gy image in the workspace
+// bias_part: *nparts x 64 partial channel sums of dx (the bias gradient of the layer below)
+int snd2_bf16_dgrad(var_ctx* c, hipStream_t s, const float* w, float* dx, float* bias_part, int* nparts, int nclips, int maxclips,
+                    void* ws) {
+    const BfWs o = bf_ws(maxclips);
+    return dgrad_launch<DGeo2>(c, s, w, at<uint4>(ws, o.gy8), at<uint4>(ws, o.wpt2), at<unsigned>(ws, o.m1), dx, nullptr, bias_part,
+                               nparts, nclips, TAG_ITHOR_S2_DGRAD);
+}
+
+// conv 3: gy (the masked gradient of the GRU's input sequence, fp32) -> dx (fp32 NCHW, masked by conv 2's sign words), its C8
+// image (= conv 2's gy image: no snd2_bf16_prepare_gy needed afterwards) and the partial channel sums of dx
+int snd3_bf16_dgrad(var_ctx* c, hipStream_t s, const float* gy_seq, const float* w, float* dx, float* bias_part, int* nparts,
+                    int nclips, int maxclips, void* ws) {
+    const BfWs o = bf_ws(maxclips);
+    const long total = (long)nclips * 8 * 511;
+    hipLaunchKernelGGL(seq_to_c8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, gy_seq, at<uint4>(ws, o.g38), total);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return dgrad_launch<DGeo3>(c, s, w, at<uint4>(ws, o.g38), at<uint4>(ws, o.wpt3), at<unsigned>(ws, o.m2), dx, at<uint2>(ws, o.gy8),
+                               bias_part, nparts, nclips, -1);
 }
 
 // gy (fp32 NCHW, already masked) -> its bf16 C8 image in the workspace: once per backward, before the two kernels that read it

@@ -256,6 +256,8 @@ long snd_bf16_workspace_bytes(int nclips);
 int snd2_bf16_fwd(var_ctx* c, hipStream_t s, const float* x, const float* w, const float* bias, float* y, int nclips,
                   int maxclips, void* ws);
 int snd3_bf16_fwd(var_ctx* c, hipStream_t s, const float* w, const float* bias, float* y, int nclips, int maxclips, void* ws);
+int snd3_bf16_dgrad(var_ctx* c, hipStream_t s, const float* gy_seq, const float* w, float* dx, float* bias_part, int* nparts,
+                    int nclips, int maxclips, void* ws);
 int snd2_bf16_prepare_gy(var_ctx* c, hipStream_t s, const float* gy, int nclips, int maxclips, void* ws);
 int snd2_bf16_dgrad(var_ctx* c, hipStream_t s, const float* w, float* dx, float* bias_part, int* nparts, int nclips, int maxclips,
                     void* ws);
