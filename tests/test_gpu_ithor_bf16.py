@@ -253,3 +253,20 @@ def test_conv3_data_gradient_bf16_kernel_vs_float64_on_rounded_operands(var_amd,
         o += p.numel()
     want = buf["gs2"].double().sum((0, 2, 3))
     assert float((got - want).abs().max()) < 1e-5 * float(buf["gs2"].abs().double().sum((0, 2, 3)).max())
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_conv3_weight_gradient_bf16_kernel_vs_float64_on_rounded_operands(var_amd, B):
+    m, tr, buf, _, _ = _after_backward(var_amd, B, 61 + B)
+    from var_amd._lib import Context
+    n = 2 * B
+    gs3 = Context.get(0).debug_buffer("ithor_gs3")[:n * 73 * 448].view(n, 73, 64, 7).permute(0, 2, 1, 3).cpu()
+    g, o = tr.grads.cpu(), 0
+    for k, p in m.named_parameters():
+        if tuple(p.shape) == (64, 64, 7, 3):
+            got = g[o:o + p.numel()].view(p.shape)
+        o += p.numel()
+    ref = torch.nn.grad.conv2d_weight(bf16_round(buf["s2"]), (64, 64, 7, 3), bf16_round(gs3), stride=2, padding=(1, 1))
+    scale = float(ref.abs().max())
+    err = float((got.double() - ref).abs().max())
+    assert scale > 0 and err < 1e-4 * scale, (err, scale)

@@ -680,12 +680,13 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
         RUN(relu_mask(c, s, st->gs[3], st->s[3], (long)rows * kGin));
         {
             const ConvDims d = snd_dims(3, nclips);
-            RUN((conv_wgrad<GS3, false, true>(c, s, d, st->s[2], st->gs[3], G + L.sw[2])));
+            if (!st->bf16) RUN((conv_wgrad<GS3, false, true>(c, s, d, st->s[2], st->gs[3], G + L.sw[2])));
             RUN(chan_sum(c, s, st->gs[3], G + L.sb[2], nclips * kSeq, 64, 7));
             if (st->bf16) {     // (also leaves gs[2]'s C8 image for conv 2's kernels and the channel sums of gs[2] = conv 2's bias gradient)
                 int nparts = 0;
                 RUN(snd3_bf16_dgrad(c, s, st->gs[3], P + L.sw[2], st->gs[2], st->bslab, &nparts, nclips, 2 * st->maxB, st->bfws));
                 RUN(slab_reduce(c, s, G + L.sb[1], st->bslab, 64, nparts, 64));
+                RUN(snd3_bf16_wgrad(c, s, G + L.sw[2], st->slab, nclips, 2 * st->maxB, st->bfws));      // (reads the dgrad's gy image)
             } else {
                 RUN((conv_dgrad<GS3, true>(c, s, d, st->gs[3], P + L.sw[2], st->gs[2], st->s[2])));
             }

@@ -33,10 +33,9 @@ __device__ __forceinline__ u32x4_t wload(__amdgpu_buffer_rsrc_t r, int lane_off,
 
 namespace {
 
-constexpr int CI = 64, CO = 64, HI = 300, WI = 20, HO = 150, WO = 13, KH = 11, KW = 5, NTAP = KH * KW;
+constexpr int CI = 64, CO = 64, HI = 300, WI = 20, HO = 150, WO = 13;      // conv 2 (the conversion kernels' callers)
 constexpr int NQ = 4;                         // quarters of 16 input channels
 constexpr int SLOT = 16;                      // bytes: 8 bf16 channels of one pixel
-constexpr int SUBP = 13 * SLOT;               // 208: sub-row pitch (10 data slots + 3 zero slots shared with the next row)
 
 __device__ __forceinline__ unsigned bf16_bits(float x) {          // round to nearest even (no NaNs in this model)
     const unsigned u = __float_as_uint(x);
@@ -489,24 +488,39 @@ __global__ void __launch_bounds__(256) seq_to_c8_kernel(const float* __restrict_
 }
 
 // ---- weight gradient -------------------------------------------------------------------------------------------
-// dW[co][ci][ky][kx] = sum_{n,oy,ox} gy[n][co][oy][ox] x[n][ci][2oy-5+ky][2ox-5+kx]: the MFMA's k index is the PIXEL,
+// dW[co][ci][ky][kx] = sum_{n,oy,ox} gy[n][co][oy][ox] x[n][ci][2oy-PH+ky][2ox-PW+kx]: the MFMA's k index is the PIXEL,
 // so both operands are read from their channel-innermost LDS images with the transposing ds_read_b64_tr_b16 (4 pixels
 // x 16 channels per 16-lane group; each lane supplies its own row address, so the stride-2 walk through the x patch
-// costs nothing).  A workgroup owns one 32-channel block of ci and one half of the 55 taps for a group of clips; wave w
-// owns 7 taps and both 32-row blocks of co: 14 accumulators (224 registers) that live across all the clips of the
-// group and are written once, to the group's slab (tap, co, ci); a fold adds the slabs in fixed order.
-// Tile = 12 output rows; a k-step is ONE output row (13 pixels + 3 slots whose gy is zero): 19 % of the matrix work is
-// padding, but every operand address is a per-lane constant plus an immediate (with 16 consecutive pixels per k-step
-// the row/column split of each pixel cost more instruction issue than the matrix instructions themselves -- one wave
-// per SIMD hides nothing).  x patch 33 rows x 4 planes (parity-split as in the forward), gy 8 planes x 12 rows x 16
-// slots, double-buffered (2 x 79 KB); every thread stages 20 fixed slots per tile, one pair per k-step, loaded a whole
-// tile before they are stored.
-constexpr int WG_TR = 12, WG_TILES = 13, WG_XR = 2 * WG_TR + 9, WG_KS = WG_TR;
-constexpr int WG_XPARB = WG_XR * SUBP, WG_XPL = 2 * WG_XPARB + 160;       // plane pitches = 64 mod 256: the four planes a
-constexpr int WG_GPL = WG_TR * 256 + 64;                                  // half-wave reads fall on disjoint banks
-constexpr int WG_XB = 4 * WG_XPL, WG_BUFB = WG_XB + 8 * WG_GPL, WG_LDSB = 2 * WG_BUFB;
-static_assert(WG_XPL % 256 == 64 && WG_GPL % 256 == 64 && WG_LDSB <= 160 * 1024, "wgrad LDS");
-constexpr int WG_TAPS = 7;                                                // per wave
+// costs nothing).  A workgroup owns one 32-channel block of ci and 4 x TAPS taps for a group of clips; wave w owns TAPS
+// taps and both 32-row blocks of co: 2 x TAPS accumulators that live across all the clips of the group and are written
+// once, to the group's slab (tap, co, ci); a fold adds the slabs in fixed order.
+// A k-step is RPK whole output rows (conv 2: one row of 13 pixels; conv 3: two rows of 7) padded to 16 slots whose gy
+// is zero: 12-19 % of the matrix work is padding, but every operand address is a per-lane constant plus an immediate
+// (with 16 consecutive pixels per k-step the row/column split of each pixel cost more instruction issue than the
+// matrix instructions themselves -- one wave per SIMD hides nothing).  x patch 4 planes (parity-split as in the
+// forward), gy 8 planes x 16 slots per k-step, double-buffered; every thread stages 20 fixed slots per tile, one pair
+// per k-step, loaded a whole tile before they are stored.
+struct WGeo2 {           // conv 2: 13 tiles of 12 output rows, 2 tap halves of 28
+    static constexpr int HI = 300, WI = 20, HO = 150, WO = 13, KH = 11, KW = 5, PH = 5, PW = 5, NSLOT = 13;
+    static constexpr int TR = 12, TILES = 13, RPK = 1, TAPS = 7, NTH = 2;
+};
+struct WGeo3 {           // conv 3: 4 tiles of 20 output rows, all 21 taps in one workgroup (6 per wave)
+    static constexpr int HI = 150, WI = 13, HO = 73, WO = 7, KH = 7, KW = 3, PH = 1, PW = 1, NSLOT = 7;
+    static constexpr int TR = 20, TILES = 4, RPK = 2, TAPS = 6, NTH = 1;
+};
+template <class G>
+struct WgLayout {
+    static constexpr int NTAP = G::KH * G::KW, KS = G::TR / G::RPK, XR = 2 * G::TR + G::KH - 2, SUBP = G::NSLOT * SLOT;
+    static constexpr int XPARB = XR * SUBP;
+    static constexpr int XPL = 2 * XPARB + (64 - (2 * XPARB) % 256 + 256) % 256;     // plane pitches = 64 mod 256: the four planes a
+    static constexpr int GPL = KS * 256 + 64;                                        // half-wave reads fall on disjoint banks
+    static constexpr int XB = 4 * XPL, BUFB = XB + 8 * GPL, LDSB = 2 * BUFB;
+    static constexpr int XP = 256 / G::WI, NP = (XR + XP - 1) / XP;                  // x rows per staging pass, passes
+    static constexpr int NPAIR = (4 * NP + 8 + 1) / 2;
+    static_assert(XPL % 256 == 64 && GPL % 256 == 64 && LDSB <= 160 * 1024, "wgrad LDS");
+    static_assert(G::TR % G::RPK == 0 && G::RPK * G::WO <= 16 && G::TR * G::WO <= 256 && NPAIR <= KS, "wgrad tile");
+    static_assert(G::TILES * G::TR >= G::HO && 4 * G::TAPS * G::NTH >= NTAP, "wgrad cover");
+};
 
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x8_t tr_read2(const unsigned char* p0, const unsigned char* p1) {
@@ -515,61 +529,70 @@ __device__ __forceinline__ bf16x8_t tr_read2(const unsigned char* p0, const unsi
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__global__ void __launch_bounds__(256) snd2_wgrad_kernel(const uint4* __restrict__ x8, const uint4* __restrict__ gy8,
-                                                         float* __restrict__ slab, int nclips, int per_group) {
+template <class G>
+__global__ void __launch_bounds__(256) snd_wgrad_kernel(const uint4* __restrict__ x8, const uint4* __restrict__ gy8,
+                                                        float* __restrict__ slab, int nclips, int per_group) {
+    using L = WgLayout<G>;
+    constexpr int TAPS = G::TAPS, KS = L::KS, NPAIR = L::NPAIR, NTAP = L::NTAP, SUBP = L::SUBP, NXS = 4 * L::NP;
     extern __shared__ __align__(16) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int g16 = (lane >> 4) & 1, qp = (lane & 15) >> 2, p = lane & 3;
-    const int cib = blockIdx.x & 1, th = (blockIdx.x >> 1) & 1, grp = blockIdx.x >> 2;
+    const int cib = blockIdx.x & 1, th = (blockIdx.x >> 1) % G::NTH, grp = (blockIdx.x >> 1) / G::NTH;
     const int clip_lo = grp * per_group, clip_hi = min(nclips, clip_lo + per_group);
-    const int ntiles = (clip_hi - clip_lo) * WG_TILES;
+    const int ntiles = (clip_hi - clip_lo) * G::TILES;
 
-    for (int i = tid; i < WG_LDSB / 16; i += 256) ((uint4*)lds)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < L::LDSB / 16; i += 256) ((uint4*)lds)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
 
-    // per lane: plane / half-slot of its 4 channels and its pixel (8 h + qp [+ 4]) of a row; plus this wave's taps
-    // (the 55th slot of the last wave repeats tap 54 and is not stored)
-    const int xlane = (2 * g16 + (p >> 1)) * WG_XPL + 8 * (p & 1) + (8 * h + qp) * SLOT;
-    const int glane = WG_XB + (2 * g16 + (p >> 1)) * WG_GPL + 8 * (p & 1) + (8 * h + qp) * SLOT;
-    int tapbase[WG_TAPS];
+    // per lane: plane / half-slot of its 4 channels and, for each of its two reads of a k-step, its pixel: slot
+    // 8 h + qp (+ 4) of the k-step = (row within the k-step, column); plus this wave's taps (slots past the layer's last
+    // tap repeat it and are not stored)
+    const int chan = (2 * g16 + (p >> 1)), half8 = 8 * (p & 1);
+    const int glane = L::XB + chan * L::GPL + half8 + (8 * h + qp) * SLOT;
+    int xl[2];
 #pragma unroll
-    for (int i = 0; i < WG_TAPS; ++i) {
-        const int t = min(th * 28 + WG_TAPS * wave + i, NTAP - 1), ky = t / KW, kx = t - ky * KW;
-        tapbase[i] = xlane + (kx & 1) * WG_XPARB + ky * SUBP + (kx >> 1) * SLOT;
+    for (int rd = 0; rd < 2; ++rd) {
+        const int idx = 8 * h + 4 * rd + qp, rs = G::RPK == 1 ? 0 : idx / G::WO, ox = idx - rs * G::WO;
+        xl[rd] = chan * L::XPL + half8 + rs * 2 * SUBP + ox * SLOT;
+    }
+    int tapbase[TAPS][2];
+#pragma unroll
+    for (int i = 0; i < TAPS; ++i) {
+        const int t = min(th * 4 * TAPS + TAPS * wave + i, NTAP - 1), ky = t / G::KW, kx = t - ky * G::KW;
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) tapbase[i][rd] = xl[rd] + (kx & 1) * L::XPARB + ky * SUBP + (kx >> 1) * SLOT;
     }
 
-    // staging, fixed slots per thread: x = 4 planes x 3 passes of 12 rows x 20 columns (threads 0..239), gy = 8 planes x
-    // 156 pixels (threads 0..155)
-    const int xr = tid / WI, xc = tid - xr * WI, xc5 = xc + 5;
-    const bool xthr = tid < 12 * WI, gthr = tid < WG_TR * WO;
-    const int xdst = (xc5 & 1) * WG_XPARB + xr * SUBP + (xc5 >> 1) * SLOT;
-    const int grow = tid / WO, gdst = WG_XB + (grow * 16 + (tid - grow * WO)) * SLOT;
-    constexpr int NPAIR = 10;                            // 12 x slots + 8 gy slots per thread
-    static_assert(NPAIR <= WG_KS, "one slot pair per k-step");
+    // staging, fixed slots per thread: x = 4 planes x NP passes of XP rows x WI columns, gy = 8 planes x TR*WO pixels
+    const int xr = tid / G::WI, xc = tid - xr * G::WI, xc5 = xc + G::PW;
+    const bool xthr = tid < L::XP * G::WI, gthr = tid < G::TR * G::WO;
+    const int xdst = (xc5 & 1) * L::XPARB + xr * SUBP + (xc5 >> 1) * SLOT;
+    const int grow = tid / G::WO;
+    const int gdst = L::XB + (grow / G::RPK) * 256 + ((grow % G::RPK) * G::WO + (tid - grow * G::WO)) * SLOT;
     auto slot_load = [&](int tile, int k) -> uint4 {
-        const int clip = clip_lo + tile / WG_TILES, t = tile % WG_TILES, oy0 = WG_TR * t;
-        if (k < 12) {
-            const int pl = k / 3, i = xr + 12 * (k % 3), yy = 2 * oy0 - 5 + i;
-            const bool ok = xthr && i < WG_XR && (unsigned)yy < (unsigned)HI;
-            return ok ? x8[((long)clip * 8 + 4 * cib + pl) * (HI * WI) + yy * WI + xc] : make_uint4(0, 0, 0, 0);
+        const int clip = clip_lo + tile / G::TILES, t = tile % G::TILES, oy0 = G::TR * t;
+        if (k < NXS) {
+            const int pl = k / L::NP, i = xr + L::XP * (k % L::NP), yy = 2 * oy0 - G::PH + i;
+            const bool ok = xthr && i < L::XR && (unsigned)yy < (unsigned)G::HI;
+            return ok ? x8[((long)clip * 8 + 4 * cib + pl) * (G::HI * G::WI) + yy * G::WI + xc] : make_uint4(0, 0, 0, 0);
         }
-        const int pl = k - 12;
-        const bool ok = gthr && oy0 + grow < HO;
-        return ok ? gy8[((long)clip * 8 + pl) * (HO * WO) + oy0 * WO + tid] : make_uint4(0, 0, 0, 0);
+        const int pl = k - NXS;
+        const bool ok = pl < 8 && gthr && oy0 + grow < G::HO;
+        return ok ? gy8[((long)clip * 8 + pl) * (G::HO * G::WO) + oy0 * G::WO + tid] : make_uint4(0, 0, 0, 0);
     };
     auto slot_store = [&](int buf, int k, uint4 v) {
-        unsigned char* base = lds + buf * WG_BUFB;
-        if (k < 12) {
-            const int pl = k / 3, i = xr + 12 * (k % 3);
-            if (xthr && i < WG_XR) *(uint4*)(base + pl * WG_XPL + xdst + 12 * (k % 3) * SUBP) = v;
-        } else if (gthr) {
-            *(uint4*)(base + (k - 12) * WG_GPL + gdst) = v;
+        unsigned char* base = lds + buf * L::BUFB;
+        if (k < NXS) {
+            const int pl = k / L::NP, i = xr + L::XP * (k % L::NP);
+            if (xthr && i < L::XR) *(uint4*)(base + pl * L::XPL + xdst + L::XP * (k % L::NP) * SUBP) = v;
+        } else if (k - NXS < 8 && gthr) {
+            *(uint4*)(base + (k - NXS) * L::GPL + gdst) = v;
         }
     };
 
-    f32x16_t acc[WG_TAPS][2];
+    f32x16_t acc[TAPS][2];
 #pragma unroll
-    for (int i = 0; i < WG_TAPS; ++i)
+    for (int i = 0; i < TAPS; ++i)
 #pragma unroll
         for (int cob = 0; cob < 2; ++cob)
 #pragma unroll
@@ -591,31 +614,31 @@ __global__ void __launch_bounds__(256) snd2_wgrad_kernel(const uint4* __restrict
 #pragma unroll 1
     for (int tile = 0; tile < ntiles; ++tile) {
         const int buf = tile & 1;
-        const unsigned char* img = lds + buf * WG_BUFB;
+        const unsigned char* img = lds + buf * L::BUFB;
         const bool have1 = tile + 1 < ntiles, have2 = tile + 2 < ntiles;
-        bf16x8_t a[2][2], b[2][WG_TAPS];
-        // fragment f of k-step ks (= output row ks: x rows 2 ks + ky): f = 0, 1: gy for the two co blocks; 2 + i: x for tap i
+        bf16x8_t a[2][2], b[2][TAPS];
+        // fragment f of k-step ks (output rows RPK ks ..: x rows 2 RPK ks + ky): f = 0, 1: gy for the two co blocks; 2 + i: x for tap i
         auto frag = [&](int ks, int set, int f) {
-            if (f < 2) a[set][f] = tr_read2(img + glane + f * 4 * WG_GPL + ks * 256, img + glane + f * 4 * WG_GPL + ks * 256 + 64);
-            else b[set][f - 2] = tr_read2(img + tapbase[f - 2] + ks * 2 * SUBP, img + tapbase[f - 2] + ks * 2 * SUBP + 64);
+            if (f < 2) a[set][f] = tr_read2(img + glane + f * 4 * L::GPL + ks * 256, img + glane + f * 4 * L::GPL + ks * 256 + 64);
+            else b[set][f - 2] = tr_read2(img + tapbase[f - 2][0] + ks * G::RPK * 2 * SUBP, img + tapbase[f - 2][1] + ks * G::RPK * 2 * SUBP);
         };
 #pragma unroll
-        for (int f = 0; f < 9; ++f) frag(0, 0, f);
+        for (int f = 0; f < TAPS + 2; ++f) frag(0, 0, f);
         __builtin_amdgcn_sched_barrier(0);
         // One wave per SIMD: whatever is not issued in the shadow of a matrix instruction is paid in full, and hipcc
         // neither interleaves the transposed reads by itself nor under sched_group_barrier -- so the order is pinned by
         // hand: per pair of matrix instructions one or two fragments of the next k-step, the staging behind the last ones.
 #pragma unroll
-        for (int ks = 0; ks < WG_KS; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             const int set = ks & 1;
 #pragma unroll
-            for (int i = 0; i < WG_TAPS; ++i) {
-                if (ks + 1 < WG_KS) {
+            for (int i = 0; i < TAPS; ++i) {
+                if (ks + 1 < KS) {
                     if (i < 2) { frag(ks + 1, set ^ 1, 2 * i); frag(ks + 1, set ^ 1, 2 * i + 1); }
                     else frag(ks + 1, set ^ 1, i + 2);
                 }
-                if (ks < NPAIR && i >= WG_TAPS - 2) {
-                    const int q = i - (WG_TAPS - 2);
+                if (ks < NPAIR && i >= TAPS - 2) {
+                    const int q = i - (TAPS - 2);
                     if (have1) slot_store(buf ^ 1, 2 * ks + q, st[ks][q]);
                     if (have2) st[ks][q] = slot_load(tile + 2, 2 * ks + q);
                 }
@@ -631,9 +654,9 @@ __global__ void __launch_bounds__(256) snd2_wgrad_kernel(const uint4* __restrict
     // slab[grp][tap][co][ci]: lanes walk ci
     float* out = slab + (long)grp * NTAP * CO * CI + 32 * cib + (lane & 31);
 #pragma unroll
-    for (int i = 0; i < WG_TAPS; ++i) {
-        const int t = th * 28 + WG_TAPS * wave + i;
-        if (t < NTAP && (th == 1 || t < 28)) {
+    for (int i = 0; i < TAPS; ++i) {
+        const int t = th * 4 * TAPS + TAPS * wave + i;
+        if (t < NTAP) {
 #pragma unroll
             for (int cob = 0; cob < 2; ++cob)
 #pragma unroll
@@ -646,13 +669,13 @@ __global__ void __launch_bounds__(256) snd2_wgrad_kernel(const uint4* __restrict
 }
 
 // dW (OIHW) += sum over the groups' slabs (tap, co, ci), in group order
-__global__ void __launch_bounds__(256) snd2_wgrad_fold_kernel(const float* __restrict__ slab, float* __restrict__ dw, int ngroups) {
+__global__ void __launch_bounds__(256) snd_wgrad_fold_kernel(const float* __restrict__ slab, float* __restrict__ dw, int ngroups, int ntap) {
     const int i = blockIdx.x * 256 + threadIdx.x;              // (tap, co, ci)
-    if (i >= NTAP * CO * CI) return;
+    if (i >= ntap * CO * CI) return;
     float a = 0.f;
-    for (int g = 0; g < ngroups; ++g) a += slab[(long)g * NTAP * CO * CI + i];
+    for (int g = 0; g < ngroups; ++g) a += slab[(long)g * ntap * CO * CI + i];
     const int ci = i & 63, co = (i >> 6) & 63, t = i >> 12;
-    dw[((long)co * CI + ci) * NTAP + t] += a;
+    dw[((long)co * CI + ci) * ntap + t] += a;
 }
 
 }  // namespace
@@ -768,26 +791,35 @@ int snd2_bf16_prepare_gy(var_ctx* c, hipStream_t s, const float* gy, int nclips,
     return VAR_OK;
 }
 
-// dW += the weight gradient from the forward's bf16 image of x and the prepared gy image; `slab` holds
-// snd2_bf16_wgrad_groups(nclips) * 55*64*64 floats
-int snd2_bf16_wgrad_groups(int nclips) { return nclips < 64 ? nclips : 64; }
-int snd2_bf16_wgrad(var_ctx* c, hipStream_t s, float* dw, float* slab, int nclips, int maxclips, void* ws) {
-    const uint4* x8 = at<uint4>(ws, bf_ws(maxclips).x8);
-    const uint4* gy8 = at<uint4>(ws, bf_ws(maxclips).gy8);
+// dW += the weight gradient from the bf16 images in the workspace (x: the layer's input, gy: the gradient wrt its output);
+// `slab` holds groups * NTAP*64*64 floats
+template <class G>
+static int wgrad_launch(var_ctx* c, hipStream_t s, const uint4* x8, const uint4* gy8, float* dw, float* slab, int nclips, int max_groups,
+                        int tag) {
+    using L = WgLayout<G>;
     static bool attr = false;
     if (!attr) {
-        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd2_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDSB));
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd_wgrad_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDSB));
         attr = true;
     }
-    int groups = snd2_bf16_wgrad_groups(nclips);
+    int groups = nclips < max_groups ? nclips : max_groups;
     const int per = (nclips + groups - 1) / groups;
     groups = (nclips + per - 1) / per;
     {
-        ProfScope prof(c, s, TAG_ITHOR_S2_WGRAD);
-        hipLaunchKernelGGL(snd2_wgrad_kernel, dim3(4 * groups), dim3(256), WG_LDSB, s, x8, gy8, slab, nclips, per);
+        ProfScope prof(c, s, tag);
+        hipLaunchKernelGGL(snd_wgrad_kernel<G>, dim3(2 * G::NTH * groups), dim3(256), L::LDSB, s, x8, gy8, slab, nclips, per);
     }
     VAR_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(snd2_wgrad_fold_kernel, dim3((NTAP * CO * CI + 255) / 256), dim3(256), 0, s, slab, dw, groups);
+    hipLaunchKernelGGL(snd_wgrad_fold_kernel, dim3((L::NTAP * CO * CI + 255) / 256), dim3(256), 0, s, slab, dw, groups, L::NTAP);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
+}
+int snd2_bf16_wgrad(var_ctx* c, hipStream_t s, float* dw, float* slab, int nclips, int maxclips, void* ws) {
+    const BfWs o = bf_ws(maxclips);
+    return wgrad_launch<WGeo2>(c, s, at<uint4>(ws, o.x8), at<uint4>(ws, o.gy8), dw, slab, nclips, 64, TAG_ITHOR_S2_WGRAD);
+}
+// conv 3: x = conv 2's C8 image (its forward's by-product), gy = the C8 image of the sequence gradient -- call after snd3_bf16_dgrad
+int snd3_bf16_wgrad(var_ctx* c, hipStream_t s, float* dw, float* slab, int nclips, int maxclips, void* ws) {
+    const BfWs o = bf_ws(maxclips);
+    return wgrad_launch<WGeo3>(c, s, at<uint4>(ws, o.y8), at<uint4>(ws, o.g38), dw, slab, nclips, 128, -1);
 }

@@ -261,8 +261,8 @@ int snd3_bf16_dgrad(var_ctx* c, hipStream_t s, const float* gy_seq, const float*
 int snd2_bf16_prepare_gy(var_ctx* c, hipStream_t s, const float* gy, int nclips, int maxclips, void* ws);
 int snd2_bf16_dgrad(var_ctx* c, hipStream_t s, const float* w, float* dx, float* bias_part, int* nparts, int nclips, int maxclips,
                     void* ws);
-int snd2_bf16_wgrad_groups(int nclips);
 int snd2_bf16_wgrad(var_ctx* c, hipStream_t s, float* dw, float* slab, int nclips, int maxclips, void* ws);
+int snd3_bf16_wgrad(var_ctx* c, hipStream_t s, float* dw, float* slab, int nclips, int maxclips, void* ws);   // after snd3_bf16_dgrad
 int ithor_debug_buffer(var_ctx* c, const char* name, void** ptr, long* nfloats);
 
 // gru_bf16.hip: one launch per GRU time step and pass (recurrent product on bf16 MFMA + gate arithmetic), bf16 mode
