@@ -152,16 +152,23 @@ __global__ void relu_mask_kernel(float* __restrict__ g, const float* __restrict_
 // (split-K weight gradients, bias-sum partials): what makes the gradients bitwise reproducible without atomics.
 __global__ void __launch_bounds__(256) slab_reduce_kernel(float* __restrict__ out, const float* __restrict__ slabs, int n,
                                                          int nsplit, long stride, int inner) {
-    // 64 outputs per workgroup; the four waves take the slabs s = w, w+4, ... and their sums are added in wave order
-    const int i = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    // 16 outputs per workgroup; 16 thread groups take the slabs s = g, g+16, ... (the small bias folds have up to 256 slabs
+    // and 64 outputs: with one slab chain per wave they were 15 us each, 30 of them per step) and their sums are added in
+    // group order
+    const int i = blockIdx.x * 16 + (threadIdx.x & 15), g = threadIdx.x >> 4;
     float acc = 0.f;
     if (i < n)
-        for (int s = w; s < nsplit; s += 4)
+        for (int s = g; s < nsplit; s += 16)
             for (int q = 0; q < inner; ++q) acc += slabs[s * stride + (long)i * inner + q];
-    __shared__ float red[4][64];
-    red[w][threadIdx.x & 63] = acc;
+    __shared__ float red[16][17];
+    red[g][threadIdx.x & 15] = acc;
     __syncthreads();
-    if (w == 0 && i < n) out[i] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (g == 0 && i < n) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[k][threadIdx.x];
+        out[i] += v;
+    }
 }
 
 // part[chunk*C + c] = sum over the chunk's share of {o < outer, i < inner} of g[(o*C + c)*inner + i]  (bias gradients
@@ -361,7 +368,7 @@ static int rec_split(int tiles, int kchunks, int cap) {
 }
 
 static int slab_reduce(var_ctx* c, hipStream_t s, float* out, const float* slabs, int n, int nsplit, long stride, int inner = 1) {
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, s, out, slabs, n, nsplit, stride, inner);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, s, out, slabs, n, nsplit, stride, inner);
     IT_CHECK(c);
     return VAR_OK;
 }
