@@ -135,7 +135,12 @@ def cpu_baseline(seconds=8.0):
 # ---- BASELINE.json configs[3] shape on ONE model replica per GPU: the iTHOR model (fp32 here; config 4 names bf16) ----
 ITHOR_FLOPS_FWD = 3318e6
 ITHOR_FLOPS_STEP = 3 * ITHOR_FLOPS_FWD - 2 * 96 * 96 * 27 * 32 - 2 * (2 * 300 * 20 * 121 * 64)   # no dX for the first convs
-ITHOR_S2_FLOPS_PER_CLIP = 2 * 150 * 13 * 64 * (64 * 11 * 5)     # the 11x5 sound convolution, any of its 3 directions
+# the 11x5 stride-2 sound convolution (300x20 -> 150x13, pad 5), any of its 3 directions: 2 * 64 * 64 * the (output
+# pixel, tap) pairs whose input pixel lies inside the map -- 1635 (rows) x 50 (columns) = 76 % of the 1950 x 55 pairs of
+# the GEMM form; the padding products are not counted as work
+_S2_ROWS = sum(sum(0 <= 2 * oy - 5 + ky < 300 for ky in range(11)) for oy in range(150))
+_S2_COLS = sum(sum(0 <= 2 * ox - 5 + kx < 20 for kx in range(5)) for ox in range(13))
+ITHOR_S2_FLOPS_PER_CLIP = 2 * 64 * 64 * _S2_ROWS * _S2_COLS
 
 
 def ithor_cpu_baseline(seconds=12.0, batch=8):
