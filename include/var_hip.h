@@ -203,8 +203,11 @@ int var_ithor_param_count(void);
 int var_ithor_plan(var_ctx* ctx, int max_batch, int img_hw);
 /* Operand precision of every product of the iTHOR model: 0 = fp32 (default; the parity path), 1 = bf16 operands
  * (round to nearest even) with fp32 accumulation on v_mfma_f32_32x32x16_bf16 -- BASELINE config 4's stated precision;
- * activations, gradients, parameters and the optimiser state stay fp32.  -1 = query.  Returns the previous setting
- * (or a negative error code); call after var_ithor_plan. */
+ * parameters, gradients, the optimiser state and every activation the model returns stay fp32.  The sound CNN's
+ * intermediate maps then live as bf16 images only; 2 = as 1, and the fp32 copies of those maps (conv 1 / conv 2 outputs and
+ * the gradient wrt conv 2's output: 1.3 GB of stores per step at batch 256 that nothing but var_debug_buffer reads) are
+ * written too -- what the layer-wise parity tests use.  -1 = query.  Returns the previous setting (or a negative error
+ * code); call after var_ithor_plan. */
 int var_ithor_set_bf16(var_ctx* ctx, int on);
 int var_ithor_encoder_fwd(var_ctx* ctx, void* stream, const float* params,
                           const void* image, int image_is_u8, long image_bstride,

@@ -33,7 +33,7 @@ def sounds(B, seed):
 @pytest.mark.parametrize("B", [1, 3])
 def test_conv2_forward_bf16_kernel_vs_float64_on_rounded_operands(var_amd, B):
     torch.manual_seed(5)
-    m = var_amd.IthorVARPretextNet(cfg(96)).to("cuda").set_precision("bf16")
+    m = var_amd.IthorVARPretextNet(cfg(96)).to("cuda").set_precision("bf16", keep_fp32_activations=True)
     pos, neg = sounds(B, 11 + B)
     with torch.no_grad():
         m(None, pos, neg)
@@ -56,7 +56,7 @@ def test_conv2_forward_bf16_kernel_vs_float64_on_rounded_operands(var_amd, B):
 
 def _after_backward(var_amd, B, seed):
     torch.manual_seed(5)
-    m = var_amd.IthorVARPretextNet(cfg(96)).to("cuda").set_precision("bf16")
+    m = var_amd.IthorVARPretextNet(cfg(96)).to("cuda").set_precision("bf16", keep_fp32_activations=True)
     pos, neg = sounds(B, seed)
     img = torch.randint(0, 256, (B, 3, 96, 96), dtype=torch.uint8, generator=torch.Generator().manual_seed(seed)).cuda()
     tr = var_amd.IthorTrainer(m)
@@ -114,7 +114,7 @@ def test_gru_recurrence_bf16_kernel_vs_float64_emulation(var_amd):
     rounds the same operands (x, W_ih, h, W_hh) to bf16 before each product and keeps everything else exact."""
     B = 2
     torch.manual_seed(5)
-    m = var_amd.IthorVARPretextNet(cfg(96)).to("cuda").set_precision("bf16")
+    m = var_amd.IthorVARPretextNet(cfg(96)).to("cuda").set_precision("bf16", keep_fp32_activations=True)
     pos, neg = sounds(B, 77)
     with torch.no_grad():
         out = m(None, pos, neg)
@@ -180,7 +180,7 @@ def test_dense_bf16_kernel_vs_float64_on_rounded_operands(var_amd, akf, bkf, M, 
     index-contiguous -> transposed reads), ragged M / N, split-K slabs and the accumulate mode."""
     import ctypes
     from var_amd._lib import Context
-    m = var_amd.IthorVARPretextNet(cfg(96)).to("cuda").set_precision("bf16")
+    m = var_amd.IthorVARPretextNet(cfg(96)).to("cuda").set_precision("bf16", keep_fp32_activations=True)
     ctx = Context.get(0)
     m._ensure_plan(ctx, 2)
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K + akf * 2 + bkf)
@@ -210,7 +210,7 @@ def test_conv3_forward_bf16_kernel_vs_float64_on_rounded_operands(var_amd, B):
     """The 7x3 stride-2 convolution through the geometry-templated staged kernel, reading conv 2's own C8 bf16 image
     (written by conv 2's store) and writing the GRU's (clip, 73, 448) sequence."""
     torch.manual_seed(5)
-    m = var_amd.IthorVARPretextNet(cfg(96)).to("cuda").set_precision("bf16")
+    m = var_amd.IthorVARPretextNet(cfg(96)).to("cuda").set_precision("bf16", keep_fp32_activations=True)
     pos, neg = sounds(B, 41 + B)
     with torch.no_grad():
         m(None, pos, neg)
@@ -270,3 +270,25 @@ def test_conv3_weight_gradient_bf16_kernel_vs_float64_on_rounded_operands(var_am
     scale = float(ref.abs().max())
     err = float((got.double() - ref).abs().max())
     assert scale > 0 and err < 1e-4 * scale, (err, scale)
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_conv1_forward_bf16_kernel_vs_float64_on_rounded_operands(var_amd, B):
+    """The 11x11 one-channel layer (taps as the MFMA k index, whole clip in LDS); its C8 image / sign words are what the
+    conv-2 tests above run on."""
+    torch.manual_seed(5)
+    m = var_amd.IthorVARPretextNet(cfg(96)).to("cuda").set_precision("bf16", keep_fp32_activations=True)
+    pos, neg = sounds(B, 71 + B)
+    with torch.no_grad():
+        m(None, pos, neg)
+    from var_amd._lib import Context
+    n = 2 * B
+    s1 = Context.get(0).debug_buffer("ithor_s1")[:n * 64 * 300 * 20].view(n, 64, 300, 20).cpu()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    x = torch.cat([pos, neg]).cpu()
+    ref = torch.relu(torch.nn.functional.conv2d(bf16_round(x), bf16_round(sd["cnn.0.weight"]), sd["cnn.0.bias"].double(),
+                                                stride=2, padding=(5, 5)))
+    assert ref.shape == s1.shape
+    scale = float(ref.abs().max())
+    err = float((s1.double() - ref).abs().max())
+    assert scale > 0.1 and err < 2e-5 * max(scale, 1.0), (err, scale)

@@ -60,7 +60,7 @@ struct ithor_state {
     void* gruws = nullptr;                                // W_hh in MFMA fragment order (gru_bf16.hip)
     void* bfws = nullptr;                                 // bf16 images / packed filters of the staged sound kernels (snd_bf16.hip)
     int gh_split = 1, dh_split = 1;
-    bool bf16 = false;
+    bool bf16 = false, keep32 = false;                    // bf16 mode; ... with the fp32 copies of the sound maps (tests)
     float *sraw = nullptr, *gsraw = nullptr;              // (clips,1024)
     float *hid_i = nullptr, *ghid_i = nullptr, *hid_s1 = nullptr, *ghid_s1 = nullptr, *hid_s2 = nullptr, *ghid_s2 = nullptr;
     float *raw = nullptr, *graw = nullptr, *emb = nullptr, *gemb = nullptr;   // (3B,3) [img | pos | neg]
@@ -490,16 +490,21 @@ static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* imag
     }
     if (nclips) {
         // clips: [pos | neg] (whichever are given), local index 0..nclips-1
-        int off = 0;
-        for (int q = 0; q < 2; ++q) {
-            const float* src = q == 0 ? pos : neg;
-            if (!src) continue;
-            RUN((conv_fwd<GS1, false, false>(c, s, snd_dims(1, B), src, P + L.sw[0], P + L.sb[0],
-                                             st->s[1] + (long)off * 64 * 300 * 20)));
-            off += B;
+        if (st->bf16) {      // both sounds in one launch: two clips per CU
+            RUN(snd1_bf16_fwd(c, s, pos ? pos : neg, B, pos && neg ? neg : nullptr, pos && neg ? B : 0, P + L.sw[0], P + L.sb[0],
+                              st->keep32 ? st->s[1] : nullptr, 2 * st->maxB, st->bfws));
+        } else {
+            int off = 0;
+            for (int q = 0; q < 2; ++q) {
+                const float* src = q == 0 ? pos : neg;
+                if (!src) continue;
+                RUN((conv_fwd<GS1, false, false>(c, s, snd_dims(1, B), src, P + L.sw[0], P + L.sb[0],
+                                                 st->s[1] + (long)off * 64 * 300 * 20)));
+                off += B;
+            }
         }
-        if (st->bf16) {      // (times its main kernel under the same tag itself)
-            RUN(snd2_bf16_fwd(c, s, st->s[1], P + L.sw[1], P + L.sb[1], st->s[2], nclips, 2 * st->maxB, st->bfws));
+        if (st->bf16) {      // (reads conv 1's C8 image; times its main kernel under the same tag itself)
+            RUN(snd2_bf16_fwd(c, s, nullptr, P + L.sw[1], P + L.sb[1], st->keep32 ? st->s[2] : nullptr, nclips, 2 * st->maxB, st->bfws));
         } else {
             ProfScope prof(c, s, TAG_ITHOR_S2_FWD);
             RUN((conv_fwd<GS2, false, false>(c, s, snd_dims(2, nclips), st->s[1], P + L.sw[1], P + L.sb[1], st->s[2])));
@@ -691,7 +696,8 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             RUN(chan_sum(c, s, st->gs[3], G + L.sb[2], nclips * kSeq, 64, 7));
             if (st->bf16) {     // (also leaves gs[2]'s C8 image for conv 2's kernels and the channel sums of gs[2] = conv 2's bias gradient)
                 int nparts = 0;
-                RUN(snd3_bf16_dgrad(c, s, st->gs[3], P + L.sw[2], st->gs[2], st->bslab, &nparts, nclips, 2 * st->maxB, st->bfws));
+                RUN(snd3_bf16_dgrad(c, s, st->gs[3], P + L.sw[2], st->keep32 ? st->gs[2] : nullptr, st->bslab, &nparts, nclips, 2 * st->maxB,
+                                    st->bfws));
                 RUN(slab_reduce(c, s, G + L.sb[1], st->bslab, 64, nparts, 64));
                 RUN(snd3_bf16_wgrad(c, s, G + L.sw[2], st->slab, nclips, 2 * st->maxB, st->bfws));      // (reads the dgrad's gy image)
             } else {
@@ -860,8 +866,8 @@ int var_ithor_set_bf16(var_ctx* c, int on) {
     CHECK_CTX(c);
     ithor_state* st = ith(c);
     if (!st) { VAR_SET_ERR(c, "var_ithor_set_bf16: var_ithor_plan first"); return VAR_ERR_PLAN; }
-    const int old = st->bf16 ? 1 : 0;
-    if (on >= 0) st->bf16 = on != 0;
+    const int old = st->bf16 ? (st->keep32 ? 2 : 1) : 0;
+    if (on >= 0) { st->bf16 = on != 0; st->keep32 = on == 2; }
     return old;
 }
 

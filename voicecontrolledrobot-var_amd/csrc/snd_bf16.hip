@@ -37,6 +37,12 @@ constexpr int CI = 64, CO = 64, HI = 300, WI = 20, HO = 150, WO = 13;      // co
 constexpr int NQ = 4;                         // quarters of 16 input channels
 constexpr int SLOT = 16;                      // bytes: 8 bf16 channels of one pixel
 
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// two floats -> two bf16 in one register (v_cvt_pk_bf16_f32: round to nearest even, as bf16_bits below)
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
 __device__ __forceinline__ unsigned bf16_bits(float x) {          // round to nearest even (no NaNs in this model)
     const unsigned u = __float_as_uint(x);
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
@@ -263,14 +269,15 @@ __global__ void __launch_bounds__(256) snd_fwd_kernel(const uint4* __restrict__ 
                             if (G::SEQ) {
                                 const int oyl = P / WO, ox = P - oyl * WO;
                                 y[((long)clip * G::HO + oyl) * (CO * WO) + co * WO + ox] = v[e];
-                            } else {
+                            } else if (y) {
                                 y[((long)clip * CO + co) * (G::HO * WO) + pix0 + P] = v[e];
                             }
                         }
                         if (y8) {       // plane 4 cb + g, this lane's half (4 h .. 4 h + 3) of the pixel's 16-byte slot
-                            const unsigned b0 = bf16_bits(v[0]), b1 = bf16_bits(v[1]), b2 = bf16_bits(v[2]), b3 = bf16_bits(v[3]);
-                            y8[(((long)clip * 8 + 4 * cb + g) * (G::HO * WO) + pix0 + P) * 2 + h] = make_uint2(b0 | (b1 << 16), b2 | (b3 << 16));
-                            mk |= ((b0 ? 1u : 0u) | (b1 ? 2u : 0u) | (b2 ? 4u : 0u) | (b3 ? 8u : 0u)) << (16 * cb + 4 * g);
+                            const unsigned p01 = pack_bf16(v[0], v[1]), p23 = pack_bf16(v[2], v[3]);
+                            y8[(((long)clip * 8 + 4 * cb + g) * (G::HO * WO) + pix0 + P) * 2 + h] = make_uint2(p01, p23);
+                            mk |= ((p01 & 0xffffu ? 1u : 0u) | (p01 >> 16 ? 2u : 0u) | (p23 & 0xffffu ? 4u : 0u) | (p23 >> 16 ? 8u : 0u))
+                                  << (16 * cb + 4 * g);
                         }
                     }
                 if (y8) ymask[((long)clip * (G::HO * WO) + pix0 + P) * 2 + h] = mk;
@@ -382,15 +389,17 @@ __device__ __forceinline__ void dgrad_pass(const unsigned char* __restrict__ img
                     const int r = 4 * g + e;
                     o[e].x = (m0 >> r) & 1u ? acc[m][0][r] : 0.f;
                     o[e].y = (m1 >> r) & 1u ? acc[m][1][r] : 0.f;
-                    float* q = dxo + (long)(32 * cb + 8 * g + 4 * h + e) * (G::HI * G::WI) + pix;
-                    if (EVEN) *(float2*)q = o[e];
-                    else { q[0] = o[e].x; if (two) q[1] = o[e].y; }
+                    if (dxo) {
+                        float* q = dxo + (long)(32 * cb + 8 * g + 4 * h + e) * (G::HI * G::WI) + pix;
+                        if (EVEN) *(float2*)q = o[e];
+                        else { q[0] = o[e].x; if (two) q[1] = o[e].y; }
+                    }
                     bsum[r] += o[e].x + o[e].y;           // the bias gradient of the layer below: channel sums of dx
                 }
                 if (dx8) {      // plane 4 cb + g of the C8 image, this lane's half of the two pixels' slots
                     uint2* q8 = dx8 + ((long)(4 * cb + g) * (G::HI * G::WI) + pix) * 2 + h;
-                    q8[0] = make_uint2(bf16_bits(o[0].x) | (bf16_bits(o[1].x) << 16), bf16_bits(o[2].x) | (bf16_bits(o[3].x) << 16));
-                    if (two) q8[2] = make_uint2(bf16_bits(o[0].y) | (bf16_bits(o[1].y) << 16), bf16_bits(o[2].y) | (bf16_bits(o[3].y) << 16));
+                    q8[0] = make_uint2(pack_bf16(o[0].x, o[1].x), pack_bf16(o[2].x, o[3].x));
+                    if (two) q8[2] = make_uint2(pack_bf16(o[0].y, o[1].y), pack_bf16(o[2].y, o[3].y));
                 }
             }
         }
@@ -450,7 +459,7 @@ __global__ void __launch_bounds__(256) snd_dgrad_kernel(const uint4* __restrict_
     for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
         const int clip = tile / G::TILES, t = tile - clip * G::TILES, u0 = G::ROWS * t;
         const unsigned* mk = mask + (long)clip * (G::HI * G::WI) * 2;
-        float* dxo = dx + (long)clip * CI * (G::HI * G::WI);
+        float* dxo = dx ? dx + (long)clip * CI * (G::HI * G::WI) : nullptr;
         uint2* dx8o = dx8 ? dx8 + (long)clip * 8 * (G::HI * G::WI) * 2 : nullptr;
         const int ntile = tile + (int)gridDim.x;
         const unsigned char* img = lds + buf * L::BUFB;
@@ -678,6 +687,120 @@ __global__ void __launch_bounds__(256) snd_wgrad_fold_kernel(const float* __rest
     dw[((long)co * CI + ci) * ntap + t] += a;
 }
 
+// ---- conv 1 (1 -> 64 channels, 11x11 stride 2 pad 5, (600,40) -> (300,20)) -------------------------------------------
+// One input channel: the whole clip (600 x 40 features) sits in LDS as bf16 with its padding (610 rows of 52 elements),
+// and the GEMM's k index is the TAP, ordered (ky, kx padded to 16): a lane's 8 consecutive k are 8 consecutive input
+// columns of one row -- four aligned ds_read_b32 (the stride-2 start 2 ox + 8 h is even) -- the 5 padding taps of a
+// row carry zero weights.  The 22 filter fragments stay in registers.  The store writes the layer's output three ways
+// at once: fp32 NCHW, the C8 bf16 image conv 2's kernels read, and the sign words conv 2's data gradient stores
+// through (in the gather-GEMM version this layer cost 0.53 ms + a 0.25 ms conversion pass).
+constexpr int C1_H = 600, C1_W = 40, C1_HO = 300, C1_WO = 20, C1_PITCH = 104, C1_ROWS = C1_H + 10 + 2;
+constexpr int C1_LDSB = C1_ROWS * C1_PITCH, C1_NBLK = (C1_HO * C1_WO + 31) / 32;
+static_assert(C1_HO * C1_WO == HI * WI, "conv 1's output is conv 2's input");
+
+// OIHW (64,1,11,11) -> [ky][cb][lane][8]: lane (r, h) holds W[32 cb + r][ky][kx = 8 h + j], zero for kx >= 11
+__global__ void __launch_bounds__(256) pack_w1_kernel(const float* __restrict__ w, uint4* __restrict__ wp) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 11 * 2 * 64) return;
+    const int lane = i & 63, cb = (i >> 6) & 1, ky = i >> 7, co = 32 * cb + (lane & 31), kx0 = 8 * (lane >> 5);
+    unsigned v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = kx0 + j < 11 ? bf16_bits(w[(co * 11 + ky) * 11 + kx0 + j]) : 0u;
+    wp[i] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+}
+
+// clips 0 .. n0-1 from x0, n0 .. nclips-1 from x1 (the positive and the negative sounds of a batch)
+__global__ void __launch_bounds__(256, 2) snd1_fwd_kernel(const float* __restrict__ x0, const float* __restrict__ x1, int n0,
+                                                          const uint4* __restrict__ wp, const float* __restrict__ bias,
+                                                          float* __restrict__ y, uint2* __restrict__ y8, unsigned* __restrict__ ymask,
+                                                          int nclips) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p31 = lane & 31;
+    for (int i = tid; i < C1_LDSB / 16; i += 256) ((uint4*)lds)[i] = make_uint4(0, 0, 0, 0);
+    u32x4_t wf[11][2];
+#pragma unroll
+    for (int ky = 0; ky < 11; ++ky)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) wf[ky][cb] = *(const u32x4_t*)(wp + (ky * 2 + cb) * 64 + lane);
+    float bv[2][16];                                            // this lane's 32 output channels' biases
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bv[cb][r] = bias[32 * cb + 8 * (r >> 2) + 4 * h + (r & 3)];
+    for (int clip = blockIdx.x; clip < nclips; clip += gridDim.x) {
+        __syncthreads();                                        // (zero fill | the previous clip's reads) before the image changes
+        const float4* src = (const float4*)(clip < n0 ? x0 + (long)clip * (C1_H * C1_W) : x1 + (long)(clip - n0) * (C1_H * C1_W));
+        constexpr int NV = (C1_H * C1_W / 4 + 255) / 256;      // 24 float4 per thread, all in flight at once
+        float4 v[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) { const int i = tid + 256 * k; v[k] = src[min(i, C1_H * C1_W / 4 - 1)]; }
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {                          // row r, columns 4 c4 .. 4 c4 + 3 -> elements 5 + column of row r + 5
+            const int i = tid + 256 * k, r = i / (C1_W / 4), c4 = i - r * (C1_W / 4);
+            if (i < C1_H * C1_W / 4) {                          // (odd first element: a 2-byte, a 4-byte and a 2-byte store)
+                unsigned char* d = lds + (r + 5) * C1_PITCH + 2 * (5 + 4 * c4);
+                *(unsigned short*)d = (unsigned short)bf16_bits(v[k].x);
+                *(unsigned*)(d + 2) = bf16_bits(v[k].y) | (bf16_bits(v[k].z) << 16);
+                *(unsigned short*)(d + 6) = (unsigned short)bf16_bits(v[k].w);
+            }
+        }
+        __syncthreads();
+        const long oclip = clip;
+        for (int g = wave; g < (C1_NBLK + 3) / 4; g += 4) {     // four 32-pixel blocks at a time
+            f32x16_t acc[4][2];
+            int base[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int P = min(32 * (4 * g + m) + p31, C1_HO * C1_WO - 1), oy = P / C1_WO, ox = P - oy * C1_WO;
+                base[m] = 2 * oy * C1_PITCH + 4 * ox + 16 * h;
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][cb][r] = 0.f;
+            }
+#pragma unroll
+            for (int ky = 0; ky < 11; ++ky) {
+                u32x4_t b[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const unsigned* q = (const unsigned*)(lds + base[m] + ky * C1_PITCH);
+                    b[m].x = q[0]; b[m].y = q[1]; b[m].z = q[2]; b[m].w = q[3];
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+                        acc[m][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[ky][cb]),
+                                                                             __builtin_bit_cast(bf16x8_t, b[m]), acc[m][cb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int P = 32 * (4 * g + m) + p31;
+                if (P < C1_HO * C1_WO) {
+                    unsigned mk = 0u;
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int co = 32 * cb + 8 * q + 4 * h + e;
+                                v[e] = fmaxf(acc[m][cb][4 * q + e] + bv[cb][4 * q + e], 0.f);
+                                if (y) y[(oclip * CO + co) * (C1_HO * C1_WO) + P] = v[e];
+                            }
+                            const unsigned p01 = pack_bf16(v[0], v[1]), p23 = pack_bf16(v[2], v[3]);
+                            y8[((oclip * 8 + 4 * cb + q) * (C1_HO * C1_WO) + P) * 2 + h] = make_uint2(p01, p23);
+                            mk |= ((p01 & 0xffffu ? 1u : 0u) | (p01 >> 16 ? 2u : 0u) | (p23 & 0xffffu ? 4u : 0u) | (p23 >> 16 ? 8u : 0u))
+                                  << (16 * cb + 4 * q);
+                        }
+                    ymask[(oclip * (C1_HO * C1_WO) + P) * 2 + h] = mk;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // workspace of the bf16 sound kernels for up to mc clips (byte offsets, 256-aligned):
@@ -685,7 +808,7 @@ __global__ void __launch_bounds__(256) snd_wgrad_fold_kernel(const float* __rest
 //   y8    conv 2's output as C8 bf16 (mc, 8, 150*13) + m2: its sign words      (written by conv 2's forward)
 //   gy8   gradient wrt conv 2's output, C8 bf16; g38: gradient wrt conv 3's output (mc, 8, 73*7), C8 bf16
 //   wp2 / wpt2 / wp3 / wpt3: fragment-ordered filters (forward / data gradient)
-struct BfWs { long x8, m1, y8, m2, gy8, g38, wp2, wpt2, wp3, wpt3, total; };
+struct BfWs { long x8, m1, y8, m2, gy8, g38, wp2, wpt2, wp3, wpt3, wp1, total; };
 constexpr long kWp2Bytes = (long)NQ * 55 * 2 * 64 * 16, kWp3Bytes = (long)NQ * 21 * 2 * 64 * 16;
 static BfWs bf_ws(int mc) {
     BfWs w{};
@@ -695,21 +818,45 @@ static BfWs bf_ws(int mc) {
     w.y8 = take((long)mc * CI * 150 * 13 * 2); w.m2 = take((long)mc * 150 * 13 * 8);
     w.gy8 = take((long)mc * CO * 150 * 13 * 2); w.g38 = take((long)mc * CO * 73 * 7 * 2);
     w.wp2 = take(kWp2Bytes); w.wpt2 = take(kWp2Bytes); w.wp3 = take(kWp3Bytes); w.wpt3 = take(kWp3Bytes);
+    w.wp1 = take(11 * 2 * 64 * 16);
     w.total = o;
     return w;
 }
 long snd_bf16_workspace_bytes(int nclips) { return bf_ws(nclips).total; }
 template <class T> static T* at(void* ws, long off) { return (T*)((char*)ws + off); }
 
-// conv 2 forward: y (fp32 NCHW) from x (fp32 NCHW, converted here); also leaves y's C8 image + sign words for conv 3
+// conv 1 forward for n0 clips of MFCC features x0 and n1 of x1 (each (n,1,600,40); either may be absent), written as clips
+// 0 .. n0+n1-1 of the layer's output: y (fp32 NCHW, optional) + its C8 image and sign words in the workspace (what
+// snd2_bf16_fwd reads)
+int snd1_bf16_fwd(var_ctx* c, hipStream_t s, const float* x0, int n0, const float* x1, int n1, const float* w, const float* bias,
+                  float* y, int maxclips, void* ws) {
+    const BfWs o = bf_ws(maxclips);
+    hipLaunchKernelGGL(pack_w1_kernel, dim3((11 * 2 * 64 + 255) / 256), dim3(256), 0, s, w, at<uint4>(ws, o.wp1));
+    VAR_HIP_CHECK(c, hipGetLastError());
+    static bool attr = false;
+    if (!attr) {
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd1_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDSB + 256));
+        attr = true;
+    }
+    const int n = n0 + n1;
+    hipLaunchKernelGGL(snd1_fwd_kernel, dim3(n < 512 ? n : 512), dim3(256), C1_LDSB + 256, s, x0, x1, n0, at<uint4>(ws, o.wp1), bias, y,
+                       at<uint2>(ws, o.x8), at<unsigned>(ws, o.m1), n);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}
+
+// conv 2 forward: y (fp32 NCHW) from the C8 image of x in the workspace (snd1_bf16_fwd's by-product; or, x given, converted
+// here from the fp32 map); also leaves y's C8 image + sign words for conv 3
 int snd2_bf16_fwd(var_ctx* c, hipStream_t s, const float* x, const float* w, const float* bias, float* y, int nclips,
                   int maxclips, void* ws) {
     const BfWs o = bf_ws(maxclips);
     using L = FwdLayout<Geo2>;
-    const long total = (long)nclips * HI * WI;
-    hipLaunchKernelGGL(to_c8_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, at<uint4>(ws, o.x8),
-                       at<unsigned>(ws, o.m1), total, HI * WI);
-    VAR_HIP_CHECK(c, hipGetLastError());
+    if (x) {
+        const long total = (long)nclips * HI * WI;
+        hipLaunchKernelGGL(to_c8_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, at<uint4>(ws, o.x8),
+                           at<unsigned>(ws, o.m1), total, HI * WI);
+        VAR_HIP_CHECK(c, hipGetLastError());
+    }
     hipLaunchKernelGGL(pack_w_kernel<false>, dim3((NQ * L::NTAP * 128 + 255) / 256), dim3(256), 0, s, w, at<uint4>(ws, o.wp2), L::NTAP);
     VAR_HIP_CHECK(c, hipGetLastError());
     static bool attr = false;

@@ -93,7 +93,7 @@ class IthorVARPretextNet(nn.Module):
                                           nn.Linear(64, config.representationDim))
         self._flat = None
         self._plan = 0
-        self._bf16 = False
+        self._bf16 = 0
         self._flatten_params()
 
     @staticmethod
@@ -143,12 +143,14 @@ class IthorVARPretextNet(nn.Module):
         if c.lib.var_ithor_set_bf16(c.handle, -1) != int(self._bf16):     # the plan is per context, the choice per model
             c.lib.var_ithor_set_bf16(c.handle, int(self._bf16))
 
-    def set_precision(self, name):
+    def set_precision(self, name, keep_fp32_activations=False):
         """'fp32' (default, the parity path) or 'bf16': bf16 operands with fp32 accumulation in every product
         (BASELINE config 4's stated precision); parameters, activations, gradients and Adam state stay fp32."""
         if name not in ("fp32", "bf16"):
             raise VarHipError("precision is 'fp32' or 'bf16'")
-        self._bf16 = name == "bf16"
+        # keep_fp32_activations: also store the fp32 copies of the sound CNN's intermediate maps (debug buffers of the
+        # layer-wise tests); the bf16 mode itself only needs their bf16 images
+        self._bf16 = (2 if keep_fp32_activations else 1) if name == "bf16" else 0
         return self
 
     def forward(self, image, sound_positive, sound_negative, is_train=False):
