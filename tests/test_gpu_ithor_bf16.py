@@ -292,3 +292,26 @@ def test_conv1_forward_bf16_kernel_vs_float64_on_rounded_operands(var_amd, B):
     scale = float(ref.abs().max())
     err = float((s1.double() - ref).abs().max())
     assert scale > 0.1 and err < 2e-5 * max(scale, 1.0), (err, scale)
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_conv1_weight_gradient_bf16_kernel_vs_float64_on_rounded_operands(var_amd, B):
+    torch.manual_seed(5)
+    m = var_amd.IthorVARPretextNet(cfg(96)).to("cuda").set_precision("bf16", keep_fp32_activations=True)
+    pos, neg = sounds(B, 81 + B)
+    img = torch.randint(0, 256, (B, 3, 96, 96), dtype=torch.uint8, generator=torch.Generator().manual_seed(B)).cuda()
+    tr = var_amd.IthorTrainer(m)
+    tr.loss_and_grads(img, pos, neg)
+    from var_amd._lib import Context
+    n = 2 * B
+    gs1 = Context.get(0).debug_buffer("ithor_gs1")[:n * 64 * 300 * 20].view(n, 64, 300, 20).cpu()
+    g, o = tr.grads.cpu(), 0
+    for k, p in m.named_parameters():
+        if k == "cnn.0.weight":
+            got = g[o:o + p.numel()].view(p.shape)
+        o += p.numel()
+    x = torch.cat([pos, neg]).cpu()
+    ref = torch.nn.grad.conv2d_weight(bf16_round(x), (64, 1, 11, 11), bf16_round(gs1), stride=2, padding=(5, 5))
+    scale = float(ref.abs().max())
+    err = float((got.double() - ref).abs().max())
+    assert scale > 0 and err < 1e-4 * scale, (err, scale)

@@ -716,14 +716,18 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             if (!st->bf16) RUN(chan_sum(c, s, st->gs[2], G + L.sb[1], nclips, 64, 150 * 13));
             if (st->bf16) {     // (its store also yields the channel sums of gs[1]: conv 1's bias gradient)
                 int nparts = 0;
-                RUN(snd2_bf16_dgrad(c, s, P + L.sw[1], st->gs[1], st->bslab, &nparts, nclips, 2 * st->maxB, st->bfws));
+                RUN(snd2_bf16_dgrad(c, s, P + L.sw[1], st->keep32 ? st->gs[1] : nullptr, st->bslab, &nparts, nclips, 2 * st->maxB, st->bfws));
                 RUN(slab_reduce(c, s, G + L.sb[0], st->bslab, 64, nparts, 64));
             } else {
                 ProfScope prof(c, s, TAG_ITHOR_S2_DGRAD);
                 RUN((conv_dgrad<GS2, false>(c, s, d, st->gs[2], P + L.sw[1], st->gs[1], st->s[1])));
             }
         }
-        {
+        if (st->bf16) {     // (reads the bf16 gradient image conv 2's data gradient wrote)
+            const float *pos = st->pos, *neg = st->neg;
+            RUN(snd1_bf16_wgrad(c, s, pos ? pos : neg, B, pos && neg ? neg : nullptr, pos && neg ? B : 0, G + L.sw[0], st->slab,
+                                2 * st->maxB, st->bfws));
+        } else {
             int off = 0;
             for (int q = 0; q < 2; ++q) {
                 const float* src = q == 0 ? st->pos : st->neg;

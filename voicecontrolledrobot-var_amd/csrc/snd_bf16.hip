@@ -321,7 +321,8 @@ struct DgLayout {
 template <class G, int A>
 __device__ __forceinline__ void dgrad_pass(const unsigned char* __restrict__ img, const int (&abase)[G::MB], __amdgpu_buffer_rsrc_t wq,
                                            int wlane, const unsigned* __restrict__ mask, int cb, float* __restrict__ dxo,
-                                           uint2* __restrict__ dx8, int u0, int wm, int p31, int h, float (&bsum)[16]) {
+                                           uint2* __restrict__ dx8, unsigned short* __restrict__ dx16, int u0, int wm, int p31, int h,
+                                           float (&bsum)[16]) {
     using L = DgLayout<G>;
     constexpr int KW = G::KW, MB = G::MB, NSET = L::NSET, NKY = A ? (G::KH + 1) / 2 : G::KH / 2, NROW = NQ * NKY;
     f32x16_t acc[MB][2];
@@ -394,6 +395,7 @@ __device__ __forceinline__ void dgrad_pass(const unsigned char* __restrict__ img
                         if (EVEN) *(float2*)q = o[e];
                         else { q[0] = o[e].x; if (two) q[1] = o[e].y; }
                     }
+                    if (EVEN && dx16) *(unsigned*)(dx16 + (long)(32 * cb + 8 * g + 4 * h + e) * (G::HI * G::WI) + pix) = pack_bf16(o[e].x, o[e].y);
                     bsum[r] += o[e].x + o[e].y;           // the bias gradient of the layer below: channel sums of dx
                 }
                 if (dx8) {      // plane 4 cb + g of the C8 image, this lane's half of the two pixels' slots
@@ -409,7 +411,7 @@ __device__ __forceinline__ void dgrad_pass(const unsigned char* __restrict__ img
 template <class G>
 __global__ void __launch_bounds__(256) snd_dgrad_kernel(const uint4* __restrict__ gy8, const uint4* __restrict__ wp,
                                                         const unsigned* __restrict__ mask, float* __restrict__ dx, uint2* __restrict__ dx8,
-                                                        float* __restrict__ bias_part, int nclips) {
+                                                        unsigned short* __restrict__ dx16, float* __restrict__ bias_part, int nclips) {
     using L = DgLayout<G>;
     constexpr int MB = G::MB;
     extern __shared__ __align__(16) unsigned char lds[];
@@ -461,12 +463,13 @@ __global__ void __launch_bounds__(256) snd_dgrad_kernel(const uint4* __restrict_
         const unsigned* mk = mask + (long)clip * (G::HI * G::WI) * 2;
         float* dxo = dx ? dx + (long)clip * CI * (G::HI * G::WI) : nullptr;
         uint2* dx8o = dx8 ? dx8 + (long)clip * 8 * (G::HI * G::WI) * 2 : nullptr;
+        unsigned short* dx16o = dx16 ? dx16 + (long)clip * CI * (G::HI * G::WI) : nullptr;
         const int ntile = tile + (int)gridDim.x;
         const unsigned char* img = lds + buf * L::BUFB;
-        dgrad_pass<G, 0>(img, abase, wq, wlane, mk, cb, dxo, dx8o, u0, wm, p31, h, bsum);
+        dgrad_pass<G, 0>(img, abase, wq, wlane, mk, cb, dxo, dx8o, dx16o, u0, wm, p31, h, bsum);
         if (ntile < ntiles) stage_load(ntile);
         __builtin_amdgcn_sched_barrier(0);
-        dgrad_pass<G, 1>(img, abase, wq, wlane, mk, cb, dxo, dx8o, u0, wm, p31, h, bsum);
+        dgrad_pass<G, 1>(img, abase, wq, wlane, mk, cb, dxo, dx8o, dx16o, u0, wm, p31, h, bsum);
         if (ntile < ntiles) stage_store(buf ^ 1);
         __syncthreads();
     }
@@ -801,14 +804,107 @@ __global__ void __launch_bounds__(256, 2) snd1_fwd_kernel(const float* __restric
     }
 }
 
+// conv 1's weight gradient: dW[co][ky][kx] = sum_{clip,oy,ox} gy[clip][co][oy][ox] x[clip][2oy-5+ky][2ox-5+kx].  k = pixel,
+// 16 flat pixels per step (6000 = 375 x 16); rows = co (gy as bf16 NCHW: a lane's 8 pixels are 16 contiguous bytes, loaded
+// straight from HBM, written in that form by conv 2's data-gradient kernel); columns = taps, 6 blocks of (two ky) x (kx
+// padded to 16).  A tap's 8 pixels of a k half are 8 consecutive DWORDS of one row of the clip's LDS image (stride-2 elements:
+// the needed half of each dword is picked with v_perm); a k half that starts at column 16 wraps into the next output row
+// after 4 pixels (+128 bytes).  Wave = (co block, 3 column blocks): 3 accumulators, no cross-wave reduction; one slab
+// (64 x 192) per workgroup, folded in workgroup order.
+constexpr int C1_COLS = 192;
+__global__ void __launch_bounds__(256, 2) snd1_wgrad_kernel(const float* __restrict__ x0, const float* __restrict__ x1, int n0,
+                                                            const unsigned short* __restrict__ gy16, float* __restrict__ slab, int nclips) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, r = lane & 31;
+    const int cb = wave & 1, jb = wave >> 1, kyl = r >> 4, kx = r & 15;
+    const unsigned sel = (kx & 1) ? 0x07060302u : 0x05040100u;
+    for (int i = tid; i < C1_LDSB / 16; i += 256) ((uint4*)lds)[i] = make_uint4(0, 0, 0, 0);
+    f32x16_t acc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+    for (int clip = blockIdx.x; clip < nclips; clip += gridDim.x) {
+        __syncthreads();
+        const float4* src = (const float4*)(clip < n0 ? x0 + (long)clip * (C1_H * C1_W) : x1 + (long)(clip - n0) * (C1_H * C1_W));
+        constexpr int NV = (C1_H * C1_W / 4 + 255) / 256;
+        float4 v[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) { const int i = tid + 256 * k; v[k] = src[min(i, C1_H * C1_W / 4 - 1)]; }
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int i = tid + 256 * k, rr = i / (C1_W / 4), c4 = i - rr * (C1_W / 4);
+            if (i < C1_H * C1_W / 4) {
+                unsigned char* d = lds + (rr + 5) * C1_PITCH + 2 * (5 + 4 * c4);
+                *(unsigned short*)d = (unsigned short)bf16_bits(v[k].x);
+                *(unsigned*)(d + 2) = bf16_bits(v[k].y) | (bf16_bits(v[k].z) << 16);
+                *(unsigned short*)(d + 6) = (unsigned short)bf16_bits(v[k].w);
+            }
+        }
+        __syncthreads();
+        const uint4* ga = (const uint4*)(gy16 + ((long)clip * CO + 32 * cb + r) * (C1_HO * C1_WO)) + h;     // + 2 ks: pixels 16 ks + 8 h ..
+        constexpr int NKS = C1_HO * C1_WO / 16, DEPTH = 4;
+        uint4 ring[DEPTH];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) ring[d] = ga[2 * d];
+#pragma unroll 1
+        for (int ks0 = 0; ks0 < NKS; ks0 += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                const int ks = ks0 + d;
+                if (ks < NKS) {                                  // uniform
+                    const uint4 a = ring[d];
+                    if (ks + DEPTH < NKS) ring[d] = ga[2 * (ks + DEPTH)];
+                    const int P0 = 16 * ks + 8 * h, oy = P0 / C1_WO, ox0 = P0 - oy * C1_WO;
+                    const unsigned char* xb = lds + (2 * oy + kyl) * C1_PITCH + ((2 * ox0 + kx) >> 1) * 4;
+                    const int hi = 16 + (ox0 == 16 ? 128 : 0);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const unsigned* q0 = (const unsigned*)(xb + (jb + 2 * i) * 2 * C1_PITCH);
+                        const unsigned* q1 = (const unsigned*)(xb + (jb + 2 * i) * 2 * C1_PITCH + hi);
+                        u32x4_t b;
+                        b.x = __builtin_amdgcn_perm(q0[1], q0[0], sel); b.y = __builtin_amdgcn_perm(q0[3], q0[2], sel);
+                        b.z = __builtin_amdgcn_perm(q1[1], q1[0], sel); b.w = __builtin_amdgcn_perm(q1[3], q1[2], sel);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
+                                                                         acc[i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    float* out = slab + (long)blockIdx.x * CO * C1_COLS + r;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) out[(32 * cb + (q & 3) + 8 * (q >> 2) + 4 * h) * C1_COLS + 32 * (jb + 2 * i)] = acc[i][q];
+}
+
+// dW (64,1,11,11) += the workgroups' slabs (co, 12 ky x 16 kx), in workgroup order: 16 slab elements x 16 slab chains per block
+__global__ void __launch_bounds__(256) snd1_wgrad_fold_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nslabs) {
+    const int i = blockIdx.x * 16 + (threadIdx.x & 15), g = threadIdx.x >> 4;          // i = co * 192 + ky * 16 + kx
+    float a = 0.f;
+    for (int s = g; s < nslabs; s += 16) a += slab[(long)s * CO * C1_COLS + i];
+    __shared__ float red[16][17];
+    red[g][threadIdx.x & 15] = a;
+    __syncthreads();
+    if (g == 0) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[k][threadIdx.x];
+        const int co = i / C1_COLS, t = i - co * C1_COLS, ky = t >> 4, kx = t & 15;
+        if (ky < 11 && kx < 11) dw[co * 121 + ky * 11 + kx] += v;
+    }
+}
+
 }  // namespace
 
 // workspace of the bf16 sound kernels for up to mc clips (byte offsets, 256-aligned):
 //   x8    conv 1's output as C8 bf16 (mc, 8, 300*20) + m1: its sign words      (written by to_c8_mask_kernel)
 //   y8    conv 2's output as C8 bf16 (mc, 8, 150*13) + m2: its sign words      (written by conv 2's forward)
 //   gy8   gradient wrt conv 2's output, C8 bf16; g38: gradient wrt conv 3's output (mc, 8, 73*7), C8 bf16
-//   wp2 / wpt2 / wp3 / wpt3: fragment-ordered filters (forward / data gradient)
-struct BfWs { long x8, m1, y8, m2, gy8, g38, wp2, wpt2, wp3, wpt3, wp1, total; };
+//   g116  gradient wrt conv 1's output, bf16 NCHW (written by conv 2's data gradient, read by conv 1's weight gradient)
+//   wp1 / wp2 / wpt2 / wp3 / wpt3: fragment-ordered filters (forward / data gradient)
+struct BfWs { long x8, m1, y8, m2, gy8, g38, g116, wp2, wpt2, wp3, wpt3, wp1, total; };
 constexpr long kWp2Bytes = (long)NQ * 55 * 2 * 64 * 16, kWp3Bytes = (long)NQ * 21 * 2 * 64 * 16;
 static BfWs bf_ws(int mc) {
     BfWs w{};
@@ -819,6 +915,7 @@ static BfWs bf_ws(int mc) {
     w.gy8 = take((long)mc * CO * 150 * 13 * 2); w.g38 = take((long)mc * CO * 73 * 7 * 2);
     w.wp2 = take(kWp2Bytes); w.wpt2 = take(kWp2Bytes); w.wp3 = take(kWp3Bytes); w.wpt3 = take(kWp3Bytes);
     w.wp1 = take(11 * 2 * 64 * 16);
+    w.g116 = take((long)mc * CO * 300 * 20 * 2);                 // gradient wrt conv 1's output, bf16 NCHW (conv 1's weight gradient)
     w.total = o;
     return w;
 }
@@ -891,7 +988,7 @@ int snd3_bf16_fwd(var_ctx* c, hipStream_t s, const float* w, const float* bias, 
 
 template <class G>
 static int dgrad_launch(var_ctx* c, hipStream_t s, const float* w, const uint4* gy8, uint4* wpt, const unsigned* mask, float* dx,
-                        uint2* dx8, float* bias_part, int* nparts, int nclips, int tag) {
+                        uint2* dx8, unsigned short* dx16, float* bias_part, int* nparts, int nclips, int tag) {
     using L = DgLayout<G>;
     hipLaunchKernelGGL(pack_w_kernel<true>, dim3((NQ * L::NTAP * 128 + 255) / 256), dim3(256), 0, s, w, wpt, L::NTAP);
     VAR_HIP_CHECK(c, hipGetLastError());
@@ -903,7 +1000,7 @@ static int dgrad_launch(var_ctx* c, hipStream_t s, const float* w, const uint4* 
     const int ntiles = nclips * G::TILES;
     *nparts = ntiles < 256 ? ntiles : 256;
     ProfScope prof(c, s, tag);
-    hipLaunchKernelGGL(snd_dgrad_kernel<G>, dim3(*nparts), dim3(256), L::LDSB, s, gy8, wpt, mask, dx, dx8, bias_part, nclips);
+    hipLaunchKernelGGL(snd_dgrad_kernel<G>, dim3(*nparts), dim3(256), L::LDSB, s, gy8, wpt, mask, dx, dx8, dx16, bias_part, nclips);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }
@@ -913,8 +1010,8 @@ static int dgrad_launch(var_ctx* c, hipStream_t s, const float* w, const uint4* 
 int snd2_bf16_dgrad(var_ctx* c, hipStream_t s, const float* w, float* dx, float* bias_part, int* nparts, int nclips, int maxclips,
                     void* ws) {
     const BfWs o = bf_ws(maxclips);
-    return dgrad_launch<DGeo2>(c, s, w, at<uint4>(ws, o.gy8), at<uint4>(ws, o.wpt2), at<unsigned>(ws, o.m1), dx, nullptr, bias_part,
-                               nparts, nclips, TAG_ITHOR_S2_DGRAD);
+    return dgrad_launch<DGeo2>(c, s, w, at<uint4>(ws, o.gy8), at<uint4>(ws, o.wpt2), at<unsigned>(ws, o.m1), dx, nullptr,
+                               at<unsigned short>(ws, o.g116), bias_part, nparts, nclips, TAG_ITHOR_S2_DGRAD);
 }
 
 // conv 3: gy (the masked gradient of the GRU's input sequence, fp32) -> dx (fp32 NCHW, masked by conv 2's sign words), its C8
@@ -926,7 +1023,7 @@ int snd3_bf16_dgrad(var_ctx* c, hipStream_t s, const float* gy_seq, const float*
     hipLaunchKernelGGL(seq_to_c8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, gy_seq, at<uint4>(ws, o.g38), total);
     VAR_HIP_CHECK(c, hipGetLastError());
     return dgrad_launch<DGeo3>(c, s, w, at<uint4>(ws, o.g38), at<uint4>(ws, o.wpt3), at<unsigned>(ws, o.m2), dx, at<uint2>(ws, o.gy8),
-                               bias_part, nparts, nclips, -1);
+                               nullptr, bias_part, nparts, nclips, -1);
 }
 
 // gy (fp32 NCHW, already masked) -> its bf16 C8 image in the workspace: once per backward, before the two kernels that read it
@@ -969,4 +1066,22 @@ int snd2_bf16_wgrad(var_ctx* c, hipStream_t s, float* dw, float* slab, int nclip
 int snd3_bf16_wgrad(var_ctx* c, hipStream_t s, float* dw, float* slab, int nclips, int maxclips, void* ws) {
     const BfWs o = bf_ws(maxclips);
     return wgrad_launch<WGeo3>(c, s, at<uint4>(ws, o.y8), at<uint4>(ws, o.g38), dw, slab, nclips, 128, -1);
+}
+
+// conv 1's weight gradient: dw (64,1,11,11) += from the MFCC features (as snd1_bf16_fwd) and the bf16 gradient image conv 2's
+// data gradient left in the workspace; slab: min(n0+n1, 512) x 64 x 192 floats
+int snd1_bf16_wgrad(var_ctx* c, hipStream_t s, const float* x0, int n0, const float* x1, int n1, float* dw, float* slab, int maxclips,
+                    void* ws) {
+    const BfWs o = bf_ws(maxclips);
+    static bool attr = false;
+    if (!attr) {
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd1_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDSB + 256));
+        attr = true;
+    }
+    const int n = n0 + n1, grid = n < 512 ? n : 512;          // (two co-resident workgroups per CU beat one with two clips: 183 vs 302 us)
+    hipLaunchKernelGGL(snd1_wgrad_kernel, dim3(grid), dim3(256), C1_LDSB + 256, s, x0, x1, n0, at<unsigned short>(ws, o.g116), slab, n);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(snd1_wgrad_fold_kernel, dim3(CO * C1_COLS / 16), dim3(256), 0, s, slab, dw, grid);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
 }

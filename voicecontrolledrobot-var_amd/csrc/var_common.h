@@ -257,6 +257,8 @@ int snd2_bf16_fwd(var_ctx* c, hipStream_t s, const float* x, const float* w, con
                   int maxclips, void* ws);
 int snd1_bf16_fwd(var_ctx* c, hipStream_t s, const float* x0, int n0, const float* x1, int n1, const float* w, const float* bias,
                   float* y, int maxclips, void* ws);
+int snd1_bf16_wgrad(var_ctx* c, hipStream_t s, const float* x0, int n0, const float* x1, int n1, float* dw, float* slab, int maxclips,
+                    void* ws);
 int snd3_bf16_fwd(var_ctx* c, hipStream_t s, const float* w, const float* bias, float* y, int nclips, int maxclips, void* ws);
 int snd3_bf16_dgrad(var_ctx* c, hipStream_t s, const float* gy_seq, const float* w, float* dx, float* bias_part, int* nparts,
                     int nclips, int maxclips, void* ws);
