@@ -219,11 +219,19 @@ def main_ithor(args, rank, local_rank, world, dev):
             ach = flops / (best[1] * 1e-3) / 1e12
             traffic = None
             try:                                                # HBM bytes per launch from the committed PMC passes
-                with open(os.path.join(ROOT, "profiles", "r01_ithor_pmc.json")) as f:
-                    k = json.load(f)["kernels"][names[best[0]]]
                 if B == 256 and args.dtype == "f32":
+                    with open(os.path.join(ROOT, "profiles", "r01_ithor_pmc.json")) as f:
+                        k = json.load(f)["kernels"]
+                    k = k.get(names[best[0]]) or k[{"forward": "gg_kernel<ConvFwdP<11x5 s2>>", "data gradient": "gg_kernel<ConvDgradS2P<11x5 s2>>",
+                                                    "weight gradient": "gg_kernel<ConvWgradP<11x5 s2>>"}[names[best[0]].split("s2 ")[1]]]
                     traffic = k["fetch_bytes"] + k["write_bytes"]
-            except (OSError, KeyError, ValueError):
+                elif B == 256:                                  # tools/pmc_traffic.sh r02_ithor_bf16 --workload ithor --dtype bf16
+                    with open(os.path.join(ROOT, "profiles", "r02_ithor_bf16_pmc_hbm_traffic.json")) as f:
+                        pm = json.load(f)
+                    want = {"forward": ("snd_fwd_kernel", "Geo2"), "data gradient": ("snd_dgrad_kernel", "DGeo2"),
+                            "weight gradient": ("snd_wgrad_kernel", "WGeo2")}[names[best[0]].split("s2 ")[1]]
+                    traffic = [v["hbm_bytes_fetch_x2_plus_write"] for kk, v in pm.items() if want[0] in kk and want[1] in kk][0]
+            except (OSError, KeyError, ValueError, IndexError):
                 pass
             roof = {"bound": "mfma", "kernel": names[best[0]], "achieved": round(ach, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,

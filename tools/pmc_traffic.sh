@@ -2,12 +2,12 @@
 # HBM traffic per kernel of one training step: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes
 # (MI355X_MICROARCH.md, HBM section: the two do not fit one pass; FETCH_SIZE x 2 on gfx950), eager launches.
 # usage (on the GPU box, from the repo root): bash tools/pmc_traffic.sh r02     -> gpurun_out/r02_pmc_hbm_traffic.json
-TAG=${1:-r02}
+TAG=${1:-r02}; shift; EXTRA="$*"      # further bench.py arguments, e.g. --workload ithor --dtype bf16
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmc_$C
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc_$C -- python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --no-graph > $R/gpurun_out/pmc_$C.log 2>&1 || exit 1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc_$C -- python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --no-graph $EXTRA > $R/gpurun_out/pmc_$C.log 2>&1 || exit 1
 done
 python3 - "$R" "$TAG" <<'PY'
 import csv, glob, json, sys, collections
