@@ -315,3 +315,36 @@ def test_conv1_weight_gradient_bf16_kernel_vs_float64_on_rounded_operands(var_am
     scale = float(ref.abs().max())
     err = float((got.double() - ref).abs().max())
     assert scale > 0 and err < 1e-4 * scale, (err, scale)
+
+
+def test_image_layers_2_and_3_bf16_kernels_vs_float64_on_rounded_operands(var_amd):
+    """img_bf16.hip: the 3x3 stride-1 layers 32 -> 32 at 96x96 and 32 -> 64 at 48x48, forward and data gradient (one kernel
+    with transposed / flipped filters), against float64 convolutions of the bf16-rounded operands."""
+    B = 2
+    torch.manual_seed(5)
+    m = var_amd.IthorVARPretextNet(cfg(96)).to("cuda").set_precision("bf16", keep_fp32_activations=True)
+    pos, neg = sounds(B, 17)
+    img = torch.randint(0, 256, (B, 3, 96, 96), dtype=torch.uint8, generator=torch.Generator().manual_seed(9)).cuda()
+    tr = var_amd.IthorTrainer(m)
+    tr.loss_and_grads(img, pos, neg)
+    from var_amd._lib import Context
+    ctx = Context.get(0)
+
+    def buf(name, c, hw):
+        return ctx.debug_buffer("ithor_" + name)[:B * c * hw * hw].view(B, c, hw, hw).cpu()
+
+    a1, a2, p2, a3 = buf("a1", 32, 96), buf("a2", 32, 96), buf("p2", 32, 48), buf("a3", 64, 48)
+    ga1, ga2, gp2, ga3 = buf("ga1", 32, 96), buf("ga2", 32, 96), buf("gp2", 32, 48), buf("ga3", 64, 48)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    w2, b2, w3, b3 = sd["imgBranch.2.weight"], sd["imgBranch.2.bias"], sd["imgBranch.5.weight"], sd["imgBranch.5.bias"]
+    F = torch.nn.functional
+
+    def close(got, ref, what):
+        scale = float(ref.abs().max())
+        err = float((got.double() - ref).abs().max())
+        assert scale > 0 and err < 2e-5 * max(scale, 1e-3 if scale < 1e-3 else scale), (what, err, scale)
+
+    close(a2, torch.relu(F.conv2d(bf16_round(a1), bf16_round(w2), b2.double(), padding=1)), "a2")
+    close(a3, torch.relu(F.conv2d(bf16_round(p2), bf16_round(w3), b3.double(), padding=1)), "a3")
+    close(ga1, F.conv_transpose2d(bf16_round(ga2), bf16_round(w2), padding=1) * (a1 > 0), "ga1")
+    close(gp2, F.conv_transpose2d(bf16_round(ga3), bf16_round(w3), padding=1), "gp2")

@@ -1,0 +1,210 @@
+// 3x3 stride-1 convolutions of the iTHOR image branch in the model's bf16 mode (models/pretext/ai2thor_pretext_model.py:
+// 7-16; layers 2 and 3: 32 -> 32 at 96x96 and 32 -> 64 at 48x48, 1.7 of the step's 10 ms on the gather-GEMM), forward
+// and data gradient as ONE kernel (the data gradient of a stride-1 3x3 convolution is the same correlation with the
+// filters transposed and flipped), on v_mfma_f32_32x32x16_bf16.
+//
+// fp32 NCHW in and out (the pooling / masking kernels around these layers stay as they are): a tile's input patch is
+// gathered once from the 8 channel planes of each pixel into a channel-innermost bf16 image in LDS ([plane of 8
+// channels][row][W + 1 slots of 16 bytes]: the zero slot in front of a row is the left padding of that row and the right
+// padding of the previous one), and every tap reads it as base + immediate offset (ds_read_b128, consecutive lanes =
+// consecutive slots).  Tile = TR rows x W columns of one image; wave = MBW 32-pixel blocks x all output-channel blocks;
+// two workgroups per CU, so one stages while the other multiplies.  Filters are re-packed per step into fragment order and
+// streamed from L2 one filter row ahead.
+#include "var_common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+__device__ __forceinline__ u32x4_t wload(__amdgpu_buffer_rsrc_t r, int lane_off, int byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, byte_off, 0);
+}
+
+// filters (COUT, CIN, 3, 3) fp32 -> fragment order [kg][tap][cb][lane][8]: lane (r, h) of block cb holds the weight that takes
+// reduction channel ic = 16 kg + 8 h + j to output channel oc = 32 cb + r at tap `tap` of the correlation:
+//   forward        W[oc][ic][tap]                  (IC = CIN, OC = COUT)
+//   data gradient  W[ic][oc][8 - tap]              (IC = COUT, OC = CIN: transposed, both axes flipped)
+__global__ void __launch_bounds__(256) c3_pack_kernel(const float* __restrict__ w, uint4* __restrict__ wp, int IC, int OC, int dgrad) {
+    const int i = blockIdx.x * 256 + threadIdx.x, ncb = OC / 32, n = (IC / 16) * 9 * ncb * 64;
+    if (i >= n) return;
+    const int lane = i & 63, cb = (i >> 6) % ncb, tap = (i / (64 * ncb)) % 9, kg = i / (64 * ncb * 9);
+    const int oc = 32 * cb + (lane & 31), ic0 = 16 * kg + 8 * (lane >> 5);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = dgrad ? w[((long)(ic0 + j) * OC + oc) * 9 + 8 - tap] : w[((long)oc * IC + ic0 + j) * 9 + tap];
+    wp[i] = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+}
+
+template <int IC, int OC, int H, int TR>
+struct C3 {
+    static constexpr int W = H, NPL = IC / 8, KG = IC / 16, NCB = OC / 32, NMB = TR * W / 32, MBW = NMB / 4;
+    static constexpr int PITCH = (W + 1) * 16, PLB = (TR + 2) * PITCH + 16, LDSB = NPL * PLB + 256;
+    static constexpr int NSLOT = NPL * (TR + 2) * W, TILES = H / TR;
+    static_assert(IC % 16 == 0 && OC % 32 == 0 && (TR * W) % 128 == 0 && H % TR == 0 && 2 * LDSB <= 160 * 1024, "c3 shape");
+};
+
+// y[b][oc][p] = epilogue(sum_{ic,tap} x[b][ic][p + tap - (1,1)] w(oc, ic, tap)); MODE 0: + bias, ReLU; MODE 1: zero where mask <= 0
+// (mask may be null)
+template <int IC, int OC, int H, int TR, int MODE>
+__global__ void __launch_bounds__(256, 2) c3_kernel(const float* __restrict__ x, const uint4* __restrict__ wp, const float* __restrict__ bias,
+                                                    const float* __restrict__ mask, float* __restrict__ y, int B) {
+    using G = C3<IC, OC, H, TR>;
+    constexpr int W = G::W, NCB = G::NCB, MBW = G::MBW, PITCH = G::PITCH, PLB = G::PLB;
+    extern __shared__ __align__(16) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p31 = lane & 31;
+    for (int i = tid; i < G::LDSB / 16; i += 256) ((uint4*)lds)[i] = make_uint4(0, 0, 0, 0);
+    int abase[MBW];
+#pragma unroll
+    for (int m = 0; m < MBW; ++m) {
+        const int P = 32 * (MBW * wave + m) + p31, yl = P / W, xx = P - yl * W;
+        abase[m] = h * PLB + yl * PITCH + xx * 16;
+    }
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, G::KG * 9 * NCB * 1024, 0x00020000);
+    float bv[NCB][16];                                          // this lane's output channels' biases
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bv[cb][r] = MODE == 0 ? bias[32 * cb + (r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
+    const int ntiles = B * G::TILES;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / G::TILES, y0 = (tile - b * G::TILES) * TR;
+        __syncthreads();                                        // the previous tile's reads (and the zero fill) are done
+        // gather: slot e = (plane, patch row, column); 8 channel planes of the pixel -> one 16-byte slot; four slots (32
+        // loads) per thread in flight
+        constexpr int NB = (G::NSLOT + 1023) / 1024;
+#pragma unroll 1
+        for (int bt = 0; bt < NB; ++bt) {
+            float v[4][8];
+            int dst[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int e = tid + 256 * (4 * bt + k);
+                asm volatile("" : "+v"(e));
+                const int pl = e / ((TR + 2) * W), r2 = e - pl * ((TR + 2) * W), i = r2 / W, xx = r2 - i * W, yy = y0 - 1 + i;
+                const bool ok = e < G::NSLOT && (unsigned)yy < (unsigned)H;
+                const float* src = x + (((long)b * IC + 8 * pl) * H + (ok ? yy : 0)) * W + xx;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float t = src[(long)j * H * W]; v[k][j] = ok ? t : 0.f; }
+                dst[k] = e < G::NSLOT ? pl * PLB + i * PITCH + (xx + 1) * 16 : -1;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (dst[k] >= 0)
+                    *(uint4*)(lds + dst[k]) = make_uint4(pack_bf16(v[k][0], v[k][1]), pack_bf16(v[k][2], v[k][3]),
+                                                         pack_bf16(v[k][4], v[k][5]), pack_bf16(v[k][6], v[k][7]));
+        }
+        __syncthreads();
+
+        f32x16_t acc[MBW][NCB];
+#pragma unroll
+        for (int m = 0; m < MBW; ++m)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][cb][r] = 0.f;
+        // rows R = (kg, ky) of three taps; filter fragments one row ahead, pixel fragments one tap ahead
+        constexpr int NROW = G::KG * 3;
+        u32x4_t wrow[2][3][NCB];
+        bf16x8_t a[2][MBW];
+        auto toff = [](int t) { const int R = t / 3, kx = t - 3 * R, kg = R / 3, ky = R - 3 * kg; return 2 * kg * PLB + ky * PITCH + kx * 16; };
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) wrow[0][kx][cb] = wload(wr, lane * 16, (kx * NCB + cb) * 1024);
+#pragma unroll
+        for (int m = 0; m < MBW; ++m) a[0][m] = *(const bf16x8_t*)(lds + abase[m] + toff(0));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int R = 0; R < NROW; ++R) {
+            const int cur = R & 1;
+            if (R + 1 < NROW) {
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) wrow[cur ^ 1][kx][cb] = wload(wr, lane * 16, (((R + 1) * 3 + kx) * NCB + cb) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int t = R * 3 + kx, ac = t & 1;
+                if (t + 1 < NROW * 3) {
+#pragma unroll
+                    for (int m = 0; m < MBW; ++m) a[ac ^ 1][m] = *(const bf16x8_t*)(lds + abase[m] + toff(t + 1));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < MBW; ++m)
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb)
+                        acc[m][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wrow[cur][kx][cb]), a[ac][m],
+                                                                             acc[m][cb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // lanes walk the pixels: 128 contiguous bytes per channel and block
+        float* yo = y + (long)b * OC * H * W + (long)y0 * W;
+        const float* mo = mask ? mask + (long)b * OC * H * W + (long)y0 * W : nullptr;
+#pragma unroll
+        for (int m = 0; m < MBW; ++m) {
+            int P = 32 * (MBW * wave + m) + p31;
+            asm volatile("" : "+v"(P));                         // (tile-invariant: hipcc would keep all 16 MBW NCB store offsets alive)
+            float gate[NCB][16];                                // the block's mask values first, all in flight (one by one between
+            if (MODE == 1 && mo) {                              // the stores they took 2.7x the whole forward kernel)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) gate[cb][r] = mo[(32 * cb + (r & 3) + 8 * (r >> 2) + 4 * h) * (H * W) + P];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int oc = 32 * cb + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    float v = acc[m][cb][r];
+                    if (MODE == 0) v = fmaxf(v + bv[cb][r], 0.f);
+                    else if (mo && !(gate[cb][r] > 0.f)) v = 0.f;
+                    yo[oc * (H * W) + P] = v;
+                }
+        }
+    }
+}
+
+template <int IC, int OC, int H, int TR, int MODE>
+int c3_launch(var_ctx* c, hipStream_t s, const float* x, const float* w, const float* bias, const float* mask, float* y, int B, void* wp) {
+    using G = C3<IC, OC, H, TR>;
+    const int n = G::KG * 9 * G::NCB * 64;
+    hipLaunchKernelGGL(c3_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, (uint4*)wp, IC, OC, MODE);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    static bool attr = false;
+    if (!attr) {
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)c3_kernel<IC, OC, H, TR, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDSB));
+        attr = true;
+    }
+    const int ntiles = B * G::TILES;
+    hipLaunchKernelGGL((c3_kernel<IC, OC, H, TR, MODE>), dim3(ntiles < 512 ? ntiles : 512), dim3(256), G::LDSB, s, x, (const uint4*)wp, bias, mask, y, B);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}
+
+}  // namespace
+
+long img_bf16_workspace_bytes() { return 4 * 9 * 4 * 1024 + 256; }      // the largest fragment table (64 -> 128 channels)
+
+// layer = 2 | 3 of the image branch at image side 96 (48 after the first pool); dgrad: x = gy, y = dx, mask = the activation whose
+// ReLU gates dx (or null); returns 1 for shapes these kernels do not cover (the caller falls back to the gather-GEMM)
+int img_bf16_conv(var_ctx* c, hipStream_t s, int layer, int side, int dgrad, const float* x, const float* w, const float* bias,
+                  const float* mask, float* y, int B, void* ws) {
+    if (layer == 2 && side == 96) return dgrad ? c3_launch<32, 32, 96, 8, 1>(c, s, x, w, bias, mask, y, B, ws)
+                                               : c3_launch<32, 32, 96, 8, 0>(c, s, x, w, bias, mask, y, B, ws);
+    if (layer == 3 && side == 48) return dgrad ? c3_launch<64, 32, 48, 8, 1>(c, s, x, w, bias, mask, y, B, ws)
+                                               : c3_launch<32, 64, 48, 8, 0>(c, s, x, w, bias, mask, y, B, ws);
+    return 1;                                                   // not covered
+}

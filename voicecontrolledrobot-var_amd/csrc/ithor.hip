@@ -57,6 +57,7 @@ struct ithor_state {
     float *GI = nullptr, *GH = nullptr, *Hb = nullptr, *R = nullptr, *Z = nullptr, *Nn = nullptr, *GHN = nullptr;
     float *DGI = nullptr, *DGH = nullptr, *DH = nullptr, *DHP = nullptr;
     float *slab = nullptr, *bslab = nullptr;              // split-K partial sums / bias-sum partials
+    void* imgws = nullptr;                                // fragment-ordered filters of img_bf16.hip
     void* gruws = nullptr;                                // W_hh in MFMA fragment order (gru_bf16.hip)
     void* bfws = nullptr;                                 // bf16 images / packed filters of the staged sound kernels (snd_bf16.hip)
     int gh_split = 1, dh_split = 1;
@@ -475,14 +476,22 @@ static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* imag
         d.xb = bstride;
         if (is_u8) RUN((conv_fwd<G3s1, true, false>(c, s, d, image, P + L.iw[0], P + L.ib[0], st->a[1])));
         else RUN((conv_fwd<G3s1, false, false>(c, s, d, image, P + L.iw[0], P + L.ib[0], st->a[1])));
-        RUN((conv_fwd<G3s1, false, false>(c, s, img_dims(st, 2, B), st->a[1], P + L.iw[1], P + L.ib[1], st->a[2])));
+        {
+            int r = st->bf16 ? img_bf16_conv(c, s, 2, hs[0], 0, st->a[1], P + L.iw[1], P + L.ib[1], nullptr, st->a[2], B, st->imgws) : 1;
+            if (r == 1) r = conv_fwd<G3s1, false, false>(c, s, img_dims(st, 2, B), st->a[1], P + L.iw[1], P + L.ib[1], st->a[2]);
+            RUN(r);
+        }
         for (int l = 2; l <= 5; ++l) {
             // pool the output of conv l into p[l], then conv l+1
             const long n = (long)B * kICh[l] * hs[l - 1] * hs[l - 1];
             const int hin = l == 2 ? hs[0] : hs[l - 2];
             hipLaunchKernelGGL(pool_fwd_kernel, g1(n), dim3(256), 0, s, st->a[l], st->p[l], n, hin, hs[l - 1]);
             IT_CHECK(c);
-            if (l < 5) RUN((conv_fwd<G3s1, false, false>(c, s, img_dims(st, l + 1, B), st->p[l], P + L.iw[l], P + L.ib[l], st->a[l + 1])));
+            if (l < 5) {
+                int r = st->bf16 ? img_bf16_conv(c, s, l + 1, hs[l - 1], 0, st->p[l], P + L.iw[l], P + L.ib[l], nullptr, st->a[l + 1], B, st->imgws) : 1;
+                if (r == 1) r = conv_fwd<G3s1, false, false>(c, s, img_dims(st, l + 1, B), st->p[l], P + L.iw[l], P + L.ib[l], st->a[l + 1]);
+                RUN(r);
+            }
             else RUN((conv_fwd<G3s2, false, false>(c, s, img_dims(st, 6, B), st->p[5], P + L.iw[5], P + L.ib[5], st->a[6])));
         }
         RUN(linear_fwd(c, s, st->a[6], P + L.ih_w0, P + L.ih_b0, st->hid_i, B, kIRaw, 128, 1));
@@ -595,7 +604,11 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             RUN((conv_wgrad<G3s1, false, false>(c, s, d, xin, st->ga[l], G + L.iw[l - 1])));
             RUN(chan_sum(c, s, st->ga[l], G + L.ib[l - 1], B, kICh[l], hin * hin));
             float* dx = l == 2 ? st->ga[1] : st->gp[l - 1];
-            RUN((conv_dgrad<G3s1, false>(c, s, d, st->ga[l], P + L.iw[l - 1], dx, l == 2 ? st->a[1] : nullptr)));
+            {
+                int r = st->bf16 ? img_bf16_conv(c, s, l, hin, 1, st->ga[l], P + L.iw[l - 1], nullptr, l == 2 ? st->a[1] : nullptr, dx, B, st->imgws) : 1;
+                if (r == 1) r = conv_dgrad<G3s1, false>(c, s, d, st->ga[l], P + L.iw[l - 1], dx, l == 2 ? st->a[1] : nullptr);
+                RUN(r);
+            }
         }
         {
             ConvDims d = img_dims(st, 1, B);
@@ -752,6 +765,24 @@ int ithor_debug_buffer(var_ctx* c, const char* name, void** ptr, long* nfloats) 
         if (!strcmp(name, a)) { *ptr = st->s[l]; *nfloats = ssz[l]; return VAR_OK; }
         if (!strcmp(name, g)) { *ptr = st->gs[l]; *nfloats = ssz[l]; return VAR_OK; }
     }
+    {   // image branch: activations a1..a6 (post-ReLU), pooled maps p2..p5, and the gradients wrt them (ga*, gp*)
+        const long B = st->maxB;
+        const int* hs = st->hs;
+        for (int l = 1; l <= 6; ++l) {
+            const long n = l <= 2 ? B * 32 * hs[0] * hs[0] : (l <= 5 ? B * kICh[l] * hs[l - 2] * hs[l - 2] : B * kIRaw);
+            char a[8], g[8];
+            snprintf(a, sizeof a, "a%d", l); snprintf(g, sizeof g, "ga%d", l);
+            if (!strcmp(name, a)) { *ptr = st->a[l]; *nfloats = n; return VAR_OK; }
+            if (!strcmp(name, g)) { *ptr = st->ga[l]; *nfloats = n; return VAR_OK; }
+        }
+        for (int l = 2; l <= 5; ++l) {
+            const long n = B * kICh[l] * hs[l - 1] * hs[l - 1];
+            char a[8], g[8];
+            snprintf(a, sizeof a, "p%d", l); snprintf(g, sizeof g, "gp%d", l);
+            if (!strcmp(name, a)) { *ptr = st->p[l]; *nfloats = n; return VAR_OK; }
+            if (!strcmp(name, g)) { *ptr = st->gp[l]; *nfloats = n; return VAR_OK; }
+        }
+    }
     VAR_SET_ERR(c, "var_debug_buffer: unknown iTHOR buffer '%s'", name);
     return VAR_ERR_ARG;
 }
@@ -836,6 +867,7 @@ int var_ithor_plan(var_ctx* c, int max_batch, int img_hw) {
     const long ohs2 = take(C2 * 64), oghs2 = take(C2 * 64);
     const long oraw = take(9 * B), ograw = take(9 * B), oemb = take(9 * B), ogemb = take(9 * B), oloss = take(64);
     const long obf = take((snd_bf16_workspace_bytes((int)C2) + 3) / 4), ogru = take((gru_bf16_workspace_bytes((int)C2) + 3) / 4);
+    const long oimg = take((img_bf16_workspace_bytes() + 3) / 4);
     VAR_HIP_CHECK(c, hipMalloc((void**)&st->ws, (size_t)total * sizeof(float)));
     float* w = (float*)st->ws;
     for (int l = 1; l <= 6; ++l) { st->a[l] = w + oa[l]; st->ga[l] = w + oga[l]; }
@@ -847,7 +879,7 @@ int var_ithor_plan(var_ctx* c, int max_batch, int img_hw) {
     st->sraw = w + osraw; st->gsraw = w + ogsraw;
     st->hid_i = w + ohi; st->ghid_i = w + oghi; st->hid_s1 = w + ohs1; st->ghid_s1 = w + oghs1;
     st->hid_s2 = w + ohs2; st->ghid_s2 = w + oghs2;
-    st->bfws = w + obf; st->gruws = w + ogru;
+    st->bfws = w + obf; st->gruws = w + ogru; st->imgws = w + oimg;
     st->raw = w + oraw; st->graw = w + ograw; st->emb = w + oemb; st->gemb = w + ogemb; st->loss = w + oloss;
     return VAR_OK;
 }

@@ -282,3 +282,8 @@ int gru_bf16_step_fwd(var_ctx* c, hipStream_t s, const float* GI, float* Hb, con
 int gru_bf16_step_bwd(var_ctx* c, hipStream_t s, float* DH, const float* Hb, const float* R, const float* Z, const float* Nn,
                       const float* GHN, float* DGI, float* DGH, int nclips, int maxclips, int step, int has_next, long dirGI,
                       long dirH, long dirS, long dirDGH, void* ws);
+
+// img_bf16.hip: 3x3 stride-1 convolutions of the iTHOR image branch (layers 2, 3) in the bf16 mode, forward and data gradient
+long img_bf16_workspace_bytes();
+int img_bf16_conv(var_ctx* c, hipStream_t s, int layer, int side, int dgrad, const float* x, const float* w, const float* bias,
+                  const float* mask, float* y, int B, void* ws);
