@@ -348,3 +348,13 @@ def test_image_layers_2_and_3_bf16_kernels_vs_float64_on_rounded_operands(var_am
     close(a3, torch.relu(F.conv2d(bf16_round(p2), bf16_round(w3), b3.double(), padding=1)), "a3")
     close(ga1, F.conv_transpose2d(bf16_round(ga2), bf16_round(w2), padding=1) * (a1 > 0), "ga1")
     close(gp2, F.conv_transpose2d(bf16_round(ga3), bf16_round(w3), padding=1), "gp2")
+    # weight gradients (pixels as the MFMA k index, transposed LDS reads)
+    g, o, got = tr.grads.cpu(), 0, {}
+    for k, p in m.named_parameters():
+        got[k] = g[o:o + p.numel()].view(p.shape)
+        o += p.numel()
+    for key, xin, gout in (("imgBranch.2.weight", a1, ga2), ("imgBranch.5.weight", p2, ga3)):
+        ref = torch.nn.grad.conv2d_weight(bf16_round(xin), tuple(sd[key].shape), bf16_round(gout), padding=1)
+        scale = float(ref.abs().max())
+        err = float((got[key].double() - ref).abs().max())
+        assert scale > 0 and err < 1e-4 * scale, (key, err, scale)

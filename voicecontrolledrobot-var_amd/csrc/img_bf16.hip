@@ -194,6 +194,168 @@ int c3_launch(var_ctx* c, hipStream_t s, const float* x, const float* w, const f
     return VAR_OK;
 }
 
+// ---- weight gradient -------------------------------------------------------------------------------------------
+// dW[co][ci][tap] = sum_{b,p} gy[b][co][p] x[b][ci][p + tap - (1,1)]: k = pixel, 16 consecutive pixels of a row per step; both
+// operands come from channel-innermost LDS images (the x patch as above, gy without padding) through the transposing
+// ds_read_b64_tr_b16 (plane pitches = 64 mod 256: conflict-free).  Wave w owns the taps w, w+4, w+8 for all (co, ci)
+// blocks; the accumulators live across all tiles of the (persistent) workgroup and go to its slab (tap, co, ci) once; a fold
+// adds the slabs in workgroup order.
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8_t tr_read2(const unsigned char* p0, const unsigned char* p1) {
+    const bf16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)p0);
+    const bf16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)p1);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int CI, int CO, int H, int TR>
+struct C3W {
+    static constexpr int W = H, NPX = CI / 8, NPG = CO / 8, NCIB = CI / 32, NCOB = CO / 32, KS = TR * W / 16, KPR = W / 16;
+    static constexpr int PITCH = (W + 1) * 16;
+    static constexpr int XPL0 = (TR + 2) * PITCH + 16, XPL = XPL0 + (64 - XPL0 % 256 + 256) % 256;
+    static constexpr int GPL0 = TR * W * 16, GPL = GPL0 + (64 - GPL0 % 256 + 256) % 256;
+    static constexpr int XB = NPX * XPL, LDSB = XB + NPG * GPL + 256;
+    static constexpr int NXS = NPX * (TR + 2) * W, NGS = NPG * TR * W, TILES = H / TR;
+    static_assert(CI % 32 == 0 && CO % 32 == 0 && W % 16 == 0 && H % TR == 0 && XPL % 256 == 64 && GPL % 256 == 64 && 2 * LDSB <= 160 * 1024, "c3w shape");
+};
+
+template <int CI, int CO, int H, int TR>
+__global__ void __launch_bounds__(256, 2) c3w_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ slab, int B) {
+    using G = C3W<CI, CO, H, TR>;
+    constexpr int W = G::W, NCIB = G::NCIB, NCOB = G::NCOB, PITCH = G::PITCH;
+    extern __shared__ __align__(16) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int g16 = (lane >> 4) & 1, qp = (lane & 15) >> 2, p = lane & 3;
+    for (int i = tid; i < G::LDSB / 16; i += 256) ((uint4*)lds)[i] = make_uint4(0, 0, 0, 0);
+    // per lane: plane / half-slot of its 4 channels, its pixel 8 h + qp (+ 4) of a k-step
+    const int chan = 2 * g16 + (p >> 1), half8 = 8 * (p & 1);
+    const int xlane = chan * G::XPL + half8 + (8 * h + qp) * 16;                    // + 4 cib planes, + (row + ky) PITCH + (x0 + kx) 16
+    const int glane = G::XB + chan * G::GPL + half8 + (8 * h + qp) * 16;            // + 4 cob planes, + ks 256
+    constexpr int NT = 3;                                        // taps wave, wave + 4, wave + 8 (< 9)
+    f32x16_t acc[NT][NCOB][NCIB];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int a = 0; a < NCOB; ++a)
+#pragma unroll
+            for (int b = 0; b < NCIB; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][a][b][r] = 0.f;
+    int tapoff[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { const int tap = min(wave + 4 * t, 8), ky = tap / 3, kx = tap - 3 * ky; tapoff[t] = xlane + ky * PITCH + kx * 16; }
+    const int ntaps = wave == 0 ? 3 : 2;
+
+    const int ntiles = B * G::TILES;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / G::TILES, y0 = (tile - b * G::TILES) * TR;
+        __syncthreads();
+        constexpr int NSL = G::NXS + G::NGS, NB = (NSL + 1023) / 1024;
+#pragma unroll 1
+        for (int bt = 0; bt < NB; ++bt) {
+            float v[4][8];
+            int dst[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int e = tid + 256 * (4 * bt + k);
+                asm volatile("" : "+v"(e));
+                const float* src;
+                bool ok;
+                if (e < G::NXS) {
+                    const int pl = e / ((TR + 2) * W), r2 = e - pl * ((TR + 2) * W), i = r2 / W, xx = r2 - i * W, yy = y0 - 1 + i;
+                    ok = (unsigned)yy < (unsigned)H;
+                    src = x + (((long)b * CI + 8 * pl) * H + (ok ? yy : 0)) * W + xx;
+                    dst[k] = pl * G::XPL + i * PITCH + (xx + 1) * 16;
+                } else {
+                    const int f = min(e - G::NXS, G::NGS - 1), pl = f / (TR * W), r2 = f - pl * (TR * W);
+                    ok = e < NSL;
+                    src = gy + (((long)b * CO + 8 * pl) * H + y0) * W + r2;
+                    dst[k] = ok ? G::XB + pl * G::GPL + r2 * 16 : -1;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float t = src[(long)j * H * W]; v[k][j] = ok ? t : 0.f; }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (dst[k] >= 0)
+                    *(uint4*)(lds + dst[k]) = make_uint4(pack_bf16(v[k][0], v[k][1]), pack_bf16(v[k][2], v[k][3]),
+                                                         pack_bf16(v[k][4], v[k][5]), pack_bf16(v[k][6], v[k][7]));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+            const int row = ks / G::KPR, x0 = 16 * (ks % G::KPR);
+            bf16x8_t fa[NCOB], fb[NT][NCIB];
+#pragma unroll
+            for (int a = 0; a < NCOB; ++a) fa[a] = tr_read2(lds + glane + a * 4 * G::GPL + ks * 256, lds + glane + a * 4 * G::GPL + ks * 256 + 64);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int bb = 0; bb < NCIB; ++bb) {
+                    const unsigned char* q = lds + tapoff[t] + bb * 4 * G::XPL + row * PITCH + x0 * 16;
+                    fb[t][bb] = tr_read2(q, q + 64);
+                }
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (t < ntaps) {                                 // uniform per wave
+#pragma unroll
+                    for (int a = 0; a < NCOB; ++a)
+#pragma unroll
+                        for (int bb = 0; bb < NCIB; ++bb)
+                            acc[t][a][bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[t][bb], acc[t][a][bb], 0, 0, 0);
+                }
+        }
+    }
+    // slab[wg][tap][co][ci]: lanes walk ci
+    float* out = slab + (long)blockIdx.x * 9 * CO * CI + (lane & 31);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tap = wave + 4 * t;
+        if (tap < 9) {
+#pragma unroll
+            for (int a = 0; a < NCOB; ++a)
+#pragma unroll
+                for (int bb = 0; bb < NCIB; ++bb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        out[((long)tap * CO + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h) * CI + 32 * bb] = acc[t][a][bb][r];
+        }
+    }
+}
+
+// dW (CO, CI, 3, 3) += the workgroups' slabs (tap, co, ci), in workgroup order: 16 slab elements x 16 slab chains per block
+__global__ void __launch_bounds__(256) c3w_fold_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nslabs, int CO, int CI) {
+    const int n = 9 * CO * CI, i = blockIdx.x * 16 + (threadIdx.x & 15), g = threadIdx.x >> 4;
+    float a = 0.f;
+    if (i < n)
+        for (int s = g; s < nslabs; s += 16) a += slab[(long)s * n + i];
+    __shared__ float red[16][17];
+    red[g][threadIdx.x & 15] = a;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[k][threadIdx.x];
+        const int ci = i % CI, co = (i / CI) % CO, tap = i / (CI * CO);
+        dw[((long)co * CI + ci) * 9 + tap] += v;
+    }
+}
+
+template <int CI, int CO, int H, int TR>
+int c3w_launch(var_ctx* c, hipStream_t s, const float* x, const float* gy, float* dw, float* slab, int B) {
+    using G = C3W<CI, CO, H, TR>;
+    static bool attr = false;
+    if (!attr) {
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)c3w_kernel<CI, CO, H, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDSB));
+        attr = true;
+    }
+    const int ntiles = B * G::TILES, grid = ntiles < 512 ? ntiles : 512;
+    hipLaunchKernelGGL((c3w_kernel<CI, CO, H, TR>), dim3(grid), dim3(256), G::LDSB, s, x, gy, slab, B);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(c3w_fold_kernel, dim3((9 * CO * CI + 15) / 16), dim3(256), 0, s, slab, dw, grid, CO, CI);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}
+
 }  // namespace
 
 long img_bf16_workspace_bytes() { return 4 * 9 * 4 * 1024 + 256; }      // the largest fragment table (64 -> 128 channels)
@@ -207,4 +369,12 @@ int img_bf16_conv(var_ctx* c, hipStream_t s, int layer, int side, int dgrad, con
     if (layer == 3 && side == 48) return dgrad ? c3_launch<64, 32, 48, 8, 1>(c, s, x, w, bias, mask, y, B, ws)
                                                : c3_launch<32, 64, 48, 8, 0>(c, s, x, w, bias, mask, y, B, ws);
     return 1;                                                   // not covered
+}
+
+// dw (COUT, CIN, 3, 3) += the weight gradient of layer 2 | 3 from its input x and the gradient gy wrt its output (fp32 NCHW);
+// slab: 512 x 9*COUT*CIN floats; returns 1 for shapes not covered
+int img_bf16_wgrad(var_ctx* c, hipStream_t s, int layer, int side, const float* x, const float* gy, float* dw, float* slab, int B) {
+    if (layer == 2 && side == 96) return c3w_launch<32, 32, 96, 4>(c, s, x, gy, dw, slab, B);
+    if (layer == 3 && side == 48) return c3w_launch<32, 64, 48, 4>(c, s, x, gy, dw, slab, B);
+    return 1;
 }

@@ -601,7 +601,11 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             IT_CHECK(c);
             const ConvDims d = img_dims(st, l, B);
             const float* xin = l == 2 ? st->a[1] : st->p[l - 1];
-            RUN((conv_wgrad<G3s1, false, false>(c, s, d, xin, st->ga[l], G + L.iw[l - 1])));
+            {
+                int r = st->bf16 ? img_bf16_wgrad(c, s, l, hin, xin, st->ga[l], G + L.iw[l - 1], st->slab, B) : 1;
+                if (r == 1) r = conv_wgrad<G3s1, false, false>(c, s, d, xin, st->ga[l], G + L.iw[l - 1]);
+                RUN(r);
+            }
             RUN(chan_sum(c, s, st->ga[l], G + L.ib[l - 1], B, kICh[l], hin * hin));
             float* dx = l == 2 ? st->ga[1] : st->gp[l - 1];
             {

@@ -287,3 +287,4 @@ int gru_bf16_step_bwd(var_ctx* c, hipStream_t s, float* DH, const float* Hb, con
 long img_bf16_workspace_bytes();
 int img_bf16_conv(var_ctx* c, hipStream_t s, int layer, int side, int dgrad, const float* x, const float* w, const float* bias,
                   const float* mask, float* y, int B, void* ws);
+int img_bf16_wgrad(var_ctx* c, hipStream_t s, int layer, int side, const float* x, const float* gy, float* dw, float* slab, int B);
