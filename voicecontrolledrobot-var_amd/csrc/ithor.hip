@@ -144,6 +144,38 @@ __global__ void pool_relu_bwd_kernel(const float* __restrict__ act, const float*
     gact[i] = g;
 }
 
+// the same for even H, one thread per 2x2 window (8-byte accesses, every activation read once), plus the window's
+// contribution to the channel sum of gact (= the bias gradient of the convolution that produced act): part[plane *
+// gridDim.x + block] = sum over the block's windows -- the caller folds them per channel (slab_reduce with inner = gridDim.x)
+__global__ void __launch_bounds__(256) pool_relu_bwd2_kernel(const float* __restrict__ act, const float* __restrict__ gpool,
+                                                            float* __restrict__ gact, float* __restrict__ part, int H, int HP) {
+    const int wi = blockIdx.x * 256 + threadIdx.x;
+    const long plane = blockIdx.y;
+    float mine = 0.f;
+    if (wi < HP * HP) {
+        const int py = wi / HP, px = wi - py * HP;
+        const float* q = act + plane * H * H + (long)(2 * py) * H + 2 * px;
+        const float2 r0 = *(const float2*)q, r1 = *(const float2*)(q + H);
+        int best = 0; float bv = r0.x;
+        if (r0.y > bv) { bv = r0.y; best = 1; }
+        if (r1.x > bv) { bv = r1.x; best = 2; }
+        if (r1.y > bv) { bv = r1.y; best = 3; }
+        const float g = bv > 0.f ? gpool[plane * HP * HP + wi] : 0.f;
+        float* o = gact + plane * H * H + (long)(2 * py) * H + 2 * px;
+        *(float2*)o = make_float2(best == 0 ? g : 0.f, best == 1 ? g : 0.f);
+        *(float2*)(o + H) = make_float2(best == 2 ? g : 0.f, best == 3 ? g : 0.f);
+        mine = g;
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = mine;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[plane * gridDim.x + blockIdx.x] = red[0];
+}
+
 __global__ void relu_mask_kernel(float* __restrict__ g, const float* __restrict__ act, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && !(act[i] > 0.f)) g[i] = 0.f;
@@ -597,8 +629,18 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
         for (int l = 5; l >= 2; --l) {
             const int hin = l == 2 ? hs[0] : hs[l - 2];       // side of conv l's output (= its input, stride 1)
             const long n = (long)B * kICh[l] * hin * hin;
-            hipLaunchKernelGGL(pool_relu_bwd_kernel, g1(n), dim3(256), 0, s, st->a[l], st->gp[l], st->ga[l], n, hin, hs[l - 1]);
-            IT_CHECK(c);
+            const int hp = hs[l - 1];
+            const int pblocks = (hp * hp + 255) / 256;
+            const bool fused = hin == 2 * hp && (long)B * kICh[l] * pblocks <= kBiasSlabFloats;      // even map: windows tile it exactly
+            if (fused) {     // gact and the bias gradient's partial sums in one pass over the activations
+                hipLaunchKernelGGL(pool_relu_bwd2_kernel, dim3(pblocks, B * kICh[l]), dim3(256), 0, s, st->a[l], st->gp[l], st->ga[l],
+                                   st->bslab, hin, hp);
+                IT_CHECK(c);
+                RUN(slab_reduce(c, s, G + L.ib[l - 1], st->bslab, kICh[l], B, (long)kICh[l] * pblocks, pblocks));
+            } else {
+                hipLaunchKernelGGL(pool_relu_bwd_kernel, g1(n), dim3(256), 0, s, st->a[l], st->gp[l], st->ga[l], n, hin, hs[l - 1]);
+                IT_CHECK(c);
+            }
             const ConvDims d = img_dims(st, l, B);
             const float* xin = l == 2 ? st->a[1] : st->p[l - 1];
             {
@@ -606,7 +648,7 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
                 if (r == 1) r = conv_wgrad<G3s1, false, false>(c, s, d, xin, st->ga[l], G + L.iw[l - 1]);
                 RUN(r);
             }
-            RUN(chan_sum(c, s, st->ga[l], G + L.ib[l - 1], B, kICh[l], hin * hin));
+            if (!fused) RUN(chan_sum(c, s, st->ga[l], G + L.ib[l - 1], B, kICh[l], hin * hin));
             float* dx = l == 2 ? st->ga[1] : st->gp[l - 1];
             {
                 int r = st->bf16 ? img_bf16_conv(c, s, l, hin, 1, st->ga[l], P + L.iw[l - 1], nullptr, l == 2 ? st->a[1] : nullptr, dx, B, st->imgws) : 1;
