@@ -54,7 +54,7 @@ struct C3 {
 // (mask may be null)
 template <int IC, int OC, int H, int TR, int MODE>
 __global__ void __launch_bounds__(256, 2) c3_kernel(const float* __restrict__ x, const uint4* __restrict__ wp, const float* __restrict__ bias,
-                                                    const float* __restrict__ mask, float* __restrict__ y, int B) {
+                                                    const float* __restrict__ mask, float* __restrict__ y, float* __restrict__ csum, int B) {
     using G = C3<IC, OC, H, TR>;
     constexpr int W = G::W, NCB = G::NCB, MBW = G::MBW, PITCH = G::PITCH, PLB = G::PLB;
     extern __shared__ __align__(16) unsigned char lds[];
@@ -72,6 +72,11 @@ __global__ void __launch_bounds__(256, 2) c3_kernel(const float* __restrict__ x,
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) bv[cb][r] = MODE == 0 ? bias[32 * cb + (r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
+    float cs[NCB][16];                                          // channel sums of what this lane stores (csum != null)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cs[cb][r] = 0.f;
     const int ntiles = B * G::TILES;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b = tile / G::TILES, y0 = (tile - b * G::TILES) * TR;
@@ -172,13 +177,30 @@ __global__ void __launch_bounds__(256, 2) c3_kernel(const float* __restrict__ x,
                     if (MODE == 0) v = fmaxf(v + bv[cb][r], 0.f);
                     else if (mo && !(gate[cb][r] > 0.f)) v = 0.f;
                     yo[oc * (H * W) + P] = v;
+                    cs[cb][r] += v;
                 }
         }
+    }
+    if (csum) {      // csum[workgroup][oc]: butterfly over the 32 pixel lanes, then the four waves in order (the bias gradient of
+        __syncthreads();                                        // the layer below when y is the gradient wrt its output)
+        float* red = (float*)lds;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = cs[cb][r];
+#pragma unroll
+                for (int d = 1; d < 32; d <<= 1) v += __shfl_xor(v, d);
+                if (p31 == 0) red[wave * OC + 32 * cb + (r & 3) + 8 * (r >> 2) + 4 * h] = v;
+            }
+        __syncthreads();
+        if (tid < OC) csum[blockIdx.x * OC + tid] = (red[tid] + red[OC + tid]) + (red[2 * OC + tid] + red[3 * OC + tid]);
     }
 }
 
 template <int IC, int OC, int H, int TR, int MODE>
-int c3_launch(var_ctx* c, hipStream_t s, const float* x, const float* w, const float* bias, const float* mask, float* y, int B, void* wp) {
+int c3_launch(var_ctx* c, hipStream_t s, const float* x, const float* w, const float* bias, const float* mask, float* y, float* csum,
+              int* nparts, int B, void* wp) {
     using G = C3<IC, OC, H, TR>;
     const int n = G::KG * 9 * G::NCB * 64;
     hipLaunchKernelGGL(c3_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, (uint4*)wp, IC, OC, MODE);
@@ -188,8 +210,9 @@ int c3_launch(var_ctx* c, hipStream_t s, const float* x, const float* w, const f
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)c3_kernel<IC, OC, H, TR, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDSB));
         attr = true;
     }
-    const int ntiles = B * G::TILES;
-    hipLaunchKernelGGL((c3_kernel<IC, OC, H, TR, MODE>), dim3(ntiles < 512 ? ntiles : 512), dim3(256), G::LDSB, s, x, (const uint4*)wp, bias, mask, y, B);
+    const int ntiles = B * G::TILES, grid = ntiles < 512 ? ntiles : 512;
+    if (nparts) *nparts = grid;
+    hipLaunchKernelGGL((c3_kernel<IC, OC, H, TR, MODE>), dim3(grid), dim3(256), G::LDSB, s, x, (const uint4*)wp, bias, mask, y, csum, B);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }
@@ -362,12 +385,13 @@ long img_bf16_workspace_bytes() { return 4 * 9 * 4 * 1024 + 256; }      // the l
 
 // layer = 2 | 3 of the image branch at image side 96 (48 after the first pool); dgrad: x = gy, y = dx, mask = the activation whose
 // ReLU gates dx (or null); returns 1 for shapes these kernels do not cover (the caller falls back to the gather-GEMM)
+// csum / nparts (optional): *nparts x OC partial channel sums of y -- for a data gradient, the bias gradient of the layer below
 int img_bf16_conv(var_ctx* c, hipStream_t s, int layer, int side, int dgrad, const float* x, const float* w, const float* bias,
-                  const float* mask, float* y, int B, void* ws) {
-    if (layer == 2 && side == 96) return dgrad ? c3_launch<32, 32, 96, 8, 1>(c, s, x, w, bias, mask, y, B, ws)
-                                               : c3_launch<32, 32, 96, 8, 0>(c, s, x, w, bias, mask, y, B, ws);
-    if (layer == 3 && side == 48) return dgrad ? c3_launch<64, 32, 48, 8, 1>(c, s, x, w, bias, mask, y, B, ws)
-                                               : c3_launch<32, 64, 48, 8, 0>(c, s, x, w, bias, mask, y, B, ws);
+                  const float* mask, float* y, float* csum, int* nparts, int B, void* ws) {
+    if (layer == 2 && side == 96) return dgrad ? c3_launch<32, 32, 96, 8, 1>(c, s, x, w, bias, mask, y, csum, nparts, B, ws)
+                                               : c3_launch<32, 32, 96, 8, 0>(c, s, x, w, bias, mask, y, csum, nparts, B, ws);
+    if (layer == 3 && side == 48) return dgrad ? c3_launch<64, 32, 48, 8, 1>(c, s, x, w, bias, mask, y, csum, nparts, B, ws)
+                                               : c3_launch<32, 64, 48, 8, 0>(c, s, x, w, bias, mask, y, csum, nparts, B, ws);
     return 1;                                                   // not covered
 }
 

@@ -509,7 +509,7 @@ static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* imag
         if (is_u8) RUN((conv_fwd<G3s1, true, false>(c, s, d, image, P + L.iw[0], P + L.ib[0], st->a[1])));
         else RUN((conv_fwd<G3s1, false, false>(c, s, d, image, P + L.iw[0], P + L.ib[0], st->a[1])));
         {
-            int r = st->bf16 ? img_bf16_conv(c, s, 2, hs[0], 0, st->a[1], P + L.iw[1], P + L.ib[1], nullptr, st->a[2], B, st->imgws) : 1;
+            int r = st->bf16 ? img_bf16_conv(c, s, 2, hs[0], 0, st->a[1], P + L.iw[1], P + L.ib[1], nullptr, st->a[2], nullptr, nullptr, B, st->imgws) : 1;
             if (r == 1) r = conv_fwd<G3s1, false, false>(c, s, img_dims(st, 2, B), st->a[1], P + L.iw[1], P + L.ib[1], st->a[2]);
             RUN(r);
         }
@@ -520,7 +520,7 @@ static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* imag
             hipLaunchKernelGGL(pool_fwd_kernel, g1(n), dim3(256), 0, s, st->a[l], st->p[l], n, hin, hs[l - 1]);
             IT_CHECK(c);
             if (l < 5) {
-                int r = st->bf16 ? img_bf16_conv(c, s, l + 1, hs[l - 1], 0, st->p[l], P + L.iw[l], P + L.ib[l], nullptr, st->a[l + 1], B, st->imgws) : 1;
+                int r = st->bf16 ? img_bf16_conv(c, s, l + 1, hs[l - 1], 0, st->p[l], P + L.iw[l], P + L.ib[l], nullptr, st->a[l + 1], nullptr, nullptr, B, st->imgws) : 1;
                 if (r == 1) r = conv_fwd<G3s1, false, false>(c, s, img_dims(st, l + 1, B), st->p[l], P + L.iw[l], P + L.ib[l], st->a[l + 1]);
                 RUN(r);
             }
@@ -626,6 +626,7 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             RUN(chan_sum(c, s, st->ga[6], G + L.ib[5], B, 128, 9));
             RUN((conv_dgrad<G3s2, false>(c, s, d, st->ga[6], P + L.iw[5], st->gp[5])));
         }
+        bool ga1_summed = false;
         for (int l = 5; l >= 2; --l) {
             const int hin = l == 2 ? hs[0] : hs[l - 2];       // side of conv l's output (= its input, stride 1)
             const long n = (long)B * kICh[l] * hin * hin;
@@ -651,9 +652,13 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             if (!fused) RUN(chan_sum(c, s, st->ga[l], G + L.ib[l - 1], B, kICh[l], hin * hin));
             float* dx = l == 2 ? st->ga[1] : st->gp[l - 1];
             {
-                int r = st->bf16 ? img_bf16_conv(c, s, l, hin, 1, st->ga[l], P + L.iw[l - 1], nullptr, l == 2 ? st->a[1] : nullptr, dx, B, st->imgws) : 1;
+                // (layer 2's data gradient is ga[1]: its channel sums are conv 1's bias gradient)
+                int nparts = 0;
+                int r = st->bf16 ? img_bf16_conv(c, s, l, hin, 1, st->ga[l], P + L.iw[l - 1], nullptr, l == 2 ? st->a[1] : nullptr, dx,
+                                                 l == 2 ? st->bslab : nullptr, &nparts, B, st->imgws) : 1;
                 if (r == 1) r = conv_dgrad<G3s1, false>(c, s, d, st->ga[l], P + L.iw[l - 1], dx, l == 2 ? st->a[1] : nullptr);
                 RUN(r);
+                if (l == 2 && nparts) { RUN(slab_reduce(c, s, G + L.ib[0], st->bslab, 32, nparts, 32)); ga1_summed = true; }
             }
         }
         {
@@ -661,7 +666,7 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             d.xb = st->bstride;
             if (st->is_u8) RUN((conv_wgrad<G3s1, true, false>(c, s, d, st->image, st->ga[1], G + L.iw[0])));
             else RUN((conv_wgrad<G3s1, false, false>(c, s, d, st->image, st->ga[1], G + L.iw[0])));
-            RUN(chan_sum(c, s, st->ga[1], G + L.ib[0], B, 32, hs[0] * hs[0]));
+            if (!ga1_summed) RUN(chan_sum(c, s, st->ga[1], G + L.ib[0], B, 32, hs[0] * hs[0]));
         }
     }
     if (nclips) {

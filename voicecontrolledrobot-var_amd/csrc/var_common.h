@@ -286,5 +286,5 @@ int gru_bf16_step_bwd(var_ctx* c, hipStream_t s, float* DH, const float* Hb, con
 // img_bf16.hip: 3x3 stride-1 convolutions of the iTHOR image branch (layers 2, 3) in the bf16 mode, forward and data gradient
 long img_bf16_workspace_bytes();
 int img_bf16_conv(var_ctx* c, hipStream_t s, int layer, int side, int dgrad, const float* x, const float* w, const float* bias,
-                  const float* mask, float* y, int B, void* ws);
+                  const float* mask, float* y, float* csum, int* nparts, int B, void* ws);
 int img_bf16_wgrad(var_ctx* c, hipStream_t s, int layer, int side, const float* x, const float* gy, float* dw, float* slab, int B);
