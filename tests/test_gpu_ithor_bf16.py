@@ -362,3 +362,23 @@ def test_image_layers_2_and_3_bf16_kernels_vs_float64_on_rounded_operands(var_am
         scale = float(ref.abs().max())
         err = float((got[key].double() - ref).abs().max())
         assert scale > 0 and err < 1e-4 * scale, (key, err, scale)
+
+
+@pytest.mark.parametrize("h,B", [(84, 3), (96, 5)])
+def test_bf16_mode_other_image_size_and_odd_batch_close_to_fp32(var_amd, h, B):
+    """Shapes the staged image kernels do not cover (84x84: 42 / 21 / 10 / 5 maps, odd ones among them) fall back to the
+    gather-GEMM inside the bf16 mode; odd batches exercise the ragged tiles of every staged kernel.  Loss and embeddings
+    against the fp32 path on the same batch."""
+    pos, neg = sounds(B, 200 + h)
+    img = torch.randint(0, 256, (B, 3, h, h), dtype=torch.uint8, generator=torch.Generator().manual_seed(h)).cuda()
+    out = {}
+    for prec in ("fp32", "bf16"):
+        torch.manual_seed(5)
+        m = var_amd.IthorVARPretextNet(cfg(h)).to("cuda").set_precision(prec)
+        tr = var_amd.IthorTrainer(m)
+        loss, feats = tr.loss_and_grads(img, pos, neg, feats=True)
+        out[prec] = (loss.item(), feats.cpu().numpy(), tr.grads.cpu().numpy().astype(np.float64))
+    assert abs(out["bf16"][0] - out["fp32"][0]) < 2e-3
+    np.testing.assert_allclose(out["bf16"][1], out["fp32"][1], atol=8e-3)
+    a, b = out["bf16"][2], out["fp32"][2]
+    assert np.isfinite(a).all() and float(np.linalg.norm(a - b) / np.linalg.norm(b)) < 0.2
