@@ -317,10 +317,11 @@ def test_conv1_weight_gradient_bf16_kernel_vs_float64_on_rounded_operands(var_am
     assert scale > 0 and err < 1e-4 * scale, (err, scale)
 
 
-def test_image_layers_2_and_3_bf16_kernels_vs_float64_on_rounded_operands(var_amd):
-    """img_bf16.hip: the 3x3 stride-1 layers 32 -> 32 at 96x96 and 32 -> 64 at 48x48, forward and data gradient (one kernel
-    with transposed / flipped filters), against float64 convolutions of the bf16-rounded operands."""
-    B = 2
+def test_image_layers_2_to_5_bf16_kernels_vs_float64_on_rounded_operands(var_amd):
+    """img_bf16.hip: the 3x3 stride-1 layers (32 -> 32 at 96x96, 32 -> 64 at 48x48, 64 -> 64 at 24x24 as whole-image tiles,
+    64 -> 128 at 12x12 as two-image tiles: the odd batch leaves one half empty), forward and data gradient (one kernel with
+    transposed / flipped filters), against float64 convolutions of the bf16-rounded operands."""
+    B = 3
     torch.manual_seed(5)
     m = var_amd.IthorVARPretextNet(cfg(96)).to("cuda").set_precision("bf16", keep_fp32_activations=True)
     pos, neg = sounds(B, 17)
@@ -348,6 +349,13 @@ def test_image_layers_2_and_3_bf16_kernels_vs_float64_on_rounded_operands(var_am
     close(a3, torch.relu(F.conv2d(bf16_round(p2), bf16_round(w3), b3.double(), padding=1)), "a3")
     close(ga1, F.conv_transpose2d(bf16_round(ga2), bf16_round(w2), padding=1) * (a1 > 0), "ga1")
     close(gp2, F.conv_transpose2d(bf16_round(ga3), bf16_round(w3), padding=1), "gp2")
+    p3, a4, p4, a5 = buf("p3", 64, 24), buf("a4", 64, 24), buf("p4", 64, 12), buf("a5", 128, 12)
+    gp3, ga4, gp4, ga5 = buf("gp3", 64, 24), buf("ga4", 64, 24), buf("gp4", 64, 12), buf("ga5", 128, 12)
+    w4, b4, w5, b5 = sd["imgBranch.8.weight"], sd["imgBranch.8.bias"], sd["imgBranch.11.weight"], sd["imgBranch.11.bias"]
+    close(a4, torch.relu(F.conv2d(bf16_round(p3), bf16_round(w4), b4.double(), padding=1)), "a4")
+    close(a5, torch.relu(F.conv2d(bf16_round(p4), bf16_round(w5), b5.double(), padding=1)), "a5")
+    close(gp3, F.conv_transpose2d(bf16_round(ga4), bf16_round(w4), padding=1), "gp3")
+    close(gp4, F.conv_transpose2d(bf16_round(ga5), bf16_round(w5), padding=1), "gp4")
     # weight gradients (pixels as the MFMA k index, transposed LDS reads)
     g, o, got = tr.grads.cpu(), 0, {}
     for k, p in m.named_parameters():

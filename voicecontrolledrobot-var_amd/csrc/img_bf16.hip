@@ -42,47 +42,46 @@ __global__ void __launch_bounds__(256) c3_pack_kernel(const float* __restrict__ 
     wp[i] = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
 }
 
-template <int IC, int OC, int H, int TR>
+// Tile = NI images x TR rows x W columns (NI > 1 only with whole images, TR = H: the 24x24 and 12x12 maps); WGS workgroups per CU.
+template <int IC, int OC, int H, int TR, int NI>
 struct C3 {
-    static constexpr int W = H, NPL = IC / 8, KG = IC / 16, NCB = OC / 32, NMB = TR * W / 32, MBW = NMB / 4;
-    static constexpr int PITCH = (W + 1) * 16, PLB = (TR + 2) * PITCH + 16, LDSB = NPL * PLB + 256;
-    static constexpr int NSLOT = NPL * (TR + 2) * W, TILES = H / TR;
-    static_assert(IC % 16 == 0 && OC % 32 == 0 && (TR * W) % 128 == 0 && H % TR == 0 && 2 * LDSB <= 160 * 1024, "c3 shape");
+    static constexpr int W = H, NPL = IC / 8, KG = IC / 16, NCB = OC / 32, M = NI * TR * W, NMB = (M + 31) / 32, MBW = (NMB + 3) / 4;
+    static constexpr int PITCH = (W + 1) * 16, PR = NI * (TR + 2), PLB = PR * PITCH + 16;
+    static constexpr int SLACK = ((128 * MBW - M + W - 1) / W + 3) * PITCH;                  // rows the unused pixel slots' taps may touch
+    static constexpr int LDSB = NPL * PLB + SLACK + 256;
+    static constexpr int NSLOT = NPL * PR * W, TILES = H / TR;
+    static_assert(IC % 16 == 0 && OC % 32 == 0 && H % TR == 0 && (NI == 1 || TR == H) && LDSB <= 160 * 1024, "c3 shape");
 };
 
 // y[b][oc][p] = epilogue(sum_{ic,tap} x[b][ic][p + tap - (1,1)] w(oc, ic, tap)); MODE 0: + bias, ReLU; MODE 1: zero where mask <= 0
-// (mask may be null)
-template <int IC, int OC, int H, int TR, int MODE>
-__global__ void __launch_bounds__(256, 2) c3_kernel(const float* __restrict__ x, const uint4* __restrict__ wp, const float* __restrict__ bias,
-                                                    const float* __restrict__ mask, float* __restrict__ y, float* __restrict__ csum, int B) {
-    using G = C3<IC, OC, H, TR>;
+// (mask may be null); csum (optional): gridDim x OC partial channel sums of y
+template <int IC, int OC, int H, int TR, int NI, int MODE, int WGS>
+__global__ void __launch_bounds__(256, WGS) c3_kernel(const float* __restrict__ x, const uint4* __restrict__ wp, const float* __restrict__ bias,
+                                                      const float* __restrict__ mask, float* __restrict__ y, float* __restrict__ csum, int B) {
+    using G = C3<IC, OC, H, TR, NI>;
     constexpr int W = G::W, NCB = G::NCB, MBW = G::MBW, PITCH = G::PITCH, PLB = G::PLB;
     extern __shared__ __align__(16) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p31 = lane & 31;
     for (int i = tid; i < G::LDSB / 16; i += 256) ((uint4*)lds)[i] = make_uint4(0, 0, 0, 0);
     int abase[MBW];
 #pragma unroll
-    for (int m = 0; m < MBW; ++m) {
-        const int P = 32 * (MBW * wave + m) + p31, yl = P / W, xx = P - yl * W;
-        abase[m] = h * PLB + yl * PITCH + xx * 16;
+    for (int m = 0; m < MBW; ++m) {                             // pixel slot P = (image of the tile, row, column); slots >= M read a valid nowhere
+        const int P = 32 * (MBW * wave + m) + p31, im = P / (TR * W), r2 = P - im * (TR * W), yl = r2 / W, xx = r2 - yl * W;
+        abase[m] = h * PLB + (im * (TR + 2) + yl) * PITCH + xx * 16;
     }
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, G::KG * 9 * NCB * 1024, 0x00020000);
-    float bv[NCB][16];                                          // this lane's output channels' biases
+    // forward: this lane's output channels' biases; data gradient: channel sums of what this lane stores (csum != null)
+    float bc[NCB][16];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bv[cb][r] = MODE == 0 ? bias[32 * cb + (r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
-    float cs[NCB][16];                                          // channel sums of what this lane stores (csum != null)
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cs[cb][r] = 0.f;
-    const int ntiles = B * G::TILES;
+        for (int r = 0; r < 16; ++r) bc[cb][r] = MODE == 0 ? bias[32 * cb + (r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
+    const int ntiles = ((B + NI - 1) / NI) * G::TILES;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int b = tile / G::TILES, y0 = (tile - b * G::TILES) * TR;
+        const int b0 = (tile / G::TILES) * NI, y0 = (tile % G::TILES) * TR;
         __syncthreads();                                        // the previous tile's reads (and the zero fill) are done
-        // gather: slot e = (plane, patch row, column); 8 channel planes of the pixel -> one 16-byte slot; four slots (32
-        // loads) per thread in flight
+        // gather: slot e = (plane, image, patch row, column); 8 channel planes of the pixel -> one 16-byte slot; four slots
+        // (32 loads) per thread in flight
         constexpr int NB = (G::NSLOT + 1023) / 1024;
 #pragma unroll 1
         for (int bt = 0; bt < NB; ++bt) {
@@ -92,12 +91,13 @@ __global__ void __launch_bounds__(256, 2) c3_kernel(const float* __restrict__ x,
             for (int k = 0; k < 4; ++k) {
                 int e = tid + 256 * (4 * bt + k);
                 asm volatile("" : "+v"(e));
-                const int pl = e / ((TR + 2) * W), r2 = e - pl * ((TR + 2) * W), i = r2 / W, xx = r2 - i * W, yy = y0 - 1 + i;
-                const bool ok = e < G::NSLOT && (unsigned)yy < (unsigned)H;
-                const float* src = x + (((long)b * IC + 8 * pl) * H + (ok ? yy : 0)) * W + xx;
+                const int pl = e / (G::PR * W), r2 = e - pl * (G::PR * W), ri = r2 / W, xx = r2 - ri * W;
+                const int im = ri / (TR + 2), i = ri - im * (TR + 2), yy = y0 - 1 + i, b = b0 + im;
+                const bool ok = e < G::NSLOT && (unsigned)yy < (unsigned)H && b < B;
+                const float* src = x + (((long)(ok ? b : 0) * IC + 8 * pl) * H + (ok ? yy : 0)) * W + xx;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float t = src[(long)j * H * W]; v[k][j] = ok ? t : 0.f; }
-                dst[k] = e < G::NSLOT ? pl * PLB + i * PITCH + (xx + 1) * 16 : -1;
+                dst[k] = e < G::NSLOT ? pl * PLB + ri * PITCH + (xx + 1) * 16 : -1;
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -154,41 +154,44 @@ __global__ void __launch_bounds__(256, 2) c3_kernel(const float* __restrict__ x,
             }
         }
         // lanes walk the pixels: 128 contiguous bytes per channel and block
-        float* yo = y + (long)b * OC * H * W + (long)y0 * W;
-        const float* mo = mask ? mask + (long)b * OC * H * W + (long)y0 * W : nullptr;
 #pragma unroll
         for (int m = 0; m < MBW; ++m) {
             int P = 32 * (MBW * wave + m) + p31;
             asm volatile("" : "+v"(P));                         // (tile-invariant: hipcc would keep all 16 MBW NCB store offsets alive)
+            const int im = P / (TR * W), b = b0 + im;
+            const bool live = P < G::M && b < B;
+            const int o0 = live ? b * (OC * H * W) + y0 * W + (P - im * (TR * W)) : 0;      // (< 2^31 floats: batch <= 1024)
             float gate[NCB][16];                                // the block's mask values first, all in flight (one by one between
-            if (MODE == 1 && mo) {                              // the stores they took 2.7x the whole forward kernel)
+            if (MODE == 1 && mask) {                            // the stores they took 2.7x the whole forward kernel)
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) gate[cb][r] = mo[(32 * cb + (r & 3) + 8 * (r >> 2) + 4 * h) * (H * W) + P];
+                    for (int r = 0; r < 16; ++r) gate[cb][r] = mask[o0 + (32 * cb + (r & 3) + 8 * (r >> 2) + 4 * h) * (H * W)];
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (live) {
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb)
+                for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int oc = 32 * cb + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    float v = acc[m][cb][r];
-                    if (MODE == 0) v = fmaxf(v + bv[cb][r], 0.f);
-                    else if (mo && !(gate[cb][r] > 0.f)) v = 0.f;
-                    yo[oc * (H * W) + P] = v;
-                    cs[cb][r] += v;
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const int oc = 32 * cb + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        float v = acc[m][cb][r];
+                        if (MODE == 0) v = fmaxf(v + bc[cb][r], 0.f);
+                        else if (mask && !(gate[cb][r] > 0.f)) v = 0.f;
+                        y[o0 + oc * (H * W)] = v;
+                        if (MODE == 1) bc[cb][r] += v;
+                    }
+            }
         }
     }
-    if (csum) {      // csum[workgroup][oc]: butterfly over the 32 pixel lanes, then the four waves in order (the bias gradient of
+    if (MODE == 1 && csum) {      // csum[workgroup][oc]: butterfly over the 32 pixel lanes, then the four waves in order (the bias gradient of
         __syncthreads();                                        // the layer below when y is the gradient wrt its output)
         float* red = (float*)lds;
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = cs[cb][r];
+                float v = bc[cb][r];
 #pragma unroll
                 for (int d = 1; d < 32; d <<= 1) v += __shfl_xor(v, d);
                 if (p31 == 0) red[wave * OC + 32 * cb + (r & 3) + 8 * (r >> 2) + 4 * h] = v;
@@ -198,21 +201,22 @@ __global__ void __launch_bounds__(256, 2) c3_kernel(const float* __restrict__ x,
     }
 }
 
-template <int IC, int OC, int H, int TR, int MODE>
+template <int IC, int OC, int H, int TR, int NI, int MODE, int WGS>
 int c3_launch(var_ctx* c, hipStream_t s, const float* x, const float* w, const float* bias, const float* mask, float* y, float* csum,
               int* nparts, int B, void* wp) {
-    using G = C3<IC, OC, H, TR>;
+    using G = C3<IC, OC, H, TR, NI>;
+    static_assert(WGS * G::LDSB <= 160 * 1024, "c3 LDS per CU");
     const int n = G::KG * 9 * G::NCB * 64;
     hipLaunchKernelGGL(c3_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, (uint4*)wp, IC, OC, MODE);
     VAR_HIP_CHECK(c, hipGetLastError());
     static bool attr = false;
     if (!attr) {
-        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)c3_kernel<IC, OC, H, TR, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDSB));
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)c3_kernel<IC, OC, H, TR, NI, MODE, WGS>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDSB));
         attr = true;
     }
-    const int ntiles = B * G::TILES, grid = ntiles < 512 ? ntiles : 512;
+    const int ntiles = ((B + NI - 1) / NI) * G::TILES, cap = 256 * WGS, grid = ntiles < cap ? ntiles : cap;
     if (nparts) *nparts = grid;
-    hipLaunchKernelGGL((c3_kernel<IC, OC, H, TR, MODE>), dim3(grid), dim3(256), G::LDSB, s, x, (const uint4*)wp, bias, mask, y, csum, B);
+    hipLaunchKernelGGL((c3_kernel<IC, OC, H, TR, NI, MODE, WGS>), dim3(grid), dim3(256), G::LDSB, s, x, (const uint4*)wp, bias, mask, y, csum, B);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }
@@ -381,17 +385,21 @@ int c3w_launch(var_ctx* c, hipStream_t s, const float* x, const float* gy, float
 
 }  // namespace
 
-long img_bf16_workspace_bytes() { return 4 * 9 * 4 * 1024 + 256; }      // the largest fragment table (64 -> 128 channels)
+long img_bf16_workspace_bytes() { return 8 * 9 * 4 * 1024 + 256; }      // the largest fragment table (128 x 64 channels)
 
 // layer = 2 | 3 of the image branch at image side 96 (48 after the first pool); dgrad: x = gy, y = dx, mask = the activation whose
 // ReLU gates dx (or null); returns 1 for shapes these kernels do not cover (the caller falls back to the gather-GEMM)
 // csum / nparts (optional): *nparts x OC partial channel sums of y -- for a data gradient, the bias gradient of the layer below
 int img_bf16_conv(var_ctx* c, hipStream_t s, int layer, int side, int dgrad, const float* x, const float* w, const float* bias,
                   const float* mask, float* y, float* csum, int* nparts, int B, void* ws) {
-    if (layer == 2 && side == 96) return dgrad ? c3_launch<32, 32, 96, 8, 1>(c, s, x, w, bias, mask, y, csum, nparts, B, ws)
-                                               : c3_launch<32, 32, 96, 8, 0>(c, s, x, w, bias, mask, y, csum, nparts, B, ws);
-    if (layer == 3 && side == 48) return dgrad ? c3_launch<64, 32, 48, 8, 1>(c, s, x, w, bias, mask, y, csum, nparts, B, ws)
-                                               : c3_launch<32, 64, 48, 8, 0>(c, s, x, w, bias, mask, y, csum, nparts, B, ws);
+#define C3_GO(IC, OC, H, TR, NI, WGS)                                                                                          \
+    return dgrad ? c3_launch<OC, IC, H, TR, NI, 1, WGS>(c, s, x, w, bias, mask, y, csum, nparts, B, ws)                         \
+                 : c3_launch<IC, OC, H, TR, NI, 0, WGS>(c, s, x, w, bias, mask, y, csum, nparts, B, ws)
+    if (layer == 2 && side == 96) { C3_GO(32, 32, 96, 8, 1, 2); }
+    if (layer == 3 && side == 48) { C3_GO(32, 64, 48, 8, 1, 2); }
+    if (layer == 4 && side == 24) { C3_GO(64, 64, 24, 24, 1, 1); }
+    if (layer == 5 && side == 12) { C3_GO(64, 128, 12, 12, 2, 1); }
+#undef C3_GO
     return 1;                                                   // not covered
 }
 
