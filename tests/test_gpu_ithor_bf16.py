@@ -365,7 +365,8 @@ def test_image_layers_2_to_5_bf16_kernels_vs_float64_on_rounded_operands(var_amd
     for key, gmap in (("imgBranch.0.bias", ga1), ("imgBranch.2.bias", ga2)):
         want = gmap.double().sum((0, 2, 3))
         assert float((got[key].double() - want).abs().max()) < 1e-5 * float(gmap.abs().double().sum((0, 2, 3)).max()), key
-    for key, xin, gout in (("imgBranch.2.weight", a1, ga2), ("imgBranch.5.weight", p2, ga3)):
+    x0 = (img.cpu().float() / 255.0)
+    for key, xin, gout in (("imgBranch.0.weight", x0, ga1), ("imgBranch.2.weight", a1, ga2), ("imgBranch.5.weight", p2, ga3)):
         ref = torch.nn.grad.conv2d_weight(bf16_round(xin), tuple(sd[key].shape), bf16_round(gout), padding=1)
         scale = float(ref.abs().max())
         err = float((got[key].double() - ref).abs().max())

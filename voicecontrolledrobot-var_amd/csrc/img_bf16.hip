@@ -383,6 +383,93 @@ int c3w_launch(var_ctx* c, hipStream_t s, const float* x, const float* gy, float
     return VAR_OK;
 }
 
+// ---- layer 1's weight gradient (3 -> 32 channels at HxH, u8 image) ---------------------------------------------------------
+// dW[co][ci][ky][kx] = sum_{b,p} gy[b][co][p] (img[b][ci][p + tap - (1,1)] / 255): k = pixel, 16 consecutive pixels of a row
+// per step; rows = co: gy is fp32 NCHW, a lane's 8 pixels are 32 contiguous bytes, loaded straight from HBM a ring of steps
+// ahead and rounded; columns = the 27 taps (ci, ky, kx): the image tile sits in LDS as bf16 [ci][row][column + 1] and a tap
+// column's 8 consecutive pixels are taken from 5 consecutive dwords with v_perm (the start is odd for kx = 0, 2).  The four
+// waves split the tile's k-steps; one slab (32 x 32) per workgroup.
+template <int H, int TR>
+__global__ void __launch_bounds__(256, 2) c1w_kernel(const unsigned char* __restrict__ img, long bstride, const float* __restrict__ gy,
+                                                     float* __restrict__ slab, int B) {
+    constexpr int W = H, PITCH = (W + 8) * 2, PLB = (TR + 2) * PITCH, KPR = W / 16, KS = TR * KPR, TILES = H / TR;
+    static_assert(W % 16 == 0 && H % TR == 0 && KS % 4 == 0, "c1w shape");
+    __shared__ __align__(16) unsigned char lds[3 * PLB + 64];
+    __shared__ float red[4][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, r = lane & 31;
+    // this lane's tap column (ci, ky, kx) (columns 27..31 repeat tap 26 and are dropped): element (row + ky, x + kx) of plane ci,
+    // elements start one slot in (column -1 = element 1; element 0 is padding for the dword pairing)
+    const int col = min(r, 26), ci = col / 9, ky = (col - 9 * ci) / 3, kx = col - 9 * ci - 3 * ky;
+    // 8 pixels from x0 + 8 h: elements e0 = x0 + 8 h + kx, e0 + 1, ...: even start (kx = 0, 2) = 4 whole dwords; odd start (kx = 1)
+    // = the high half of each dword with the low half of the next
+    const int cbase = ci * PLB + ky * PITCH + ((8 * h + kx - (kx == 1 ? 1 : 0)) >> 1) * 4;
+    const unsigned sel = kx == 1 ? 0x05040302u : 0x03020100u;
+    for (int i = tid; i < (3 * PLB + 64) / 16; i += 256) ((uint4*)lds)[i] = make_uint4(0, 0, 0, 0);
+    f32x16_t acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    const int ntiles = B * TILES;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / TILES, y0 = (tile - b * TILES) * TR;
+        __syncthreads();
+        for (int e = tid; e < 3 * (TR + 2) * (W / 4); e += 256) {          // 4 pixels per thread: u8 -> /255 -> bf16
+            const int pl = e / ((TR + 2) * (W / 4)), r2 = e - pl * ((TR + 2) * (W / 4)), i = r2 / (W / 4), x4 = r2 - i * (W / 4), yy = y0 - 1 + i;
+            unsigned v = 0;
+            if ((unsigned)yy < (unsigned)H) v = *(const unsigned*)(img + b * bstride + ((long)pl * H + yy) * W + 4 * x4);
+            const float f0 = (float)(v & 255u) / 255.f, f1 = (float)((v >> 8) & 255u) / 255.f, f2 = (float)((v >> 16) & 255u) / 255.f,
+                        f3 = (float)(v >> 24) / 255.f;
+            unsigned short* d = (unsigned short*)(lds + pl * PLB + i * PITCH) + 1 + 4 * x4;       // odd element: 2 + 4 + 2 bytes
+            const unsigned p01 = pack_bf16(f0, f1), p23 = pack_bf16(f2, f3);
+            d[0] = (unsigned short)p01; *(unsigned*)(d + 1) = (p01 >> 16) | (p23 << 16); d[3] = (unsigned short)(p23 >> 16);
+        }
+        __syncthreads();
+        const float* ga = gy + ((long)b * 32 + r) * H * W + (long)y0 * W + 8 * h;         // + 16 ks
+        constexpr int NW = KS / 4, DEPTH = NW < 6 ? NW : 6;                               // this wave's k-steps ks = wave + 4 j
+        float4 ring[DEPTH][2];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) { const float4* q = (const float4*)(ga + 16 * (wave + 4 * d)); ring[d][0] = q[0]; ring[d][1] = q[1]; }
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int ks = wave + 4 * j;
+            const float4 a0 = ring[j % DEPTH][0], a1 = ring[j % DEPTH][1];
+            if (j + DEPTH < NW) { const float4* q = (const float4*)(ga + 16 * (wave + 4 * (j + DEPTH))); ring[j % DEPTH][0] = q[0]; ring[j % DEPTH][1] = q[1]; }
+            const int row = ks / KPR, x0 = 16 * (ks - row * KPR);
+            const unsigned* q = (const unsigned*)(lds + cbase + row * PITCH + x0 * 2);
+            u32x4_t bq, aq;
+            bq.x = __builtin_amdgcn_perm(q[1], q[0], sel); bq.y = __builtin_amdgcn_perm(q[2], q[1], sel);
+            bq.z = __builtin_amdgcn_perm(q[3], q[2], sel); bq.w = __builtin_amdgcn_perm(q[4], q[3], sel);
+            aq.x = pack_bf16(a0.x, a0.y); aq.y = pack_bf16(a0.z, a0.w); aq.z = pack_bf16(a1.x, a1.y); aq.w = pack_bf16(a1.z, a1.w);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, aq), __builtin_bit_cast(bf16x8_t, bq), acc, 0, 0, 0);
+        }
+    }
+    // the four waves' partial sums, in wave order; slab[wg][co][column]
+#pragma unroll
+    for (int q = 0; q < 16; ++q) red[wave][q][lane] = acc[q];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            slab[((long)blockIdx.x * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * 32 + r] = (red[0][q][lane] + red[1][q][lane]) + (red[2][q][lane] + red[3][q][lane]);
+    }
+}
+
+// dW (32, 3, 3, 3) += the slabs (co, column), in workgroup order
+__global__ void __launch_bounds__(256) c1w_fold_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nslabs) {
+    const int i = blockIdx.x * 16 + (threadIdx.x & 15), g = threadIdx.x >> 4;            // i = co * 32 + column
+    float a = 0.f;
+    for (int s = g; s < nslabs; s += 16) a += slab[(long)s * 1024 + i];
+    __shared__ float red[16][17];
+    red[g][threadIdx.x & 15] = a;
+    __syncthreads();
+    if (g == 0) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[k][threadIdx.x];
+        const int co = i >> 5, colm = i & 31;
+        if (colm < 27) dw[co * 27 + colm] += v;
+    }
+}
+
 }  // namespace
 
 long img_bf16_workspace_bytes() { return 8 * 9 * 4 * 1024 + 256; }      // the largest fragment table (128 x 64 channels)
@@ -409,4 +496,16 @@ int img_bf16_wgrad(var_ctx* c, hipStream_t s, int layer, int side, const float* 
     if (layer == 2 && side == 96) return c3w_launch<32, 32, 96, 4>(c, s, x, gy, dw, slab, B);
     if (layer == 3 && side == 48) return c3w_launch<32, 64, 48, 4>(c, s, x, gy, dw, slab, B);
     return 1;
+}
+
+// layer 1's weight gradient from the u8 image batch (bstride bytes between images, 3 planes of side x side first) and the
+// gradient gy wrt its output (fp32 NCHW); slab: 512 x 1024 floats; returns 1 for shapes not covered
+int img_bf16_wgrad1(var_ctx* c, hipStream_t s, int side, const void* image, long bstride, const float* gy, float* dw, float* slab, int B) {
+    if (side != 96) return 1;
+    const int ntiles = B * (96 / 8), grid = ntiles < 512 ? ntiles : 512;
+    hipLaunchKernelGGL((c1w_kernel<96, 8>), dim3(grid), dim3(256), 0, s, (const unsigned char*)image, bstride, gy, slab, B);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(c1w_fold_kernel, dim3(1024 / 16), dim3(256), 0, s, slab, dw, grid);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
 }

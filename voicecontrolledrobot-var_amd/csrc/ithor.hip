@@ -664,7 +664,11 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
         {
             ConvDims d = img_dims(st, 1, B);
             d.xb = st->bstride;
-            if (st->is_u8) RUN((conv_wgrad<G3s1, true, false>(c, s, d, st->image, st->ga[1], G + L.iw[0])));
+            if (st->is_u8) {
+                int r = st->bf16 ? img_bf16_wgrad1(c, s, hs[0], st->image, st->bstride, st->ga[1], G + L.iw[0], st->slab, B) : 1;
+                if (r == 1) r = conv_wgrad<G3s1, true, false>(c, s, d, st->image, st->ga[1], G + L.iw[0]);
+                RUN(r);
+            }
             else RUN((conv_wgrad<G3s1, false, false>(c, s, d, st->image, st->ga[1], G + L.iw[0])));
             if (!ga1_summed) RUN(chan_sum(c, s, st->ga[1], G + L.ib[0], B, 32, hs[0] * hs[0]));
         }

@@ -288,3 +288,4 @@ long img_bf16_workspace_bytes();
 int img_bf16_conv(var_ctx* c, hipStream_t s, int layer, int side, int dgrad, const float* x, const float* w, const float* bias,
                   const float* mask, float* y, float* csum, int* nparts, int B, void* ws);
 int img_bf16_wgrad(var_ctx* c, hipStream_t s, int layer, int side, const float* x, const float* gy, float* dw, float* slab, int B);
+int img_bf16_wgrad1(var_ctx* c, hipStream_t s, int side, const void* image, long bstride, const float* gy, float* dw, float* slab, int B);
