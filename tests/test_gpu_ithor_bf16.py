@@ -391,3 +391,19 @@ def test_bf16_mode_other_image_size_and_odd_batch_close_to_fp32(var_amd, h, B):
     np.testing.assert_allclose(out["bf16"][1], out["fp32"][1], atol=8e-3)
     a, b = out["bf16"][2], out["fp32"][2]
     assert np.isfinite(a).all() and float(np.linalg.norm(a - b) / np.linalg.norm(b)) < 0.2
+
+
+def test_bf16_mode_single_sound_inputs(var_amd):
+    """VAR_forward's routing in the bf16 mode: only the positive or only the negative sound given (the staged sound kernels
+    then see one clip source and half the clips); each must equal the corresponding half of the two-sound call."""
+    B = 3
+    torch.manual_seed(5)
+    m = var_amd.IthorVARPretextNet(cfg(96)).to("cuda").set_precision("bf16")
+    pos, neg = sounds(B, 303)
+    with torch.no_grad():
+        both = m(None, pos, neg)
+        p_both, n_both = both["sound_feat_positive"].clone(), both["sound_feat_negative"].clone()
+        only_p = m(None, pos, None)["sound_feat_positive"].clone()
+        only_n = m(None, None, neg)["sound_feat_negative"].clone()
+    np.testing.assert_allclose(only_p.cpu().numpy(), p_both.cpu().numpy(), atol=1e-6)
+    np.testing.assert_allclose(only_n.cpu().numpy(), n_both.cpu().numpy(), atol=1e-6)
