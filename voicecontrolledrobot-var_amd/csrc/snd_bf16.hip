@@ -31,6 +31,15 @@ __device__ __forceinline__ u32x4_t wload(__amdgpu_buffer_rsrc_t r, int lane_off,
     return __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, byte_off, 0);
 }
 
+PH_DECL();
+#ifdef VAR_PHASES
+extern "C" int var_debug_phases_snd(unsigned long long* out) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 namespace {
 
 constexpr int CI = 64, CO = 64, HI = 300, WI = 20, HO = 150, WO = 13;      // conv 2 (the conversion kernels' callers)
@@ -150,42 +159,46 @@ __global__ void __launch_bounds__(256) snd_fwd_kernel(const uint4* __restrict__ 
         abase[m] = h * PLANEB + oyl * 2 * SUBP + ox * SLOT;
     }
 
-    // staging: a quarter of a tile's patch = 2 planes x nrows x WI slots through registers.
-    // Column c of the map sits at parity (c + PW) & 1, slot (c + PW) >> 1 of its sub-row.
+    // staging: a quarter of a tile's patch = 2 planes x NR rows x WI slots through registers (every tile stages the NR rows
+    // of the largest one: a slot's plane / row / column are then per-thread constants, computed once -- with one wave per SIMD
+    // the per-slot divisions of every quarter were paid in full).  Column c of the map sits at parity (c + PW) & 1, slot
+    // (c + PW) >> 1 of its sub-row.
     constexpr int NST = L::NST;
     uint4 sreg[NST];
+    int s_src[NST], s_dst[NST], s_row[NST];                     // source slot within the quarter image (from row y0), LDS offset, patch row
+    unsigned sok = 0u;                                          // which of the slots in flight lie inside the map
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+        const int e = tid + 256 * k, hh = e >= L::NR * G::WI ? 1 : 0, e2 = e - hh * L::NR * G::WI, i = e2 / G::WI, c5 = e2 - i * G::WI + G::PW;
+        const bool in = e < 2 * L::NR * G::WI;
+        s_src[k] = hh * (G::HI * G::WI) + e2;
+        s_dst[k] = in ? hh * PLANEB + (c5 & 1) * PARB + i * SUBP + (c5 >> 1) * SLOT : -1;
+        s_row[k] = in ? i : -100000;
+    }
     auto stage_load = [&](int tile, int q) {
         const int clip = tile / G::TILES, t = tile - clip * G::TILES;
-        const int y0 = 2 * G::row0(t) - G::PH, nrows = 2 * G::rows(t) + KH - 2;
-        const uint4* src = x8 + ((long)clip * 8 + 2 * q) * (G::HI * G::WI);
+        const int y0 = 2 * G::row0(t) - G::PH;
+        const uint4* src = x8 + ((long)clip * 8 + 2 * q) * (G::HI * G::WI) + (long)y0 * G::WI;
+        // (loads from a clamped address; the zeroing waits for the LDS store: a select on the loaded value made every load wait)
+        sok = 0u;
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
-            int e = tid + 256 * k;
-            asm volatile("" : "+v"(e));                     // (loop-invariant otherwise: hipcc would keep all of it live)
-            const int hh = e >= nrows * G::WI ? 1 : 0, e2 = e - hh * nrows * G::WI;
-            const int i = e2 / G::WI, yy = y0 + i;
-            const bool ok = e2 < nrows * G::WI && (unsigned)yy < (unsigned)G::HI;
-            sreg[k] = ok ? src[(long)hh * (G::HI * G::WI) + (long)y0 * G::WI + e2] : make_uint4(0, 0, 0, 0);
+            const bool ok = (unsigned)(y0 + s_row[k]) < (unsigned)G::HI;
+            sreg[k] = src[ok ? s_src[k] : 5 * G::WI];
+            sok |= ok ? 1u << k : 0u;
         }
     };
-    auto stage_store = [&](int tile, int buf) {
-        const int t = tile % G::TILES;
-        const int nrows = 2 * G::rows(t) + KH - 2;
+    auto stage_store = [&](int, int buf) {
 #pragma unroll
-        for (int k = 0; k < NST; ++k) {
-            int e = tid + 256 * k;
-            asm volatile("" : "+v"(e));
-            const int hh = e >= nrows * G::WI ? 1 : 0, e2 = e - hh * nrows * G::WI;
-            const int i = e2 / G::WI, c5 = e2 - i * G::WI + G::PW;
-            if (e2 < nrows * G::WI)
-                *(uint4*)(lds + buf * BUFB + hh * PLANEB + (c5 & 1) * PARB + i * SUBP + (c5 >> 1) * SLOT) = sreg[k];
-        }
+        for (int k = 0; k < NST; ++k)
+            if (s_dst[k] >= 0) *(uint4*)(lds + buf * BUFB + s_dst[k]) = (sok >> k) & 1u ? sreg[k] : make_uint4(0, 0, 0, 0);
     };
 
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, NQ * NTAP * 2048, 0x00020000);
     int tile = blockIdx.x;
     if (tile < ntiles) { stage_load(tile, 0); stage_store(tile, 0); }
     __syncthreads();
+    PH_INIT(0);
 
     for (; tile < ntiles; tile += gridDim.x) {
         f32x16_t acc[4][2];
@@ -201,13 +214,16 @@ __global__ void __launch_bounds__(256) snd_fwd_kernel(const uint4* __restrict__ 
             const int buf = q & 1;
             const int ntile = q < NQ - 1 ? tile : tile + (int)gridDim.x, nq = (q + 1) & 3;
             const bool have = ntile < ntiles;
+            PH(4);
             if (have) stage_load(ntile, nq);
             __builtin_amdgcn_sched_barrier(0);
+            PH(0);
 
             const unsigned char* img = lds + buf * BUFB;
             const int wq0 = q * NTAP * 2048;
             // software pipeline, pinned with sched_barriers (left alone, hipcc sinks every load to its use and waits
-            // for it there): filter fragments one filter ROW ahead, pixel fragments one TAP ahead
+            // for it there): filter fragments one filter ROW ahead, pixel fragments one TAP ahead.  (Two rows ahead, and the
+            // next quarter's first rows loaded across the staging barrier, changed nothing: 465 -> 463 us.)
             u32x4_t wrow[2][KW][2];
             bf16x8_t a[2][4];
             auto toff = [](int tap) { const int ky = tap / KW, kx = tap - ky * KW; return ky * SUBP + (kx & 1) * PARB + (kx >> 1) * SLOT; };
@@ -245,16 +261,25 @@ __global__ void __launch_bounds__(256) snd_fwd_kernel(const uint4* __restrict__ 
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            PH(1);
             if (have) stage_store(ntile, buf ^ 1);
+            PH(2);
             __syncthreads();
+            PH(3);
         }
 
         // bias + ReLU; lanes walk the pixels (NCHW: 128 contiguous bytes per channel and block)
         const int clip = tile / G::TILES, t = tile - clip * G::TILES;
         const int npx = G::rows(t) * WO, pix0 = G::row0(t) * WO;
+        float bv[2][16];                                        // this lane's 32 biases, in one batch (one by one in front of each
+#pragma unroll                                                  // store they cost a quarter of the kernel)
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bv[cb][r] = bias[32 * cb + 8 * (r >> 2) + 4 * h + (r & 3)];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            const int P = 128 * wave + 32 * m + p31;
+            int P = 128 * wave + 32 * m + p31;
+            asm volatile("" : "+v"(P));                         // (tile-invariant: hipcc would keep every store offset alive across tiles)
             if (P < npx) {
                 unsigned mk = 0u;
 #pragma unroll
@@ -265,7 +290,7 @@ __global__ void __launch_bounds__(256) snd_fwd_kernel(const uint4* __restrict__ 
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int co = 32 * cb + 8 * g + 4 * h + e;
-                            v[e] = fmaxf(acc[m][cb][4 * g + e] + bias[co], 0.f);
+                            v[e] = fmaxf(acc[m][cb][4 * g + e] + bv[cb][4 * g + e], 0.f);
                             if (G::SEQ) {
                                 const int oyl = P / WO, ox = P - oyl * WO;
                                 y[((long)clip * G::HO + oyl) * (CO * WO) + co * WO + ox] = v[e];
@@ -429,15 +454,18 @@ __global__ void __launch_bounds__(256) snd_dgrad_kernel(const uint4* __restrict_
     }
     constexpr int NSL = L::NSL, NST = L::NST;
     uint4 sreg[NST];
+    unsigned sok = 0u;
     auto stage_load = [&](int tile) {
         const int clip = tile / G::TILES, t = tile - clip * G::TILES, oy0 = G::ROWS * t + L::DYMIN;
+        sok = 0u;
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
             int e = tid + 256 * k;
             asm volatile("" : "+v"(e));                     // keep the slots' index arithmetic out of the registers
             const int pl = e / (L::PR * G::WO), e2 = e - pl * (L::PR * G::WO), oy = oy0 + e2 / G::WO;
             const bool ok = e < NSL && (unsigned)oy < (unsigned)G::HO;
-            sreg[k] = ok ? gy8[((long)clip * 8 + pl) * (G::HO * G::WO) + oy0 * G::WO + e2] : make_uint4(0, 0, 0, 0);
+            sreg[k] = gy8[ok ? ((long)clip * 8 + pl) * (G::HO * G::WO) + oy0 * G::WO + e2 : 0];      // (zeroed at the LDS store)
+            sok |= ok ? 1u << k : 0u;
         }
     };
     auto stage_store = [&](int buf) {
@@ -446,7 +474,8 @@ __global__ void __launch_bounds__(256) snd_dgrad_kernel(const uint4* __restrict_
             int e = tid + 256 * k;
             asm volatile("" : "+v"(e));
             const int pl = e / (L::PR * G::WO), e2 = e - pl * (L::PR * G::WO), i = e2 / G::WO;
-            if (e < NSL) *(uint4*)(lds + buf * L::BUFB + pl * L::PLB + i * L::SUBP + (e2 - i * G::WO) * SLOT) = sreg[k];
+            if (e < NSL)
+                *(uint4*)(lds + buf * L::BUFB + pl * L::PLB + i * L::SUBP + (e2 - i * G::WO) * SLOT) = (sok >> k) & 1u ? sreg[k] : make_uint4(0, 0, 0, 0);
         }
     };
     // (rows past the patch and the slots past a row's WO pixels are only read by unused pixel slots / as the zero column)
