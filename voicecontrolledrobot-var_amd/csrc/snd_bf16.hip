@@ -357,6 +357,18 @@ __device__ __forceinline__ void dgrad_pass(const unsigned char* __restrict__ img
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][b][r] = 0.f;
+    // the pass's mask words first: their latency runs under the matrix loop (loaded in the epilogue, one pixel block at a
+    // time, they and the stores behind them took as long as the loop itself)
+    constexpr bool EVEN = G::WI % 2 == 0;
+    unsigned mw[MB][2];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        const int P = 32 * MB * wm + 32 * m + p31, ul = P / L::V, v = P - ul * L::V, iy = 2 * (u0 + ul) + A;
+        const bool live = P < G::ROWS * L::V && iy < G::HI, two = EVEN || 2 * v + 1 < G::WI;
+        const int pix = live ? iy * G::WI + 2 * v : 0;
+        mw[m][0] = mask[2 * pix + h];
+        mw[m][1] = mask[2 * pix + (two ? 2 : 0) + h];
+    }
     // row R = (q, i): ky = 2 i + 1 - A
     auto wofs = [](int R, int kx) { const int q = R / NKY, i = R - q * NKY; return (q * L::NTAP + (2 * i + 1 - A) * KW + kx) * 2048; };
     auto aofs = [](int R, int d) {              // pixel fragment set d: dx = DXMAX - d
@@ -399,14 +411,13 @@ __device__ __forceinline__ void dgrad_pass(const unsigned char* __restrict__ img
     }
     // masked store: this lane's pixel pair (iy, 2v | 2v+1), channels 32 cb + 8 g + 4 h + e = register 4 g + e = bit
     // 16 cb + 4 g + e of the pixel's mask word (dxo points at the clip)
-    constexpr bool EVEN = G::WI % 2 == 0;
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
         const int P = 32 * MB * wm + 32 * m + p31, ul = P / L::V, v = P - ul * L::V, iy = 2 * (u0 + ul) + A;
         if (P < G::ROWS * L::V && iy < G::HI) {
             const int pix = iy * G::WI + 2 * v;
             const bool two = EVEN || 2 * v + 1 < G::WI;
-            const unsigned m0 = mask[2 * pix + h] >> (16 * cb), m1 = two ? mask[2 * pix + 2 + h] >> (16 * cb) : 0u;
+            const unsigned m0 = mw[m][0] >> (16 * cb), m1 = two ? mw[m][1] >> (16 * cb) : 0u;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float2 o[4];
