@@ -484,17 +484,23 @@ def main():
 
     for _ in range(max(2, args.warmup // 2)):                  # eager warm-up: lazy kernel attributes, workspace plan
         eager_step()
-    # pick the dominant conv kernel family (one profiled eager step per candidate)
+    # pick the dominant conv kernel family by the kernel's OWN duration (three profiled eager steps per candidate with every
+    # launch on one stream: what the rocprofv3 kernel-stats average reads too; beside the side stream's kernels the event
+    # bracket of whichever kernel runs next to the MFCC reads longest, which says nothing about that kernel)
     dom_tag = None
     if not args.no_roofline:
         best = -1.0
+        sel_mask = ctx.set_streams(0)
         for tag in list(range(0, 10)) + list(range(11, 15)):
             ctx.profile_select(tag)
-            eager_step()
+            for _ in range(3):
+                eager_step()
+                torch.cuda.synchronize()
             ms, n = ctx.profile_read()
             if n and ms / n > best:
                 best, dom_tag = ms / n, tag
         ctx.profile_select(-1)
+        ctx.set_streams(sel_mask)
     # roofline leg: HIP events (var_profile_select) around every launch of the dominant kernel, on the
     # stream it is launched on, over eagerly launched steps of the same workload (events cannot be
     # read back from inside a replayed graph)
