@@ -1,24 +1,27 @@
-// The 11x5 stride-2 convolution of the iTHOR sound CNN (models/pretext/ai2thor_pretext_model.py:24-26, conv 2:
-// 64 -> 64 channels, (n,64,300,20) -> (n,64,150,13), 45 % of the model's arithmetic) on v_mfma_f32_32x32x16_bf16 --
-// the bf16 mode's own kernels (BASELINE config 4), replacing the gather-GEMM instances of gg.h for this layer.
+// The sound CNN of the iTHOR model (models/pretext/ai2thor_pretext_model.py:22-28: conv 11x11 s2 1 -> 64, conv 11x5 s2
+// 64 -> 64 -- 45 % of the model's arithmetic --, conv 7x3 s2 64 -> 64) in the model's bf16 mode (BASELINE config 4), all three
+// layers in all three directions on v_mfma_f32_32x32x16_bf16, replacing the gather-GEMM instances of gg.h.
 //
-// The gather-GEMM loads every operand element once per USE (an input element of this layer is used by 55/4 taps): in
-// bf16 its matrix instructions are 16x shorter and the kernel ends up bound by the load path (6 wave-loads per MFMA).
-// Here the input patch of a tile is staged ONCE into LDS, as bf16, and every tap reads it from there:
+// The gather-GEMM loads every operand element once per USE (an input element of conv 2 is used by 55/4 taps): in bf16 its
+// matrix instructions are 16x shorter and the kernel ends up bound by the load path (6 wave-loads per MFMA).  Here the
+// input patch of a tile is staged ONCE into LDS, as bf16, and every tap reads it from there.  The activations between
+// the layers live as "C8" bf16 images: (clip, C/8, H, W, 8) -- a pixel's 8 channels are the 16 bytes one lane of the MFMA
+// supplies (k = 8h .. 8h+7), a plane row is one contiguous run -- each written by the kernel that produces the map
+// (conv 1's and conv 2's forward stores; conv 3's data-gradient store for the gradient image conv 2's backward reads),
+// together with one 32-bit word of ReLU signs per (pixel, lane half) in the order the data-gradient stores want them.
 //
-//   HBM   activations in "C8" form: (n, C/8, H, W, 8) bf16 -- a pixel's 8 channels are the 16 bytes one lane of the
-//         MFMA supplies (k = 8h .. 8h+7), a plane row is one contiguous run.
-//   tile  one clip x 38|37 output rows x 13 columns = <= 512 pixel slots = 16 MFMA column blocks, 4 per wave; both
-//         32-row blocks of the 64 output channels: 8 accumulators (128 registers) per wave.  4 tiles per clip, one
+// Forward (conv 2 and 3: snd_fwd_kernel<Geo>, the geometry is a type):
+//   tile  one clip x 38|37 output rows x 13 columns (conv 3: the whole 73 x 7 map) = <= 512 pixel slots = 16 MFMA column
+//         blocks, 4 per wave; both 32-row blocks of the 64 output channels: 8 accumulators (128 registers) per wave.  One
 //         workgroup (4 waves, one per SIMD) per CU, persistent.
-//   K     4 quarters of 16 input channels x 55 taps; one quarter of the patch (85 rows) is in LDS while the next one
-//         is being loaded (register-staged, double-buffered: 2 x 70.7 KB).
-//   LDS   per quarter [k half h][column parity][row][13 slots of 16 B]: a stride-2 tap walks consecutive 16-byte
-//         slots when the lanes walk the output row (ds_read_b128, conflict-free), the three/two zero slots of a
-//         sub-row are the padding columns of this row AND of the next one, so a tap is base + IMMEDIATE offset: no
-//         bounds test, no address arithmetic in the loop.
+//   K     4 quarters of 16 input channels x all taps; one quarter of the patch is in LDS while the next one is being
+//         loaded (register-staged, double-buffered: 2 x 70 KB).
+//   LDS   per quarter [k half h][column parity][row][slots of 16 B]: a stride-2 tap walks consecutive 16-byte slots when
+//         the lanes walk the output row (ds_read_b128), the zero slots of a sub-row are the padding columns of this row
+//         AND of the next one, so a tap is base + IMMEDIATE offset: no bounds test, no address arithmetic in the loop.
 //   W     re-packed per step into fragment order (quarter, tap, channel block, lane): one 16-byte load per lane and
 //         MFMA row block, straight from L2 into registers, one filter row ahead.
+// Data gradient (snd_dgrad_kernel<DGeo>), weight gradient (snd_wgrad_kernel<WGeo>) and conv 1 (snd1_*): see their sections.
 #include "var_common.h"
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
