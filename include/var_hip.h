@@ -209,6 +209,15 @@ int var_ithor_plan(var_ctx* ctx, int max_batch, int img_hw);
  * written too -- what the layer-wise parity tests use.  -1 = query.  Returns the previous setting (or a negative error
  * code); call after var_ithor_plan. */
 int var_ithor_set_bf16(var_ctx* ctx, int on);
+/* bf16 mode only: run the 73 time steps of each GRU pass as ONE persistent launch (1, the default) in which the workgroups
+ * of a 64-clip slice hand the recurrent state to each other through memory, or as one launch per time step (0).  Both
+ * give bit-identical results.  The persistent form needs its whole grid (32 workgroups per 64 clips) resident at once:
+ * it is skipped by itself when the grid exceeds the device's CU count, and every wait in it is bounded -- if a wait
+ * expires (e.g. another process holds part of the GPU) the launch ends, var_ithor_gru_status() reports a non-zero word
+ * from then on and the step's embeddings / gradient are overwritten with NaN rather than left partially updated.
+ * -1 = query; returns the previous setting.  var_ithor_gru_status copies the status word (blocking). */
+int var_ithor_set_gru_sequence(var_ctx* ctx, int on);
+int var_ithor_gru_status(var_ctx* ctx, unsigned* word);
 int var_ithor_encoder_fwd(var_ctx* ctx, void* stream, const float* params,
                           const void* image, int image_is_u8, long image_bstride,
                           const float* snd_pos, const float* snd_neg, int B, int H,

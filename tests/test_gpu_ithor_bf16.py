@@ -407,3 +407,35 @@ def test_bf16_mode_single_sound_inputs(var_amd):
         only_n = m(None, None, neg)["sound_feat_negative"].clone()
     np.testing.assert_allclose(only_p.cpu().numpy(), p_both.cpu().numpy(), atol=1e-6)
     np.testing.assert_allclose(only_n.cpu().numpy(), n_both.cpu().numpy(), atol=1e-6)
+
+
+@pytest.mark.parametrize("B", [3, 40])
+def test_gru_one_launch_per_pass_equals_one_launch_per_step(var_amd, B):
+    """The persistent GRU kernels (73 steps in one launch, the workgroups of a clip slice handing the state over through
+    memory) do the per-step kernels' arithmetic in the same order: loss and every gradient must be bit-identical, and no
+    hand-off may have timed out.  B = 40 is two clip slices, the second ragged (80 clips = 64 + 16)."""
+    import ctypes
+    from var_amd._lib import Context
+    torch.manual_seed(5)
+    m = var_amd.IthorVARPretextNet(cfg(96)).to("cuda").set_precision("bf16")
+    pos, neg = sounds(B, 17)
+    img = torch.randint(0, 256, (B, 3, 96, 96), dtype=torch.uint8, generator=torch.Generator().manual_seed(4)).cuda()
+    tr = var_amd.IthorTrainer(m)
+    tr.loss_and_grads(img, pos, neg)                      # (plans the context)
+    ctx = Context.get(0)
+    out = {}
+    try:
+        for mode in (0, 1, 1):
+            assert ctx.lib.var_ithor_set_gru_sequence(ctx.handle, mode) >= 0
+            loss, _ = tr.loss_and_grads(img, pos, neg)
+            torch.cuda.synchronize()
+            out.setdefault(mode, []).append((float(loss), tr.grads.clone()))
+    finally:
+        ctx.lib.var_ithor_set_gru_sequence(ctx.handle, 1)
+    word = ctypes.c_uint(123)
+    assert ctx.lib.var_ithor_gru_status(ctx.handle, ctypes.byref(word)) == 0 and word.value == 0
+    (l0, g0), = out[0]
+    for l1, g1 in out[1]:
+        assert torch.isfinite(g1).all()
+        assert l1 == l0
+        assert torch.equal(g1, g0), float((g1 - g0).abs().max())

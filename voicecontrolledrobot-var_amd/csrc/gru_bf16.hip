@@ -16,6 +16,8 @@
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) unsigned gu32;
 
 namespace {
 
@@ -93,7 +95,7 @@ __global__ void __launch_bounds__(512) gru_step_fwd_kernel(const float* __restri
         const int clip = min(64 * cs + 32 * cbk + (lane & 31), nclips - 1);
         const uint4* hsrc = (const uint4*)(H16 + (((long)dir * (SEQ + 1) + step) * nclips + clip) * (GH / 4)) + 16 * kq + h;
         const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, (int)kWfBytes, 0x00020000);
-        const int wbase = ((dir * NJS + js) * 32 + 8 * kq) * 3 * 1024;
+        const int wbase = __builtin_amdgcn_readfirstlane(((dir * NJS + js) * 32 + 8 * kq) * 3 * 1024);   // (wave-uniform: a scalar offset)
         u32x4_t a[8][3];
         uint4 b[8];
 #pragma unroll
@@ -174,7 +176,7 @@ __global__ void __launch_bounds__(512) gru_step_bwd_kernel(float* __restrict__ D
         const int clip = min(64 * cs + 32 * cbk + (lane & 31), nclips - 1);
         const uint4* gsrc = (const uint4*)(DG16 + (((long)dir * SEQ + step + 1) * nclips + clip) * (G3 / 4)) + 48 * kq + h;
         const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, (int)kWbBytes, 0x00020000);
-        const int wbase = ((dir * NJS + js) * 96 + 24 * kq) * 1024;
+        const int wbase = __builtin_amdgcn_readfirstlane(((dir * NJS + js) * 96 + 24 * kq) * 1024);
         u32x4_t a[24];
         uint4 b[24];
 #pragma unroll
@@ -222,6 +224,216 @@ __global__ void __launch_bounds__(512) gru_step_bwd_kernel(float* __restrict__ D
     i16[0] = pr; i16[GH / 4] = pz; i16[2 * GH / 4] = make_uint2(pack2(dn.x, dn.y), pack2(dn.z, dn.w));
 }
 
+// ---- the whole sequence in one launch -----------------------------------------------------------------------------
+// A step couples the 512 hidden units of ONE clip, never two clips: the 16 workgroups (hidden slices) of a (direction,
+// 64-clip slice) form a group that only has to wait for itself.  One persistent launch per pass keeps W_hh's fragments
+// in registers for all 73 steps and replaces the kernel boundary by a 16-arrival counter per (group, step).  The
+// hand-off follows the guide's write-through form (MI355X_MICROARCH.md, inter-workgroup visibility, first table row):
+// every handed-off byte (the bf16 state / gate-gradient rows) is stored sc1 and drained by its wave (s_waitcnt vmcnt(0))
+// before the workgroup's barrier, ONE lane then adds to the counter (agent scope), ONE lane of each consumer polls it
+// with sc1 loads, the workgroup's barrier follows, and every load of those bytes is an sc1 buffer load to registers.
+// Everything else a step stores (fp32 states, saved gates, DGI / DGH) is read by later launches only.  The spin is
+// bounded: a group that never completes (a grid that is not resident) sets the time-out word and every workgroup leaves.
+constexpr unsigned kSpinMax = 1u << 18;
+constexpr int kSc1 = 16;                                 // buffer aux bit: sc1
+
+__device__ __forceinline__ int wait_count(unsigned* cnt, unsigned want, unsigned* tmo, unsigned code) {
+    for (unsigned spins = 0; spins < kSpinMax; ++spins) {
+        if (__hip_atomic_load((gu32*)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return 1;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    __hip_atomic_store((gu32*)tmo, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return 0;
+}
+
+__global__ void __launch_bounds__(512) gru_seq_fwd_kernel(const float* __restrict__ GI, float* __restrict__ Hb, uint2* H16,
+                                                          const uint4* __restrict__ wf, const float* __restrict__ b_hh, long dirP,
+                                                          float* __restrict__ R, float* __restrict__ Z, float* __restrict__ Nn,
+                                                          float* __restrict__ GHN, int nclips, long dirGI, long dirH, long dirS,
+                                                          int save, unsigned* cnt0, unsigned* tmo) {
+    extern __shared__ float red[];                       // [cbk 2][kq 4][gate 3][r 16][RS] | go
+    int* go = (int*)(red + 2 * 4 * 3 * 16 * RS);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, cbk = wave & 1, kq = wave >> 1;
+    const int js = blockIdx.x, cs = blockIdx.y, dir = blockIdx.z;
+    const int jq = tid & 7, cl = tid >> 3, clip = 64 * cs + cl, clipc = min(clip, nclips - 1);
+    const int j = 32 * js + 4 * jq;
+    unsigned* cnt = cnt0 + (dir * gridDim.y + cs) * (SEQ + 1);
+    const float* bh = b_hh + dir * dirP + j;
+    const float4 br = *(const float4*)bh, bz = *(const float4*)(bh + GH), bn = *(const float4*)(bh + 2 * GH);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, (int)kWfBytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc((void*)H16, 0, 2 * (SEQ + 1) * nclips * GH * 2, 0x00020000);
+    const int wbase = __builtin_amdgcn_readfirstlane(((dir * NJS + js) * 32 + 8 * kq) * 3 * 1024);   // (wave-uniform: a scalar offset)
+    u32x4_t a[8][3];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) a[i][g] = wload(wr, lane * 16, wbase + (i * 3 + g) * 1024);
+    const int ldoff = min(64 * cs + 32 * cbk + (lane & 31), nclips - 1) * (GH * 2) + (16 * kq + h) * 16;   // this lane's operand bytes in a step's rows
+    const int stoff = clipc * (GH * 2) + (8 * js + jq) * 8;                                                  // its bf16 output
+    float4 hp = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int step = 0; step < SEQ; ++step) {
+        const int t = dir ? SEQ - 1 - step : step;
+        const float* gi = GI + dir * dirGI + ((long)clipc * SEQ + t) * G3 + j;
+        const float4 gr = *(const float4*)gi, gz = *(const float4*)(gi + GH), gn = *(const float4*)(gi + 2 * GH);
+        if (step) {
+            if (tid == 0) *go = wait_count(cnt + step, NJS, tmo, 1 + step);
+            __syncthreads();
+            if (!*go) break;
+        }
+        const int rows = ((dir * (SEQ + 1) + step) * nclips) * (GH * 2);
+        u32x4_t b[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) b[i] = __builtin_amdgcn_raw_buffer_load_b128(hr, ldoff + 32 * i, rows, kSc1);
+        f32x16_t acc[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[i][g]), __builtin_bit_cast(bf16x8_t, b[i]),
+                                                                 acc[g], 0, 0, 0);
+        float* dst = red + ((cbk * 4 + kq) * 3) * 16 * RS + lane;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(g * 16 + r) * RS] = acc[g][r];
+        __syncthreads();
+        if (clip < nclips) {
+            float gh[3][4];
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v += red[((((cl >> 5) * 4 + q) * 3 + g) * 16 + 4 * (jq >> 1) + e) * RS + (cl & 31) + 32 * (jq & 1)];
+                    gh[g][e] = v;
+                }
+            float* hnext = Hb + dir * dirH + (long)(step + 1) * nclips * GH + (long)clip * GH + j;
+            const long so = dir * dirS + (long)step * nclips * GH + (long)clip * GH + j;
+            float4 o, rr, zz, nn, gg;
+#define GRU_LANE(c, e)                                                     \
+    {                                                                      \
+        const float r_ = sigmoidf_(gr.c + (gh[0][e] + br.c));              \
+        const float z_ = sigmoidf_(gz.c + (gh[1][e] + bz.c));              \
+        const float ghn_ = gh[2][e] + bn.c;                                \
+        const float n_ = tanhf_(gn.c + r_ * ghn_);                          \
+        o.c = (1.f - z_) * n_ + z_ * hp.c;                                 \
+        rr.c = r_; zz.c = z_; nn.c = n_; gg.c = ghn_;                      \
+    }
+            GRU_LANE(x, 0) GRU_LANE(y, 1) GRU_LANE(z, 2) GRU_LANE(w, 3)
+#undef GRU_LANE
+            u32x2_t o16;
+            o16.x = pack2(o.x, o.y); o16.y = pack2(o.z, o.w);
+            __builtin_amdgcn_raw_buffer_store_b64(o16, hr, stoff, rows + nclips * (GH * 2), kSc1);
+            *(float4*)hnext = o;
+            if (save) { *(float4*)(R + so) = rr; *(float4*)(Z + so) = zz; *(float4*)(Nn + so) = nn; *(float4*)(GHN + so) = gg; }
+            hp = o;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add((gu32*)(cnt + step + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__global__ void __launch_bounds__(512) gru_seq_bwd_kernel(float* __restrict__ DH, const float* __restrict__ Hb, const uint4* __restrict__ wb,
+                                                          uint2* DG16, uint2* __restrict__ DGI16, const float* __restrict__ R,
+                                                          const float* __restrict__ Z, const float* __restrict__ Nn,
+                                                          const float* __restrict__ GHN, float* __restrict__ DGI, float* __restrict__ DGH,
+                                                          int nclips, long dirGI, long dirH, long dirS, long dirDGH, unsigned* cnt0,
+                                                          unsigned* tmo) {
+    extern __shared__ float red[];                       // [cbk 2][kq 4][r 16][RS] | go
+    int* go = (int*)(red + 2 * 4 * 16 * RS);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, cbk = wave & 1, kq = wave >> 1;
+    const int js = blockIdx.x, cs = blockIdx.y, dir = blockIdx.z;
+    const int jq = tid & 7, cl = tid >> 3, clip = 64 * cs + cl, clipc = min(clip, nclips - 1);
+    const int j = 32 * js + 4 * jq;
+    unsigned* cnt = cnt0 + (dir * gridDim.y + cs) * (SEQ + 1);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, (int)kWbBytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void*)DG16, 0, 2 * SEQ * nclips * G3 * 2, 0x00020000);
+    const int wbase = __builtin_amdgcn_readfirstlane(((dir * NJS + js) * 96 + 24 * kq) * 1024);
+    u32x4_t a[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) a[i] = wload(wr, lane * 16, wbase + i * 1024);
+    const int ldoff = min(64 * cs + 32 * cbk + (lane & 31), nclips - 1) * (G3 * 2) + (48 * kq + h) * 16;
+    const int stoff = clipc * (G3 * 2) + (8 * js + jq) * 8;
+    float* dh = DH + (long)dir * nclips * GH + (long)clipc * GH + j;
+    float4 d4 = *(const float4*)dh;
+    for (int step = SEQ - 1; step >= 0; --step) {
+        const int t = dir ? SEQ - 1 - step : step;
+        const long so = dir * dirS + (long)step * nclips * GH + (long)clipc * GH + j;
+        const float* hprev = Hb + dir * dirH + (long)step * nclips * GH + (long)clipc * GH + j;
+        const float4 r4 = *(const float4*)(R + so), z4 = *(const float4*)(Z + so), n4 = *(const float4*)(Nn + so);
+        const float4 g4 = *(const float4*)(GHN + so), hp = *(const float4*)hprev;
+        const int rows = ((dir * SEQ + step) * nclips) * (G3 * 2);
+        float dp[4] = {0.f, 0.f, 0.f, 0.f};
+        if (step < SEQ - 1) {
+            if (tid == 0) *go = wait_count(cnt + step + 1, NJS, tmo, 101 + step);
+            __syncthreads();
+            if (!*go) break;
+            u32x4_t b[24];
+#pragma unroll
+            for (int i = 0; i < 24; ++i) b[i] = __builtin_amdgcn_raw_buffer_load_b128(gr, ldoff + 32 * i, rows + nclips * (G3 * 2), kSc1);
+            f32x16_t acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 24; ++i)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[i]), __builtin_bit_cast(bf16x8_t, b[i]), acc, 0, 0, 0);
+            float* dst = red + (cbk * 4 + kq) * 16 * RS + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[r * RS] = acc[r];
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dp[e] += red[(((cl >> 5) * 4 + q) * 16 + 4 * (jq >> 1) + e) * RS + (cl & 31) + 32 * (jq & 1)];
+        }
+        if (clip < nclips) {
+            float* dgi = DGI + dir * dirGI + ((long)clip * SEQ + t) * G3 + j;
+            float* dgh = DGH + dir * dirDGH + ((long)step * nclips + clip) * G3 + j;
+            float4 dr, dz, dn, dnr, dd;
+#define GRU_LANE(c, e)                                                     \
+    {                                                                      \
+        const float dh_ = d4.c + dp[e];                                    \
+        const float dn_ = dh_ * (1.f - z4.c) * (1.f - n4.c * n4.c);        \
+        dz.c = dh_ * (hp.c - n4.c) * z4.c * (1.f - z4.c);                  \
+        dr.c = dn_ * g4.c * r4.c * (1.f - r4.c);                           \
+        dn.c = dn_; dnr.c = dn_ * r4.c; dd.c = dh_ * z4.c;                 \
+    }
+            GRU_LANE(x, 0) GRU_LANE(y, 1) GRU_LANE(z, 2) GRU_LANE(w, 3)
+#undef GRU_LANE
+            u32x2_t pr, pz, pn;
+            pr.x = pack2(dr.x, dr.y); pr.y = pack2(dr.z, dr.w);
+            pz.x = pack2(dz.x, dz.y); pz.y = pack2(dz.z, dz.w);
+            pn.x = pack2(dnr.x, dnr.y); pn.y = pack2(dnr.z, dnr.w);
+            __builtin_amdgcn_raw_buffer_store_b64(pr, gr, stoff, rows, kSc1);
+            __builtin_amdgcn_raw_buffer_store_b64(pz, gr, stoff + GH * 2, rows, kSc1);
+            __builtin_amdgcn_raw_buffer_store_b64(pn, gr, stoff + 2 * GH * 2, rows, kSc1);
+            *(float4*)dgi = dr; *(float4*)(dgi + GH) = dz; *(float4*)(dgi + 2 * GH) = dn;
+            *(float4*)dgh = dr; *(float4*)(dgh + GH) = dz; *(float4*)(dgh + 2 * GH) = dnr;
+            uint2* i16 = DGI16 + ((long)dir * SEQ * nclips + (long)clip * SEQ + t) * (G3 / 4) + 8 * js + jq;
+            i16[0] = make_uint2(pr.x, pr.y); i16[GH / 4] = make_uint2(pz.x, pz.y);
+            i16[2 * GH / 4] = make_uint2(pack2(dn.x, dn.y), pack2(dn.z, dn.w));
+            d4 = dd;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add((gu32*)(cnt + step), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (clip < nclips) *(float4*)dh = d4;
+}
+
+// a timed-out sequence kernel has left partial results: make that loud in the gradient (NaN) rather than silent
+__global__ void gru_poison_kernel(const unsigned* __restrict__ tmo, float* __restrict__ g, int n) {
+    if (*tmo == 0) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) g[i] = __uint_as_float(0x7fc00000u);
+}
+
 // fp32 -> bf16, 8 elements per thread (n % 8 == 0)
 __global__ void __launch_bounds__(256) to_bf16_kernel(const float4* __restrict__ x, uint4* __restrict__ y, long n8) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -236,11 +448,17 @@ __global__ void __launch_bounds__(256) to_bf16_kernel(const float4* __restrict__
 static inline long h16_bytes(int mc) { return 2L * (SEQ + 1) * mc * GH * 2; }
 static inline long dg16_bytes(int mc) { return 2L * SEQ * mc * G3 * 2; }
 static inline long x16_bytes(int mc) { return (long)SEQ * mc * 448 * 2; }
-long gru_bf16_workspace_bytes(int mc) { return kWfBytes + kWbBytes + h16_bytes(mc) + 2 * dg16_bytes(mc) + x16_bytes(mc) + 256; }
+// hand-off words of the sequence kernels: [time-out word, 3 pad | forward counters (dir, clip slice, step 0..73) | backward counters]
+static inline int sync_counters(int mc) { return 2 * ((mc + 63) / 64) * (SEQ + 1); }
+static inline long sync_bytes(int mc) { return ((4 + 2L * sync_counters(mc)) * 4 + 255) & ~255L; }
+long gru_bf16_workspace_bytes(int mc) {
+    return kWfBytes + kWbBytes + h16_bytes(mc) + 2 * dg16_bytes(mc) + ((x16_bytes(mc) + 255) & ~255L) + sync_bytes(mc) + 256;
+}
 void* gru_bf16_h16(void* ws) { return (char*)ws + kWfBytes + kWbBytes; }
 void* gru_bf16_dgh16(void* ws, int mc) { return (char*)gru_bf16_h16(ws) + h16_bytes(mc); }
 void* gru_bf16_dgi16(void* ws, int mc) { return (char*)gru_bf16_dgh16(ws, mc) + dg16_bytes(mc); }
 void* gru_bf16_x16(void* ws, int mc) { return (char*)gru_bf16_dgi16(ws, mc) + dg16_bytes(mc); }
+static unsigned* gru_sync(void* ws, int mc) { return (unsigned*)((char*)gru_bf16_x16(ws, mc) + ((x16_bytes(mc) + 255) & ~255L)); }
 constexpr int kFwdLds = 2 * 4 * 3 * 16 * RS * 4, kBwdLds = 2 * 4 * 16 * RS * 4;
 
 // the GRU's input sequence (fp32, n floats, n % 8 == 0) as bf16 for the dense products
@@ -263,6 +481,7 @@ int gru_bf16_pack(var_ctx* c, hipStream_t s, const float* w_hh, long dirP, int n
     static bool attr = false;
     if (!attr) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)gru_step_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds));
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)gru_seq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds + 16));
         attr = true;
     }
     return VAR_OK;
@@ -283,5 +502,57 @@ int gru_bf16_step_bwd(var_ctx* c, hipStream_t s, float* DH, const float* Hb, con
                        (const uint4*)((const char*)ws + kWfBytes), (uint2*)gru_bf16_dgh16(ws, maxclips),
                        (uint2*)gru_bf16_dgi16(ws, maxclips), R, Z, Nn, GHN, DGI, DGH, nclips, step, has_next, dirGI, dirH, dirS, dirDGH);
     VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}
+
+// ---- one launch per pass (gru_seq_*_kernel) ---------------------------------------------------------------------
+// The sequence kernels need every workgroup of the grid resident at once (one 512-thread workgroup per CU): return 1, and
+// the caller takes the per-step launches, when the grid is larger than the device.
+static int seq_fits(var_ctx* c, int nclips) {
+    static int cus = 0;
+    if (!cus && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) cus = 1;
+    return 2 * NJS * ((nclips + 63) / 64) <= cus;
+}
+
+int gru_bf16_reset_timeout(var_ctx* c, hipStream_t s, int maxclips, void* ws) {
+    VAR_HIP_CHECK(c, hipMemsetAsync(gru_sync(ws, maxclips), 0, 16, s));
+    return VAR_OK;
+}
+
+int gru_bf16_seq_fwd(var_ctx* c, hipStream_t s, const float* GI, float* Hb, const float* b_hh, long dirP, float* R, float* Z, float* Nn,
+                     float* GHN, int nclips, int maxclips, long dirGI, long dirH, long dirS, int save, void* ws) {
+    if (!seq_fits(c, nclips)) return 1;
+    unsigned* sync = gru_sync(ws, maxclips);
+    VAR_HIP_CHECK(c, hipMemsetAsync(sync + 4, 0, 4L * sync_counters(maxclips), s));
+    hipLaunchKernelGGL(gru_seq_fwd_kernel, dim3(NJS, (nclips + 63) / 64, 2), dim3(512), kFwdLds + 16, s, GI, Hb, (uint2*)gru_bf16_h16(ws),
+                       (const uint4*)ws, b_hh, dirP, R, Z, Nn, GHN, nclips, dirGI, dirH, dirS, save, sync + 4, sync);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}
+
+// grads: the parameter gradient (n floats), overwritten with NaN by a trailing check if either sequence kernel timed out
+int gru_bf16_seq_bwd(var_ctx* c, hipStream_t s, float* DH, const float* Hb, const float* R, const float* Z, const float* Nn,
+                     const float* GHN, float* DGI, float* DGH, int nclips, int maxclips, long dirGI, long dirH, long dirS, long dirDGH,
+                     void* ws) {
+    if (!seq_fits(c, nclips)) return 1;
+    unsigned* sync = gru_sync(ws, maxclips);
+    unsigned* cnt = sync + 4 + sync_counters(maxclips);
+    VAR_HIP_CHECK(c, hipMemsetAsync(cnt, 0, 4L * sync_counters(maxclips), s));
+    hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3(NJS, (nclips + 63) / 64, 2), dim3(512), kBwdLds + 16, s, DH, Hb,
+                       (const uint4*)((const char*)ws + kWfBytes), (uint2*)gru_bf16_dgh16(ws, maxclips),
+                       (uint2*)gru_bf16_dgi16(ws, maxclips), R, Z, Nn, GHN, DGI, DGH, nclips, dirGI, dirH, dirS, dirDGH, cnt, sync);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}
+
+int gru_bf16_poison_on_timeout(var_ctx* c, hipStream_t s, float* grads, int n, int maxclips, void* ws) {
+    hipLaunchKernelGGL(gru_poison_kernel, dim3((n + 255) / 256), dim3(256), 0, s, gru_sync(ws, maxclips), grads, n);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}
+
+// blocking: the time-out word (0 = every hand-off of every sequence launch so far completed)
+int gru_bf16_timeout_word(var_ctx* c, int maxclips, void* ws, unsigned* out) {
+    VAR_HIP_CHECK(c, hipMemcpy(out, gru_sync(ws, maxclips), 4, hipMemcpyDeviceToHost));
     return VAR_OK;
 }

@@ -61,6 +61,7 @@ struct ithor_state {
     void* gruws = nullptr;                                // W_hh in MFMA fragment order (gru_bf16.hip)
     void* bfws = nullptr;                                 // bf16 images / packed filters of the staged sound kernels (snd_bf16.hip)
     int gh_split = 1, dh_split = 1;
+    bool gru_seq = true;                                  // bf16 mode: each GRU pass as one persistent launch (gru_bf16.hip)
     bool bf16 = false, keep32 = false;                    // bf16 mode; ... with the fp32 copies of the sound maps (tests)
     float *sraw = nullptr, *gsraw = nullptr;              // (clips,1024)
     float *hid_i = nullptr, *ghid_i = nullptr, *hid_s1 = nullptr, *ghid_s1 = nullptr, *hid_s2 = nullptr, *ghid_s2 = nullptr;
@@ -569,7 +570,14 @@ static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* imag
         }
         for (int d = 0; d < 2; ++d) VAR_HIP_CHECK(c, hipMemsetAsync(st->Hb + d * dirH, 0, sizeof(float) * nclips * kGh, s));
         if (st->bf16) RUN(gru_bf16_pack(c, s, P + L.w_hh[0], dirP, nclips, st->gruws));
-        for (int step = 0; step < kSeq; ++step) {
+        int whole = 0;       // the 73 steps in one launch
+        if (st->bf16 && st->gru_seq) {
+            const int r = gru_bf16_seq_fwd(c, s, st->GI, st->Hb, P + L.b_hh[0], dirP, st->R, st->Z, st->Nn, st->GHN, nclips, 2 * st->maxB,
+                                           dirGI, dirH, dirS, save ? 1 : 0, st->gruws);
+            if (r < 0) return r;
+            whole = r == 0;
+        }
+        for (int step = 0; step < kSeq && !whole; ++step) {
             if (st->bf16) {      // product + gates in one launch (gru_bf16.hip)
                 RUN(gru_bf16_step_fwd(c, s, st->GI, st->Hb, P + L.b_hh[0], dirP, st->R, st->Z, st->Nn, st->GHN, nclips, 2 * st->maxB, step,
                                       dirGI, dirH, dirS, save ? 1 : 0, st->gruws));
@@ -600,6 +608,7 @@ static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* imag
         hipLaunchKernelGGL(l2norm_fwd_kernel, g1(nclips), dim3(256), 0, s, st->raw + 3 * (long)st->maxB,
                            st->emb + 3 * (long)st->maxB, nclips);
         IT_CHECK(c);
+        if (st->bf16 && st->gru_seq) RUN(gru_bf16_poison_on_timeout(c, s, st->emb + 3 * (long)st->maxB, 3 * nclips, 2 * st->maxB, st->gruws));
     }
     return VAR_OK;
 }
@@ -692,7 +701,14 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
                            (long)nclips * kGh, 1);
         IT_CHECK(c);
         const int dh_split = rec_split(4 * ((nclips + 63) / 64) * 2, kG3 / GG_KC, 8);
-        for (int step = kSeq - 1; step >= 0; --step) {
+        int whole = 0;
+        if (st->bf16 && st->gru_seq) {
+            const int r = gru_bf16_seq_bwd(c, s, st->DH, st->Hb, st->R, st->Z, st->Nn, st->GHN, st->DGI, st->DGH, nclips, 2 * st->maxB,
+                                           dirGI, dirH, dirS, dirDGH, st->gruws);
+            if (r < 0) return r;
+            whole = r == 0;
+        }
+        for (int step = kSeq - 1; step >= 0 && !whole; --step) {
             if (st->bf16) {      // dh = DH + dgh(step+1) W_hh, then the step's gate derivatives, in one launch
                 RUN(gru_bf16_step_bwd(c, s, st->DH, st->Hb, st->R, st->Z, st->Nn, st->GHN, st->DGI, st->DGH, nclips, 2 * st->maxB, step,
                                       step == kSeq - 1 ? 0 : 1, dirGI, dirH, dirS, dirDGH, st->gruws));
@@ -805,6 +821,7 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             }
             if (!st->bf16) RUN(chan_sum(c, s, st->gs[1], G + L.sb[0], nclips, 64, 300 * 20));
         }
+        if (st->bf16 && st->gru_seq) RUN(gru_bf16_poison_on_timeout(c, s, G, min(L.total, 65536), 2 * st->maxB, st->gruws));
     }
     return VAR_OK;
 }
@@ -936,6 +953,8 @@ int var_ithor_plan(var_ctx* c, int max_batch, int img_hw) {
     st->hid_s2 = w + ohs2; st->ghid_s2 = w + oghs2;
     st->bfws = w + obf; st->gruws = w + ogru; st->imgws = w + oimg;
     st->raw = w + oraw; st->graw = w + ograw; st->emb = w + oemb; st->gemb = w + ogemb; st->loss = w + oloss;
+    RUN(gru_bf16_reset_timeout(c, nullptr, (int)C2, st->gruws));
+    VAR_HIP_CHECK(c, hipStreamSynchronize(nullptr));
     return VAR_OK;
 }
 
@@ -960,6 +979,23 @@ int var_ithor_set_bf16(var_ctx* c, int on) {
     const int old = st->bf16 ? (st->keep32 ? 2 : 1) : 0;
     if (on >= 0) { st->bf16 = on != 0; st->keep32 = on == 2; }
     return old;
+}
+
+int var_ithor_set_gru_sequence(var_ctx* c, int on) {
+    CHECK_CTX(c);
+    ithor_state* st = ith(c);
+    if (!st) { VAR_SET_ERR(c, "var_ithor_set_gru_sequence: var_ithor_plan first"); return VAR_ERR_PLAN; }
+    const int old = st->gru_seq ? 1 : 0;
+    if (on >= 0) st->gru_seq = on != 0;
+    return old;
+}
+
+int var_ithor_gru_status(var_ctx* c, unsigned* word) {
+    CHECK_CTX(c);
+    ithor_state* st = ith(c);
+    if (!st || !word) { VAR_SET_ERR(c, "var_ithor_gru_status: var_ithor_plan first"); return VAR_ERR_PLAN; }
+    VAR_HIP_CHECK(c, hipSetDevice(c->device));
+    return gru_bf16_timeout_word(c, 2 * st->maxB, st->gruws, word);
 }
 
 int var_ithor_encoder_fwd(var_ctx* c, void* stream, const float* params, const void* image, int image_is_u8,

@@ -282,6 +282,16 @@ int gru_bf16_step_fwd(var_ctx* c, hipStream_t s, const float* GI, float* Hb, con
 int gru_bf16_step_bwd(var_ctx* c, hipStream_t s, float* DH, const float* Hb, const float* R, const float* Z, const float* Nn,
                       const float* GHN, float* DGI, float* DGH, int nclips, int maxclips, int step, int has_next, long dirGI,
                       long dirH, long dirS, long dirDGH, void* ws);
+// the 73 steps of a pass in ONE persistent launch (workgroups of a clip slice hand the state over through L2 / HBM); 1 = the
+// grid would not be resident on this device, take the per-step launches
+int gru_bf16_seq_fwd(var_ctx* c, hipStream_t s, const float* GI, float* Hb, const float* b_hh, long dirP, float* R, float* Z, float* Nn,
+                     float* GHN, int nclips, int maxclips, long dirGI, long dirH, long dirS, int save, void* ws);
+int gru_bf16_seq_bwd(var_ctx* c, hipStream_t s, float* DH, const float* Hb, const float* R, const float* Z, const float* Nn,
+                     const float* GHN, float* DGI, float* DGH, int nclips, int maxclips, long dirGI, long dirH, long dirS, long dirDGH,
+                     void* ws);
+int gru_bf16_reset_timeout(var_ctx* c, hipStream_t s, int maxclips, void* ws);
+int gru_bf16_poison_on_timeout(var_ctx* c, hipStream_t s, float* grads, int n, int maxclips, void* ws);
+int gru_bf16_timeout_word(var_ctx* c, int maxclips, void* ws, unsigned* out);
 
 // img_bf16.hip: 3x3 stride-1 convolutions of the iTHOR image branch (layers 2, 3) in the bf16 mode, forward and data gradient
 long img_bf16_workspace_bytes();
