@@ -1,7 +1,9 @@
 // The recurrence of the iTHOR model's bidirectional GRU(448 -> 512) in its bf16 mode (models/pretext/ai2thor_pretext_model.py:
-// 31-33; torch.nn.GRU gate order r, z, n): ONE kernel per time step and pass that does the recurrent product on
-// v_mfma_f32_32x32x16_bf16 AND the gate arithmetic, instead of a split-K gather-GEMM launch + its partial slabs + a gate
-// kernel per step (32 us per step; the 146 dependent steps were 25 % of the bf16 training step).
+// 31-33; torch.nn.GRU gate order r, z, n): the recurrent product on v_mfma_f32_32x32x16_bf16 AND the gate arithmetic in one
+// kernel, instead of a split-K gather-GEMM launch + its partial slabs + a gate kernel per step (32 us per step; the 146
+// dependent steps were 25 % of the bf16 training step).  Two forms with identical arithmetic: one launch per time step
+// (gru_step_*: 10.7 / 15.9 us per step with the kernel boundary), and the whole pass in one persistent launch
+// (gru_seq_*: 6.9 / 11.9 us per step) whose workgroups hand the state over in memory -- see the note above gru_seq_fwd_kernel.
 //
 //   forward   gh[j][clip] = sum_k W_hh[g 512 + j][k] h[clip][k]         (3 gates x 32 hidden units x 64 clips per workgroup, K = 512)
 //             r, z, n, h' from gi (the input projection), gh, b_hh; saved r, z, n, gh_n for the backward
@@ -18,6 +20,18 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) unsigned gu32;
+
+PH_DECL();
+#ifdef VAR_PHASES
+extern "C" int var_debug_phases_gru(unsigned long long* out) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#define PH_INIT3() unsigned long long ph_t = clock64(); const bool ph_on = blockIdx.x == 3 && blockIdx.y == 1 && blockIdx.z == 0 && threadIdx.x == 0
+#else
+#define PH_INIT3()
+#endif
 
 namespace {
 
@@ -70,14 +84,20 @@ __global__ void __launch_bounds__(256) gru_pack_kernel(const float* __restrict__
 // is read as its bf16 copy H16 (written by the previous step next to the fp32 state).  The four K quarters meet in LDS;
 // the gate phase re-maps the tile so that 8 consecutive lanes hold the 32 hidden units of ONE clip (128-byte rows of
 // gi / r / z / n / h) instead of one clip per lane.
-constexpr int RS = 66;                                  // LDS row stride of a 64-lane accumulator row
+constexpr int RS = 66;                                  // LDS stride (16-byte slots) of a 64-lane block of accumulator quads
+// The K partials meet in LDS as 16-byte quads (the 4 consecutive rows a lane holds per register quad): slot of
+// (partial-and-gate block pg, register quad rq, clip column c, lane half h).  The rotation by 8 h and the block stride of 66
+// make both sides conflict-free for ds_*_b128: a 16-lane group of the writing wave covers 16 consecutive columns of one
+// half, one of the gate phase (two clips x 8 hidden quads) covers 2 rq + c + 8 h = sixteen different slots mod 16
+// (ds_read_b32 moves a quarter of the bytes per clock: the 48 scalar reads per thread were 1 us of a 6.9 us step).
+__device__ __forceinline__ int quad_slot(int pg, int rq, int c, int h) { return (pg * 4 + rq) * RS + ((c + 8 * h) & 31) + 32 * h; }
 
 __global__ void __launch_bounds__(512) gru_step_fwd_kernel(const float* __restrict__ GI, float* __restrict__ Hb, uint2* __restrict__ H16,
                                                            const uint4* __restrict__ wf, const float* __restrict__ b_hh, long dirP,
                                                            float* __restrict__ R, float* __restrict__ Z, float* __restrict__ Nn,
                                                            float* __restrict__ GHN, int nclips, int step, long dirGI, long dirH,
                                                            long dirS, int save) {
-    extern __shared__ float red[];                       // [cbk 2][kq 4][gate 3][r 16][RS]
+    extern __shared__ __attribute__((aligned(16))) float red[];                       // quad_slot((cbk 4 + kq) 3 + gate, ..) x 16 B
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, cbk = wave & 1, kq = wave >> 1;
     const int js = blockIdx.x, cs = blockIdx.y, dir = blockIdx.z;
     // the gate phase's operands first (thread = (clip_l = tid / 8, hidden quad jq = tid % 8)): their HBM latency runs
@@ -115,11 +135,12 @@ __global__ void __launch_bounds__(512) gru_step_fwd_kernel(const float* __restri
             for (int g = 0; g < 3; ++g)
                 acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[i][g]), __builtin_bit_cast(bf16x8_t, b[i]),
                                                                  acc[g], 0, 0, 0);
-        float* dst = red + ((cbk * 4 + kq) * 3) * 16 * RS + lane;
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dst[(g * 16 + r) * RS] = acc[g][r];
+            for (int rq = 0; rq < 4; ++rq)
+                ((float4*)red)[quad_slot((cbk * 4 + kq) * 3 + g, rq, lane & 31, h)] =
+                    make_float4(acc[g][4 * rq], acc[g][4 * rq + 1], acc[g][4 * rq + 2], acc[g][4 * rq + 3]);
     }
     __syncthreads();
     // gate phase: thread = (clip_l = tid / 8, hidden quad jq = tid % 8): units 32 js + 4 jq + 0..3, which the accumulators hold
@@ -127,14 +148,15 @@ __global__ void __launch_bounds__(512) gru_step_fwd_kernel(const float* __restri
     if (clip >= nclips) return;
     float gh[3][4];
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
+    for (int g = 0; g < 3; ++g) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float v = 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v += red[((((cl >> 5) * 4 + q) * 3 + g) * 16 + 4 * (jq >> 1) + e) * RS + (cl & 31) + 32 * (jq & 1)];
-            gh[g][e] = v;
+        for (int q = 0; q < 4; ++q) {
+            const float4 p = ((const float4*)red)[quad_slot(((cl >> 5) * 4 + q) * 3 + g, jq >> 1, cl & 31, jq & 1)];
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
         }
+        gh[g][0] = v.x; gh[g][1] = v.y; gh[g][2] = v.z; gh[g][3] = v.w;
+    }
     float* hnext = Hb + dir * dirH + (long)(step + 1) * nclips * GH + (long)clip * GH + j;
     const long so = dir * dirS + (long)step * nclips * GH + (long)clip * GH + j;
     float4 o, rr, zz, nn, gg;
@@ -161,7 +183,7 @@ __global__ void __launch_bounds__(512) gru_step_bwd_kernel(float* __restrict__ D
                                                            const float* __restrict__ Nn, const float* __restrict__ GHN,
                                                            float* __restrict__ DGI, float* __restrict__ DGH, int nclips, int step,
                                                            int has_next, long dirGI, long dirH, long dirS, long dirDGH) {
-    extern __shared__ float red[];                       // [cbk 2][kq 4][r 16][RS]
+    extern __shared__ __attribute__((aligned(16))) float red[];                       // quad_slot(cbk 4 + kq, ..) x 16 B
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, cbk = wave & 1, kq = wave >> 1;
     const int js = blockIdx.x, cs = blockIdx.y, dir = blockIdx.z;
     const int jq = tid & 7, cl = tid >> 3, clip = 64 * cs + cl, clipc = min(clip, nclips - 1);
@@ -187,18 +209,19 @@ __global__ void __launch_bounds__(512) gru_step_bwd_kernel(float* __restrict__ D
 #pragma unroll
         for (int i = 0; i < 24; ++i)
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[i]), __builtin_bit_cast(bf16x8_t, b[i]), acc, 0, 0, 0);
-        float* dst = red + (cbk * 4 + kq) * 16 * RS + lane;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dst[r * RS] = acc[r];
+        for (int rq = 0; rq < 4; ++rq)
+            ((float4*)red)[quad_slot(cbk * 4 + kq, rq, lane & 31, h)] = make_float4(acc[4 * rq], acc[4 * rq + 1], acc[4 * rq + 2], acc[4 * rq + 3]);
         __syncthreads();
     }
     if (clip >= nclips) return;
     float dp[4] = {0.f, 0.f, 0.f, 0.f};
     if (has_next) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dp[e] += red[(((cl >> 5) * 4 + q) * 16 + 4 * (jq >> 1) + e) * RS + (cl & 31) + 32 * (jq & 1)];
+        for (int q = 0; q < 4; ++q) {
+            const float4 p = ((const float4*)red)[quad_slot((cl >> 5) * 4 + q, jq >> 1, cl & 31, jq & 1)];
+            dp[0] += p.x; dp[1] += p.y; dp[2] += p.z; dp[3] += p.w;
+        }
     }
     float* dgi = DGI + dir * dirGI + ((long)clip * SEQ + t) * G3 + j;
     float* dgh = DGH + dir * dirDGH + ((long)step * nclips + clip) * G3 + j;
@@ -251,7 +274,7 @@ __global__ void __launch_bounds__(512) gru_seq_fwd_kernel(const float* __restric
                                                           float* __restrict__ R, float* __restrict__ Z, float* __restrict__ Nn,
                                                           float* __restrict__ GHN, int nclips, long dirGI, long dirH, long dirS,
                                                           int save, unsigned* cnt0, unsigned* tmo) {
-    extern __shared__ float red[];                       // [cbk 2][kq 4][gate 3][r 16][RS] | go
+    extern __shared__ __attribute__((aligned(16))) float red[];                       // quad_slot((cbk 4 + kq) 3 + gate, ..) x 16 B | go
     int* go = (int*)(red + 2 * 4 * 3 * 16 * RS);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, cbk = wave & 1, kq = wave >> 1;
     const int js = blockIdx.x, cs = blockIdx.y, dir = blockIdx.z;
@@ -271,7 +294,9 @@ __global__ void __launch_bounds__(512) gru_seq_fwd_kernel(const float* __restric
     const int ldoff = min(64 * cs + 32 * cbk + (lane & 31), nclips - 1) * (GH * 2) + (16 * kq + h) * 16;   // this lane's operand bytes in a step's rows
     const int stoff = clipc * (GH * 2) + (8 * js + jq) * 8;                                                  // its bf16 output
     float4 hp = make_float4(0.f, 0.f, 0.f, 0.f);
+    PH_INIT3();
     for (int step = 0; step < SEQ; ++step) {
+        PH(0);
         const int t = dir ? SEQ - 1 - step : step;
         const float* gi = GI + dir * dirGI + ((long)clipc * SEQ + t) * G3 + j;
         const float4 gr = *(const float4*)gi, gz = *(const float4*)(gi + GH), gn = *(const float4*)(gi + 2 * GH);
@@ -279,11 +304,16 @@ __global__ void __launch_bounds__(512) gru_seq_fwd_kernel(const float* __restric
             if (tid == 0) *go = wait_count(cnt + step, NJS, tmo, 1 + step);
             __syncthreads();
             if (!*go) break;
+            PH(1);
         }
         const int rows = ((dir * (SEQ + 1) + step) * nclips) * (GH * 2);
         u32x4_t b[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) b[i] = __builtin_amdgcn_raw_buffer_load_b128(hr, ldoff + 32 * i, rows, kSc1);
+#ifdef VAR_PHASES
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PH(2);
+#endif
         f32x16_t acc[3];
 #pragma unroll
         for (int g = 0; g < 3; ++g)
@@ -295,23 +325,27 @@ __global__ void __launch_bounds__(512) gru_seq_fwd_kernel(const float* __restric
             for (int g = 0; g < 3; ++g)
                 acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[i][g]), __builtin_bit_cast(bf16x8_t, b[i]),
                                                                  acc[g], 0, 0, 0);
-        float* dst = red + ((cbk * 4 + kq) * 3) * 16 * RS + lane;
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dst[(g * 16 + r) * RS] = acc[g][r];
+            for (int rq = 0; rq < 4; ++rq)
+                ((float4*)red)[quad_slot((cbk * 4 + kq) * 3 + g, rq, lane & 31, h)] =
+                    make_float4(acc[g][4 * rq], acc[g][4 * rq + 1], acc[g][4 * rq + 2], acc[g][4 * rq + 3]);
+        PH(3);
         __syncthreads();
+        PH(4);
         if (clip < nclips) {
             float gh[3][4];
 #pragma unroll
-            for (int g = 0; g < 3; ++g)
+            for (int g = 0; g < 3; ++g) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = 0.f;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v += red[((((cl >> 5) * 4 + q) * 3 + g) * 16 + 4 * (jq >> 1) + e) * RS + (cl & 31) + 32 * (jq & 1)];
-                    gh[g][e] = v;
+                for (int q = 0; q < 4; ++q) {
+                    const float4 p = ((const float4*)red)[quad_slot(((cl >> 5) * 4 + q) * 3 + g, jq >> 1, cl & 31, jq & 1)];
+                    v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
                 }
+                gh[g][0] = v.x; gh[g][1] = v.y; gh[g][2] = v.z; gh[g][3] = v.w;
+            }
             float* hnext = Hb + dir * dirH + (long)(step + 1) * nclips * GH + (long)clip * GH + j;
             const long so = dir * dirS + (long)step * nclips * GH + (long)clip * GH + j;
             float4 o, rr, zz, nn, gg;
@@ -333,8 +367,11 @@ __global__ void __launch_bounds__(512) gru_seq_fwd_kernel(const float* __restric
             if (save) { *(float4*)(R + so) = rr; *(float4*)(Z + so) = zz; *(float4*)(Nn + so) = nn; *(float4*)(GHN + so) = gg; }
             hp = o;
         }
+        PH(5);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PH(6);
         __syncthreads();
+        PH(7);
         if (tid == 0) __hip_atomic_fetch_add((gu32*)(cnt + step + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -345,7 +382,7 @@ __global__ void __launch_bounds__(512) gru_seq_bwd_kernel(float* __restrict__ DH
                                                           const float* __restrict__ GHN, float* __restrict__ DGI, float* __restrict__ DGH,
                                                           int nclips, long dirGI, long dirH, long dirS, long dirDGH, unsigned* cnt0,
                                                           unsigned* tmo) {
-    extern __shared__ float red[];                       // [cbk 2][kq 4][r 16][RS] | go
+    extern __shared__ __attribute__((aligned(16))) float red[];                       // quad_slot(cbk 4 + kq, ..) x 16 B | go
     int* go = (int*)(red + 2 * 4 * 16 * RS);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, cbk = wave & 1, kq = wave >> 1;
     const int js = blockIdx.x, cs = blockIdx.y, dir = blockIdx.z;
@@ -362,7 +399,9 @@ __global__ void __launch_bounds__(512) gru_seq_bwd_kernel(float* __restrict__ DH
     const int stoff = clipc * (G3 * 2) + (8 * js + jq) * 8;
     float* dh = DH + (long)dir * nclips * GH + (long)clipc * GH + j;
     float4 d4 = *(const float4*)dh;
+    PH_INIT3();
     for (int step = SEQ - 1; step >= 0; --step) {
+        PH(10);
         const int t = dir ? SEQ - 1 - step : step;
         const long so = dir * dirS + (long)step * nclips * GH + (long)clipc * GH + j;
         const float* hprev = Hb + dir * dirH + (long)step * nclips * GH + (long)clipc * GH + j;
@@ -374,23 +413,31 @@ __global__ void __launch_bounds__(512) gru_seq_bwd_kernel(float* __restrict__ DH
             if (tid == 0) *go = wait_count(cnt + step + 1, NJS, tmo, 101 + step);
             __syncthreads();
             if (!*go) break;
+            PH(11);
             u32x4_t b[24];
 #pragma unroll
             for (int i = 0; i < 24; ++i) b[i] = __builtin_amdgcn_raw_buffer_load_b128(gr, ldoff + 32 * i, rows + nclips * (G3 * 2), kSc1);
+#ifdef VAR_PHASES
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PH(12);
+#endif
             f32x16_t acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
             for (int i = 0; i < 24; ++i)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[i]), __builtin_bit_cast(bf16x8_t, b[i]), acc, 0, 0, 0);
-            float* dst = red + (cbk * 4 + kq) * 16 * RS + lane;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dst[r * RS] = acc[r];
+            for (int rq = 0; rq < 4; ++rq)
+                ((float4*)red)[quad_slot(cbk * 4 + kq, rq, lane & 31, h)] = make_float4(acc[4 * rq], acc[4 * rq + 1], acc[4 * rq + 2], acc[4 * rq + 3]);
+            PH(13);
             __syncthreads();
+            PH(14);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) dp[e] += red[(((cl >> 5) * 4 + q) * 16 + 4 * (jq >> 1) + e) * RS + (cl & 31) + 32 * (jq & 1)];
+            for (int q = 0; q < 4; ++q) {
+                const float4 p = ((const float4*)red)[quad_slot((cl >> 5) * 4 + q, jq >> 1, cl & 31, jq & 1)];
+                dp[0] += p.x; dp[1] += p.y; dp[2] += p.z; dp[3] += p.w;
+            }
         }
         if (clip < nclips) {
             float* dgi = DGI + dir * dirGI + ((long)clip * SEQ + t) * G3 + j;
@@ -420,8 +467,11 @@ __global__ void __launch_bounds__(512) gru_seq_bwd_kernel(float* __restrict__ DH
             i16[2 * GH / 4] = make_uint2(pack2(dn.x, dn.y), pack2(dn.z, dn.w));
             d4 = dd;
         }
+        PH(15);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PH(16);
         __syncthreads();
+        PH(17);
         if (tid == 0) __hip_atomic_fetch_add((gu32*)(cnt + step), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (clip < nclips) *(float4*)dh = d4;
