@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(512) gru_seq_bwd_kernel(float* __restrict__ DH
                                                           const float* __restrict__ Z, const float* __restrict__ Nn,
                                                           const float* __restrict__ GHN, float* __restrict__ DGI, float* __restrict__ DGH,
                                                           int nclips, long dirGI, long dirH, long dirS, long dirDGH, unsigned* cnt0,
-                                                          unsigned* tmo) {
+                                                          unsigned* tmo, float* __restrict__ bias_part) {
     extern __shared__ __attribute__((aligned(16))) float red[];                       // quad_slot(cbk 4 + kq, ..) x 16 B | go
     int* go = (int*)(red + 2 * 4 * 16 * RS);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, cbk = wave & 1, kq = wave >> 1;
@@ -399,6 +399,7 @@ __global__ void __launch_bounds__(512) gru_seq_bwd_kernel(float* __restrict__ DH
     const int stoff = clipc * (G3 * 2) + (8 * js + jq) * 8;
     float* dh = DH + (long)dir * nclips * GH + (long)clipc * GH + j;
     float4 d4 = *(const float4*)dh;
+    float4 sr = make_float4(0.f, 0.f, 0.f, 0.f), sz = sr, sn = sr, snr = sr;     // this thread's share of the bias gradients
     PH_INIT3();
     for (int step = SEQ - 1; step >= 0; --step) {
         PH(10);
@@ -466,6 +467,10 @@ __global__ void __launch_bounds__(512) gru_seq_bwd_kernel(float* __restrict__ DH
             i16[0] = make_uint2(pr.x, pr.y); i16[GH / 4] = make_uint2(pz.x, pz.y);
             i16[2 * GH / 4] = make_uint2(pack2(dn.x, dn.y), pack2(dn.z, dn.w));
             d4 = dd;
+            sr.x += dr.x; sr.y += dr.y; sr.z += dr.z; sr.w += dr.w;
+            sz.x += dz.x; sz.y += dz.y; sz.z += dz.z; sz.w += dz.w;
+            sn.x += dn.x; sn.y += dn.y; sn.z += dn.z; sn.w += dn.w;
+            snr.x += dnr.x; snr.y += dnr.y; snr.z += dnr.z; snr.w += dnr.w;
         }
         PH(15);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -475,6 +480,33 @@ __global__ void __launch_bounds__(512) gru_seq_bwd_kernel(float* __restrict__ DH
         if (tid == 0) __hip_atomic_fetch_add((gu32*)(cnt + step), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (clip < nclips) *(float4*)dh = d4;
+    // bias gradients: b_ih = sum over (clip, t) of (dr, dz, dn), b_hh of (dr, dz, dn r) -- this workgroup's 64 clips summed
+    // in a fixed order (8 clips of a wave by lane exchange, the 8 waves through LDS); the slices of a direction are folded
+    // by the caller.  (A launch that timed out leaves partial sums: the caller's time-out check poisons the gradient.)
+    float4 v[4] = {sr, sz, sn, snr};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int m = 8; m < 64; m <<= 1) {
+            v[k].x += __shfl_xor(v[k].x, m); v[k].y += __shfl_xor(v[k].y, m);
+            v[k].z += __shfl_xor(v[k].z, m); v[k].w += __shfl_xor(v[k].w, m);
+        }
+    float4* bs = (float4*)red;                           // [wave 8][kind 4][jq 8]
+    __syncthreads();
+    if (lane < 8)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bs[(wave * 4 + k) * 8 + lane] = v[k];
+    __syncthreads();
+    if (tid < 32) {
+        const int k = tid >> 3, q = tid & 7;
+        float4 t = bs[k * 8 + q];
+        for (int w = 1; w < 8; ++w) { const float4 u = bs[(w * 4 + k) * 8 + q]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        // [dir][slice][b_ih: r z n | b_hh: r z n][512]
+        float* o = bias_part + ((long)(dir * gridDim.y + cs) * 6) * GH + 32 * js + 4 * q;
+        if (k < 3) *(float4*)(o + k * GH) = t;
+        if (k < 2) *(float4*)(o + (3 + k) * GH) = t;
+        if (k == 3) *(float4*)(o + 5 * GH) = t;
+    }
 }
 
 // a timed-out sequence kernel has left partial results: make that loud in the gradient (NaN) rather than silent
@@ -498,17 +530,21 @@ __global__ void __launch_bounds__(256) to_bf16_kernel(const float4* __restrict__
 static inline long h16_bytes(int mc) { return 2L * (SEQ + 1) * mc * GH * 2; }
 static inline long dg16_bytes(int mc) { return 2L * SEQ * mc * G3 * 2; }
 static inline long x16_bytes(int mc) { return (long)SEQ * mc * 448 * 2; }
+constexpr long kWih16Bytes = 2L * G3 * 448 * 2;          // W_ih as bf16, [dir][1536][448]
+static inline long bias_part_bytes(int mc) { return 2L * ((mc + 63) / 64) * 6 * GH * 4; }   // [dir][clip slice][6][512] fp32
 // hand-off words of the sequence kernels: [time-out word, 3 pad | forward counters (dir, clip slice, step 0..73) | backward counters]
 static inline int sync_counters(int mc) { return 2 * ((mc + 63) / 64) * (SEQ + 1); }
 static inline long sync_bytes(int mc) { return ((4 + 2L * sync_counters(mc)) * 4 + 255) & ~255L; }
 long gru_bf16_workspace_bytes(int mc) {
-    return kWfBytes + kWbBytes + h16_bytes(mc) + 2 * dg16_bytes(mc) + ((x16_bytes(mc) + 255) & ~255L) + sync_bytes(mc) + 256;
+    return kWfBytes + kWbBytes + h16_bytes(mc) + 2 * dg16_bytes(mc) + ((x16_bytes(mc) + 255) & ~255L) + sync_bytes(mc) + kWih16Bytes + bias_part_bytes(mc) + 256;
 }
 void* gru_bf16_h16(void* ws) { return (char*)ws + kWfBytes + kWbBytes; }
 void* gru_bf16_dgh16(void* ws, int mc) { return (char*)gru_bf16_h16(ws) + h16_bytes(mc); }
 void* gru_bf16_dgi16(void* ws, int mc) { return (char*)gru_bf16_dgh16(ws, mc) + dg16_bytes(mc); }
 void* gru_bf16_x16(void* ws, int mc) { return (char*)gru_bf16_dgi16(ws, mc) + dg16_bytes(mc); }
 static unsigned* gru_sync(void* ws, int mc) { return (unsigned*)((char*)gru_bf16_x16(ws, mc) + ((x16_bytes(mc) + 255) & ~255L)); }
+void* gru_bf16_wih16(void* ws, int mc) { return (char*)gru_sync(ws, mc) + sync_bytes(mc); }
+float* gru_bf16_bias_part(void* ws, int mc) { return (float*)((char*)gru_bf16_wih16(ws, mc) + kWih16Bytes); }
 constexpr int kFwdLds = 2 * 4 * 3 * 16 * RS * 4, kBwdLds = 2 * 4 * 16 * RS * 4;
 
 // the GRU's input sequence (fp32, n floats, n % 8 == 0) as bf16 for the dense products
@@ -520,7 +556,12 @@ int gru_bf16_convert_x(var_ctx* c, hipStream_t s, const float* x, long n, int ma
 }
 
 // once per forward: both fragment tables of W_hh, and the zero initial state's bf16 copy
-int gru_bf16_pack(var_ctx* c, hipStream_t s, const float* w_hh, long dirP, int nclips, void* ws) {
+int gru_bf16_pack(var_ctx* c, hipStream_t s, const float* w_hh, const float* w_ih, long dirP, int nclips, int maxclips, void* ws) {
+    for (int d = 0; d < 2; ++d) {                        // W_ih [dir][1536][448] as bf16: the A operand of the input projection and of dX
+        const long n8 = (long)G3 * 448 / 8;
+        hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, (const float4*)(w_ih + d * dirP),
+                           (uint4*)gru_bf16_wih16(ws, maxclips) + d * n8, n8);
+    }
     uint4* wf = (uint4*)ws;
     uint4* wb = (uint4*)((char*)ws + kWfBytes);
     const int n = (int)((kWfBytes + kWbBytes) / 16);
@@ -590,7 +631,8 @@ int gru_bf16_seq_bwd(var_ctx* c, hipStream_t s, float* DH, const float* Hb, cons
     VAR_HIP_CHECK(c, hipMemsetAsync(cnt, 0, 4L * sync_counters(maxclips), s));
     hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3(NJS, (nclips + 63) / 64, 2), dim3(512), kBwdLds + 16, s, DH, Hb,
                        (const uint4*)((const char*)ws + kWfBytes), (uint2*)gru_bf16_dgh16(ws, maxclips),
-                       (uint2*)gru_bf16_dgi16(ws, maxclips), R, Z, Nn, GHN, DGI, DGH, nclips, dirGI, dirH, dirS, dirDGH, cnt, sync);
+                       (uint2*)gru_bf16_dgi16(ws, maxclips), R, Z, Nn, GHN, DGI, DGH, nclips, dirGI, dirH, dirS, dirDGH, cnt, sync,
+                       gru_bf16_bias_part(ws, maxclips));
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }

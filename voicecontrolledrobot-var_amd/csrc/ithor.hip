@@ -563,13 +563,16 @@ static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* imag
             p.Bm = st->s[3]; p.sbk = 1; p.sbn = kGin; p.zB = 0;
             p.C = st->GI; p.scm = 1; p.scn = kG3; p.zC = dirGI; p.bias = P + L.b_ih[0]; p.zbias = dirP;
             if (st->bf16) {
+                RUN(gru_bf16_pack(c, s, P + L.w_hh[0], P + L.w_ih[0], dirP, nclips, 2 * st->maxB, st->gruws));
                 RUN(gru_bf16_convert_x(c, s, st->s[3], (long)rows * kGin, 2 * st->maxB, st->gruws));
-                use_bf16_copies(c, p, nullptr, gru_bf16_x16(st->gruws, 2 * st->maxB));
+                auto q = p;
+                q.zA = (long)kG3 * kGin;
+                use_bf16_copies(c, q, gru_bf16_wih16(st->gruws, 2 * st->maxB), gru_bf16_x16(st->gruws, 2 * st->maxB));
+                if (q.a16) p = q; else use_bf16_copies(c, p, nullptr, gru_bf16_x16(st->gruws, 2 * st->maxB));
             }
             RUN(gg(c, s, p, 2));
         }
         for (int d = 0; d < 2; ++d) VAR_HIP_CHECK(c, hipMemsetAsync(st->Hb + d * dirH, 0, sizeof(float) * nclips * kGh, s));
-        if (st->bf16) RUN(gru_bf16_pack(c, s, P + L.w_hh[0], dirP, nclips, st->gruws));
         int whole = 0;       // the 73 steps in one launch
         if (st->bf16 && st->gru_seq) {
             const int r = gru_bf16_seq_fwd(c, s, st->GI, st->Hb, P + L.b_hh[0], dirP, st->R, st->Z, st->Nn, st->GHN, nclips, 2 * st->maxB,
@@ -756,6 +759,13 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             for (int d = 0; d < 2; ++d) RUN(slab_reduce(c, s, G + L.w_ih[d], st->slab + d * onei, (int)onei, p.nsplit, 2 * onei));
         }
         for (int d = 0; d < 2; ++d) {
+            if (whole) {     // the sequence kernel summed its 64-clip slices on the way: fold the slices (no second pass over DGI / DGH)
+                const int ncs = (nclips + 63) / 64;
+                const float* part = gru_bf16_bias_part(st->gruws, 2 * st->maxB) + (long)d * ncs * 6 * kGh;
+                RUN(slab_reduce(c, s, G + L.b_ih[d], part, kG3, ncs, 6L * kGh));
+                RUN(slab_reduce(c, s, G + L.b_hh[d], part + kG3, kG3, ncs, 6L * kGh));
+                continue;
+            }
             RUN(chan_sum(c, s, st->DGI + d * dirGI, G + L.b_ih[d], rows, kG3, 1));
             RUN(chan_sum(c, s, st->DGH + d * dirDGH, G + L.b_hh[d], rows, kG3, 1));
         }
@@ -764,13 +774,16 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             p.M = kGin; p.N = rows; p.K = kG3; p.nsplit = 1;
             p.A = P + L.w_ih[0]; p.sam = 1; p.sak = kGin; p.Bm = st->DGI; p.sbk = 1; p.sbn = kG3;
             p.C = st->gs[3]; p.scm = 1; p.scn = kGin;
-            use_bf16_copies(c, p, nullptr, gru_bf16_dgi16(st->gruws, 2 * st->maxB));
+            const unsigned short* w16 = (const unsigned short*)gru_bf16_wih16(st->gruws, 2 * st->maxB);
+            use_bf16_copies(c, p, w16, gru_bf16_dgi16(st->gruws, 2 * st->maxB));
+            if (!p.a16) use_bf16_copies(c, p, nullptr, gru_bf16_dgi16(st->gruws, 2 * st->maxB));
             RUN(gg(c, s, p));
             DenseP<false, true, 1> q{};
             q.M = kGin; q.N = rows; q.K = kG3; q.nsplit = 1;
             q.A = P + L.w_ih[1]; q.sam = 1; q.sak = kGin; q.Bm = st->DGI + dirGI; q.sbk = 1; q.sbn = kG3;
             q.C = st->gs[3]; q.scm = 1; q.scn = kGin;
-            use_bf16_copies(c, q, nullptr, (const unsigned short*)gru_bf16_dgi16(st->gruws, 2 * st->maxB) + dirGI);
+            use_bf16_copies(c, q, w16 + (long)kG3 * kGin, (const unsigned short*)gru_bf16_dgi16(st->gruws, 2 * st->maxB) + dirGI);
+            if (!q.a16) use_bf16_copies(c, q, nullptr, (const unsigned short*)gru_bf16_dgi16(st->gruws, 2 * st->maxB) + dirGI);
             RUN(gg(c, s, q));
         }
         RUN(relu_mask(c, s, st->gs[3], st->s[3], (long)rows * kGin));

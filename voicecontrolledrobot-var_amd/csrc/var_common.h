@@ -276,7 +276,11 @@ void* gru_bf16_dgh16(void* ws, int maxclips); //   gate gradients wrt gh (dir, s
 void* gru_bf16_dgi16(void* ws, int maxclips); //   gate gradients wrt gi (dir, clip*73+t, 1536)
 void* gru_bf16_x16(void* ws, int maxclips);   //   the input sequence (clip*73+t, 448)
 int gru_bf16_convert_x(var_ctx* c, hipStream_t s, const float* x, long n, int maxclips, void* ws);
-int gru_bf16_pack(var_ctx* c, hipStream_t s, const float* w_hh, long dirP, int nclips, void* ws);
+void* gru_bf16_wih16(void* ws, int maxclips); //   W_ih (dir, 1536, 448)
+// fp32 (dir, clip slice of 64, [b_ih: r z n | b_hh: r z n], 512): per-slice bias-gradient sums left by gru_bf16_seq_bwd
+float* gru_bf16_bias_part(void* ws, int maxclips);
+// once per forward, before the input projection: W_hh's fragment tables, W_ih's bf16 copy, the zero initial state
+int gru_bf16_pack(var_ctx* c, hipStream_t s, const float* w_hh, const float* w_ih, long dirP, int nclips, int maxclips, void* ws);
 int gru_bf16_step_fwd(var_ctx* c, hipStream_t s, const float* GI, float* Hb, const float* b_hh, long dirP, float* R, float* Z,
                       float* Nn, float* GHN, int nclips, int maxclips, int step, long dirGI, long dirH, long dirS, int save, void* ws);
 int gru_bf16_step_bwd(var_ctx* c, hipStream_t s, float* DH, const float* Hb, const float* R, const float* Z, const float* Nn,
