@@ -132,6 +132,29 @@ extern "C" int var_debug_phases_mfcc(unsigned long long* out) {
 }
 #endif
 
+// PSF = the python_speech_features flavour of the same pipeline (iTHOR / FSC; header of mfcc_psf.hip): frames start at
+// t * 160 with a zero-padded tail instead of being centred with reflected ends, the signal is pre-emphasised
+// (y[n] = x[n] - .97 x[n-1], y[0] = x[0]) and not normalised, symmetric Hamming, power / 512, the library's integer-bin
+// triangles, log with eps for exact zeros, liftered DCT, coefficient 0 := log(frame energy).  What differs in the kernel:
+// where a frame's samples come from, the pre-emphasis (the previous sample is the neighbouring lane's: one DPP move),
+// and the energy (Parseval: sum_k<=256 |X_k|^2 = (512 sum_n f_n^2 + |X_0|^2 + |X_256|^2) / 2 -- the mel products only
+// read bands of the spectrum); everything else is table contents.
+constexpr float kPsfEps = 2.220446049250313e-16f;    // numpy.finfo(float).eps, the library's stand-in for log(0)
+constexpr float kPreemph = 0.97f;
+
+// lane j of each 16-lane row receives lane (j - 1) & 15's value (row_ror:1)
+__device__ __forceinline__ uint32_t row_ror1(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x121, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float row_sum16(float e) {          // every lane of a 16-lane row gets the row's sum
+    e += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, e), 0x128, 0xf, 0xf, false));
+    e += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, e), 0x124, 0xf, 0xf, false));
+    e += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, e), 0x122, 0xf, 0xf, false));
+    e += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, e), 0x121, 0xf, 0xf, false));
+    return e;
+}
+
+template <bool PSF>
 __global__ void __launch_bounds__(NTHR, 2)
 mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const int* __restrict__ clip_index,
             int pcm_stride, int out_frames, int total_frames, const float* __restrict__ tab, float* __restrict__ out) {
@@ -142,6 +165,7 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
     __shared__ __attribute__((aligned(16))) float part[4 * 3 * 4 * 64]; // mel partial sums of the four waves
     __shared__ __attribute__((aligned(16))) float lmel[FT * LPITCH];    // log-mel tile (A operand of the DCT products)
     __shared__ int live_s[2 * FT];                                      // [parity][frame]
+    __shared__ float en_s[2 * FT];                                      // PSF: frame energy
     const float* win = lds + L_WIN;                 // window / 32768, zero outside its 400 taps
     cplx* tbuf = (cplx*)(lds + L_TBUF);             // transpose tile; then the spectrum Z[k] (256 per frame)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -187,10 +211,17 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
     auto frame_of = [&](const FrameMeta& m) {
         FrameRef r;
         r.N = m.N < pcm_stride ? m.N : pcm_stride;
-        r.live = m.inb && r.N > 0 && m.t < 1 + r.N / HOP;
         r.sig = pcm + (size_t)m.row * pcm_stride;
-        r.p0 = m.t * HOP - NFFT / 2;
-        r.interior = r.live && r.p0 >= 0 && r.p0 + NFFT <= r.N && !(pcm_stride & 1);
+        if (PSF) {
+            const int T = r.N > WIN ? 1 + (r.N - WIN + HOP - 1) / HOP : 1;
+            r.live = m.inb && r.N > 0 && m.t < T;
+            r.p0 = m.t * HOP;
+            r.interior = r.live && r.p0 > 0 && r.p0 + NFFT <= r.N && !(pcm_stride & 1);
+        } else {
+            r.live = m.inb && r.N > 0 && m.t < 1 + r.N / HOP;
+            r.p0 = m.t * HOP - NFFT / 2;
+            r.interior = r.live && r.p0 >= 0 && r.p0 + NFFT <= r.N && !(pcm_stride & 1);
+        }
         return r;
     };
     // sample pairs of the frame, one tile ahead: lane j takes z[16 n1 + j] = (x[32 n1 + 2 j], x[32 n1 + 2 j + 1]).
@@ -209,8 +240,10 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
 #pragma unroll
             for (int n1 = 0; n1 < 16; ++n1) {
                 int a = r.p0 + 32 * n1 + 2 * j, b = a + 1;
-                a = a < 0 ? -a : a; b = b < 0 ? -b : b;
-                a = a >= Nc ? 2 * (Nc - 1) - a : a; b = b >= Nc ? 2 * (Nc - 1) - b : b;
+                if (!PSF) {       // reflected ends (PSF: positions past the end are masked after the pre-emphasis)
+                    a = a < 0 ? -a : a; b = b < 0 ? -b : b;
+                    a = a >= Nc ? 2 * (Nc - 1) - a : a; b = b >= Nc ? 2 * (Nc - 1) - b : b;
+                }
                 a = a < 0 ? 0 : (a >= Nc ? Nc - 1 : a); b = b < 0 ? 0 : (b >= Nc ? Nc - 1 : b);
                 a = r.live ? a : 0; b = r.live ? b : 0;
                 lo[n1] = (uint16_t)r.sig[a];
@@ -221,11 +254,15 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
         }
     };
 
+    // PSF: the sample in front of the frame (0 for the clip's first frame: y[0] = x[0]), in the high half like a pair's
+    auto fetch_prev = [&](const FrameRef& r) { return (PSF && r.live && r.p0 > 0) ? (uint32_t)(uint16_t)r.sig[r.p0 - 1] << 16 : 0u; };
+
     PH_INIT(5);
     int tile = blockIdx.x;
     FrameRef fr = frame_of(meta_of(tile));
     uint32_t two[16];
     fetch(fr, two);
+    uint32_t pm1 = fetch_prev(fr);
     FrameMeta mnext = meta_of(tile + gridDim.x);
     int par = 0;
     // (measured: handing the tiles out through a device-wide atomic counter -- to balance the runs of dead tiles of
@@ -243,18 +280,44 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
             }
             fr = frame_of(mnext);
             fetch(fr, two);
+            pm1 = fetch_prev(fr);
             mnext = meta_of(tile + 2 * gridDim.x);
             continue;
         }
         PH(1);
         cplx v[16];
         // 1. windowed samples
+        float en = 0.f;
+        if (PSF) {
+            const bool edge = __builtin_amdgcn_ballot_w64(fr.live && !fr.interior) != 0ull;      // wave-uniform
+            uint32_t carry = pm1;
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1)
-            v[n1] = f2{(float)(int16_t)(two[n1] & 0xffff), (float)((int32_t)two[n1] >> 16)} * *(const f2*)(win + 32 * n1 + 2 * j);
+            for (int n1 = 0; n1 < 16; ++n1) {
+                const uint32_t rot = row_ror1(two[n1]);              // the pair in front of this lane's (lane 0: of the next n1's)
+                const uint32_t before = j == 0 ? carry : rot;
+                carry = rot;
+                const float xl = (float)(int16_t)(two[n1] & 0xffff), xh = (float)((int32_t)two[n1] >> 16);
+                const float xp = (float)((int32_t)before >> 16);
+                f2 y = f2{xl - kPreemph * xp, xh - kPreemph * xl};
+                if (edge) {                                          // zero padding past the clip's end
+                    const int pos = fr.p0 + 32 * n1 + 2 * j;
+                    y.x = pos < fr.N ? y.x : 0.f;
+                    y.y = pos + 1 < fr.N ? y.y : 0.f;
+                }
+                v[n1] = y * *(const f2*)(win + 32 * n1 + 2 * j);
+                const f2 sq = v[n1] * v[n1];
+                en += sq.x + sq.y;
+            }
+            en = row_sum16(en);
+        } else {
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1)
+                v[n1] = f2{(float)(int16_t)(two[n1] & 0xffff), (float)((int32_t)two[n1] >> 16)} * *(const f2*)(win + 32 * n1 + 2 * j);
+        }
         // the next tile's samples fly during the rest of this one (its clip row / length were fetched a tile earlier)
         fr = frame_of(mnext);
         fetch(fr, two);
+        pm1 = fetch_prev(fr);
         mnext = meta_of(tile + 2 * gridDim.x);
         __builtin_amdgcn_sched_barrier(0);          // keep the loads HERE (hipcc otherwise sinks them towards their first use)
         PH(2);
@@ -291,7 +354,11 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
             const f2 q = X * X;
             pf[k] = q.x + q.y;
         }
-        if (j == 0) { const float r = v[0].x - v[0].y; pf[256] = 4.f * r * r; }     // bin 256 = (Re Z0 - Im Z0)^2
+        if (j == 0) {
+            const float r = v[0].x - v[0].y, p256 = 4.f * r * r;                     // bin 256 = (Re Z0 - Im Z0)^2
+            pf[256] = p256;
+            if (PSF) en_s[par + fi] = 0.5f * en + (pf[0] + p256) * (1.f / 4096.f);   // sum of the 257 bins of |X|^2 / 512
+        }
         PH(6);
         __syncthreads();                                            // (1) power tile complete
         PH(7);
@@ -324,7 +391,7 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
             s += part[((2 * 3 + q) * 4 + r) * 64 + l2];
             s += part[((3 * 3 + q) * 4 + r) * 64 + l2];
             const int frame = 4 * (l2 >> 4) + r, mel = 16 * q + (l2 & 15);
-            if (mel < NMEL) lmel[frame * LPITCH + mel] = __logf(s + 1e-6f);     // v_log_f32: 1 ulp, s + 1e-6 is never denormal
+            if (mel < NMEL) lmel[frame * LPITCH + mel] = PSF ? __logf(s == 0.f ? kPsfEps : s) : __logf(s + 1e-6f);   // v_log_f32: 1 ulp
         }
         PH(10);
         __syncthreads();                                            // (3) log-mel tile complete
@@ -340,7 +407,9 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
             for (int r = 0; r < 4; ++r) {
                 const int frame = 4 * (lane >> 4) + r;
                 const int fo = tile * FT + frame;
-                if (coef < NMFCC && fo < total_frames) out[(size_t)fo * NMFCC + coef] = live_s[par + frame] ? d[r] : 0.f;
+                float val = d[r];
+                if (PSF && coef == 0) { const float e = en_s[par + frame]; val = __logf(e == 0.f ? kPsfEps : e); }    // appendEnergy
+                if (coef < NMFCC && fo < total_frames) out[(size_t)fo * NMFCC + coef] = live_s[par + frame] ? val : 0.f;
             }
         }
         PH(12);
@@ -350,17 +419,18 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
 }
 }  // namespace
 
-int mfcc_build_tables(var_ctx* c) {
+// window / twiddle / mel / DCT tables of one flavour (Kuka: torchaudio.transforms.MFCC; psf: python_speech_features.mfcc)
+static int build_tables(var_ctx* c, bool psf, float** dev) {
     std::vector<float> tb(TB_TOTAL, 0.f);
-    for (int i = 0; i < WIN; i++) tb[TB_WIN + i] = (float)(0.54 - 0.46 * cos(2.0 * M_PI * i / WIN));
+    for (int i = 0; i < WIN; i++) tb[TB_WIN + i] = (float)(0.54 - 0.46 * cos(2.0 * M_PI * i / (psf ? WIN - 1 : WIN)));   // np.hamming | periodic
     for (int m = 0; m < 256; m++) {
         tb[TB_TW256 + 2 * m] = (float)cos(-2.0 * M_PI * m / 256.0);
         tb[TB_TW256 + 2 * m + 1] = (float)sin(-2.0 * M_PI * m / 256.0);
         tb[TB_TW512 + 2 * m] = (float)cos(-2.0 * M_PI * m / 512.0);
         tb[TB_TW512 + 2 * m + 1] = (float)sin(-2.0 * M_PI * m / 512.0);
     }
-    for (int i = 0; i < WIN; i++) tb[TB_WIN512 + WOFF + i] = tb[TB_WIN + i] * (1.f / 32768.f);   // exact: power of two
-    // HTK mel triangles: torchaudio.functional.melscale_fbanks(257, 0, 8000, 40, 16000, None, 'htk')
+    if (psf) for (int i = 0; i < WIN; i++) tb[TB_WIN512 + i] = tb[TB_WIN + i];                        // frame at the start of the buffer, int16 units
+    else for (int i = 0; i < WIN; i++) tb[TB_WIN512 + WOFF + i] = tb[TB_WIN + i] * (1.f / 32768.f);   // centred; exact: power of two
     const double sr = 16000.0;
     const double m_min = 0.0, m_max = 2595.0 * log10(1.0 + (sr / 2.0) / 700.0);
     double fpts[NMEL + 2];
@@ -371,10 +441,23 @@ int mfcc_build_tables(var_ctx* c) {
     std::vector<double> fb((size_t)NFREQ * NMEL, 0.0);
     for (int m = 0; m < NMEL; m++)
         for (int k = 0; k < NFREQ; k++) {
-            const double f = (sr / 2.0) * k / (NFREQ - 1);
-            const double down = (f - fpts[m]) / (fpts[m + 1] - fpts[m]);
-            const double up = (fpts[m + 2] - f) / (fpts[m + 2] - fpts[m + 1]);
-            const double w = fmax(0.0, fmin(down, up));
+            double w;
+            if (psf) {
+                // get_filterbanks(40, 512, 16000, 0, 8000): triangles between the bins floor((nfft + 1) hz / samplerate),
+                // times the 1 / nfft of powspec
+                const double b0 = floor((NFFT + 1) * fpts[m] / sr), b1 = floor((NFFT + 1) * fpts[m + 1] / sr),
+                             b2 = floor((NFFT + 1) * fpts[m + 2] / sr);
+                w = 0.0;
+                if (k >= b0 && k < b1) w = (k - b0) / (b1 - b0);
+                else if (k >= b1 && k < b2) w = (b2 - k) / (b2 - b1);
+                w *= 1.0 / NFFT;
+            } else {
+                // HTK mel triangles: torchaudio.functional.melscale_fbanks(257, 0, 8000, 40, 16000, None, 'htk')
+                const double f = (sr / 2.0) * k / (NFREQ - 1);
+                const double down = (f - fpts[m]) / (fpts[m + 1] - fpts[m]);
+                const double up = (fpts[m + 2] - f) / (fpts[m + 2] - fpts[m + 1]);
+                w = fmax(0.0, fmin(down, up));
+            }
             fb[(size_t)k * NMEL + m] = w;
             // every non-zero weight must fall inside the band its filter tile reads
             const int tl = m / 16;
@@ -390,7 +473,7 @@ int mfcc_build_tables(var_ctx* c) {
             for (int q = 0; q < kMelSteps[tl] / 4; q++, slot++)
                 for (int lane = 0; lane < 64; lane++) {
                     const int k = kMelK0[tl] + 4 * (4 * q + wave) + (lane >> 4), m = 16 * tl + (lane & 15);
-                    tb[TB_MELB + (wave * kMelSlots + slot) * 64 + lane] = (k < NFREQ && m < NMEL) ? 0.25f * (float)fb[(size_t)k * NMEL + m] : 0.f;   // the power tile holds 4 |X|^2
+                    tb[TB_MELB + (wave * kMelSlots + slot) * 64 + lane] = (k < NFREQ && m < NMEL) ? (float)(0.25 * fb[(size_t)k * NMEL + m]) : 0.f;   // the power tile holds 4 |X|^2
                 }
     }
     for (int tl = 0; tl < 3; tl++)
@@ -401,25 +484,42 @@ int mfcc_build_tables(var_ctx* c) {
                 if (k < NMFCC) {
                     v = cos(M_PI / NMEL * (n + 0.5) * k) * sqrt(2.0 / NMEL);
                     if (k == 0) v *= 1.0 / sqrt(2.0);
+                    if (psf) v *= 1.0 + (22.0 / 2.0) * sin(M_PI * k / 22.0);          // lifter(cepstra, L = 22)
                 }
                 tb[TB_DCTB + (tl * 10 + s) * 64 + lane] = (float)v;
             }
     static_assert(TB_TOTAL % 4 == 0, "table size");
-    VAR_HIP_CHECK(c, hipMalloc((void**)&c->mfcc_tab, sizeof(float) * TB_TOTAL));
-    VAR_HIP_CHECK(c, hipMemcpy(c->mfcc_tab, tb.data(), sizeof(float) * TB_TOTAL, hipMemcpyHostToDevice));
-    VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)mfcc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MFCC_LDS_BYTES));
+    VAR_HIP_CHECK(c, hipMalloc((void**)dev, sizeof(float) * TB_TOTAL));
+    VAR_HIP_CHECK(c, hipMemcpy(*dev, tb.data(), sizeof(float) * TB_TOTAL, hipMemcpyHostToDevice));
+    if (psf) VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)mfcc_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MFCC_LDS_BYTES));
+    else VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)mfcc_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MFCC_LDS_BYTES));
     return VAR_OK;
+}
+
+int mfcc_build_tables(var_ctx* c) { return build_tables(c, false, &c->mfcc_tab); }
+
+template <bool PSF>
+static int launch_flavour(var_ctx* c, hipStream_t s, const int16_t* pcm, const int* lens, const int* clip_index, int nclips,
+                          int pcm_stride, int out_frames, const float* tab, float* out, const char* who) {
+    const long total = (long)nclips * out_frames;
+    if (total > (1L << 23)) { VAR_SET_ERR(c, "%s: %d clips x %d frames is too many", who, nclips, out_frames); return VAR_ERR_ARG; }
+    const int ntiles = (int)((total + FT - 1) / FT);
+    const int grid = ntiles < 512 ? ntiles : 512;              // persistent: two 70 KB workgroups per CU
+    hipLaunchKernelGGL(mfcc_kernel<PSF>, dim3(grid), dim3(NTHR), MFCC_LDS_BYTES, s, pcm, lens, clip_index, pcm_stride, out_frames,
+                       (int)total, tab, out);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}
+
+// python_speech_features flavour (var_mfcc_psf, mfcc_psf.hip); its tables are built on first use
+int launch_mfcc_psf(var_ctx* c, hipStream_t s, const int16_t* pcm, const int* lens, const int* clip_index, int nclips,
+                    int pcm_stride, int out_frames, float* out) {
+    if (!c->mfcc_psf_tab) { const int r = build_tables(c, true, &c->mfcc_psf_tab); if (r != VAR_OK) return r; }
+    return launch_flavour<true>(c, s, pcm, lens, clip_index, nclips, pcm_stride, out_frames, c->mfcc_psf_tab, out, "var_mfcc_psf");
 }
 
 int launch_mfcc(var_ctx* c, hipStream_t s, const int16_t* pcm, const int* lens, const int* clip_index, int nclips,
                 int pcm_stride, int out_frames, float* out) {
     ProfScope prof(c, s, TAG_MFCC);
-    const long total = (long)nclips * out_frames;
-    if (total > (1L << 23)) { VAR_SET_ERR(c, "var_mfcc: %d clips x %d frames is too many", nclips, out_frames); return VAR_ERR_ARG; }
-    const int ntiles = (int)((total + FT - 1) / FT);
-    const int grid = ntiles < 512 ? ntiles : 512;              // persistent: two 70 KB workgroups per CU
-    hipLaunchKernelGGL(mfcc_kernel, dim3(grid), dim3(NTHR), MFCC_LDS_BYTES, s, pcm, lens, clip_index, pcm_stride, out_frames,
-                       (int)total, c->mfcc_tab, out);
-    VAR_HIP_CHECK(c, hipGetLastError());
-    return VAR_OK;
+    return launch_flavour<false>(c, s, pcm, lens, clip_index, nclips, pcm_stride, out_frames, c->mfcc_tab, out, "var_mfcc");
 }

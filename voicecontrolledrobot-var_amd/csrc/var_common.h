@@ -204,6 +204,8 @@ extern "C" int retire_block(var_ctx* c, void* p);   // api.hip: keep a supersede
 int mfcc_build_tables(var_ctx* c);
 int launch_mfcc_any(var_ctx* c, hipStream_t s, const int16_t* pcm, const int* lens, const int* clip_index, int nclips,
                     int pcm_stride, int out_frames, int n_fft, int win, int hop, float* out);
+int launch_mfcc_psf(var_ctx* c, hipStream_t s, const int16_t* pcm, const int* lens, const int* clip_index, int nclips,
+                    int pcm_stride, int out_frames, float* out);     // mfcc.hip, PSF flavour
 void mfcc_any_forget(var_ctx* c);
 void ithor_free(var_ctx* c);
 void armnet_free(var_ctx* c);
