@@ -11,6 +11,7 @@ Workload = BASELINE.json configs[1]: Kuka + GoogleCommand shapes, per-GPU batch 
 Rank 0 prints ONE JSON line."""
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -181,6 +182,8 @@ def main_ithor(args, rank, local_rank, world, dev):
     cfg = types.SimpleNamespace(img_dim=(3, 96, 96), sound_dim=(1, 600, 40), representationDim=3)
     torch.manual_seed(977)                                      # iTHOR pretextEnvSeed; identical weights on every rank
     model = var_amd.IthorVARPretextNet(cfg).to(dev).set_precision("bf16" if args.dtype == "bf16" else "fp32")
+    if args.rehearse_one_device:
+        model.set_gru_sequence(False)      # ranks share the card: the persistent GRU launches need their whole grid resident
     peak = 2500.0 if args.dtype == "bf16" else F32_MFMA_PEAK      # dense MFMA peak of the operand type, TFLOP/s
     tr = var_amd.IthorTrainer(model, lr=1e-4, weight_decay=1e-6, margin=1.0)
     g = torch.Generator(device=dev).manual_seed(rank)
@@ -264,6 +267,12 @@ def main_ithor(args, rank, local_rank, world, dev):
                           "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "launch": "hip-graph replay" if use_graph else "eager",
                           "final_loss": round(float(tr.loss.item()), 6)},
                "mfma_frac_whole_step": round(value / world * ITHOR_FLOPS_STEP / 1e12 / peak, 4)}
+        if args.dtype == "bf16":
+            # the persistent GRU launches report expired hand-off waits here (0 = none; the step is NaN-poisoned otherwise)
+            out["config"]["gru"] = "one launch per time step" if args.rehearse_one_device else "one persistent launch per pass"
+            out["config"]["gru_handoff_status"] = model.gru_status(local_rank)
+            if out["config"]["gru_handoff_status"] or not math.isfinite(out["config"]["final_loss"]):
+                raise SystemExit("bench.py: a GRU hand-off wait expired (is another process using this GPU?)")
         if roof:
             out["roofline"] = roof
         if not args.no_cpu_baseline and world == 1:

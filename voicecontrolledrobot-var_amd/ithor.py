@@ -142,6 +142,24 @@ class IthorVARPretextNet(nn.Module):
         c.check(c.lib.var_ithor_plan(c.handle, int(batch), int(self.config.img_dim[1])), "var_ithor_plan")
         if c.lib.var_ithor_set_bf16(c.handle, -1) != int(self._bf16):     # the plan is per context, the choice per model
             c.lib.var_ithor_set_bf16(c.handle, int(self._bf16))
+        seq = int(getattr(self, "_gru_sequence", True))
+        if c.lib.var_ithor_set_gru_sequence(c.handle, -1) != seq:
+            c.lib.var_ithor_set_gru_sequence(c.handle, seq)
+
+    def set_gru_sequence(self, on=True):
+        """bf16 mode: run each GRU pass as one persistent launch (default) or as one launch per time step (same results).
+        The persistent form needs its whole grid resident at once -- switch it off when several processes share one GPU
+        (include/var_hip.h: var_ithor_set_gru_sequence; a launch whose waits expire poisons the step with NaN)."""
+        self._gru_sequence = bool(on)
+        return self
+
+    def gru_status(self, device_index=None):
+        """0 if every hand-off of every persistent GRU launch so far completed (blocking read of the status word)."""
+        import ctypes
+        c = Context.get(self.flat_parameters().device.index if device_index is None else device_index)
+        w = ctypes.c_uint(0)
+        c.check(c.lib.var_ithor_gru_status(c.handle, ctypes.byref(w)), "var_ithor_gru_status")
+        return int(w.value)
 
     def set_precision(self, name, keep_fp32_activations=False):
         """'fp32' (default, the parity path) or 'bf16': bf16 operands with fp32 accumulation in every product
