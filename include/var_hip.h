@@ -215,7 +215,8 @@ int var_ithor_set_bf16(var_ctx* ctx, int on);
  * it is skipped by itself when the grid exceeds the device's CU count, and every wait in it is bounded -- if a wait
  * expires (e.g. another process holds part of the GPU) the launch ends, var_ithor_gru_status() reports a non-zero word
  * from then on and the step's embeddings / gradient are overwritten with NaN rather than left partially updated.
- * -1 = query; returns the previous setting.  var_ithor_gru_status copies the status word (blocking). */
+ * -1 = query; returns the previous setting; setting a form (0 / 1) also clears the status word (after a
+ * hipDeviceSynchronize-like wait on the null stream).  var_ithor_gru_status copies the status word (blocking). */
 int var_ithor_set_gru_sequence(var_ctx* ctx, int on);
 int var_ithor_gru_status(var_ctx* ctx, unsigned* word);
 int var_ithor_encoder_fwd(var_ctx* ctx, void* stream, const float* params,
@@ -306,6 +307,10 @@ int var_profile_select(var_ctx* ctx, int tag);
 int var_profile_read(var_ctx* ctx, float* total_ms, int* count);
 int var_set_streams(var_ctx* ctx, int mask);
 int var_debug_buffer(var_ctx* ctx, const char* name, void** ptr, long* nfloats);
+/* tests: the next persistent GRU forward is launched one workgroup short per hand-off group, so that no group can
+ * complete -- what the resident part of a grid sees when the rest is not: every wait must expire (about 0.3 s), the
+ * launch must end, var_ithor_gru_status must read non-zero and the step's outputs must be NaN. */
+int var_debug_ithor_gru_drop_workgroup(var_ctx* ctx);
 int var_debug_ithor_dense(var_ctx* ctx, void* stream, int a_kfast, int b_kfast, const float* a, const float* b,
                           float* c, int M, int N, int K, int nsplit, int add);
 

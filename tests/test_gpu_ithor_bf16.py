@@ -455,3 +455,34 @@ def test_gru_one_launch_per_pass_equals_one_launch_per_step(var_amd, B):
             b[lo:hi] = 0
         assert torch.equal(a, b), float((a - b).abs().max())
     assert torch.equal(out[1][0][1], out[1][1][1])        # and the persistent form is deterministic
+
+
+def test_gru_persistent_launch_ends_when_its_grid_is_incomplete(var_amd):
+    """Every wait of the persistent GRU kernels is bounded.  With one workgroup of each hand-off group missing (what the
+    resident part of a grid sees when the rest cannot be scheduled) the launch must END, report it in the status word, and
+    the step must be loud -- NaN loss and gradient -- rather than half updated; afterwards the context works again."""
+    import time
+    from var_amd._lib import Context
+    B = 3
+    torch.manual_seed(5)
+    m = var_amd.IthorVARPretextNet(cfg(96)).to("cuda").set_precision("bf16")
+    pos, neg = sounds(B, 23)
+    img = torch.randint(0, 256, (B, 3, 96, 96), dtype=torch.uint8, generator=torch.Generator().manual_seed(8)).cuda()
+    tr = var_amd.IthorTrainer(m)
+    loss, _ = tr.loss_and_grads(img, pos, neg)
+    torch.cuda.synchronize()
+    good_loss, good = float(loss), tr.grads.clone()
+    assert m.gru_status() == 0
+    ctx = Context.get(0)
+    assert ctx.lib.var_debug_ithor_gru_drop_workgroup(ctx.handle) == 0
+    t0 = time.time()
+    loss, _ = tr.loss_and_grads(img, pos, neg)
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 20.0                        # ended (the waits expire after ~0.3 s)
+    assert m.gru_status() != 0
+    assert not np.isfinite(float(loss)) and not bool(torch.isfinite(tr.grads).all())
+    assert ctx.lib.var_ithor_set_gru_sequence(ctx.handle, 1) == 1          # clears the status word
+    assert m.gru_status() == 0
+    loss, _ = tr.loss_and_grads(img, pos, neg)
+    torch.cuda.synchronize()
+    assert float(loss) == good_loss and torch.equal(tr.grads, good)

@@ -69,6 +69,7 @@ _SIGNATURES = {
     "var_ithor_set_bf16": (_i, [_vp, _i]),
     "var_ithor_set_gru_sequence": (_i, [_vp, _i]),
     "var_ithor_gru_status": (_i, [_vp, _vp]),
+    "var_debug_ithor_gru_drop_workgroup": (_i, [_vp]),
     "var_ithor_encoder_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i]),
     "var_ithor_saved_generation": (_i, [_vp]),
     "var_ithor_encoder_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),

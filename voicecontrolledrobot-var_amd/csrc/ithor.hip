@@ -61,6 +61,7 @@ struct ithor_state {
     void* gruws = nullptr;                                // W_hh in MFMA fragment order (gru_bf16.hip)
     void* bfws = nullptr;                                 // bf16 images / packed filters of the staged sound kernels (snd_bf16.hip)
     int gh_split = 1, dh_split = 1;
+    bool gru_drop_one = false;                            // tests: the next persistent forward misses a workgroup per group
     bool gru_seq = true;                                  // bf16 mode: each GRU pass as one persistent launch (gru_bf16.hip)
     bool bf16 = false, keep32 = false;                    // bf16 mode; ... with the fp32 copies of the sound maps (tests)
     float *sraw = nullptr, *gsraw = nullptr;              // (clips,1024)
@@ -576,7 +577,8 @@ static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* imag
         int whole = 0;       // the 73 steps in one launch
         if (st->bf16 && st->gru_seq) {
             const int r = gru_bf16_seq_fwd(c, s, st->GI, st->Hb, P + L.b_hh[0], dirP, st->R, st->Z, st->Nn, st->GHN, nclips, 2 * st->maxB,
-                                           dirGI, dirH, dirS, save ? 1 : 0, st->gruws);
+                                           dirGI, dirH, dirS, save ? 1 : 0, st->gruws, st->gru_drop_one ? 1 : 0);
+            st->gru_drop_one = false;
             if (r < 0) return r;
             whole = r == 0;
         }
@@ -999,8 +1001,21 @@ int var_ithor_set_gru_sequence(var_ctx* c, int on) {
     ithor_state* st = ith(c);
     if (!st) { VAR_SET_ERR(c, "var_ithor_set_gru_sequence: var_ithor_plan first"); return VAR_ERR_PLAN; }
     const int old = st->gru_seq ? 1 : 0;
-    if (on >= 0) st->gru_seq = on != 0;
+    if (on >= 0) {
+        st->gru_seq = on != 0;
+        VAR_HIP_CHECK(c, hipSetDevice(c->device));
+        RUN(gru_bf16_reset_timeout(c, nullptr, 2 * st->maxB, st->gruws));      // (setting the form also clears the status word)
+        VAR_HIP_CHECK(c, hipStreamSynchronize(nullptr));
+    }
     return old;
+}
+
+int var_debug_ithor_gru_drop_workgroup(var_ctx* c) {
+    CHECK_CTX(c);
+    ithor_state* st = ith(c);
+    if (!st) { VAR_SET_ERR(c, "var_debug_ithor_gru_drop_workgroup: var_ithor_plan first"); return VAR_ERR_PLAN; }
+    st->gru_drop_one = true;
+    return VAR_OK;
 }
 
 int var_ithor_gru_status(var_ctx* c, unsigned* word) {
@@ -1090,6 +1105,8 @@ int var_ithor_loss_grad(var_ctx* c, void* stream, const float* params, const voi
     float* lo = loss_out ? loss_out : st->loss;
     RUN(launch_triplet(c, s, st->emb, st->emb + 3 * mB, st->emb + 3 * mB + 3L * B, B, margin, inv_count, lo, st->gemb,
                        st->gemb + 3 * mB, st->gemb + 3 * mB + 3L * B));
+    // (the hinge swallows NaN embeddings -- max(0, NaN) = 0 --: a forward whose GRU hand-off expired must not report loss 0)
+    if (st->bf16 && st->gru_seq) RUN(gru_bf16_poison_on_timeout(c, s, lo, 1, 2 * st->maxB, st->gruws));
     if (feats_out) {
         // (B,9) = [a | p | n]
         VAR_HIP_CHECK(c, hipMemcpy2DAsync(feats_out, 9 * sizeof(float), st->emb, 3 * sizeof(float), 3 * sizeof(float), B,

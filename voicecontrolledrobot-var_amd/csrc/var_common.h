@@ -291,7 +291,7 @@ int gru_bf16_step_bwd(var_ctx* c, hipStream_t s, float* DH, const float* Hb, con
 // the 73 steps of a pass in ONE persistent launch (workgroups of a clip slice hand the state over through L2 / HBM); 1 = the
 // grid would not be resident on this device, take the per-step launches
 int gru_bf16_seq_fwd(var_ctx* c, hipStream_t s, const float* GI, float* Hb, const float* b_hh, long dirP, float* R, float* Z, float* Nn,
-                     float* GHN, int nclips, int maxclips, long dirGI, long dirH, long dirS, int save, void* ws);
+                     float* GHN, int nclips, int maxclips, long dirGI, long dirH, long dirS, int save, void* ws, int drop_one);
 int gru_bf16_seq_bwd(var_ctx* c, hipStream_t s, float* DH, const float* Hb, const float* R, const float* Z, const float* Nn,
                      const float* GHN, float* DGI, float* DGH, int nclips, int maxclips, long dirGI, long dirH, long dirS, long dirDGH,
                      void* ws);
