@@ -57,6 +57,8 @@ struct ithor_state {
     float *GI = nullptr, *GH = nullptr, *Hb = nullptr, *R = nullptr, *Z = nullptr, *Nn = nullptr, *GHN = nullptr;
     float *DGI = nullptr, *DGH = nullptr, *DH = nullptr, *DHP = nullptr;
     float *slab = nullptr, *bslab = nullptr;              // split-K partial sums / bias-sum partials
+    long bs_used = 0;                                     // bslab is handed out in pieces (bs_take) so that the folds can wait
+    void* folds = nullptr;                                // FoldJobs*: folds of bslab partials, run together (flush_folds)
     void* imgws = nullptr;                                // fragment-ordered filters of img_bf16.hip
     void* gruws = nullptr;                                // W_hh in MFMA fragment order (gru_bf16.hip)
     void* bfws = nullptr;                                 // bf16 images / packed filters of the staged sound kernels (snd_bf16.hip)
@@ -86,6 +88,7 @@ void ithor_free(var_ctx* c) {
     ithor_state* st = ith(c);
     if (!st) return;
     if (st->ws) (void)hipFree(st->ws);
+    free(st->folds);
     delete st;
     c->ith = nullptr;
 }
@@ -204,6 +207,45 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(float* __restrict__ ou
         for (int k = 0; k < 16; ++k) v += red[k][threadIdx.x];
         out[i] += v;
     }
+}
+
+// Up to 24 of those folds in ONE launch (the bias-gradient folds of a backward pass: 64-1536 outputs each, 2-8 workgroups,
+// 5-9 us apiece as launches of their own).  Jobs are independent: different outputs, partial sums in regions of their own.
+struct FoldJob { float* out; const float* slabs; long stride; int n, nsplit, inner, blk0; };
+constexpr int kMaxFoldJobs = 24;
+struct FoldJobs { FoldJob j[kMaxFoldJobs]; int count; };
+__global__ void __launch_bounds__(256) fold_jobs_kernel(const FoldJobs J) {
+    int k = 0;
+    while (k + 1 < J.count && (int)blockIdx.x >= J.j[k + 1].blk0) ++k;
+    const FoldJob& f = J.j[k];
+    const int i = ((int)blockIdx.x - f.blk0) * 16 + (threadIdx.x & 15), g = threadIdx.x >> 4;
+    float acc = 0.f;
+    if (i < f.n)
+        for (int s = g; s < f.nsplit; s += 16)
+            for (int q = 0; q < f.inner; ++q) acc += f.slabs[s * f.stride + (long)i * f.inner + q];
+    __shared__ float red[16][17];
+    red[g][threadIdx.x & 15] = acc;
+    __syncthreads();
+    if (g == 0 && i < f.n) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v += red[q][threadIdx.x];
+        f.out[i] += v;
+    }
+}
+
+// the same fold for a few long slabs (split-K weight gradients: n up to 786 K, 2-16 slabs): one thread per 4 outputs,
+// the slabs added in order -- whole-line accesses instead of 64-byte runs, and no idle chains
+__global__ void __launch_bounds__(256) slab_reduce_wide_kernel(float4* __restrict__ out, const float4* __restrict__ slabs, int n4,
+                                                              int nsplit, long stride4) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 v = out[i];
+    for (int s = 0; s < nsplit; ++s) {
+        const float4 p = slabs[s * stride4 + i];
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    out[i] = v;
 }
 
 // part[chunk*C + c] = sum over the chunk's share of {o < outer, i < inner} of g[(o*C + c)*inner + i]  (bias gradients
@@ -382,7 +424,8 @@ static int conv_dgrad(var_ctx* c, hipStream_t s, const ConvDims& d, const float*
     }
 }
 static constexpr long kSlabFloats = 24L << 20;        // split-K slabs (96 MB)
-static constexpr long kBiasSlabFloats = 1L << 20;
+static constexpr long kBiasSlabFloats = 4L << 20;     // bias-sum partials of a whole backward pass (bs_take)
+static constexpr long kPartFloats = 1L << 18;          // room for a kernel that reports its partial count after the launch
 
 // the kernel gives split s the chunks [s*per, (s+1)*per), per = ceil(chunks / nsplit): trim nsplit so that no split
 // is empty (an empty split would leave its slab unwritten)
@@ -402,7 +445,44 @@ static int rec_split(int tiles, int kchunks, int cap) {
     return eff_split(kchunks * GG_KC, ns);
 }
 
+static int flush_folds(var_ctx* c, hipStream_t s) {
+    FoldJobs* J = (FoldJobs*)ith(c)->folds;
+    if (!J || !J->count) return VAR_OK;
+    const FoldJob& last = J->j[J->count - 1];
+    const int blocks = last.blk0 + (last.n + 15) / 16;
+    hipLaunchKernelGGL(fold_jobs_kernel, dim3(blocks), dim3(256), 0, s, *J);
+    J->count = 0;
+    IT_CHECK(c);
+    return VAR_OK;
+}
+// n floats of the bias-partial buffer that stay untouched until the next flush_folds
+static float* bs_take(var_ctx* c, hipStream_t s, long n) {
+    ithor_state* st = ith(c);
+    n = (n + 63) & ~63L;
+    if (st->bs_used + n > kBiasSlabFloats) { (void)flush_folds(c, s); st->bs_used = 0; }
+    float* p = st->bslab + st->bs_used;
+    st->bs_used += n;
+    return p;
+}
 static int slab_reduce(var_ctx* c, hipStream_t s, float* out, const float* slabs, int n, int nsplit, long stride, int inner = 1) {
+    ithor_state* st = ith(c);
+    if (st->folds && slabs >= st->bslab && slabs < st->bslab + kBiasSlabFloats) {     // partials from bs_take: fold later, together
+        FoldJobs* J = (FoldJobs*)st->folds;
+        for (int k = 0; k < J->count; ++k)                   // (two folds into the same outputs keep their order)
+            if (out < J->j[k].out + J->j[k].n && J->j[k].out < out + n) { const int r = flush_folds(c, s); if (r != VAR_OK) return r; break; }
+        if (J->count == kMaxFoldJobs) { const int r = flush_folds(c, s); if (r != VAR_OK) return r; }
+        FoldJob& f = J->j[J->count];
+        f.out = out; f.slabs = slabs; f.stride = stride; f.n = n; f.nsplit = nsplit; f.inner = inner;
+        f.blk0 = J->count ? J->j[J->count - 1].blk0 + (J->j[J->count - 1].n + 15) / 16 : 0;
+        J->count++;
+        return VAR_OK;
+    }
+    if (inner == 1 && nsplit <= 16 && n >= 4096 && n % 4 == 0 && stride % 4 == 0 && (((uintptr_t)out | (uintptr_t)slabs) & 15) == 0) {
+        hipLaunchKernelGGL(slab_reduce_wide_kernel, dim3((n / 4 + 255) / 256), dim3(256), 0, s, (float4*)out, (const float4*)slabs, n / 4,
+                           nsplit, stride / 4);
+        IT_CHECK(c);
+        return VAR_OK;
+    }
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, s, out, slabs, n, nsplit, stride, inner);
     IT_CHECK(c);
     return VAR_OK;
@@ -427,11 +507,11 @@ static int conv_wgrad(var_ctx* c, hipStream_t s, const ConvDims& d, const void* 
     return VAR_OK;
 }
 static int chan_sum(var_ctx* c, hipStream_t s, const float* g, float* out, int outer, int C, int inner) {
-    float* part = ith(c)->bslab;
     if (inner < 64) {
         const int cols = C * inner;
         int chunks = (outer + 255) / 256;
         if (chunks > 32) chunks = 32;
+        float* part = bs_take(c, s, (long)chunks * cols);
         hipLaunchKernelGGL(col_sum_kernel, dim3((cols + 63) / 64, chunks), dim3(256), 0, s, g, part, outer, cols);
         IT_CHECK(c);
         return slab_reduce(c, s, out, part, C, chunks, cols, inner);
@@ -440,6 +520,7 @@ static int chan_sum(var_ctx* c, hipStream_t s, const float* g, float* out, int o
     int chunks = (int)((tot + 8191) / 8192);
     if (chunks > 32) chunks = 32;
     if (chunks < 1) chunks = 1;
+    float* part = bs_take(c, s, (long)chunks * C);
     hipLaunchKernelGGL(chan_sum_kernel, dim3(C, chunks), dim3(256), 0, s, g, part, outer, C, inner);
     IT_CHECK(c);
     return slab_reduce(c, s, out, part, C, chunks, C);
@@ -626,6 +707,9 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
     const int B = st->B, nclips = st->nclips;
     const long mB = st->maxB;
     VAR_HIP_CHECK(c, hipMemsetAsync(G, 0, sizeof(float) * L.total, s));
+    st->bs_used = 0;                                           // the pass's bias partials and their folds (flush_folds at its end)
+    if (!st->folds) st->folds = calloc(1, sizeof(FoldJobs));
+    if (st->folds) ((FoldJobs*)st->folds)->count = 0;
     if (st->has_img) {
         hipLaunchKernelGGL(l2norm_bwd_kernel, g1(B), dim3(256), 0, s, st->raw, st->gemb, st->graw, B);
         IT_CHECK(c);
@@ -648,10 +732,11 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             const int pblocks = (hp * hp + 255) / 256;
             const bool fused = hin == 2 * hp && (long)B * kICh[l] * pblocks <= kBiasSlabFloats;      // even map: windows tile it exactly
             if (fused) {     // gact and the bias gradient's partial sums in one pass over the activations
+                float* part = bs_take(c, s, (long)B * kICh[l] * pblocks);
                 hipLaunchKernelGGL(pool_relu_bwd2_kernel, dim3(pblocks, B * kICh[l]), dim3(256), 0, s, st->a[l], st->gp[l], st->ga[l],
-                                   st->bslab, hin, hp);
+                                   part, hin, hp);
                 IT_CHECK(c);
-                RUN(slab_reduce(c, s, G + L.ib[l - 1], st->bslab, kICh[l], B, (long)kICh[l] * pblocks, pblocks));
+                RUN(slab_reduce(c, s, G + L.ib[l - 1], part, kICh[l], B, (long)kICh[l] * pblocks, pblocks));
             } else {
                 hipLaunchKernelGGL(pool_relu_bwd_kernel, g1(n), dim3(256), 0, s, st->a[l], st->gp[l], st->ga[l], n, hin, hs[l - 1]);
                 IT_CHECK(c);
@@ -668,11 +753,16 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             {
                 // (layer 2's data gradient is ga[1]: its channel sums are conv 1's bias gradient)
                 int nparts = 0;
+                float* part = l == 2 && st->bf16 ? bs_take(c, s, kPartFloats) : nullptr;
                 int r = st->bf16 ? img_bf16_conv(c, s, l, hin, 1, st->ga[l], P + L.iw[l - 1], nullptr, l == 2 ? st->a[1] : nullptr, dx,
-                                                 l == 2 ? st->bslab : nullptr, &nparts, B, st->imgws) : 1;
+                                                 part, &nparts, B, st->imgws) : 1;
                 if (r == 1) r = conv_dgrad<G3s1, false>(c, s, d, st->ga[l], P + L.iw[l - 1], dx, l == 2 ? st->a[1] : nullptr);
                 RUN(r);
-                if (l == 2 && nparts) { RUN(slab_reduce(c, s, G + L.ib[0], st->bslab, 32, nparts, 32)); ga1_summed = true; }
+                if (l == 2 && nparts) {
+                    if ((long)nparts * 32 > kPartFloats) { VAR_SET_ERR(c, "iTHOR backward: %d bias partials", nparts); return VAR_ERR_STATE; }
+                    RUN(slab_reduce(c, s, G + L.ib[0], part, 32, nparts, 32));
+                    ga1_summed = true;
+                }
             }
         }
         {
@@ -795,9 +885,11 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             RUN(chan_sum(c, s, st->gs[3], G + L.sb[2], nclips * kSeq, 64, 7));
             if (st->bf16) {     // (also leaves gs[2]'s C8 image for conv 2's kernels and the channel sums of gs[2] = conv 2's bias gradient)
                 int nparts = 0;
-                RUN(snd3_bf16_dgrad(c, s, st->gs[3], P + L.sw[2], st->keep32 ? st->gs[2] : nullptr, st->bslab, &nparts, nclips, 2 * st->maxB,
+                float* part = bs_take(c, s, kPartFloats);
+                RUN(snd3_bf16_dgrad(c, s, st->gs[3], P + L.sw[2], st->keep32 ? st->gs[2] : nullptr, part, &nparts, nclips, 2 * st->maxB,
                                     st->bfws));
-                RUN(slab_reduce(c, s, G + L.sb[1], st->bslab, 64, nparts, 64));
+                if ((long)nparts * 64 > kPartFloats) { VAR_SET_ERR(c, "iTHOR backward: %d bias partials", nparts); return VAR_ERR_STATE; }
+                RUN(slab_reduce(c, s, G + L.sb[1], part, 64, nparts, 64));
                 RUN(snd3_bf16_wgrad(c, s, G + L.sw[2], st->slab, nclips, 2 * st->maxB, st->bfws));      // (reads the dgrad's gy image)
             } else {
                 RUN((conv_dgrad<GS3, true>(c, s, d, st->gs[3], P + L.sw[2], st->gs[2], st->s[2])));
@@ -815,8 +907,10 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             if (!st->bf16) RUN(chan_sum(c, s, st->gs[2], G + L.sb[1], nclips, 64, 150 * 13));
             if (st->bf16) {     // (its store also yields the channel sums of gs[1]: conv 1's bias gradient)
                 int nparts = 0;
-                RUN(snd2_bf16_dgrad(c, s, P + L.sw[1], st->keep32 ? st->gs[1] : nullptr, st->bslab, &nparts, nclips, 2 * st->maxB, st->bfws));
-                RUN(slab_reduce(c, s, G + L.sb[0], st->bslab, 64, nparts, 64));
+                float* part = bs_take(c, s, kPartFloats);
+                RUN(snd2_bf16_dgrad(c, s, P + L.sw[1], st->keep32 ? st->gs[1] : nullptr, part, &nparts, nclips, 2 * st->maxB, st->bfws));
+                if ((long)nparts * 64 > kPartFloats) { VAR_SET_ERR(c, "iTHOR backward: %d bias partials", nparts); return VAR_ERR_STATE; }
+                RUN(slab_reduce(c, s, G + L.sb[0], part, 64, nparts, 64));
             } else {
                 ProfScope prof(c, s, TAG_ITHOR_S2_DGRAD);
                 RUN((conv_dgrad<GS2, false>(c, s, d, st->gs[2], P + L.sw[1], st->gs[1], st->s[1])));
@@ -836,8 +930,9 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             }
             if (!st->bf16) RUN(chan_sum(c, s, st->gs[1], G + L.sb[0], nclips, 64, 300 * 20));
         }
-        if (st->bf16 && st->gru_seq) RUN(gru_bf16_poison_on_timeout(c, s, G, min(L.total, 65536), 2 * st->maxB, st->gruws));
     }
+    RUN(flush_folds(c, s));
+    if (nclips && st->bf16 && st->gru_seq) RUN(gru_bf16_poison_on_timeout(c, s, G, min(L.total, 65536), 2 * st->maxB, st->gruws));
     return VAR_OK;
 }
 
