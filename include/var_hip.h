@@ -300,7 +300,9 @@ int var_mfcc_psf(var_ctx* ctx, void* stream, const int16_t* pcm, const int* lens
  * var_debug_ithor_dense: one dense product of the iTHOR model's bf16 mode through the kernel its schedule would pick,
  * C[m + n*M] (+= when `add`) = sum_k A(m,k) B(k,n), A(m,k) = a[m*K + k] if a_kfast else a[k*M + m], B likewise with
  * b[n*K + k] | b[k*N + n]; nsplit > 1 writes split-K slabs C + s*M*N instead (device pointers, fp32).  Returns 1 when
- * the staged bf16 kernel (dense_bf16.h) ran, 0 when the shapes fell back to the gather-GEMM, < 0 on error. */
+ * the staged bf16 kernel (dense_bf16.h) ran, 0 when the shapes fell back to the gather-GEMM, < 0 on error.  `add` bit 1:
+ * both operands are first copied to bf16 and handed over as copies, as the model's schedule does for its big products
+ * (nsplit must be 1); then 2 is returned when the resident-panel kernel (K = 448, both operands k-fast) took it. */
 int var_profile_tag_count(void);
 const char* var_profile_tag_name(int tag);
 int var_profile_select(var_ctx* ctx, int tag);

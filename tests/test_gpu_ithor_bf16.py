@@ -486,3 +486,31 @@ def test_gru_persistent_launch_ends_when_its_grid_is_incomplete(var_amd):
     loss, _ = tr.loss_and_grads(img, pos, neg)
     torch.cuda.synchronize()
     assert float(loss) == good_loss and torch.equal(tr.grads, good)
+
+
+@pytest.mark.parametrize("akf,bkf,M,N,K,add,want", [(1, 1, 1536, 1024 + 128 * 3, 448, 0, 2), (1, 1, 256, 2048, 448, 1, 2),
+                                                     (1, 1, 1536, 292, 448, 0, 1), (0, 1, 448, 1168, 1536, 1, 1),
+                                                     (0, 0, 512, 1536, 2336, 0, 1)])
+def test_dense_products_on_bf16_operand_copies(var_amd, akf, bkf, M, N, K, add, want):
+    """The big products read bf16 COPIES of their operands (add bit 1 of var_debug_ithor_dense): the tile kernel's bf16
+    staging paths, and the resident-panel kernel that the GRU input projection takes (K = 448, both operands k-fast, many
+    n tiles: return code 2) -- several n tiles per workgroup, groups with unequal tile counts, bias-free accumulate mode."""
+    from var_amd._lib import Context
+    m = var_amd.IthorVARPretextNet(cfg(96)).to("cuda").set_precision("bf16")
+    ctx = Context.get(0)
+    m._ensure_plan(ctx, 2)
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(K, N, generator=g)
+    a_dev = (A if akf else A.T).contiguous().cuda()
+    b_dev = (B.T if bkf else B).contiguous().cuda()
+    out = torch.full((N, M), 0.25 if add else float("nan"), device="cuda")
+    rc = ctx.lib.var_debug_ithor_dense(ctx.handle, None, akf, bkf, a_dev.data_ptr(), b_dev.data_ptr(), out.data_ptr(), M, N, K,
+                                       1, 2 | add)
+    torch.cuda.synchronize()
+    assert rc == want, rc
+    ref = (bf16_round(A) @ bf16_round(B)).T
+    got = out.double().cpu() - (0.25 if add else 0.0)
+    assert torch.isfinite(got).all()
+    err = float((got - ref).abs().max())
+    assert err < 2e-5 * float(ref.abs().max()) * max(1.0, (K / 512) ** 0.5), err

@@ -210,6 +210,125 @@ __global__ void __launch_bounds__(256) kernel(const DenseP<AK, BK, MODE> p, int 
     }
 }
 
+// ---- K-contiguous x K-contiguous products with a short K and a very long N (the GRU input projection: M 1536, K 448,
+// N 37 376 rows of (clip, t), fp32 output of 459 MB) -------------------------------------------------------------------
+// In the tile kernel above every 128 x 128 output tile loads both operands again (230 KB from L2 for 14.7 MFLOP) through a
+// one-step prefetch, and the product ran at 13 % of the matrix peak / 1.5 TB/s of stores.  Here a workgroup keeps its
+// 128-row panel of A (all of K: 115 KB) in LDS for its whole life and streams B: k-steps of 32 through a register ring of
+// 14 stages (a whole tile of loads in flight) and a double-buffered 8 KB LDS image, flattened over the workgroup's n
+// tiles, so that the load stream never drains between tiles.  One workgroup per CU.  293 -> 222 us for the input
+// projection (2.1 TB/s of fp32 stores: the store of C is what is left).
+constexpr int RES_KSTEPS = 14, RES_K = RES_KSTEPS * TK, RES_RING = 14;
+constexpr int RES_ROW = RES_K * 2 + 16;                   // bytes per A row: = 144 mod 256, 16 consecutive rows hit 16 different 16-byte bank groups
+constexpr int RES_LDS = 128 * RES_ROW + 2 * IMGK;
+
+template <int MODE>
+__global__ void __launch_bounds__(256) resident_a_kernel(const DenseP<true, true, MODE> p, int mt, int ngroups) {
+    extern __shared__ __align__(16) unsigned char rlds[];
+    unsigned char* const wimg = rlds;                      // [128 m][RES_K] bf16, row pitch RES_ROW
+    unsigned char* const ximg = rlds + 128 * RES_ROW;      // 2 x IMGK
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
+    const int mi = blockIdx.x % mt, grp = (blockIdx.x / mt) % ngroups, bz = blockIdx.x / (mt * ngroups);
+    const int m0 = mi * TM;
+    const unsigned short* A = (const unsigned short*)p.A + bz * p.zA;
+    const unsigned short* B = (const unsigned short*)p.Bm + bz * p.zB;
+    // the A panel: 128 rows x 56 16-byte chunks
+    constexpr int PER = 128 * (RES_K / 8) / 256;           // 28 chunks per thread, seven loads in flight at a time
+    static_assert(128 * (RES_K / 8) % 256 == 0 && PER % 7 == 0, "A panel chunks");
+    for (int b0 = 0; b0 < PER; b0 += 7) {
+        float4 v[7];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int q = tid + 256 * (b0 + u), row = q / (RES_K / 8), ch = q - row * (RES_K / 8);
+            v[u] = *(const float4*)(A + (long)min(m0 + row, p.M - 1) * p.sam + 8 * ch);
+        }
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int q = tid + 256 * (b0 + u), row = q / (RES_K / 8), ch = q - row * (RES_K / 8);
+            *(float4*)(wimg + row * RES_ROW + ch * 16) = keep(v[u], m0 + row < p.M);
+        }
+    }
+    const int nt = (p.N + TN - 1) / TN;
+    const int ntiles = grp < nt ? (nt - grp + ngroups - 1) / ngroups : 0;      // n tiles grp, grp + ngroups, ...
+    Stage<true, true> ring[RES_RING];
+    // stream position g = tile * 14 + ks
+    // (every load and LDS store of the stream is unconditional -- past the end the last tile is loaded again and never used --:
+    //  with `if (g < total)` around them hipcc cannot count the loads in flight and waits for ALL of them at every step)
+    if (ntiles == 0) return;
+    auto issue = [&](Stage<true, true>& st, int tile, int ks) {
+        st.load(B, p.sbn, 1, (grp + min(tile, ntiles - 1) * ngroups) * TN, ks * TK, p.N, p.K, tid);
+    };
+#pragma unroll
+    for (int r = 0; r < RES_RING - 1; ++r) issue(ring[r], 0, r);
+    ring[0].store(ximg, tid);
+    __syncthreads();
+    float bv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + 64 * wm + 32 * i + (lane & 31);
+        bv[i] = (p.bias && m < p.M) ? p.bias[bz * p.zbias + m] : 0.f;
+    }
+    for (int tile = 0; tile < ntiles; ++tile) {
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < RES_KSTEPS; ++ks) {
+            const int g = tile * RES_KSTEPS + ks;
+            // the stage that was stored to LDS before this step is free: it takes the load RES_RING - 1 steps ahead
+            issue(ring[(ks + RES_RING - 1) % RES_RING], tile + (ks + RES_RING - 1) / RES_KSTEPS, (ks + RES_RING - 1) % RES_KSTEPS);
+            const unsigned char* xb = ximg + (g & 1) * IMGK;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                d16_bf16x8_t fa[2], fb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    fa[i] = *(const d16_bf16x8_t*)(wimg + (32 * (2 * wm + i) + (lane & 31)) * RES_ROW + ((2 * (2 * ks + k2) + (lane >> 5)) << 4));
+                    fb[i] = frag<true>(xb, 2 * wn + i, k2, lane);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[jj], fa[i], acc[i][jj], 0, 0, 0);
+            }
+            ring[(ks + 1) % RES_RING].store(ximg + ((g + 1) & 1) * IMGK, tid);
+            __syncthreads();
+        }
+        // The tile's 64 stores per thread go out in one block BEHIND the loads of the whole next tile (the ring is a tile
+        // deep): loads and stores share one in-order counter, so a load issued after a store waits for that store -- and
+        // the stores complete slowly.  Measured: ring of 7 stages 231 us, 14 stages 222 us; the stores spread over the
+        // next tile's k-steps (5 per step from a copy of the accumulators) 261 / 252 us.
+        const int n0 = (grp + tile * ngroups) * TN;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float* cm = p.C + bz * p.zC + m0 + 64 * wm + 32 * i + (lane & 31);      // scm == 1, M % 128 == 0
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + 64 * wn + 32 * jj + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (n < p.N) {
+                        float v = acc[i][jj][r] + bv[i];
+                        if (MODE == 1) v += cm[(long)n * p.scn];
+                        if (p.relu) v = v > 0.f ? v : 0.f;
+                        cm[(long)n * p.scn] = v;
+                    }
+                }
+        }
+    }
+}
+
+template <bool AK, bool BK, int MODE>
+inline bool resident_a_eligible(const DenseP<AK, BK, MODE>& p) {
+    return AK && BK && MODE != 2 && p.a16 && p.b16 && p.K == RES_K && p.nsplit == 1 && p.sak == 1 && p.sbk == 1 && p.scm == 1 &&
+           p.M % TM == 0 && p.N >= 8 * TN;
+}
+
 // shapes the kernel takes: 16-byte aligned runs along each operand's contiguous index
 template <bool AK, bool BK, int MODE>
 inline bool eligible(const DenseP<AK, BK, MODE>& p) {
@@ -226,6 +345,23 @@ inline bool eligible(const DenseP<AK, BK, MODE>& p) {
 template <bool AK, bool BK, int MODE>
 inline int launch(var_ctx* c, hipStream_t s, const DenseP<AK, BK, MODE>& p, int batches) {
     const int mt = (p.M + TM - 1) / TM, nt = (p.N + TN - 1) / TN, zt = batches * p.nsplit;
+    if constexpr (AK && BK && MODE != 2) {
+        if (resident_a_eligible(p)) {                      // one workgroup per CU, each with its A panel and a share of the n tiles
+            static bool attr[2] = {false, false};
+            if (!attr[MODE]) {
+                VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)resident_a_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, RES_LDS));
+                attr[MODE] = true;
+            }
+            int cus = 256;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+            int ngroups = cus / (mt * batches);
+            if (ngroups < 1) ngroups = 1;
+            if (ngroups > nt) ngroups = nt;
+            hipLaunchKernelGGL(resident_a_kernel<MODE>, dim3(mt * ngroups * batches), dim3(256), RES_LDS, s, p, mt, ngroups);
+            VAR_HIP_CHECK(c, hipGetLastError());
+            return VAR_OK;
+        }
+    }
     const int group = MODE == 2 ? mt * nt : mt;            // tiles of one K split | m tiles of one n tile
     const int nchunks = mt * nt * zt / group, padded = (nchunks + 7) / 8 * 8;
     const dim3 grid(padded * group);

@@ -555,6 +555,13 @@ int gru_bf16_convert_x(var_ctx* c, hipStream_t s, const float* x, long n, int ma
     return VAR_OK;
 }
 
+// n floats (n % 8 == 0) -> bf16
+int gru_bf16_to_bf16(var_ctx* c, hipStream_t s, const float* x, void* y, long n) {
+    hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, s, (const float4*)x, (uint4*)y, n / 8);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}
+
 // once per forward: both fragment tables of W_hh, and the zero initial state's bf16 copy
 int gru_bf16_pack(var_ctx* c, hipStream_t s, const float* w_hh, const float* w_ih, long dirP, int nclips, int maxclips, void* ws) {
     for (int d = 0; d < 2; ++d) {                        // W_ih [dir][1536][448] as bf16: the A operand of the input projection and of dX

@@ -972,6 +972,26 @@ int ithor_debug_buffer(var_ctx* c, const char* name, void** ptr, long* nfloats) 
 template <bool AK, bool BK>
 static int debug_dense(var_ctx* c, hipStream_t s, const float* a, const float* b, float* out, int M, int N, int K, int nsplit, int add) {
     const long sam = AK ? K : 1, sak = AK ? 1 : M, sbk = BK ? 1 : N, sbn = BK ? K : 1;
+    if (add & 2) {      // both operands as bf16 copies, as the schedule hands the big products over (no split)
+        if (nsplit > 1 || ((long)M * K) % 8 || ((long)N * K) % 8) return VAR_ERR_ARG;
+        void *a16 = nullptr, *b16 = nullptr;
+        VAR_HIP_CHECK(c, hipMalloc(&a16, (size_t)M * K * 2));
+        VAR_HIP_CHECK(c, hipMalloc(&b16, (size_t)N * K * 2));
+        int r = gru_bf16_to_bf16(c, s, a, a16, (long)M * K);
+        if (r == VAR_OK) r = gru_bf16_to_bf16(c, s, b, b16, (long)N * K);
+        int took = 0;
+        auto run = [&](auto p) {
+            p.M = M; p.N = N; p.K = K; p.nsplit = 1;
+            p.A = a; p.sam = sam; p.sak = sak; p.Bm = b; p.sbk = sbk; p.sbn = sbn; p.C = out; p.scm = 1; p.scn = M;
+            use_bf16_copies(c, p, a16, b16);
+            took = p.a16 && p.b16 ? (dense16::resident_a_eligible(p) ? 2 : 1) : 0;
+            return gg(c, s, p);
+        };
+        if (r == VAR_OK) r = (add & 1) ? run(DenseP<AK, BK, 1>{}) : run(DenseP<AK, BK, 0>{});
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(a16); (void)hipFree(b16);
+        return r != VAR_OK ? r : took;
+    }
     if (nsplit > 1) {
         DenseP<AK, BK, 2> p{};
         p.M = M; p.N = N; p.K = K; p.nsplit = eff_split(K, nsplit);

@@ -277,6 +277,7 @@ void* gru_bf16_h16(void* ws);                 // bf16 copies: states (dir, step 
 void* gru_bf16_dgh16(void* ws, int maxclips); //   gate gradients wrt gh (dir, step, clip, 1536)
 void* gru_bf16_dgi16(void* ws, int maxclips); //   gate gradients wrt gi (dir, clip*73+t, 1536)
 void* gru_bf16_x16(void* ws, int maxclips);   //   the input sequence (clip*73+t, 448)
+int gru_bf16_to_bf16(var_ctx* c, hipStream_t s, const float* x, void* y, long n);     // n % 8 == 0
 int gru_bf16_convert_x(var_ctx* c, hipStream_t s, const float* x, long n, int maxclips, void* ws);
 void* gru_bf16_wih16(void* ws, int maxclips); //   W_ih (dir, 1536, 448)
 // fp32 (dir, clip slice of 64, [b_ih: r z n | b_hh: r z n], 512): per-slice bias-gradient sums left by gru_bf16_seq_bwd
