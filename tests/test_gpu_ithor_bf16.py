@@ -490,11 +490,14 @@ def test_gru_persistent_launch_ends_when_its_grid_is_incomplete(var_amd):
 
 @pytest.mark.parametrize("akf,bkf,M,N,K,add,want", [(1, 1, 1536, 1024 + 128 * 3, 448, 0, 2), (1, 1, 256, 2048, 448, 1, 2),
                                                      (1, 1, 1536, 292, 448, 0, 1), (0, 1, 448, 1168, 1536, 1, 1),
-                                                     (0, 0, 512, 1536, 2336, 0, 1)])
+                                                     (0, 0, 512, 1536, 2336, 0, 1), (1, 0, 256, 520, 1632, 0, 1),
+                                                     (0, 1, 448, 300, 1640, 0, 1)])
 def test_dense_products_on_bf16_operand_copies(var_amd, akf, bkf, M, N, K, add, want):
     """The big products read bf16 COPIES of their operands (add bit 1 of var_debug_ithor_dense): the tile kernel's bf16
     staging paths, and the resident-panel kernel that the GRU input projection takes (K = 448, both operands k-fast, many
-    n tiles: return code 2) -- several n tiles per workgroup, groups with unequal tile counts, bias-free accumulate mode."""
+    n tiles: return code 2) -- several n tiles per workgroup, groups with unequal tile counts, bias-free accumulate mode;
+    the register-ring variant of the tile kernel (a k-fast operand, >= 32 k-steps) with trip counts that are not multiples
+    of the ring (51 and 52 steps, a K tail of 8) and ragged N."""
     from var_amd._lib import Context
     m = var_amd.IthorVARPretextNet(cfg(96)).to("cuda").set_precision("bf16")
     ctx = Context.get(0)

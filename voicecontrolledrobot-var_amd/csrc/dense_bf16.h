@@ -210,6 +210,88 @@ __global__ void __launch_bounds__(256) kernel(const DenseP<AK, BK, MODE> p, int 
     }
 }
 
+// The same tile with a register ring of RING_D stages for products with a long K loop and both operands as bf16 copies (a
+// stage is 8 + 8 registers): the loads of a k-step are in flight for RING_D - 1 steps instead of one.  Every load and LDS
+// store is unconditional (hipcc then counts the loads in flight instead of waiting for all of them); steps past the
+// split's end load zeros (the k limit handed to Stage::load is the split's end), so the trip count is rounded up to a
+// multiple of RING_D.
+constexpr int RING_D = 4;
+template <bool AK, bool BK, int MODE>
+__global__ void __launch_bounds__(256) ring_kernel(const DenseP<AK, BK, MODE> p, int mt, int nt, int group, int nchunks) {
+    constexpr int IA = AK ? IMGK : IMGT, IB = BK ? IMGK : IMGT;
+    __shared__ __align__(16) unsigned char lds[2 * (IA + IB)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
+    const int L = blockIdx.x, chunk = (L & 7) + 8 * ((L >> 3) / group), j = chunk * group + (L >> 3) % group;
+    if (chunk >= nchunks) return;
+    const int mi = j % mt, ni = (j / mt) % nt, zi = j / (mt * nt);
+    const int m0 = mi * TM, n0 = ni * TN;
+    const int nsplit = p.nsplit, bz = zi / nsplit, sz = zi - bz * nsplit;
+    const int ktiles = (p.K + TK - 1) / TK, per = (ktiles + nsplit - 1) / nsplit;
+    const int t_lo = sz * per, t_hi = min(ktiles, t_lo + per);
+    const int kend = min(p.K, t_hi * TK);                   // loads at k >= kend give zeros
+    const void* A = (const void*)((const unsigned short*)p.A + bz * p.zA);
+    const void* B = (const void*)((const unsigned short*)p.Bm + bz * p.zB);
+    const long a_si = p.sam, a_sk = p.sak, b_si = p.sbn, b_sk = p.sbk;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+
+    Stage<AK, true> ra[RING_D];
+    Stage<BK, true> rb[RING_D];
+#pragma unroll
+    for (int d = 0; d < RING_D - 1; ++d) {
+        ra[d].load(A, a_si, a_sk, m0, (t_lo + d) * TK, p.M, kend, tid);
+        rb[d].load(B, b_si, b_sk, n0, (t_lo + d) * TK, p.N, kend, tid);
+    }
+    ra[0].store(lds, tid);
+    rb[0].store(lds + IA, tid);
+    __syncthreads();
+    for (int t0 = t_lo; t0 < t_hi; t0 += RING_D) {
+#pragma unroll
+        for (int d = 0; d < RING_D; ++d) {
+            const int t = t0 + d;
+            ra[(d + RING_D - 1) % RING_D].load(A, a_si, a_sk, m0, (t + RING_D - 1) * TK, p.M, kend, tid);
+            rb[(d + RING_D - 1) % RING_D].load(B, b_si, b_sk, n0, (t + RING_D - 1) * TK, p.N, kend, tid);
+            const unsigned char* ia = lds + (d & 1) * (IA + IB);       // (t - t_lo) & 1 == d & 1: RING_D is even
+            const unsigned char* ib = ia + IA;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                d16_bf16x8_t fa[2], fb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { fa[i] = frag<AK>(ia, 2 * wm + i, ks, lane); fb[i] = frag<BK>(ib, 2 * wn + i, ks, lane); }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[jj], fa[i], acc[i][jj], 0, 0, 0);
+            }
+            unsigned char* na = lds + ((d + 1) & 1) * (IA + IB);
+            ra[(d + 1) % RING_D].store(na, tid);
+            rb[(d + 1) % RING_D].store(na + IA, tid);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + 64 * wm + 32 * i + (lane & 31);
+        if (m >= p.M) continue;
+        const auto cm = p.c_m(m, bz, sz);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + 64 * wn + 32 * jj + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (n < p.N) p.store(cm, n, acc[i][jj][r], bz);
+            }
+    }
+}
+static_assert(RING_D % 2 == 0, "the LDS buffer parity follows the ring position");
+
 // ---- K-contiguous x K-contiguous products with a short K and a very long N (the GRU input projection: M 1536, K 448,
 // N 37 376 rows of (clip, t), fp32 output of 459 MB) -------------------------------------------------------------------
 // In the tile kernel above every 128 x 128 output tile loads both operands again (230 KB from L2 for 14.7 MFLOP) through a
@@ -365,7 +447,10 @@ inline int launch(var_ctx* c, hipStream_t s, const DenseP<AK, BK, MODE>& p, int 
     const int group = MODE == 2 ? mt * nt : mt;            // tiles of one K split | m tiles of one n tile
     const int nchunks = mt * nt * zt / group, padded = (nchunks + 7) / 8 * 8;
     const dim3 grid(padded * group);
-    if (p.a16 && p.b16) hipLaunchKernelGGL((kernel<AK, BK, MODE, true, true>), grid, dim3(256), 0, s, p, mt, nt, group, nchunks);
+    const int ksteps = ((p.K + TK - 1) / TK + p.nsplit - 1) / p.nsplit;
+    // (measured: dX, K 1536, B k-fast: 175 + 115 -> 135 + 92 us; dW, K 4672 per split, both operands index-fast: 184 -> 195 us)
+    if ((AK || BK) && p.a16 && p.b16 && ksteps >= 32) hipLaunchKernelGGL((ring_kernel<AK, BK, MODE>), grid, dim3(256), 0, s, p, mt, nt, group, nchunks);
+    else if (p.a16 && p.b16) hipLaunchKernelGGL((kernel<AK, BK, MODE, true, true>), grid, dim3(256), 0, s, p, mt, nt, group, nchunks);
     else if (p.b16) hipLaunchKernelGGL((kernel<AK, BK, MODE, false, true>), grid, dim3(256), 0, s, p, mt, nt, group, nchunks);
     else if (p.a16) { VAR_SET_ERR(c, "dense16: a bf16 copy of A alone is not instantiated"); return VAR_ERR_ARG; }
     else hipLaunchKernelGGL((kernel<AK, BK, MODE, false, false>), grid, dim3(256), 0, s, p, mt, nt, group, nchunks);
