@@ -886,7 +886,10 @@ __global__ void __launch_bounds__(256, 2) snd1_wgrad_kernel(const float* __restr
         }
         __syncthreads();
         const uint4* ga = (const uint4*)(gy16 + ((long)clip * CO + 32 * cb + r) * (C1_HO * C1_WO)) + h;     // + 2 ks: pixels 16 ks + 8 h ..
-        constexpr int NKS = C1_HO * C1_WO / 16, DEPTH = 4;
+        // gy comes straight from HBM: DEPTH k-steps of loads in flight per wave, unconditional (past the end the last step
+        // is loaded again) so that hipcc counts them instead of waiting for all: depth 4 (conditional) 189 us, 8: 161 us,
+        // 16: 175 us (spills).  What is left is the LDS side: 12 narrow reads per step and wave for 3 matrix instructions
+        constexpr int NKS = C1_HO * C1_WO / 16, DEPTH = 8;
         uint4 ring[DEPTH];
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) ring[d] = ga[2 * d];
@@ -895,9 +898,10 @@ __global__ void __launch_bounds__(256, 2) snd1_wgrad_kernel(const float* __restr
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
                 const int ks = ks0 + d;
-                if (ks < NKS) {                                  // uniform
+                {
                     const uint4 a = ring[d];
-                    if (ks + DEPTH < NKS) ring[d] = ga[2 * (ks + DEPTH)];
+                    ring[d] = ga[2 * min(ks + DEPTH, NKS - 1)];
+                    if (ks >= NKS) continue;                     // uniform: the tail of the last group
                     const int P0 = 16 * ks + 8 * h, oy = P0 / C1_WO, ox0 = P0 - oy * C1_WO;
                     const unsigned char* xb = lds + (2 * oy + kyl) * C1_PITCH + ((2 * ox0 + kx) >> 1) * 4;
                     const int hi = 16 + (ox0 == 16 ? 128 : 0);
