@@ -624,19 +624,31 @@ __global__ void __launch_bounds__(256) snd_wgrad_kernel(const uint4* __restrict_
     const int xdst = (xc5 & 1) * L::XPARB + xr * SUBP + (xc5 >> 1) * SLOT;
     const int grow = tid / G::WO;
     const int gdst = L::XB + (grow / G::RPK) * 256 + ((grow % G::RPK) * G::WO + (tid - grow * G::WO)) * SLOT;
+    // Every global load of the pipeline is UNCONDITIONAL -- clamped address, the zero for out-of-range slots chosen when the
+    // slot is stored to LDS a tile later, the tile after next clamped to the last one instead of `if (tile + 2 < ntiles)` --:
+    // with any load behind a branch hipcc cannot count the loads in flight and waits for (almost) all of them in the
+    // middle of every tile, i.e. for loads issued a k-step earlier.
+    auto slot_ok = [&](int tile, int k) -> bool {
+        const int t = tile % G::TILES, oy0 = G::TR * t;
+        if (k < NXS) {
+            const int i = xr + L::XP * (k % L::NP), yy = 2 * oy0 - G::PH + i;
+            return xthr && i < L::XR && (unsigned)yy < (unsigned)G::HI;
+        }
+        return k - NXS < 8 && gthr && oy0 + grow < G::HO;
+    };
     auto slot_load = [&](int tile, int k) -> uint4 {
         const int clip = clip_lo + tile / G::TILES, t = tile % G::TILES, oy0 = G::TR * t;
         if (k < NXS) {
             const int pl = k / L::NP, i = xr + L::XP * (k % L::NP), yy = 2 * oy0 - G::PH + i;
-            const bool ok = xthr && i < L::XR && (unsigned)yy < (unsigned)G::HI;
-            return ok ? x8[((long)clip * 8 + 4 * cib + pl) * (G::HI * G::WI) + yy * G::WI + xc] : make_uint4(0, 0, 0, 0);
+            const int yc = min(max(yy, 0), G::HI - 1), xcc = min(xc, G::WI - 1);
+            return x8[((long)clip * 8 + 4 * cib + pl) * (G::HI * G::WI) + yc * G::WI + xcc];
         }
-        const int pl = k - NXS;
-        const bool ok = pl < 8 && gthr && oy0 + grow < G::HO;
-        return ok ? gy8[((long)clip * 8 + pl) * (G::HO * G::WO) + oy0 * G::WO + tid] : make_uint4(0, 0, 0, 0);
+        const int pl = min(k - NXS, 7);
+        return gy8[((long)clip * 8 + pl) * (G::HO * G::WO) + min(oy0 * G::WO + tid, G::HO * G::WO - 1)];
     };
-    auto slot_store = [&](int buf, int k, uint4 v) {
+    auto slot_store = [&](int buf, int k, uint4 v, bool ok) {
         unsigned char* base = lds + buf * L::BUFB;
+        if (!ok) v = make_uint4(0, 0, 0, 0);
         if (k < NXS) {
             const int pl = k / L::NP, i = xr + L::XP * (k % L::NP);
             if (xthr && i < L::XR) *(uint4*)(base + pl * L::XPL + xdst + L::XP * (k % L::NP) * SUBP) = v;
@@ -656,21 +668,22 @@ __global__ void __launch_bounds__(256) snd_wgrad_kernel(const uint4* __restrict_
     // Slot pair j of tile T+1 is stored (into the other buffer) at k-step j of tile T and its registers are re-loaded at
     // once with the pair of tile T+2: every load has a whole tile to land.
     uint4 st[NPAIR][2];
-    if (ntiles > 0) {
+    if (ntiles == 0) return;                               // (never: the launcher sizes the groups so that each has a clip)
+    const int last = ntiles - 1;
 #pragma unroll
-        for (int k = 0; k < 2 * NPAIR; ++k) slot_store(0, k, slot_load(0, k));
-    }
-    if (ntiles > 1) {
+    for (int j = 0; j < NPAIR; ++j) { st[j][0] = slot_load(0, 2 * j); st[j][1] = slot_load(0, 2 * j + 1); }      // (all in flight, then stored)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < NPAIR; ++j) { st[j][0] = slot_load(1, 2 * j); st[j][1] = slot_load(1, 2 * j + 1); }
-    }
+    for (int j = 0; j < NPAIR; ++j) { slot_store(0, 2 * j, st[j][0], slot_ok(0, 2 * j)); slot_store(0, 2 * j + 1, st[j][1], slot_ok(0, 2 * j + 1)); }
+#pragma unroll
+    for (int j = 0; j < NPAIR; ++j) { st[j][0] = slot_load(min(1, last), 2 * j); st[j][1] = slot_load(min(1, last), 2 * j + 1); }
     __syncthreads();
 
 #pragma unroll 1
     for (int tile = 0; tile < ntiles; ++tile) {
         const int buf = tile & 1;
         const unsigned char* img = lds + buf * L::BUFB;
-        const bool have1 = tile + 1 < ntiles, have2 = tile + 2 < ntiles;
+        const int t1 = min(tile + 1, last), t2 = min(tile + 2, last);      // (past the end: the last tile again, never used)
         bf16x8_t a[2][2], b[2][TAPS];
         // fragment f of k-step ks (output rows RPK ks ..: x rows 2 RPK ks + ky): f = 0, 1: gy for the two co blocks; 2 + i: x for tap i
         auto frag = [&](int ks, int set, int f) {
@@ -694,8 +707,8 @@ __global__ void __launch_bounds__(256) snd_wgrad_kernel(const uint4* __restrict_
                 }
                 if (ks < NPAIR && i >= TAPS - 2) {
                     const int q = i - (TAPS - 2);
-                    if (have1) slot_store(buf ^ 1, 2 * ks + q, st[ks][q]);
-                    if (have2) st[ks][q] = slot_load(tile + 2, 2 * ks + q);
+                    slot_store(buf ^ 1, 2 * ks + q, st[ks][q], slot_ok(t1, 2 * ks + q));
+                    st[ks][q] = slot_load(t2, 2 * ks + q);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[set][0], b[set][i], acc[i][0], 0, 0, 0);
