@@ -112,8 +112,9 @@ __device__ __forceinline__ void img_dgrad_body(const float* __restrict__ gy, con
                     const float2 xv = *(const float2*)(x + oc);
                     xm0[r] = xv.x; xm1[r] = xv.y;
                 } else {
+                    const float t1 = x[oc + (2 * i + 1 < C::W ? 1 : 0)];      // (unconditional: a load behind a branch is waited for at once)
                     xm0[r] = x[oc];
-                    xm1[r] = 2 * i + 1 < C::W ? x[oc + 1] : 0.f;
+                    xm1[r] = 2 * i + 1 < C::W ? t1 : 0.f;
                 }
             }
         }
@@ -308,9 +309,12 @@ __device__ __forceinline__ void img_dgrad16_body(const float* __restrict__ gy, c
         const bool ok = ppvalid && iy < C::H;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+            // (unconditional loads from clamped addresses, the zero selected afterwards: `ok ? x[oc] : 0.f` is compiled as a
+            //  branch around each load with a full wait behind it -- sixteen load latencies in a row)
             const size_t oc = o0 + (size_t)r * C::H * C::W + (size_t)(ok ? iy : 0) * C::W;
-            xm[py][r][0] = ok ? x[oc] : 0.f;
-            xm[py][r][1] = (ok && 2 * i + 1 < C::W) ? x[oc + 1] : 0.f;
+            const float t0 = x[oc], t1 = x[oc + (2 * i + 1 < C::W ? 1 : 0)];
+            xm[py][r][0] = ok ? t0 : 0.f;
+            xm[py][r][1] = (ok && 2 * i + 1 < C::W) ? t1 : 0.f;
         }
     }
     __syncthreads();
