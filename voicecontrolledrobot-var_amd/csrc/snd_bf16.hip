@@ -141,7 +141,9 @@ __global__ void __launch_bounds__(256) pack_w_kernel(const float* __restrict__ w
 
 // y: bias + ReLU, fp32 NCHW or (SEQ) the (clip, oy, co*WO + ox) sequence; y8 / ymask (optional): the same values as the next
 // layer's C8 bf16 image and the sign words its data-gradient kernel stores through (to_c8_mask_kernel's layouts)
-template <class G>
+// (F32: the fp32 copy of a non-sequence output exists; y8 / ymask exist exactly when the output is not the sequence --
+//  compile-time, as run-time null checks they were a scalar branch in front of every store)
+template <class G, bool F32>
 __global__ void __launch_bounds__(256) snd_fwd_kernel(const uint4* __restrict__ x8, const uint4* __restrict__ wp,
                                                       const float* __restrict__ bias, float* __restrict__ y, uint2* __restrict__ y8,
                                                       unsigned* __restrict__ ymask, int nclips) {
@@ -294,21 +296,21 @@ __global__ void __launch_bounds__(256) snd_fwd_kernel(const uint4* __restrict__ 
                         for (int e = 0; e < 4; ++e) {
                             const int co = 32 * cb + 8 * g + 4 * h + e;
                             v[e] = fmaxf(acc[m][cb][4 * g + e] + bv[cb][4 * g + e], 0.f);
-                            if (G::SEQ) {
+                            if constexpr (G::SEQ) {
                                 const int oyl = P / WO, ox = P - oyl * WO;
                                 y[((long)clip * G::HO + oyl) * (CO * WO) + co * WO + ox] = v[e];
-                            } else if (y) {
+                            } else if constexpr (F32) {
                                 y[((long)clip * CO + co) * (G::HO * WO) + pix0 + P] = v[e];
                             }
                         }
-                        if (y8) {       // plane 4 cb + g, this lane's half (4 h .. 4 h + 3) of the pixel's 16-byte slot
+                        if constexpr (!G::SEQ) {       // plane 4 cb + g, this lane's half (4 h .. 4 h + 3) of the pixel's 16-byte slot
                             const unsigned p01 = pack_bf16(v[0], v[1]), p23 = pack_bf16(v[2], v[3]);
                             y8[(((long)clip * 8 + 4 * cb + g) * (G::HO * WO) + pix0 + P) * 2 + h] = make_uint2(p01, p23);
                             mk |= ((p01 & 0xffffu ? 1u : 0u) | (p01 >> 16 ? 2u : 0u) | (p23 & 0xffffu ? 4u : 0u) | (p23 >> 16 ? 8u : 0u))
                                   << (16 * cb + 4 * g);
                         }
                     }
-                if (y8) ymask[((long)clip * (G::HO * WO) + pix0 + P) * 2 + h] = mk;
+                if constexpr (!G::SEQ) ymask[((long)clip * (G::HO * WO) + pix0 + P) * 2 + h] = mk;
             }
         }
     }
@@ -329,10 +331,12 @@ __global__ void __launch_bounds__(256) snd_fwd_kernel(const uint4* __restrict__ 
 struct DGeo2 {           // conv 2: dx (300,20) from gy (150,13); 6 tiles of 25 rows u
     static constexpr int HI = 300, WI = 20, HO = 150, WO = 13, KH = 11, KW = 5, PH = 5, PW = 5;
     static constexpr int ROWS = 25, TILES = 6, MB = 4, NSLOT = 13;
+    static constexpr bool OUT8 = false, OUT16 = true;      // besides the optional fp32 dx: bf16 NCHW for conv 1's weight gradient
 };
 struct DGeo3 {           // conv 3: dx (150,13) from gy (73,7); 3 tiles of 25 rows u; the 7th pixel pair of a row is half empty
     static constexpr int HI = 150, WI = 13, HO = 73, WO = 7, KH = 7, KW = 3, PH = 1, PW = 1;
     static constexpr int ROWS = 25, TILES = 3, MB = 3, NSLOT = 8;
+    static constexpr bool OUT8 = true, OUT16 = false;      // the C8 image = conv 2's gy
 };
 template <class G>
 struct DgLayout {
@@ -346,7 +350,8 @@ struct DgLayout {
     static_assert((V - 1) + DXMAX < G::NSLOT + (G::NSLOT > G::WO ? 0 : 1) || G::NSLOT > G::WO, "zero slot");
 };
 
-template <class G, int A>
+// (which outputs exist is compile-time: as run-time null checks they were two scalar branches in front of every store)
+template <class G, int A, bool F32>
 __device__ __forceinline__ void dgrad_pass(const unsigned char* __restrict__ img, const int (&abase)[G::MB], __amdgpu_buffer_rsrc_t wq,
                                            int wlane, const unsigned* __restrict__ mask, int cb, float* __restrict__ dxo,
                                            uint2* __restrict__ dx8, unsigned short* __restrict__ dx16, int u0, int wm, int p31, int h,
@@ -429,15 +434,15 @@ __device__ __forceinline__ void dgrad_pass(const unsigned char* __restrict__ img
                     const int r = 4 * g + e;
                     o[e].x = (m0 >> r) & 1u ? acc[m][0][r] : 0.f;
                     o[e].y = (m1 >> r) & 1u ? acc[m][1][r] : 0.f;
-                    if (dxo) {
+                    if constexpr (F32) {
                         float* q = dxo + (long)(32 * cb + 8 * g + 4 * h + e) * (G::HI * G::WI) + pix;
                         if (EVEN) *(float2*)q = o[e];
                         else { q[0] = o[e].x; if (two) q[1] = o[e].y; }
                     }
-                    if (EVEN && dx16) *(unsigned*)(dx16 + (long)(32 * cb + 8 * g + 4 * h + e) * (G::HI * G::WI) + pix) = pack_bf16(o[e].x, o[e].y);
+                    if constexpr (EVEN && G::OUT16) *(unsigned*)(dx16 + (long)(32 * cb + 8 * g + 4 * h + e) * (G::HI * G::WI) + pix) = pack_bf16(o[e].x, o[e].y);
                     bsum[r] += o[e].x + o[e].y;           // the bias gradient of the layer below: channel sums of dx
                 }
-                if (dx8) {      // plane 4 cb + g of the C8 image, this lane's half of the two pixels' slots
+                if constexpr (G::OUT8) {      // plane 4 cb + g of the C8 image, this lane's half of the two pixels' slots
                     uint2* q8 = dx8 + ((long)(4 * cb + g) * (G::HI * G::WI) + pix) * 2 + h;
                     q8[0] = make_uint2(pack_bf16(o[0].x, o[1].x), pack_bf16(o[2].x, o[3].x));
                     if (two) q8[2] = make_uint2(pack_bf16(o[0].y, o[1].y), pack_bf16(o[2].y, o[3].y));
@@ -447,7 +452,7 @@ __device__ __forceinline__ void dgrad_pass(const unsigned char* __restrict__ img
     }
 }
 
-template <class G>
+template <class G, bool F32>
 __global__ void __launch_bounds__(256) snd_dgrad_kernel(const uint4* __restrict__ gy8, const uint4* __restrict__ wp,
                                                         const unsigned* __restrict__ mask, float* __restrict__ dx, uint2* __restrict__ dx8,
                                                         unsigned short* __restrict__ dx16, float* __restrict__ bias_part, int nclips) {
@@ -509,10 +514,10 @@ __global__ void __launch_bounds__(256) snd_dgrad_kernel(const uint4* __restrict_
         unsigned short* dx16o = dx16 ? dx16 + (long)clip * CI * (G::HI * G::WI) : nullptr;
         const int ntile = tile + (int)gridDim.x;
         const unsigned char* img = lds + buf * L::BUFB;
-        dgrad_pass<G, 0>(img, abase, wq, wlane, mk, cb, dxo, dx8o, dx16o, u0, wm, p31, h, bsum);
+        dgrad_pass<G, 0, F32>(img, abase, wq, wlane, mk, cb, dxo, dx8o, dx16o, u0, wm, p31, h, bsum);
         if (ntile < ntiles) stage_load(ntile);
         __builtin_amdgcn_sched_barrier(0);
-        dgrad_pass<G, 1>(img, abase, wq, wlane, mk, cb, dxo, dx8o, dx16o, u0, wm, p31, h, bsum);
+        dgrad_pass<G, 1, F32>(img, abase, wq, wlane, mk, cb, dxo, dx8o, dx16o, u0, wm, p31, h, bsum);
         if (ntile < ntiles) stage_store(buf ^ 1);
         __syncthreads();
     }
@@ -769,6 +774,7 @@ __global__ void __launch_bounds__(256) pack_w1_kernel(const float* __restrict__ 
 }
 
 // clips 0 .. n0-1 from x0, n0 .. nclips-1 from x1 (the positive and the negative sounds of a batch)
+template <bool F32>
 __global__ void __launch_bounds__(256, 2) snd1_fwd_kernel(const float* __restrict__ x0, const float* __restrict__ x1, int n0,
                                                           const uint4* __restrict__ wp, const float* __restrict__ bias,
                                                           float* __restrict__ y, uint2* __restrict__ y8, unsigned* __restrict__ ymask,
@@ -846,7 +852,7 @@ __global__ void __launch_bounds__(256, 2) snd1_fwd_kernel(const float* __restric
                             for (int e = 0; e < 4; ++e) {
                                 const int co = 32 * cb + 8 * q + 4 * h + e;
                                 v[e] = fmaxf(acc[m][cb][4 * q + e] + bv[cb][4 * q + e], 0.f);
-                                if (y) y[(oclip * CO + co) * (C1_HO * C1_WO) + P] = v[e];
+                                if constexpr (F32) y[(oclip * CO + co) * (C1_HO * C1_WO) + P] = v[e];
                             }
                             const unsigned p01 = pack_bf16(v[0], v[1]), p23 = pack_bf16(v[2], v[3]);
                             y8[((oclip * 8 + 4 * cb + q) * (C1_HO * C1_WO) + P) * 2 + h] = make_uint2(p01, p23);
@@ -992,12 +998,15 @@ int snd1_bf16_fwd(var_ctx* c, hipStream_t s, const float* x0, int n0, const floa
     VAR_HIP_CHECK(c, hipGetLastError());
     static bool attr = false;
     if (!attr) {
-        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd1_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDSB + 256));
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd1_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDSB + 256));
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd1_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDSB + 256));
         attr = true;
     }
     const int n = n0 + n1;
-    hipLaunchKernelGGL(snd1_fwd_kernel, dim3(n < 512 ? n : 512), dim3(256), C1_LDSB + 256, s, x0, x1, n0, at<uint4>(ws, o.wp1), bias, y,
-                       at<uint2>(ws, o.x8), at<unsigned>(ws, o.m1), n);
+    if (y) hipLaunchKernelGGL(snd1_fwd_kernel<true>, dim3(n < 512 ? n : 512), dim3(256), C1_LDSB + 256, s, x0, x1, n0, at<uint4>(ws, o.wp1), bias,
+                              y, at<uint2>(ws, o.x8), at<unsigned>(ws, o.m1), n);
+    else hipLaunchKernelGGL(snd1_fwd_kernel<false>, dim3(n < 512 ? n : 512), dim3(256), C1_LDSB + 256, s, x0, x1, n0, at<uint4>(ws, o.wp1), bias,
+                            y, at<uint2>(ws, o.x8), at<unsigned>(ws, o.m1), n);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }
@@ -1018,13 +1027,16 @@ int snd2_bf16_fwd(var_ctx* c, hipStream_t s, const float* x, const float* w, con
     VAR_HIP_CHECK(c, hipGetLastError());
     static bool attr = false;
     if (!attr) {
-        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd_fwd_kernel<Geo2>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDSB));
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd_fwd_kernel<Geo2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDSB));
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd_fwd_kernel<Geo2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDSB));
         attr = true;
     }
     const int ntiles = nclips * Geo2::TILES;
     ProfScope prof(c, s, TAG_ITHOR_S2_FWD);
-    hipLaunchKernelGGL(snd_fwd_kernel<Geo2>, dim3(ntiles < 256 ? ntiles : 256), dim3(256), L::LDSB, s, at<uint4>(ws, o.x8),
-                       at<uint4>(ws, o.wp2), bias, y, at<uint2>(ws, o.y8), at<unsigned>(ws, o.m2), nclips);
+    if (y) hipLaunchKernelGGL((snd_fwd_kernel<Geo2, true>), dim3(ntiles < 256 ? ntiles : 256), dim3(256), L::LDSB, s, at<uint4>(ws, o.x8),
+                              at<uint4>(ws, o.wp2), bias, y, at<uint2>(ws, o.y8), at<unsigned>(ws, o.m2), nclips);
+    else hipLaunchKernelGGL((snd_fwd_kernel<Geo2, false>), dim3(ntiles < 256 ? ntiles : 256), dim3(256), L::LDSB, s, at<uint4>(ws, o.x8),
+                            at<uint4>(ws, o.wp2), bias, y, at<uint2>(ws, o.y8), at<unsigned>(ws, o.m2), nclips);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }
@@ -1037,10 +1049,10 @@ int snd3_bf16_fwd(var_ctx* c, hipStream_t s, const float* w, const float* bias, 
     VAR_HIP_CHECK(c, hipGetLastError());
     static bool attr = false;
     if (!attr) {
-        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd_fwd_kernel<Geo3>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDSB));
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd_fwd_kernel<Geo3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDSB));
         attr = true;
     }
-    hipLaunchKernelGGL(snd_fwd_kernel<Geo3>, dim3(nclips < 256 ? nclips : 256), dim3(256), L::LDSB, s, at<uint4>(ws, o.y8),
+    hipLaunchKernelGGL((snd_fwd_kernel<Geo3, true>), dim3(nclips < 256 ? nclips : 256), dim3(256), L::LDSB, s, at<uint4>(ws, o.y8),
                        at<uint4>(ws, o.wp3), bias, y, (uint2*)nullptr, (unsigned*)nullptr, nclips);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
@@ -1054,13 +1066,16 @@ static int dgrad_launch(var_ctx* c, hipStream_t s, const float* w, const uint4* 
     VAR_HIP_CHECK(c, hipGetLastError());
     static bool attr = false;
     if (!attr) {
-        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd_dgrad_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDSB));
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd_dgrad_kernel<G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDSB));
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd_dgrad_kernel<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDSB));
         attr = true;
     }
+    if ((dx8 != nullptr) != G::OUT8 || (dx16 != nullptr) != G::OUT16) { VAR_SET_ERR(c, "sound data gradient: output set does not match the layer"); return VAR_ERR_ARG; }
     const int ntiles = nclips * G::TILES;
     *nparts = ntiles < 256 ? ntiles : 256;
     ProfScope prof(c, s, tag);
-    hipLaunchKernelGGL(snd_dgrad_kernel<G>, dim3(*nparts), dim3(256), L::LDSB, s, gy8, wpt, mask, dx, dx8, dx16, bias_part, nclips);
+    if (dx) hipLaunchKernelGGL((snd_dgrad_kernel<G, true>), dim3(*nparts), dim3(256), L::LDSB, s, gy8, wpt, mask, dx, dx8, dx16, bias_part, nclips);
+    else hipLaunchKernelGGL((snd_dgrad_kernel<G, false>), dim3(*nparts), dim3(256), L::LDSB, s, gy8, wpt, mask, dx, dx8, dx16, bias_part, nclips);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }
