@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(512) gru_seq_bwd_kernel(float* __restrict__ DH
                                                           const float* __restrict__ Z, const float* __restrict__ Nn,
                                                           const float* __restrict__ GHN, float* __restrict__ DGI, float* __restrict__ DGH,
                                                           int nclips, long dirGI, long dirH, long dirS, long dirDGH, unsigned* cnt0,
-                                                          unsigned* tmo, float* __restrict__ bias_part) {
+                                                          unsigned* tmo, float* __restrict__ bias_part, int store32) {
     extern __shared__ __attribute__((aligned(16))) float red[];                       // quad_slot(cbk 4 + kq, ..) x 16 B | go
     int* go = (int*)(red + 2 * 4 * 16 * RS);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, cbk = wave & 1, kq = wave >> 1;
@@ -461,8 +461,10 @@ __global__ void __launch_bounds__(512) gru_seq_bwd_kernel(float* __restrict__ DH
             __builtin_amdgcn_raw_buffer_store_b64(pr, gr, stoff, rows, kSc1);
             __builtin_amdgcn_raw_buffer_store_b64(pz, gr, stoff + GH * 2, rows, kSc1);
             __builtin_amdgcn_raw_buffer_store_b64(pn, gr, stoff + 2 * GH * 2, rows, kSc1);
-            *(float4*)dgi = dr; *(float4*)(dgi + GH) = dz; *(float4*)(dgi + 2 * GH) = dn;
-            *(float4*)dgh = dr; *(float4*)(dgh + GH) = dz; *(float4*)(dgh + 2 * GH) = dnr;
+            if (store32) {      // (the fp32 arrays: nothing reads them when the products take the bf16 copies and the bias sums are formed here)
+                *(float4*)dgi = dr; *(float4*)(dgi + GH) = dz; *(float4*)(dgi + 2 * GH) = dn;
+                *(float4*)dgh = dr; *(float4*)(dgh + GH) = dz; *(float4*)(dgh + 2 * GH) = dnr;
+            }
             uint2* i16 = DGI16 + ((long)dir * SEQ * nclips + (long)clip * SEQ + t) * (G3 / 4) + 8 * js + jq;
             i16[0] = make_uint2(pr.x, pr.y); i16[GH / 4] = make_uint2(pz.x, pz.y);
             i16[2 * GH / 4] = make_uint2(pack2(dn.x, dn.y), pack2(dn.z, dn.w));
@@ -633,7 +635,7 @@ int gru_bf16_seq_fwd(var_ctx* c, hipStream_t s, const float* GI, float* Hb, cons
 // grads: the parameter gradient (n floats), overwritten with NaN by a trailing check if either sequence kernel timed out
 int gru_bf16_seq_bwd(var_ctx* c, hipStream_t s, float* DH, const float* Hb, const float* R, const float* Z, const float* Nn,
                      const float* GHN, float* DGI, float* DGH, int nclips, int maxclips, long dirGI, long dirH, long dirS, long dirDGH,
-                     void* ws) {
+                     void* ws, int store32) {
     if (!seq_fits(c, nclips)) return 1;
     unsigned* sync = gru_sync(ws, maxclips);
     unsigned* cnt = sync + 4 + sync_counters(maxclips);
@@ -641,7 +643,7 @@ int gru_bf16_seq_bwd(var_ctx* c, hipStream_t s, float* DH, const float* Hb, cons
     hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3(NJS, (nclips + 63) / 64, 2), dim3(512), kBwdLds + 16, s, DH, Hb,
                        (const uint4*)((const char*)ws + kWfBytes), (uint2*)gru_bf16_dgh16(ws, maxclips),
                        (uint2*)gru_bf16_dgi16(ws, maxclips), R, Z, Nn, GHN, DGI, DGH, nclips, dirGI, dirH, dirS, dirDGH, cnt, sync,
-                       gru_bf16_bias_part(ws, maxclips));
+                       gru_bf16_bias_part(ws, maxclips), store32);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }

@@ -798,8 +798,10 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
         const int dh_split = rec_split(4 * ((nclips + 63) / 64) * 2, kG3 / GG_KC, 8);
         int whole = 0;
         if (st->bf16 && st->gru_seq) {
+            // (the fp32 gate gradients have no reader in this form -- the four products take the bf16 copies, the bias sums
+            //  are formed in the kernel --: 0.9 GB of stores per pass at batch 256; written only for the debug mode)
             const int r = gru_bf16_seq_bwd(c, s, st->DH, st->Hb, st->R, st->Z, st->Nn, st->GHN, st->DGI, st->DGH, nclips, 2 * st->maxB,
-                                           dirGI, dirH, dirS, dirDGH, st->gruws);
+                                           dirGI, dirH, dirS, dirDGH, st->gruws, st->keep32 ? 1 : 0);
             if (r < 0) return r;
             whole = r == 0;
         }
@@ -837,6 +839,7 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
                 use_bf16_copies(c, q, gru_bf16_h16(st->gruws), gru_bf16_dgh16(st->gruws, 2 * st->maxB));
                 if (q.a16) p = q;
             }
+            if (whole && !p.b16) { VAR_SET_ERR(c, "iTHOR backward: dW_hh needs the fp32 gate gradients the GRU pass did not write"); return VAR_ERR_STATE; }
             RUN(gg(c, s, p, 2));
             for (int d = 0; d < 2; ++d) RUN(slab_reduce(c, s, G + L.w_hh[d], st->slab + d * one, (int)one, p.nsplit, 2 * one));
             // dW_ih[dir][g][i] = sum_{clip,t} DGI[dir][clip,t][g] * X[clip,t][i]
@@ -847,6 +850,7 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             p.C = st->slab; p.scm = 1; p.scn = kGin; p.zC = onei; p.sC = 2 * onei;
             p.a16 = p.b16 = 0;
             use_bf16_copies(c, p, gru_bf16_x16(st->gruws, 2 * st->maxB), gru_bf16_dgi16(st->gruws, 2 * st->maxB));
+            if (whole && !p.b16) { VAR_SET_ERR(c, "iTHOR backward: dW_ih needs the fp32 gate gradients the GRU pass did not write"); return VAR_ERR_STATE; }
             RUN(gg(c, s, p, 2));
             for (int d = 0; d < 2; ++d) RUN(slab_reduce(c, s, G + L.w_ih[d], st->slab + d * onei, (int)onei, p.nsplit, 2 * onei));
         }
@@ -876,6 +880,7 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             q.C = st->gs[3]; q.scm = 1; q.scn = kGin;
             use_bf16_copies(c, q, w16 + (long)kG3 * kGin, (const unsigned short*)gru_bf16_dgi16(st->gruws, 2 * st->maxB) + dirGI);
             if (!q.a16) use_bf16_copies(c, q, nullptr, (const unsigned short*)gru_bf16_dgi16(st->gruws, 2 * st->maxB) + dirGI);
+            if (whole && !(p.b16 && q.b16)) { VAR_SET_ERR(c, "iTHOR backward: dX needs the fp32 gate gradients the GRU pass did not write"); return VAR_ERR_STATE; }
             RUN(gg(c, s, q));
         }
         RUN(relu_mask(c, s, st->gs[3], st->s[3], (long)rows * kGin));

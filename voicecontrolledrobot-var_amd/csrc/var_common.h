@@ -295,7 +295,7 @@ int gru_bf16_seq_fwd(var_ctx* c, hipStream_t s, const float* GI, float* Hb, cons
                      float* GHN, int nclips, int maxclips, long dirGI, long dirH, long dirS, int save, void* ws, int drop_one);
 int gru_bf16_seq_bwd(var_ctx* c, hipStream_t s, float* DH, const float* Hb, const float* R, const float* Z, const float* Nn,
                      const float* GHN, float* DGI, float* DGH, int nclips, int maxclips, long dirGI, long dirH, long dirS, long dirDGH,
-                     void* ws);
+                     void* ws, int store32);      // store32 = 0: DGI / DGH (fp32) are not written, only their bf16 copies
 int gru_bf16_reset_timeout(var_ctx* c, hipStream_t s, int maxclips, void* ws);
 int gru_bf16_poison_on_timeout(var_ctx* c, hipStream_t s, float* grads, int n, int maxclips, void* ws);
 int gru_bf16_timeout_word(var_ctx* c, int maxclips, void* ws, unsigned* out);
