@@ -409,11 +409,12 @@ def test_bf16_mode_single_sound_inputs(var_amd):
     np.testing.assert_allclose(only_n.cpu().numpy(), n_both.cpu().numpy(), atol=1e-6)
 
 
-@pytest.mark.parametrize("B", [3, 40])
+@pytest.mark.parametrize("B", [1, 3, 40, 100])
 def test_gru_one_launch_per_pass_equals_one_launch_per_step(var_amd, B):
     """The persistent GRU kernels (73 steps in one launch, the workgroups of a clip slice handing the state over through
     memory) do the per-step kernels' arithmetic in the same order: loss and gradients must be bit-identical, and no
-    hand-off may have timed out.  B = 40 is two clip slices, the second ragged (80 clips = 64 + 16)."""
+    hand-off may have timed out.  B = 40 is two clip slices, the second ragged (80 clips = 64 + 16); B = 100 four slices
+    (200 clips: the resident-panel input projection and the ring variants of the dense kernel run at that size too)."""
     import ctypes
     from var_amd._lib import Context
     torch.manual_seed(5)
