@@ -59,10 +59,31 @@ __device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.f + __e
 __device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
 
 // W_hh (dir stride dirP floats; [1536][512]) -> both fragment tables
+// ... and, in the same launch (they were seven launches of a few us each): W_ih -> bf16, zero initial states (fp32 and bf16
+// rows of step 0, both directions), zero forward hand-off counters
+struct GruPrep { const float* w_ih; uint4* wih16; uint4* h16; uint4* hb; unsigned* cnt; long h16dir, hbdir; int nrow16, nrow32, ncnt; };
 __global__ void __launch_bounds__(256) gru_pack_kernel(const float* __restrict__ w_hh, long dirP, uint4* __restrict__ wf,
-                                                       uint4* __restrict__ wb) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+                                                       uint4* __restrict__ wb, const GruPrep q) {
+    int i = blockIdx.x * 256 + threadIdx.x;
     const int nf = 2 * NJS * 32 * 3 * 64, nb = 2 * NJS * 96 * 64;
+    if (i >= nf + nb) {
+        i -= nf + nb;
+        const int n8 = G3 * 448 / 8;
+        if (i < 2 * n8) {                                    // W_ih [dir][1536][448]
+            const int d = i / n8, e = i - d * n8;
+            const float4* x = (const float4*)(q.w_ih + d * dirP) + 2 * e;
+            const float4 a = x[0], b = x[1];
+            q.wih16[i] = make_uint4(pack2(a.x, a.y), pack2(a.z, a.w), pack2(b.x, b.y), pack2(b.z, b.w));
+            return;
+        }
+        i -= 2 * n8;
+        if (i < 2 * q.nrow16) { const int d = i / q.nrow16; q.h16[d * q.h16dir + (i - d * q.nrow16)] = make_uint4(0, 0, 0, 0); return; }
+        i -= 2 * q.nrow16;
+        if (i < 2 * q.nrow32) { const int d = i / q.nrow32; q.hb[d * q.hbdir + (i - d * q.nrow32)] = make_uint4(0, 0, 0, 0); return; }
+        i -= 2 * q.nrow32;
+        if (i < q.ncnt) q.cnt[i] = 0u;
+        return;
+    }
     unsigned v[8];
     if (i < nf) {
         const int lane = i & 63, gate = (i >> 6) % 3, ks = (i / 192) & 31, js = (i / (192 * 32)) % NJS, dir = i / (192 * 32 * NJS);
@@ -565,19 +586,18 @@ int gru_bf16_to_bf16(var_ctx* c, hipStream_t s, const float* x, void* y, long n)
 }
 
 // once per forward: both fragment tables of W_hh, and the zero initial state's bf16 copy
-int gru_bf16_pack(var_ctx* c, hipStream_t s, const float* w_hh, const float* w_ih, long dirP, int nclips, int maxclips, void* ws) {
-    for (int d = 0; d < 2; ++d) {                        // W_ih [dir][1536][448] as bf16: the A operand of the input projection and of dX
-        const long n8 = (long)G3 * 448 / 8;
-        hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, (const float4*)(w_ih + d * dirP),
-                           (uint4*)gru_bf16_wih16(ws, maxclips) + d * n8, n8);
-    }
+int gru_bf16_pack(var_ctx* c, hipStream_t s, const float* w_hh, const float* w_ih, long dirP, int nclips, int maxclips, float* Hb,
+                  long dirH, void* ws) {
     uint4* wf = (uint4*)ws;
     uint4* wb = (uint4*)((char*)ws + kWfBytes);
-    const int n = (int)((kWfBytes + kWbBytes) / 16);
-    hipLaunchKernelGGL(gru_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w_hh, dirP, wf, wb);
+    GruPrep q{};
+    q.w_ih = w_ih; q.wih16 = (uint4*)gru_bf16_wih16(ws, maxclips);      // the A operand of the input projection and of dX
+    q.h16 = (uint4*)gru_bf16_h16(ws); q.h16dir = (long)(SEQ + 1) * nclips * GH * 2 / 16; q.nrow16 = nclips * GH * 2 / 16;
+    q.hb = (uint4*)Hb; q.hbdir = dirH * 4 / 16; q.nrow32 = nclips * GH * 4 / 16;
+    q.cnt = gru_sync(ws, maxclips) + 4; q.ncnt = sync_counters(maxclips);
+    const int n = (int)((kWfBytes + kWbBytes) / 16) + 2 * (G3 * 448 / 8) + 2 * q.nrow16 + 2 * q.nrow32 + q.ncnt;
+    hipLaunchKernelGGL(gru_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w_hh, dirP, wf, wb, q);
     VAR_HIP_CHECK(c, hipGetLastError());
-    for (int d = 0; d < 2; ++d)                          // H16 [dir][step 0]
-        VAR_HIP_CHECK(c, hipMemsetAsync((char*)gru_bf16_h16(ws) + (long)d * (SEQ + 1) * nclips * GH * 2, 0, (long)nclips * GH * 2, s));
     static bool attr = false;
     if (!attr) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)gru_step_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds));
@@ -622,8 +642,7 @@ int gru_bf16_reset_timeout(var_ctx* c, hipStream_t s, int maxclips, void* ws) {
 int gru_bf16_seq_fwd(var_ctx* c, hipStream_t s, const float* GI, float* Hb, const float* b_hh, long dirP, float* R, float* Z, float* Nn,
                      float* GHN, int nclips, int maxclips, long dirGI, long dirH, long dirS, int save, void* ws, int drop_one) {
     if (!seq_fits(c, nclips)) return 1;
-    unsigned* sync = gru_sync(ws, maxclips);
-    VAR_HIP_CHECK(c, hipMemsetAsync(sync + 4, 0, 4L * sync_counters(maxclips), s));
+    unsigned* sync = gru_sync(ws, maxclips);                 // (its counters were zeroed by gru_bf16_pack, which precedes every forward)
     // drop_one (tests): one hidden slice of every group is not launched, so no group ever completes -- what a grid that is
     // not fully resident looks like to the others: their waits must expire and the launch must end
     hipLaunchKernelGGL(gru_seq_fwd_kernel, dim3(drop_one ? NJS - 1 : NJS, (nclips + 63) / 64, 2), dim3(512), kFwdLds + 16, s, GI, Hb, (uint2*)gru_bf16_h16(ws),

@@ -645,7 +645,7 @@ static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* imag
             p.Bm = st->s[3]; p.sbk = 1; p.sbn = kGin; p.zB = 0;
             p.C = st->GI; p.scm = 1; p.scn = kG3; p.zC = dirGI; p.bias = P + L.b_ih[0]; p.zbias = dirP;
             if (st->bf16) {
-                RUN(gru_bf16_pack(c, s, P + L.w_hh[0], P + L.w_ih[0], dirP, nclips, 2 * st->maxB, st->gruws));
+                RUN(gru_bf16_pack(c, s, P + L.w_hh[0], P + L.w_ih[0], dirP, nclips, 2 * st->maxB, st->Hb, dirH, st->gruws));
                 RUN(gru_bf16_convert_x(c, s, st->s[3], (long)rows * kGin, 2 * st->maxB, st->gruws));
                 auto q = p;
                 q.zA = (long)kG3 * kGin;
@@ -654,7 +654,8 @@ static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* imag
             }
             RUN(gg(c, s, p, 2));
         }
-        for (int d = 0; d < 2; ++d) VAR_HIP_CHECK(c, hipMemsetAsync(st->Hb + d * dirH, 0, sizeof(float) * nclips * kGh, s));
+        if (!st->bf16)      // (bf16 mode: gru_bf16_pack zeroed the initial states)
+            for (int d = 0; d < 2; ++d) VAR_HIP_CHECK(c, hipMemsetAsync(st->Hb + d * dirH, 0, sizeof(float) * nclips * kGh, s));
         int whole = 0;       // the 73 steps in one launch
         if (st->bf16 && st->gru_seq) {
             const int r = gru_bf16_seq_fwd(c, s, st->GI, st->Hb, P + L.b_hh[0], dirP, st->R, st->Z, st->Nn, st->GHN, nclips, 2 * st->maxB,

@@ -282,8 +282,10 @@ int gru_bf16_convert_x(var_ctx* c, hipStream_t s, const float* x, long n, int ma
 void* gru_bf16_wih16(void* ws, int maxclips); //   W_ih (dir, 1536, 448)
 // fp32 (dir, clip slice of 64, [b_ih: r z n | b_hh: r z n], 512): per-slice bias-gradient sums left by gru_bf16_seq_bwd
 float* gru_bf16_bias_part(void* ws, int maxclips);
-// once per forward, before the input projection: W_hh's fragment tables, W_ih's bf16 copy, the zero initial state
-int gru_bf16_pack(var_ctx* c, hipStream_t s, const float* w_hh, const float* w_ih, long dirP, int nclips, int maxclips, void* ws);
+// once per forward, before the input projection, ONE launch: W_hh's fragment tables, W_ih's bf16 copy, the zero initial
+// state (row 0 of Hb, direction stride dirH floats, and of the bf16 copy), zero forward hand-off counters
+int gru_bf16_pack(var_ctx* c, hipStream_t s, const float* w_hh, const float* w_ih, long dirP, int nclips, int maxclips, float* Hb,
+                  long dirH, void* ws);
 int gru_bf16_step_fwd(var_ctx* c, hipStream_t s, const float* GI, float* Hb, const float* b_hh, long dirP, float* R, float* Z,
                       float* Nn, float* GHN, int nclips, int maxclips, int step, long dirGI, long dirH, long dirS, int save, void* ws);
 int gru_bf16_step_bwd(var_ctx* c, hipStream_t s, float* DH, const float* Hb, const float* R, const float* Z, const float* Nn,
