@@ -101,9 +101,11 @@ __device__ __forceinline__ void img_dgrad_body(const float* __restrict__ gy, con
         const bool leader = kc == 0 && part < 2;
         const int iy_pre = band * C::RI + 2 * j + py;
         const bool st_ok = ppvalid && unit < total_units && iy_pre < C::H;
-        const size_t o_pre = (size_t)b * C::CIN * C::H * C::W + (size_t)(st_ok ? iy_pre : 0) * C::W + 2 * i;
+        const size_t o_pre = (size_t)(st_ok ? b : 0) * C::CIN * C::H * C::W + (size_t)(st_ok ? iy_pre : 0) * C::W + 2 * i;
         float xm0[16], xm1[16];
-        if (leader && st_ok) {
+        // (the branch is wave-uniform and the loads inside unconditional -- clamped addresses for lanes without a pixel --:
+        //  behind the per-lane `st_ok` they were waited for before the branch was left, i.e. before the matrix work)
+        if (leader) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -112,9 +114,10 @@ __device__ __forceinline__ void img_dgrad_body(const float* __restrict__ gy, con
                     const float2 xv = *(const float2*)(x + oc);
                     xm0[r] = xv.x; xm1[r] = xv.y;
                 } else {
-                    const float t1 = x[oc + (2 * i + 1 < C::W ? 1 : 0)];      // (unconditional: a load behind a branch is waited for at once)
+                    // (unconditional, from a clamped address, and NOT selected here: a load behind a branch is waited for at
+                    //  once, and so is one whose value feeds a select -- the epilogue only uses xm1 where 2 i + 1 < W)
                     xm0[r] = x[oc];
-                    xm1[r] = 2 * i + 1 < C::W ? t1 : 0.f;
+                    xm1[r] = x[oc + (2 * i + 1 < C::W ? 1 : 0)];
                 }
             }
         }
@@ -309,12 +312,11 @@ __device__ __forceinline__ void img_dgrad16_body(const float* __restrict__ gy, c
         const bool ok = ppvalid && iy < C::H;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            // (unconditional loads from clamped addresses, the zero selected afterwards: `ok ? x[oc] : 0.f` is compiled as a
-            //  branch around each load with a full wait behind it -- sixteen load latencies in a row)
+            // (unconditional loads from clamped addresses: `ok ? x[oc] : 0.f` is compiled as a branch around each load with a
+            //  full wait behind it -- sixteen load latencies in a row)
             const size_t oc = o0 + (size_t)r * C::H * C::W + (size_t)(ok ? iy : 0) * C::W;
-            const float t0 = x[oc], t1 = x[oc + (2 * i + 1 < C::W ? 1 : 0)];
-            xm[py][r][0] = ok ? t0 : 0.f;
-            xm[py][r][1] = (ok && 2 * i + 1 < C::W) ? t1 : 0.f;
+            xm[py][r][0] = x[oc];                                            // (raw: the epilogue uses them only where ok / 2 i + 1 < W;
+            xm[py][r][1] = x[oc + (2 * i + 1 < C::W ? 1 : 0)];               //  a select here would wait for the loads before the matrix work)
         }
     }
     __syncthreads();
