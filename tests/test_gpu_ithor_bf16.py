@@ -518,3 +518,39 @@ def test_dense_products_on_bf16_operand_copies(var_amd, akf, bkf, M, N, K, add, 
     assert torch.isfinite(got).all()
     err = float((got - ref).abs().max())
     assert err < 2e-5 * float(ref.abs().max()) * max(1.0, (K / 512) ** 0.5), err
+
+
+@pytest.mark.parametrize("h", [96, 84])
+def test_image_layer_6_as_a_dense_layer_vs_float64_on_rounded_operands(var_amd, h):
+    """bf16 mode, batch >= 64: the last image convolution (3x3 stride 2 on the 6x6 | 5x5 pooled map) runs as two dense
+    products over the filter scattered into a (1152, 128 HP HP) matrix.  Forward (bias + ReLU) and data gradient against
+    float64 convolutions of the bf16-rounded operands."""
+    B = 64
+    torch.manual_seed(5)
+    m = var_amd.IthorVARPretextNet(cfg(h)).to("cuda").set_precision("bf16")
+    pos, neg = sounds(B, 31)
+    img = torch.randint(0, 256, (B, 3, h, h), dtype=torch.uint8, generator=torch.Generator().manual_seed(h + 1)).cuda()
+    tr = var_amd.IthorTrainer(m)
+    tr.loss_and_grads(img, pos, neg)
+    from var_amd._lib import Context
+    ctx = Context.get(0)
+    hp = 6 if h == 96 else 5
+
+    def buf(name, c, hw):
+        return ctx.debug_buffer("ithor_" + name)[:B * c * hw * hw].view(B, c, hw, hw).cpu()
+
+    p5, a6, gp5, ga6 = buf("p5", 128, hp), buf("a6", 128, 3), buf("gp5", 128, hp), buf("ga6", 128, 3)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    w6, b6 = sd["imgBranch.14.weight"], sd["imgBranch.14.bias"]
+    assert tuple(w6.shape) == (128, 128, 3, 3)
+    F = torch.nn.functional
+
+    def close(got, ref, what):
+        scale = float(ref.abs().max())
+        err = float((got.double() - ref).abs().max())
+        assert scale > 0 and err < 3e-5 * scale, (what, err, scale)
+
+    close(a6, torch.relu(F.conv2d(bf16_round(p5), bf16_round(w6), b6.double(), stride=2, padding=1)), "a6")
+    ref = F.conv_transpose2d(bf16_round(ga6), bf16_round(w6), stride=2, padding=1, output_padding=hp - 5)
+    assert tuple(ref.shape) == tuple(gp5.shape)
+    close(gp5, ref, "gp5")

@@ -59,6 +59,10 @@ struct ithor_state {
     float *slab = nullptr, *bslab = nullptr;              // split-K partial sums / bias-sum partials
     long bs_used = 0;                                     // bslab is handed out in pieces (bs_take) so that the folds can wait
     void* folds = nullptr;                                // FoldJobs*: folds of bslab partials, run together (flush_folds)
+    // bf16 mode, layer 6 as a dense layer (l6_*): the expanded filter matrix, its bias, bf16 copies of the two activations
+    unsigned short *l6w = nullptr, *l6x = nullptr, *l6g = nullptr;
+    float* l6b = nullptr;
+    bool l6_ready = false;                                // this forward built l6w / l6b (the backward re-uses them)
     void* imgws = nullptr;                                // fragment-ordered filters of img_bf16.hip
     void* gruws = nullptr;                                // W_hh in MFMA fragment order (gru_bf16.hip)
     void* bfws = nullptr;                                 // bf16 images / packed filters of the staged sound kernels (snd_bf16.hip)
@@ -576,6 +580,74 @@ static ConvDims snd_dims(int l, int n) {                              // l = 1..
 
 #define RUN(x) do { int r_ = (x); if (r_ != VAR_OK) return r_; } while (0)
 
+// ---- layer 6 (3x3 stride 2 on a 6 x 6 | 5 x 5 map -> 3 x 3) as a dense layer, bf16 mode -----------------------------------
+// On maps this small the gather-GEMM spends 93 us on 0.7 GFLOP (and 46 us on the data gradient).  The convolution IS a
+// matrix product with the image's whole input map as the reduction index: out[b][oc*9 + p] = sum_k W'[oc*9 + p][k] x[b][k],
+// k = c*HP*HP + iy*HP + ix, W' = the filter scattered to the positions each output pixel sees (zeros elsewhere: 4x the
+// arithmetic, still nothing).  W' is rebuilt from the parameters in every forward (10 MB of bf16); both products then run
+// on the dense kernel like every other big product of the mode, the data gradient with W' transposed by its strides.
+__global__ void __launch_bounds__(256) l6_expand_kernel(const float* __restrict__ w, const float* __restrict__ bias, uint4* __restrict__ wx,
+                                                        float* __restrict__ bx, int HP) {
+    const int KX = 128 * HP * HP, K8 = KX / 8;
+    const int i = blockIdx.x * 256 + threadIdx.x;               // (m, 8 consecutive k)
+    if (i < kIRaw) bx[i] = bias[i / 9];
+    if (i >= kIRaw * K8) return;
+    const int m = i / K8, k0 = (i - m * K8) * 8, oc = m / 9, p = m - oc * 9, oy = p / 3, ox = p - oy * 3;
+    unsigned v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = k0 + e, c = k / (HP * HP), r = k - c * HP * HP, iy = r / HP, ix = r - iy * HP;
+        const int ky = iy - (2 * oy - 1), kx = ix - (2 * ox - 1);
+        const bool hit = (unsigned)ky < 3u && (unsigned)kx < 3u;
+        const float t = w[((oc * 128 + c) * 3 + (hit ? ky : 0)) * 3 + (hit ? kx : 0)];
+        v[e] = hit ? dense16::bf16_bits(t) : 0u;
+    }
+    wx[i] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+}
+
+// 0 = done on the dense kernel, 1 = take the convolution path (fp32 mode, batch < 64, a map the expansion does not cover)
+static int l6_dense_fwd(var_ctx* c, hipStream_t s, const float* P, int B) {
+    ithor_state* st = ith(c);
+    const IthorLayout& L = st->L;
+    const int HP = st->hs[4], KX = 128 * HP * HP;
+    st->l6_ready = false;
+    if (!st->bf16 || B < 64 || st->hs[5] != 3 || (HP != 5 && HP != 6) || !st->l6w) return 1;
+    hipLaunchKernelGGL(l6_expand_kernel, g1((long)kIRaw * (KX / 8)), dim3(256), 0, s, P + L.iw[5], P + L.ib[5], (uint4*)st->l6w, st->l6b, HP);
+    IT_CHECK(c);
+    RUN(gru_bf16_to_bf16(c, s, st->p[5], st->l6x, (long)B * KX));
+    // 9 x 2 tiles only: K is split 8 ways over the grid (slabs), a finish pass adds them with bias and ReLU
+    DenseP<true, true, 2> p{};
+    p.M = kIRaw; p.N = B; p.K = KX; p.nsplit = eff_split(KX, 8, dense16::TK);
+    p.A = (const float*)st->l6w; p.sam = KX; p.sak = 1; p.a16 = 1;
+    p.Bm = (const float*)st->l6x; p.sbk = 1; p.sbn = KX; p.b16 = 1;
+    p.C = st->slab; p.scm = 1; p.scn = kIRaw; p.sC = (long)B * kIRaw;
+    if (!dense16::eligible(p) || p.nsplit * p.sC > kSlabFloats) return 1;
+    RUN(gg(c, s, p));
+    const long n = (long)B * kIRaw;
+    hipLaunchKernelGGL(gg_finish_kernel, g1(n), dim3(256), 0, s, st->a[6], st->slab, n, p.nsplit, p.sC, P + L.ib[5], 128, 9, 1);
+    IT_CHECK(c);
+    st->l6_ready = true;
+    return VAR_OK;
+}
+// gp[5] = ga[6] W'  (after l6_dense_fwd of the same step)
+static int l6_dense_dgrad(var_ctx* c, hipStream_t s, int B) {
+    ithor_state* st = ith(c);
+    const int HP = st->hs[4], KX = 128 * HP * HP;
+    if (!st->bf16 || !st->l6_ready) return 1;
+    RUN(gru_bf16_to_bf16(c, s, st->ga[6], st->l6g, (long)B * kIRaw));
+    DenseP<false, true, 2> p{};
+    p.M = KX; p.N = B; p.K = kIRaw; p.nsplit = eff_split(kIRaw, 4, dense16::TK);
+    p.A = (const float*)st->l6w; p.sam = 1; p.sak = KX; p.a16 = 1;
+    p.Bm = (const float*)st->l6g; p.sbk = 1; p.sbn = kIRaw; p.b16 = 1;
+    p.C = st->slab; p.scm = 1; p.scn = KX; p.sC = (long)B * KX;
+    if (!dense16::eligible(p) || p.nsplit * p.sC > kSlabFloats) return 1;
+    RUN(gg(c, s, p));
+    const long n = (long)B * KX;
+    hipLaunchKernelGGL(gg_finish_kernel, g1(n), dim3(256), 0, s, st->gp[5], st->slab, n, p.nsplit, p.sC, (const float*)nullptr, 1, 1, 0);
+    IT_CHECK(c);
+    return VAR_OK;
+}
+
 // ---- forward ----------------------------------------------------------------------------------------------------
 static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* image, int is_u8, long bstride, const float* pos,
                      const float* neg, int B, bool save) {
@@ -607,7 +679,11 @@ static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* imag
                 if (r == 1) r = conv_fwd<G3s1, false, false>(c, s, img_dims(st, l + 1, B), st->p[l], P + L.iw[l], P + L.ib[l], st->a[l + 1]);
                 RUN(r);
             }
-            else RUN((conv_fwd<G3s2, false, false>(c, s, img_dims(st, 6, B), st->p[5], P + L.iw[5], P + L.ib[5], st->a[6])));
+            else {
+                int r = l6_dense_fwd(c, s, P, B);
+                if (r == 1) r = conv_fwd<G3s2, false, false>(c, s, img_dims(st, 6, B), st->p[5], P + L.iw[5], P + L.ib[5], st->a[6]);
+                RUN(r);
+            }
         }
         RUN(linear_fwd(c, s, st->a[6], P + L.ih_w0, P + L.ih_b0, st->hid_i, B, kIRaw, 128, 1));
         RUN(linear_fwd(c, s, st->hid_i, P + L.ih_w1, P + L.ih_b1, st->raw, B, 128, 3, 0));
@@ -723,7 +799,9 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
             const ConvDims d = img_dims(st, 6, B);
             RUN((conv_wgrad<G3s2, false, false>(c, s, d, st->p[5], st->ga[6], G + L.iw[5])));
             RUN(chan_sum(c, s, st->ga[6], G + L.ib[5], B, 128, 9));
-            RUN((conv_dgrad<G3s2, false>(c, s, d, st->ga[6], P + L.iw[5], st->gp[5])));
+            int r = l6_dense_dgrad(c, s, B);
+            if (r == 1) r = conv_dgrad<G3s2, false>(c, s, d, st->ga[6], P + L.iw[5], st->gp[5]);
+            RUN(r);
         }
         bool ga1_summed = false;
         for (int l = 5; l >= 2; --l) {
@@ -1076,6 +1154,8 @@ int var_ithor_plan(var_ctx* c, int max_batch, int img_hw) {
     const long oraw = take(9 * B), ograw = take(9 * B), oemb = take(9 * B), ogemb = take(9 * B), oloss = take(64);
     const long obf = take((snd_bf16_workspace_bytes((int)C2) + 3) / 4), ogru = take((gru_bf16_workspace_bytes((int)C2) + 3) / 4);
     const long oimg = take((img_bf16_workspace_bytes() + 3) / 4);
+    const long kx6 = 128L * 36;                                // layer 6 as a dense layer: room for the 6 x 6 map
+    const long ol6w = take(kIRaw * kx6 / 2), ol6x = take(B * kx6 / 2), ol6g = take(B * kIRaw / 2 + 8), ol6b = take(kIRaw);
     VAR_HIP_CHECK(c, hipMalloc((void**)&st->ws, (size_t)total * sizeof(float)));
     float* w = (float*)st->ws;
     for (int l = 1; l <= 6; ++l) { st->a[l] = w + oa[l]; st->ga[l] = w + oga[l]; }
@@ -1088,6 +1168,7 @@ int var_ithor_plan(var_ctx* c, int max_batch, int img_hw) {
     st->hid_i = w + ohi; st->ghid_i = w + oghi; st->hid_s1 = w + ohs1; st->ghid_s1 = w + oghs1;
     st->hid_s2 = w + ohs2; st->ghid_s2 = w + oghs2;
     st->bfws = w + obf; st->gruws = w + ogru; st->imgws = w + oimg;
+    st->l6w = (unsigned short*)(w + ol6w); st->l6x = (unsigned short*)(w + ol6x); st->l6g = (unsigned short*)(w + ol6g); st->l6b = w + ol6b;
     st->raw = w + oraw; st->graw = w + ograw; st->emb = w + oemb; st->gemb = w + ogemb; st->loss = w + oloss;
     RUN(gru_bf16_reset_timeout(c, nullptr, (int)C2, st->gruws));
     VAR_HIP_CHECK(c, hipStreamSynchronize(nullptr));
