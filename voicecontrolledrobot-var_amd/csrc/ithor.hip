@@ -530,25 +530,119 @@ static int chan_sum(var_ctx* c, hipStream_t s, const float* g, float* out, int o
     return slab_reduce(c, s, out, part, C, chunks, C);
 }
 
+// ---- the heads' small Linear layers in bf16 mode ---------------------------------------------------------------------
+// 128 -> 3, 128 -> 64, 64 -> 3, 1024 -> 128 over a few hundred rows: one or a handful of GEMM tiles each, 9-26 us apiece
+// on either GEMM engine (pure launch / pipeline latency), eleven products per step.  Plain vector-ALU kernels instead:
+// operands rounded to bf16 like every product of the mode, fp32 accumulation in a fixed order.
+__device__ __forceinline__ float bf16r(float x) { return __uint_as_float(dense16::bf16_bits(x) << 16); }
+// Y[row][o] = act(b[o] + sum_k X[row][k] W[o][k]): one wave per (row, o), lanes stride K (both rows read coalesced)
+__global__ void __launch_bounds__(256) small_linear_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                               const float* __restrict__ b, float* __restrict__ Y, int rows, int K, int O,
+                                                               int relu) {
+    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (pair >= rows * O) return;
+    const int row = pair / O, o = pair - row * O;
+    const float* x = X + (long)row * K;
+    const float* w = W + (long)o * K;
+    float acc = 0.f;
+    int k = lane;
+    for (; k + 64 * 7 < K; k += 64 * 8) {
+        float a[8], bb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a[u] = x[k + 64 * u]; bb[u] = w[k + 64 * u]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += bf16r(a[u]) * bf16r(bb[u]);
+    }
+    for (; k < K; k += 64) acc += bf16r(x[k]) * bf16r(w[k]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
+    if (lane == 0) { float v = acc + (b ? b[o] : 0.f); Y[pair] = relu ? fmaxf(v, 0.f) : v; }
+}
+// dW[o][k] = sum_row dY[row][o] X[row][k]: one thread per (o, k), consecutive threads walk k
+__global__ void __launch_bounds__(256) small_linear_dw_kernel(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ dW,
+                                                              int rows, int K, int O) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= O * K) return;
+    const int o = i / K, k = i - o * K;
+    float acc = 0.f;
+    int r = 0;
+    for (; r + 16 <= rows; r += 16) {                        // 32 loads in flight, then 16 products in row order
+        float g[16], x[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { g[u] = dY[(long)(r + u) * O + o]; x[u] = X[(long)(r + u) * K + k]; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += bf16r(g[u]) * bf16r(x[u]);
+    }
+    for (; r < rows; ++r) acc += bf16r(dY[(long)r * O + o]) * bf16r(X[(long)r * K + k]);
+    dW[i] = acc;
+}
+// dX[row][k] = sum_o dY[row][o] W[o][k]: one thread per (row, k)
+__global__ void __launch_bounds__(256) small_linear_dx_kernel(const float* __restrict__ W, const float* __restrict__ dY, float* __restrict__ dX,
+                                                              int rows, int K, int O) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * K) return;
+    const int row = i / K, k = i - row * K;
+    float acc = 0.f;
+    int o = 0;
+    for (; o + 16 <= O; o += 16) {
+        float g[16], w[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { g[u] = dY[(long)row * O + o + u]; w[u] = W[(long)(o + u) * K + k]; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += bf16r(g[u]) * bf16r(w[u]);
+    }
+    for (; o < O; ++o) acc += bf16r(dY[(long)row * O + o]) * bf16r(W[(long)o * K + k]);
+    dX[i] = acc;
+}
+static inline bool small_linear(const ithor_state* st, int rows, int K, int O) { return st->bf16 && (long)rows * K * O <= (80L << 20); }
+
 // Y (rows, O) = X (rows, K) W^T + b, optional ReLU
 static int linear_fwd(var_ctx* c, hipStream_t s, const float* X, const float* W, const float* b, float* Y, int rows, int K,
                       int O, int relu) {
     DenseP<true, true, 0> p{};
     p.M = O; p.N = rows; p.K = K; p.nsplit = 1;
     p.A = W; p.sam = K; p.sak = 1; p.Bm = X; p.sbk = 1; p.sbn = K; p.C = Y; p.scm = 1; p.scn = O; p.bias = b; p.relu = relu;
+    ithor_state* st = ith(c);
+    const int tiles = ((O + dense16::TM - 1) / dense16::TM) * ((rows + dense16::TN - 1) / dense16::TN);
+    if (st->bf16 && dense16::eligible(p) && tiles <= 16 && K >= 512) {
+        // a handful of tiles with a long K (the image head's 1152 -> 128 at batch 256 is TWO tiles: 67 us): split K over the
+        // grid into slabs, add them with bias and activation in a finish pass
+        DenseP<true, true, 2> q{};
+        q.M = O; q.N = rows; q.K = K; q.nsplit = eff_split(K, 128 / tiles > 16 ? 16 : 128 / tiles, dense16::TK);
+        q.A = W; q.sam = K; q.sak = 1; q.Bm = X; q.sbk = 1; q.sbn = K; q.C = st->slab; q.scm = 1; q.scn = O; q.sC = (long)rows * O;
+        if (q.nsplit > 1 && q.nsplit * q.sC <= kSlabFloats && dense16::eligible(q)) {
+            int r = gg(c, s, q); if (r) return r;
+            const long n = (long)rows * O;
+            hipLaunchKernelGGL(gg_finish_kernel, g1(n), dim3(256), 0, s, Y, st->slab, n, q.nsplit, q.sC, b, O, 1, relu);
+            IT_CHECK(c);
+            return VAR_OK;
+        }
+    }
+    if (small_linear(st, rows, K, O)) {
+        hipLaunchKernelGGL(small_linear_fwd_kernel, dim3((rows * O + 3) / 4), dim3(256), 0, s, X, W, b, Y, rows, K, O, relu);
+        IT_CHECK(c);
+        return VAR_OK;
+    }
     return gg(c, s, p);
 }
 // backward of that layer from dY (already masked by the layer's own ReLU): dW += dY^T X, db += colsum(dY), dX = dY W
 static int linear_bwd(var_ctx* c, hipStream_t s, const float* X, const float* W, const float* dY, float* dW, float* db,
                       float* dX, int rows, int K, int O) {
-    {
+    const bool small = small_linear(ith(c), rows, K, O);
+    if (small) {
+        hipLaunchKernelGGL(small_linear_dw_kernel, g1((long)O * K), dim3(256), 0, s, X, dY, dW, rows, K, O);
+        IT_CHECK(c);
+    } else {
         DenseP<false, false, 0> p{};
         p.M = K; p.N = O; p.K = rows; p.nsplit = 1;
         p.A = X; p.sam = 1; p.sak = K; p.Bm = dY; p.sbk = O; p.sbn = 1; p.C = dW; p.scm = 1; p.scn = K;
         int r = gg(c, s, p); if (r) return r;
     }
     int r = chan_sum(c, s, dY, db, rows, O, 1); if (r) return r;
-    if (dX) {
+    if (dX && small) {
+        hipLaunchKernelGGL(small_linear_dx_kernel, g1((long)rows * K), dim3(256), 0, s, W, dY, dX, rows, K, O);
+        IT_CHECK(c);
+    } else if (dX) {
         DenseP<false, true, 0> p{};
         p.M = K; p.N = rows; p.K = O; p.nsplit = 1;
         p.A = W; p.sam = 1; p.sak = K; p.Bm = dY; p.sbk = 1; p.sbn = O; p.C = dX; p.scm = 1; p.scn = K;
