@@ -42,6 +42,30 @@ __global__ void __launch_bounds__(256) c3_pack_kernel(const float* __restrict__ 
     wp[i] = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
 }
 
+// all eight tables of a step (layers 2-5, forward and data gradient) in one launch: table t = 2 (layer - 2) + dgrad at wp + t * kTabU4
+constexpr int kTabU4 = 8 * 9 * 4 * 64;                          // uint4 per table region (the largest: 128 x 64 channels)
+struct PackAll { const float* w[4]; };
+__global__ void __launch_bounds__(256) c3_pack_all_kernel(const PackAll q, uint4* __restrict__ wp) {
+    constexpr int IC[4] = {32, 32, 64, 64}, OC[4] = {32, 64, 64, 128};
+    int i = blockIdx.x * 256 + threadIdx.x;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int l = t >> 1, dgrad = t & 1, ic = dgrad ? OC[l] : IC[l], oc = dgrad ? IC[l] : OC[l];
+        const int ncb = oc / 32, n = (ic / 16) * 9 * ncb * 64;
+        if (i < n) {
+            const int lane = i & 63, cb = (i >> 6) % ncb, tap = (i / (64 * ncb)) % 9, kg = i / (64 * ncb * 9);
+            const int o = 32 * cb + (lane & 31), ic0 = 16 * kg + 8 * (lane >> 5);
+            const float* w = q.w[l];
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = dgrad ? w[((long)(ic0 + j) * oc + o) * 9 + 8 - tap] : w[((long)o * ic + ic0 + j) * 9 + tap];
+            wp[t * kTabU4 + i] = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+            return;
+        }
+        i -= n;
+    }
+}
+
 // Tile = NI images x TR rows x W columns (NI > 1 only with whole images, TR = H: the 24x24 and 12x12 maps); WGS workgroups per CU.
 template <int IC, int OC, int H, int TR, int NI>
 struct C3 {
@@ -203,12 +227,15 @@ __global__ void __launch_bounds__(256, WGS) c3_kernel(const float* __restrict__ 
 
 template <int IC, int OC, int H, int TR, int NI, int MODE, int WGS>
 int c3_launch(var_ctx* c, hipStream_t s, const float* x, const float* w, const float* bias, const float* mask, float* y, float* csum,
-              int* nparts, int B, void* wp) {
+              int* nparts, int B, void* wp, int prepacked) {
     using G = C3<IC, OC, H, TR, NI>;
     static_assert(WGS * G::LDSB <= 160 * 1024, "c3 LDS per CU");
     const int n = G::KG * 9 * G::NCB * 64;
-    hipLaunchKernelGGL(c3_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, (uint4*)wp, IC, OC, MODE);
-    VAR_HIP_CHECK(c, hipGetLastError());
+    static_assert(G::KG * 9 * G::NCB * 64 <= kTabU4, "fragment table region");
+    if (!prepacked) {
+        hipLaunchKernelGGL(c3_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, (uint4*)wp, IC, OC, MODE);
+        VAR_HIP_CHECK(c, hipGetLastError());
+    }
     static bool attr = false;
     if (!attr) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)c3_kernel<IC, OC, H, TR, NI, MODE, WGS>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDSB));
@@ -472,16 +499,28 @@ __global__ void __launch_bounds__(256) c1w_fold_kernel(const float* __restrict__
 
 }  // namespace
 
-long img_bf16_workspace_bytes() { return 8 * 9 * 4 * 1024 + 256; }      // the largest fragment table (128 x 64 channels)
+long img_bf16_workspace_bytes() { return 8L * kTabU4 * 16 + 256; }       // eight fragment tables (layers 2-5, forward / data gradient)
+
+// the eight tables from the four filters (OIHW fp32) in one launch; afterwards img_bf16_conv(..., prepacked = 1)
+int img_bf16_pack_all(var_ctx* c, hipStream_t s, const float* w2, const float* w3, const float* w4, const float* w5, void* ws) {
+    PackAll q{{w2, w3, w4, w5}};
+    int total = 0;
+    constexpr int IC[4] = {32, 32, 64, 64}, OC[4] = {32, 64, 64, 128};
+    for (int l = 0; l < 4; ++l) total += ((IC[l] / 16) * 9 * (OC[l] / 32) + (OC[l] / 16) * 9 * (IC[l] / 32)) * 64;      // forward + data gradient
+    hipLaunchKernelGGL(c3_pack_all_kernel, dim3((total + 255) / 256), dim3(256), 0, s, q, (uint4*)ws);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}
 
 // layer = 2 | 3 of the image branch at image side 96 (48 after the first pool); dgrad: x = gy, y = dx, mask = the activation whose
 // ReLU gates dx (or null); returns 1 for shapes these kernels do not cover (the caller falls back to the gather-GEMM)
 // csum / nparts (optional): *nparts x OC partial channel sums of y -- for a data gradient, the bias gradient of the layer below
 int img_bf16_conv(var_ctx* c, hipStream_t s, int layer, int side, int dgrad, const float* x, const float* w, const float* bias,
-                  const float* mask, float* y, float* csum, int* nparts, int B, void* ws) {
+                  const float* mask, float* y, float* csum, int* nparts, int B, void* ws, int prepacked) {
+    void* tab = (uint4*)ws + (2 * (layer - 2) + (dgrad ? 1 : 0)) * kTabU4;      // (layer 2..5 checked below)
 #define C3_GO(IC, OC, H, TR, NI, WGS)                                                                                          \
-    return dgrad ? c3_launch<OC, IC, H, TR, NI, 1, WGS>(c, s, x, w, bias, mask, y, csum, nparts, B, ws)                         \
-                 : c3_launch<IC, OC, H, TR, NI, 0, WGS>(c, s, x, w, bias, mask, y, csum, nparts, B, ws)
+    return dgrad ? c3_launch<OC, IC, H, TR, NI, 1, WGS>(c, s, x, w, bias, mask, y, csum, nparts, B, tab, prepacked)             \
+                 : c3_launch<IC, OC, H, TR, NI, 0, WGS>(c, s, x, w, bias, mask, y, csum, nparts, B, tab, prepacked)
     if (layer == 2 && side == 96) { C3_GO(32, 32, 96, 8, 1, 2); }
     if (layer == 3 && side == 48) { C3_GO(32, 64, 48, 8, 1, 2); }
     if (layer == 4 && side == 24) { C3_GO(64, 64, 24, 24, 1, 1); }

@@ -62,6 +62,7 @@ struct ithor_state {
     // bf16 mode, layer 6 as a dense layer (l6_*): the expanded filter matrix, its bias, bf16 copies of the two activations
     unsigned short *l6w = nullptr, *l6x = nullptr, *l6g = nullptr;
     float* l6b = nullptr;
+    bool img_packed = false;                              // this forward packed the filters of layers 2-5 (img_bf16_pack_all)
     bool l6_ready = false;                                // this forward built l6w / l6b (the backward re-uses them)
     void* imgws = nullptr;                                // fragment-ordered filters of img_bf16.hip
     void* gruws = nullptr;                                // W_hh in MFMA fragment order (gru_bf16.hip)
@@ -753,12 +754,17 @@ static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* imag
     const int nclips = (pos ? B : 0) + (neg ? B : 0);
     st->nclips = nclips;
     if (image) {
+        st->img_packed = false;
+        if (st->bf16 && hs[0] == 96) {      // the eight filter tables of layers 2-5 (forward and data gradient) in one launch
+            RUN(img_bf16_pack_all(c, s, P + L.iw[1], P + L.iw[2], P + L.iw[3], P + L.iw[4], st->imgws));
+            st->img_packed = true;
+        }
         ConvDims d = img_dims(st, 1, B);
         d.xb = bstride;
         if (is_u8) RUN((conv_fwd<G3s1, true, false>(c, s, d, image, P + L.iw[0], P + L.ib[0], st->a[1])));
         else RUN((conv_fwd<G3s1, false, false>(c, s, d, image, P + L.iw[0], P + L.ib[0], st->a[1])));
         {
-            int r = st->bf16 ? img_bf16_conv(c, s, 2, hs[0], 0, st->a[1], P + L.iw[1], P + L.ib[1], nullptr, st->a[2], nullptr, nullptr, B, st->imgws) : 1;
+            int r = st->bf16 ? img_bf16_conv(c, s, 2, hs[0], 0, st->a[1], P + L.iw[1], P + L.ib[1], nullptr, st->a[2], nullptr, nullptr, B, st->imgws, st->img_packed ? 1 : 0) : 1;
             if (r == 1) r = conv_fwd<G3s1, false, false>(c, s, img_dims(st, 2, B), st->a[1], P + L.iw[1], P + L.ib[1], st->a[2]);
             RUN(r);
         }
@@ -769,7 +775,7 @@ static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* imag
             hipLaunchKernelGGL(pool_fwd_kernel, g1(n), dim3(256), 0, s, st->a[l], st->p[l], n, hin, hs[l - 1]);
             IT_CHECK(c);
             if (l < 5) {
-                int r = st->bf16 ? img_bf16_conv(c, s, l + 1, hs[l - 1], 0, st->p[l], P + L.iw[l], P + L.ib[l], nullptr, st->a[l + 1], nullptr, nullptr, B, st->imgws) : 1;
+                int r = st->bf16 ? img_bf16_conv(c, s, l + 1, hs[l - 1], 0, st->p[l], P + L.iw[l], P + L.ib[l], nullptr, st->a[l + 1], nullptr, nullptr, B, st->imgws, st->img_packed ? 1 : 0) : 1;
                 if (r == 1) r = conv_fwd<G3s1, false, false>(c, s, img_dims(st, l + 1, B), st->p[l], P + L.iw[l], P + L.ib[l], st->a[l + 1]);
                 RUN(r);
             }
@@ -928,7 +934,7 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
                 int nparts = 0;
                 float* part = l == 2 && st->bf16 ? bs_take(c, s, kPartFloats) : nullptr;
                 int r = st->bf16 ? img_bf16_conv(c, s, l, hin, 1, st->ga[l], P + L.iw[l - 1], nullptr, l == 2 ? st->a[1] : nullptr, dx,
-                                                 part, &nparts, B, st->imgws) : 1;
+                                                 part, &nparts, B, st->imgws, st->img_packed ? 1 : 0) : 1;
                 if (r == 1) r = conv_dgrad<G3s1, false>(c, s, d, st->ga[l], P + L.iw[l - 1], dx, l == 2 ? st->a[1] : nullptr);
                 RUN(r);
                 if (l == 2 && nparts) {

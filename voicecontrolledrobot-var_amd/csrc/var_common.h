@@ -305,6 +305,8 @@ int gru_bf16_timeout_word(var_ctx* c, int maxclips, void* ws, unsigned* out);
 // img_bf16.hip: 3x3 stride-1 convolutions of the iTHOR image branch (layers 2, 3) in the bf16 mode, forward and data gradient
 long img_bf16_workspace_bytes();
 int img_bf16_conv(var_ctx* c, hipStream_t s, int layer, int side, int dgrad, const float* x, const float* w, const float* bias,
-                  const float* mask, float* y, float* csum, int* nparts, int B, void* ws);
+                  const float* mask, float* y, float* csum, int* nparts, int B, void* ws, int prepacked);
+// the fragment tables of layers 2-5 (forward and data gradient) in one launch; img_bf16_conv(..., prepacked = 1) then skips its own
+int img_bf16_pack_all(var_ctx* c, hipStream_t s, const float* w2, const float* w3, const float* w4, const float* w5, void* ws);
 int img_bf16_wgrad(var_ctx* c, hipStream_t s, int layer, int side, const float* x, const float* gy, float* dw, float* slab, int B);
 int img_bf16_wgrad1(var_ctx* c, hipStream_t s, int side, const void* image, long bstride, const float* gy, float* dw, float* slab, int B);
