@@ -560,22 +560,24 @@ __global__ void __launch_bounds__(256) small_linear_fwd_kernel(const float* __re
     if (lane == 0) { float v = acc + (b ? b[o] : 0.f); Y[pair] = relu ? fmaxf(v, 0.f) : v; }
 }
 // dW[o][k] = sum_row dY[row][o] X[row][k]: one thread per (o, k), consecutive threads walk k
+// (and db[o] = sum_row dY[row][o], unrounded, by the thread of k = 0: it reads that column anyway)
 __global__ void __launch_bounds__(256) small_linear_dw_kernel(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ dW,
-                                                              int rows, int K, int O) {
+                                                              float* __restrict__ db, int rows, int K, int O) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= O * K) return;
     const int o = i / K, k = i - o * K;
-    float acc = 0.f;
+    float acc = 0.f, gs = 0.f;
     int r = 0;
     for (; r + 16 <= rows; r += 16) {                        // 32 loads in flight, then 16 products in row order
         float g[16], x[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) { g[u] = dY[(long)(r + u) * O + o]; x[u] = X[(long)(r + u) * K + k]; }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) acc += bf16r(g[u]) * bf16r(x[u]);
+        for (int u = 0; u < 16; ++u) { acc += bf16r(g[u]) * bf16r(x[u]); gs += g[u]; }
     }
-    for (; r < rows; ++r) acc += bf16r(dY[(long)r * O + o]) * bf16r(X[(long)r * K + k]);
+    for (; r < rows; ++r) { const float g = dY[(long)r * O + o]; acc += bf16r(g) * bf16r(X[(long)r * K + k]); gs += g; }
     dW[i] = acc;
+    if (k == 0) db[o] = gs;
 }
 // dX[row][k] = sum_o dY[row][o] W[o][k]: one thread per (row, k)
 __global__ void __launch_bounds__(256) small_linear_dx_kernel(const float* __restrict__ W, const float* __restrict__ dY, float* __restrict__ dX,
@@ -631,7 +633,7 @@ static int linear_bwd(var_ctx* c, hipStream_t s, const float* X, const float* W,
                       float* dX, int rows, int K, int O) {
     const bool small = small_linear(ith(c), rows, K, O);
     if (small) {
-        hipLaunchKernelGGL(small_linear_dw_kernel, g1((long)O * K), dim3(256), 0, s, X, dY, dW, rows, K, O);
+        hipLaunchKernelGGL(small_linear_dw_kernel, g1((long)O * K), dim3(256), 0, s, X, dY, dW, db, rows, K, O);
         IT_CHECK(c);
     } else {
         DenseP<false, false, 0> p{};
@@ -639,7 +641,7 @@ static int linear_bwd(var_ctx* c, hipStream_t s, const float* X, const float* W,
         p.A = X; p.sam = 1; p.sak = K; p.Bm = dY; p.sbk = O; p.sbn = 1; p.C = dW; p.scm = 1; p.scn = K;
         int r = gg(c, s, p); if (r) return r;
     }
-    int r = chan_sum(c, s, dY, db, rows, O, 1); if (r) return r;
+    int r = small ? VAR_OK : chan_sum(c, s, dY, db, rows, O, 1); if (r) return r;
     if (dX && small) {
         hipLaunchKernelGGL(small_linear_dx_kernel, g1((long)rows * K), dim3(256), 0, s, W, dY, dX, rows, K, O);
         IT_CHECK(c);
