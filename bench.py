@@ -94,7 +94,7 @@ def parity_vs_cpu(var_amd, model, pool, batch=64):
     on the same (image, audio) triplets (BASELINE.md section 3's last bullet; north_star: within 1e-3 fp32).  The MFCC
     features come from the HIP front-end for both sides (its own parity vs the numpy oracle is tests/test_gpu_parity.py's)."""
     from oracle.torch_oracle import KukaNetCPU
-    row = pool.epoch_index_table(batch)[0]
+    row = pool.epoch_index_table(batch, drop_last=True)[0]
     img = pool.images[row[:batch].long()].contiguous()
     feats = var_amd.mfcc(pool.clips, row[3 * batch:], out_frames=100, clip_index=row[batch:3 * batch])
     pos, neg = feats[:batch].contiguous(), feats[batch:].contiguous()
@@ -471,7 +471,7 @@ def main():
 
     def next_row():
         if state["tab"] is None or state["row"] >= state["tab"].shape[0]:
-            state["tab"], state["row"] = pool.epoch_index_table(B), 0
+            state["tab"], state["row"] = pool.epoch_index_table(B, drop_last=True), 0
         r = state["tab"][state["row"]]
         state["row"] += 1
         return r

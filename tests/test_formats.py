@@ -75,7 +75,7 @@ def test_wav_ingest_and_pickle_pool(tmp_path):
             else:
                 assert start[c] <= int(ids[r, i]) < start[c] + count[c]          # a clip of the right class
                 assert int(pool.len_tab[r, i]) == lens[int(ids[r, i])]
-    tab = pool.index_table(8, 7)
+    tab = pool.index_table(8, 7, drop_last=False)
     assert tab.shape == (10, 40) and tab.dtype == torch.int32
     for e in range(2):                                                           # every epoch is a permutation
         assert sorted(tab[5 * e:5 * e + 5, :8].reshape(-1).tolist()) == list(range(40))

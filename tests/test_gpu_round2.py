@@ -164,7 +164,7 @@ def test_ragged_epoch_300_at_batch_128(var_amd, golden_dir):
     pool = var_amd.SyntheticTripletPool(300, hw=84, seed=31, clips_per_class=4).freeze_pairs()
     spe, bt = pool.steps_per_epoch(B), pool.tail_batch(B)
     assert (spe, bt) == (3, 44)
-    table = pool.index_table(B, 2 * spe)
+    table = pool.index_table(B, 2 * spe, drop_last=False)
     assert table.shape == (6, 5 * B)
     mb = make_model(var_amd, sd)
     tb = var_amd.VARTrainer(mb, lr=1e-3)

@@ -48,7 +48,8 @@ def test_epoch_table_keeps_the_short_last_batch():
     assert torch.equal(tab[2, 132:176], pool.len_tab[0, idx]) and torch.equal(tab[2, 176:220], pool.len_tab[1, idx])
     assert int(tab[2, 220:].abs().sum()) == 0
     assert pool.epoch_index_table(128, drop_last=True).shape == (2, 640)
-    assert pool.index_table(128, 7).shape[0] == 9                      # whole epochs
+    assert pool.index_table(128, 7, drop_last=False).shape[0] == 9     # whole epochs, each with its short row
+    assert pool.index_table(128, 7).shape[0] == 8                      # default: full rows only (a padded row run as a full batch would train on zeros)
 
 
 def test_replayed_ragged_epochs_equal_reference_steps():
@@ -63,7 +64,7 @@ def test_replayed_ragged_epochs_equal_reference_steps():
     pool = _pool(22)
     B, spe, bt = 8, pool.steps_per_epoch(8), pool.tail_batch(8)
     assert (spe, bt) == (3, 6)
-    table = pool.index_table(B, 2 * spe)
+    table = pool.index_table(B, 2 * spe, drop_last=False)
     replay, _load = tr.capture_epoch_steps(pool.images, pool.clips, B, table, steps_per_epoch=spe, tail_batch=bt)
     ref = CPUTrainer(state_dict=sd, lr=1e-3)
     for row in range(2 * spe):
@@ -88,7 +89,7 @@ def test_ragged_table_arguments_are_checked():
     model = var_amd.VARPretextNet(_cfg())
     tr = var_amd.VARTrainer(model, _ctx=OracleContext())
     pool = _pool(22)
-    table = pool.index_table(8, 3)
+    table = pool.index_table(8, 3, drop_last=False)
     with pytest.raises(var_amd.VarHipError):
         tr.capture_epoch_steps(pool.images, pool.clips, 8, table, steps_per_epoch=2, tail_batch=6)   # 3 % 2 != 0
     with pytest.raises(var_amd.VarHipError):

@@ -10,7 +10,7 @@ cfg = types.SimpleNamespace(img_dim=(3, HW, HW), sound_dim=(1, 100, 40), represe
 torch.manual_seed(453)
 pool = var_amd.SyntheticTripletPool(4096, hw=HW, seed=0, clips_per_class=64).freeze_pairs()
 rows = 64
-table = pool.index_table(B, rows)[:rows].contiguous()
+table = pool.index_table(B, rows, drop_last=True)[:rows].contiguous()
 
 def timeit(step, n=300, warm=30):
     for _ in range(warm): step()

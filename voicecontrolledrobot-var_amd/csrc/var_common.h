@@ -188,14 +188,27 @@ struct ProfScope {
 
 // Phase timing inside a kernel (tuning builds only: -DVAR_PHASES): thread 0 of one workgroup accumulates the
 // shader-clock cycles between PH(i) marks into g_phase[i]; var_debug_phases() reads and clears them.
+#ifndef VAR_PH_THREAD
+#define VAR_PH_THREAD 0
+#endif
 #ifdef VAR_PHASES
 #define PH_DECL() static __device__ unsigned long long g_phase[32]
-#define PH_INIT(blk) unsigned long long ph_t = clock64(); const bool ph_on = (int)blockIdx.x == (blk) && threadIdx.x == 0
+#define PH_INIT2(blk, thr) unsigned long long ph_t = clock64(); const bool ph_on = (int)blockIdx.x == (blk) && (int)threadIdx.x == (thr)
+#define PH_INIT(blk) PH_INIT2(blk, 0)
 #define PH(i) do { if (ph_on) { const unsigned long long t_ = clock64(); g_phase[i] += t_ - ph_t; ph_t = t_; } } while (0)
+// register-accumulated form (PHR_INIT / PHR / PHR_FLUSH): a mark touches no memory, so it does not wait for the kernel's own
+// outstanding loads and stores the way PH()'s read-modify-write of g_phase does; 16 phases, written out once at the end
+#define PHR_INIT(blk, thr) unsigned long long ph_t = clock64(), ph_a[16] = {0}; const bool ph_on = (int)blockIdx.x == (blk) && (int)threadIdx.x == (thr)
+#define PHR(i) do { const unsigned long long t_ = clock64(); ph_a[i] += t_ - ph_t; ph_t = t_; } while (0)
+#define PHR_FLUSH() do { if (ph_on) { for (int i_ = 0; i_ < 16; ++i_) g_phase[i_] += ph_a[i_]; } } while (0)
 #else
 #define PH_DECL()
 #define PH_INIT(blk)
+#define PH_INIT2(blk, thr)
 #define PH(i)
+#define PHR_INIT(blk, thr)
+#define PHR(i)
+#define PHR_FLUSH()
 #endif
 
 static inline int conv_out(int h) { return (h - 1) / 2 + 1; }   // 3x3 s2 p1
@@ -224,6 +237,12 @@ int launch_img_fwd(var_ctx* c, hipStream_t s, const float* params, const void* i
                    long bstride, const int* image_index, int B);
 int launch_img_fwd_head(var_ctx* c, hipStream_t s, const float* params, const void* image, int is_u8, long bstride,
                         const int* image_index, int B);
+int launch_img_fwd_head2(var_ctx* c, hipStream_t s, const float* params, const void* image, int is_u8, long bstride,
+                         const int* image_index, int B);      // img_head2.hip: the 84 x 84 form, two small workgroups per CU
+#ifndef VAR_HEAD2_G
+#define VAR_HEAD2_G 256
+#endif
+static constexpr int kHead2G = VAR_HEAD2_G;   // persistent workgroups of img_head2_kernel (one image = NB tiles each)
 int launch_img_fwd_mid(var_ctx* c, hipStream_t s, const float* params, int B, bool with_head);
 // (launch_img_fwd also leaves c->relu1)
 // default: the whole sound branch -- MFCC front-end, sound CNN and sound head, forward and backward -- beside the image

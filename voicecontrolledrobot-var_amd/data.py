@@ -201,8 +201,11 @@ class TripletPool:
             tab = torch.cat([tab, tail], dim=0)
         return tab.contiguous()
 
-    def index_table(self, batch, min_rows, drop_last=False):
-        """At least `min_rows` step rows: whole shuffled epochs (epoch_index_table) back to back."""
+    def index_table(self, batch, min_rows, drop_last=True):
+        """At least `min_rows` step rows: whole shuffled epochs (epoch_index_table) back to back.  Full rows only by
+        default: a table with short last rows (drop_last=False) must be handed to capture_epoch_steps together with
+        tail_batch / steps_per_epoch -- run as full batches its zero-padded tail rows would train on (image 0, clip 0,
+        length 0) and silently skew loss and throughput."""
         parts, rows = [], 0
         while rows < min_rows:
             parts.append(self.epoch_index_table(batch, drop_last))

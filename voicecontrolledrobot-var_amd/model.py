@@ -28,7 +28,10 @@ def _encoder_forward(module, need_grad, image, pos, neg):
     H = module.config.img_dim[1]
     c.ensure_plan(B, H)
     stream = current_stream_handle()
-    module.hip_weights(c)                  # this model's packed image: bound, re-packed only if the parameters changed
+    # The eager module path re-packs on EVERY forward (one ~9 us kernel): torch's version counters do not see edits made
+    # through `.data` (p.data.mul_(), nn.init on m.weight.data), and a stale packed image is a silent wrong answer.  The
+    # latency paths -- VARTrainer's captured steps, IntrinsicReward's graphs -- own their image and never come through here.
+    module.hip_weights(c, force=True)
     mk = lambda n: torch.empty((B, n), dtype=torch.float32, device=dev)
     image_feat = mk(3) if image is not None else None
     image_raw = mk(576) if image is not None else None
@@ -156,10 +159,17 @@ class VARPretextNet(nn.Module):
         return all(p.data_ptr() == base + 4 * o and p.dtype == torch.float32
                    for p, o in zip(self._named_in_order(), PARAM_OFFSETS))
 
+    def pack(self, ctx=None):
+        """Re-pack this model's kernel-side weight image from the parameters now (after ANY direct edit of them)."""
+        return self.hip_weights(ctx, force=True)
+
     def hip_weights(self, ctx=None, force=False):
         """This model's packed weight image on its device context, bound for the next C-ABI calls; re-packed when the
-        parameters changed since the last pack (load_state_dict, an external optimiser, .to(), edits of the arena --
-        torch's version counters tell) or when `force`d.  VARTrainer's own Adam keeps the image current by itself."""
+        parameters changed since the last pack as far as torch's version counters tell (load_state_dict, an external
+        optimiser, .to(), in-place ops on the parameters) or when `force`d.  NOT detected: edits through `.data`
+        (p.data.mul_(), nn.init on m.weight.data) -- those bump no counter; forward() therefore always forces, and code
+        that binds the image itself (trainers, graphs) calls pack() after such edits.  VARTrainer's own Adam keeps the
+        image current by itself."""
         flat = self.flat_parameters()
         if ctx is None:
             ctx = Context.get(flat.device.index)
