@@ -213,10 +213,16 @@ int var_ithor_set_bf16(var_ctx* ctx, int on);
  * of a 64-clip slice hand the recurrent state to each other through memory, or as one launch per time step (0).  Both
  * give bit-identical results.  The persistent form needs its whole grid (32 workgroups per 64 clips) resident at once:
  * it is skipped by itself when the grid exceeds the device's CU count, and every wait in it is bounded -- if a wait
- * expires (e.g. another process holds part of the GPU) the launch ends, var_ithor_gru_status() reports a non-zero word
- * from then on and the step's embeddings / gradient are overwritten with NaN rather than left partially updated.
- * -1 = query; returns the previous setting; setting a form (0 / 1) also clears the status word (after a
- * hipDeviceSynchronize-like wait on the null stream).  var_ithor_gru_status copies the status word (blocking). */
+ * expires (e.g. another process holds part of the GPU) the launch ends and the step's embeddings / gradient are
+ * overwritten with NaN rather than left partially updated.  The time-out word of the CURRENT step also guards the
+ * optimiser: var_adam_step / var_adam_step_dev over this model's arena (n == var_ithor_param_count()) then leave
+ * parameters, moments and step count untouched, so a transient time-out costs one step, not the run.  The next
+ * var_ithor_* forward clears the current word by itself and files the event in two sticky words (count, last code).
+ * var_ithor_gru_status copies the status (blocking): the current step's code (1 + t forward, 101 + t backward) if it
+ * timed out, else 0x40000000 | code of the last earlier time-out, else 0.  The residency test uses the occupancy the
+ * runtime grants the two sequence kernels (hipOccupancyMaxActiveBlocksPerMultiprocessor), not just the CU count.
+ * -1 = query; returns the previous setting; setting a form (0 / 1) also clears every status word (after a
+ * hipDeviceSynchronize-like wait on the null stream). */
 int var_ithor_set_gru_sequence(var_ctx* ctx, int on);
 int var_ithor_gru_status(var_ctx* ctx, unsigned* word);
 int var_ithor_encoder_fwd(var_ctx* ctx, void* stream, const float* params,

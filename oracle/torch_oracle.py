@@ -35,19 +35,23 @@ class KukaNetCPU(nn.Module):
 
 
 class CPUTrainer:
-    def __init__(self, state_dict=None, lr=1e-4, weight_decay=1e-6, margin=1.0, hw=84):
+    def __init__(self, state_dict=None, lr=1e-4, weight_decay=1e-6, margin=1.0, hw=84, dtype=torch.float32):
+        """dtype=torch.float64: the same step on the same fp32 inputs and initial weights with every product, sum and the
+        optimiser state in double -- the yardstick that tells the rounding drift of one fp32 implementation from another's."""
         self.model = KukaNetCPU(hw)
         if state_dict is not None:
             self.model.load_state_dict({k: torch.as_tensor(v) for k, v in state_dict.items()})
+        self.dtype = dtype
+        self.model.to(dtype)
         self.model.train()
         self.opt = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay)
         self.crit = torch.nn.TripletMarginLoss(margin=margin, p=2)
 
     def step(self, image_u8, pos, neg):
-        image = (image_u8 / 255.).float()
+        image = (image_u8 / 255.).float().to(self.dtype)               # the fp32 quotient of dataset.py:67-68, then widened
         self.model.zero_grad()
         self.opt.zero_grad()
-        a, p, n = self.model(image, pos.float(), neg.float())
+        a, p, n = self.model(image, pos.float().to(self.dtype), neg.float().to(self.dtype))
         loss = self.crit(a, p, n)
         loss.backward()
         self.opt.step()

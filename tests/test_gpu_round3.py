@@ -1,0 +1,296 @@
+"""GPU tests added in round 3 (run with -m gpu on an MI355X): what the round-2 review asked for -- the bf16 mode at the size
+it is benchmarked at, a parameter-trajectory bound against a float64 yardstick, the optimiser's behaviour after a timed-out
+persistent GRU launch, edits of the parameters behind torch's version counters."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mfcc_np  # noqa: E402  (checker only)
+from oracle.torch_oracle import CPUTrainer, IthorNetCPU, KukaNetCPU  # noqa: E402
+
+
+def cfg(h=84):
+    return types.SimpleNamespace(img_dim=(3, h, h), sound_dim=(1, 100, 40), representationDim=3)
+
+
+def icfg(h=96):
+    return types.SimpleNamespace(img_dim=(3, h, h), sound_dim=(1, 600, 40), representationDim=3)
+
+
+def load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name)))
+
+
+@pytest.fixture(scope="module")
+def var_amd():
+    import var_amd as m
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return m
+
+
+def make_model(var_amd, sd, h=84):
+    m = var_amd.VARPretextNet(cfg(h))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return m.to("cuda")
+
+
+def cpu_features(pool, clip_idx, lens):
+    out = np.zeros((len(clip_idx), 1, 100, 40), np.float32)
+    clips = pool.clips.cpu().numpy()
+    for i, (c, n) in enumerate(zip(clip_idx.tolist(), lens.tolist())):
+        if n > 0:
+            out[i] = mfcc_np.process_sound_feat(mfcc_np.mfcc_torchaudio(clips[c, :n]).astype(np.float32))
+    return torch.from_numpy(out)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# parameters edited through .data (no version counter moves): the eager forward must still see them
+# ------------------------------------------------------------------------------------------------------------------
+def test_forward_sees_parameter_edits_made_through_dot_data(var_amd, golden_dir):
+    sd = load(golden_dir, "kuka_weights.npz")
+    fx = load(golden_dir, "kuka_h84.npz")
+    m = make_model(var_amd, sd)
+    args = tuple(torch.from_numpy(fx[k]).cuda() for k in ("image", "sound_positive", "sound_negative"))
+    with torch.no_grad():
+        d0 = m(*args)
+    before = (m.flat_parameters()._version, sum(p._version for p in m.parameters()))
+    for p in m.parameters():
+        p.data.mul_(0.5)                                    # bumps neither counter (the round-2 advisor's case)
+    torch.nn.init.constant_(m.imgTriplet[2].bias.data, 0.25)
+    assert (m.flat_parameters()._version, sum(p._version for p in m.parameters())) == before
+    with torch.no_grad():
+        d1 = m(*args)
+    ref = KukaNetCPU(84)
+    ref.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()})
+    with torch.no_grad():
+        a, p_, n_ = ref((torch.from_numpy(fx["image"]) / 255.).float(), torch.from_numpy(fx["sound_positive"]),
+                        torch.from_numpy(fx["sound_negative"]))
+    assert not torch.equal(d1["image_feat"], d0["image_feat"])
+    for k, want in (("image_feat", a), ("sound_feat_positive", p_), ("sound_feat_negative", n_)):
+        assert float((d1[k].cpu() - want).abs().max()) < 1e-5, k
+    # the explicit form for code that binds the packed image itself
+    w = m.pack()
+    assert w is m.hip_weights()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# trajectory: HIP vs float64, with torch-fp32 vs float64 as the yardstick
+# ------------------------------------------------------------------------------------------------------------------
+def test_config2_parameter_trajectory_against_a_float64_yardstick(var_amd, golden_dir):
+    """10 optimisation steps at batch 256 (BASELINE configs[1]) three times on the same fp32 inputs and initial weights:
+    the HIP replayed graph, torch fp32 on the CPU, torch float64 on the CPU.  Rounding moves Adam's normalised update by
+    percents near this initialisation, so the yardstick is not a constant: the HIP parameters must be no further from
+    the float64 run than 2x what torch's own fp32 run is -- in the mean, at the 99th percentile and at the 99.9th."""
+    sd = load(golden_dir, "kuka_weights.npz")
+    B, steps = 256, 10
+    pool = var_amd.SyntheticTripletPool(768, hw=84, seed=21, clips_per_class=3).freeze_pairs()
+    table = pool.index_table(B, steps, drop_last=True)[:steps].contiguous()
+    m = make_model(var_amd, sd)
+    tr = var_amd.VARTrainer(m, lr=1e-4, weight_decay=1e-6)
+    replay, _ = tr.capture_epoch_steps(pool.images, pool.clips, B, table)
+    r32 = CPUTrainer(state_dict=sd, lr=1e-4, weight_decay=1e-6)
+    r64 = CPUTrainer(state_dict=sd, lr=1e-4, weight_decay=1e-6, dtype=torch.float64)
+    cache = {}
+
+    def feats_of(idx, lens):
+        key = (tuple(idx.tolist()), tuple(lens.tolist()))
+        if key not in cache:
+            cache[key] = cpu_features(pool, idx, lens)
+        return cache[key]
+    tcpu = table.cpu()
+    for s in range(steps):
+        r = tcpu[s]
+        img = pool.images[r[:B].long()].cpu()
+        fp, fn = feats_of(r[B:2 * B], r[3 * B:4 * B]), feats_of(r[2 * B:3 * B], r[4 * B:])
+        l64 = r64.step(img, fp, fn)
+        l32 = r32.step(img, fp, fn)
+        got = float(replay().item())
+        assert abs(got - l64) < 2e-5 * (s + 1), (s, got, l64)
+        assert abs(got - l64) <= 2.0 * abs(l32 - l64) + 2e-6 * (s + 1), (s, got, l32, l64)
+    flat_of = lambda t: torch.cat([t.model.state_dict()[k].reshape(-1).double() for k, _ in var_amd.PARAM_SPECS])  # noqa: E731
+    truth = flat_of(r64)
+    d_hip = (m.flat_parameters().cpu().double() - truth).abs()
+    d_t32 = (flat_of(r32) - truth).abs()
+    q = lambda t, f: float(torch.quantile(t, f))           # noqa: E731
+    print("after 10 steps, |param - float64 run|: HIP mean %.3e p99 %.3e p99.9 %.3e max %.3e | torch fp32 mean %.3e p99 %.3e "
+          "p99.9 %.3e max %.3e" % (d_hip.mean(), q(d_hip, .99), q(d_hip, .999), d_hip.max(),
+                                   d_t32.mean(), q(d_t32, .99), q(d_t32, .999), d_t32.max()))
+    assert float(d_hip.mean()) <= 2.0 * float(d_t32.mean()) + 1e-9
+    assert q(d_hip, .99) <= 2.0 * q(d_t32, .99) + 1e-8
+    assert q(d_hip, .999) <= 2.0 * q(d_t32, .999) + 1e-7
+    # and an absolute frame for the numbers above: both fp32 runs stay within a few percent of the distance Adam can
+    # travel in 10 steps (1e-3) at the 99.9th percentile
+    assert q(d_hip, .999) < 0.1 * steps * 1e-4
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# iTHOR bf16 mode at the size the bench runs it at: B = 256 -> 512 clips -> 256 persistent GRU workgroups
+# ------------------------------------------------------------------------------------------------------------------
+def _ithor_batch(B, seed):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randint(0, 256, (B, 3, 96, 96), dtype=torch.uint8, generator=g)
+    snd = torch.randn(2 * B, 1, 600, 40, generator=g) * 3
+    snd[1, :, 350:] = 0.0                                   # a zero-padded clip, as processSoundFeat leaves short ones
+    return img, snd[:B].contiguous(), snd[B:].contiguous()
+
+
+def _param_spans(m):
+    spans, o = {}, 0
+    for k, prm in m.named_parameters():
+        spans[k] = (o, o + prm.numel())
+        o += prm.numel()
+    return spans
+
+
+def test_ithor_bf16_at_the_benchmarked_batch_256(var_amd):
+    """(1) the persistent GRU launches (256 workgroups on 256 CUs: the full-residency edge) against the per-step launches:
+    identical loss and gradients (GRU bias gradients: summation order only), no hand-off timed out, deterministic;
+    (2) bf16 vs fp32 on the same batch: loss, embeddings, gradient within the drift bounds of the small-batch tests;
+    (3) the fp32 path against the CPU oracle on a 16-sample slice of the same batch."""
+    import ctypes
+    from var_amd._lib import Context
+    B = 256
+    img, pos, neg = (t.cuda() for t in _ithor_batch(B, 41))
+    torch.manual_seed(977)
+    ref = IthorNetCPU()
+    sd = ref.state_dict()
+    out = {}
+    for prec in ("fp32", "bf16"):
+        m = var_amd.IthorVARPretextNet(icfg(96))
+        m.load_state_dict(sd)
+        m = m.to("cuda").set_precision(prec)
+        tr = var_amd.IthorTrainer(m)
+        loss, feats = tr.loss_and_grads(img, pos, neg, feats=True)
+        torch.cuda.synchronize()
+        out[prec] = (float(loss), feats.clone(), tr.grads.clone())
+        if prec == "bf16":
+            ctx = Context.get(0)
+            assert m.gru_status() == 0
+            per = {}
+            try:
+                for mode in (0, 1, 1):
+                    assert ctx.lib.var_ithor_set_gru_sequence(ctx.handle, mode) >= 0
+                    l, _ = tr.loss_and_grads(img, pos, neg)
+                    torch.cuda.synchronize()
+                    per.setdefault(mode, []).append((float(l), tr.grads.clone()))
+            finally:
+                ctx.lib.var_ithor_set_gru_sequence(ctx.handle, 1)
+            word = ctypes.c_uint(123)
+            assert ctx.lib.var_ithor_gru_status(ctx.handle, ctypes.byref(word)) == 0 and word.value == 0
+            (l0, g0), = per[0]
+            spans = _param_spans(m)
+            bias = [k for k in spans if k.startswith("rnn.bias")]
+            for l1, g1 in per[1]:
+                assert torch.isfinite(g1).all() and l1 == l0 == out["bf16"][0]
+                a, b = g1.clone(), g0.clone()
+                for k in bias:
+                    lo, hi = spans[k]
+                    assert float((a[lo:hi] - b[lo:hi]).abs().max()) <= 2e-6 * float(b[lo:hi].abs().max()) + 1e-12, k
+                    a[lo:hi] = 0
+                    b[lo:hi] = 0
+                assert torch.equal(a, b), float((a - b).abs().max())
+            assert torch.equal(per[1][0][1], per[1][1][1])
+            assert torch.equal(per[1][0][1], out["bf16"][2])
+    l32, f32, g32 = out["fp32"]
+    l16, f16, g16 = out["bf16"]
+    assert abs(l16 - l32) < 2e-3, (l16, l32)
+    assert float((f16 - f32).abs().max()) < 1e-2
+    l2 = lambda a, b: float((a - b).norm() / b.norm())       # noqa: E731
+    assert l2(g16, g32) < 0.15, l2(g16, g32)
+    # (3) 16 samples of the batch through the CPU oracle: a sample's embeddings do not depend on the rest of the batch
+    sl = slice(64, 80)
+    with torch.no_grad():
+        a, p_, n_ = ref((img[sl].cpu() / 255.).float(), pos[sl].cpu(), neg[sl].cpu())
+    want = torch.cat([a, p_, n_], 1)
+    assert float((f32[sl].cpu() - want).abs().max()) < 1e-4
+    assert float((f16[sl].cpu() - want).abs().max()) < 1e-2
+
+
+def test_ithor_bf16_gradient_drift_is_traced_to_routing_flips(var_amd):
+    """Where the bf16 gradient leaves the fp32 one, the cause must be visible: a ReLU gate (here: of the two wide sound
+    convolutions, whose activations the debug buffers keep) that differs between the two forwards.  Every differing gate
+    must sit at a pre-activation within bf16 rounding of zero -- the surviving side of the pair is tiny against the layer's
+    scale -- and the gates that differ are a small fraction; with them the 5-8 % L2 drift of the sound-branch gradients
+     is routing, not arithmetic."""
+    from var_amd._lib import Context
+    B = 8
+    img, pos, neg = (t.cuda() for t in _ithor_batch(B, 43))
+    torch.manual_seed(977)
+    sd = IthorNetCPU().state_dict()
+    acts, grads = {}, {}
+    for prec in ("fp32", "bf16"):
+        m = var_amd.IthorVARPretextNet(icfg(96))
+        m.load_state_dict(sd)
+        m = m.to("cuda").set_precision(prec, keep_fp32_activations=True)
+        tr = var_amd.IthorTrainer(m)
+        tr.loss_and_grads(img, pos, neg)
+        torch.cuda.synchronize()
+        ctx = Context.get(0)
+        n = 2 * B
+        acts[prec] = {"s1": ctx.debug_buffer("ithor_s1")[:n * 64 * 300 * 20].clone(),
+                      "s2": ctx.debug_buffer("ithor_s2")[:n * 64 * 150 * 13].clone()}
+        grads[prec] = tr.grads.clone()
+        spans = _param_spans(m)
+    nflip = 0
+    for k in ("s1", "s2"):
+        a32, a16 = acts["fp32"][k], acts["bf16"][k]
+        scale = float(a32.abs().max())
+        flip = (a32 > 0) != (a16 > 0)
+        nflip += int(flip.sum())
+        frac = float(flip.float().mean())
+        assert frac < 0.01, (k, frac)
+        if flip.any():
+            survivor = torch.maximum(a32[flip], a16[flip])
+            assert float(survivor.max()) < 2e-2 * scale, (k, float(survivor.max()), scale)
+        # away from the gates the two activations agree to bf16 operand rounding
+        assert float((a32 - a16).abs().max()) < 3e-2 * scale, k
+    worst = {}
+    for k, (lo, hi) in spans.items():
+        d = float((grads["bf16"][lo:hi] - grads["fp32"][lo:hi]).norm() / (grads["fp32"][lo:hi].norm() + 1e-30))
+        worst[k] = d
+        # (weights: 30 %; the small bias vectors -- 32 to 128 sums over every pixel of a max-pooled map, where a single
+        #  pool winner changing hands moves the whole sum -- 50 %)
+        assert d < (0.3 if hi - lo >= 1024 else 0.5), (k, d)
+    drifted = {k: v for k, v in worst.items() if v > 0.03}
+    if drifted:
+        assert nflip > 0, f"gradient tensors drift by more than 3 % in L2 without a single differing gate: {drifted}"
+    print("gates that differ:", nflip, "| worst per-tensor L2 drift:", max(worst.values()))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# a timed-out persistent GRU launch: the optimiser must skip that step, the next one must run
+# ------------------------------------------------------------------------------------------------------------------
+def test_gru_time_out_skips_the_optimiser_step_and_clears_itself(var_amd):
+    from var_amd._lib import Context
+    B = 3
+    img, pos, neg = (t.cuda() for t in _ithor_batch(B, 45))
+    torch.manual_seed(5)
+    m = var_amd.IthorVARPretextNet(icfg(96)).to("cuda").set_precision("bf16")
+    tr = var_amd.IthorTrainer(m)
+    tr.step(img, pos, neg)                                  # a good step (plans the context, moves the moments off zero)
+    torch.cuda.synchronize()
+    assert m.gru_status() == 0
+    p0, m0, v0 = m.flat_parameters().clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone()
+    ctx = Context.get(0)
+    assert ctx.lib.var_debug_ithor_gru_drop_workgroup(ctx.handle) == 0
+    loss = tr.step(img, pos, neg)                           # the forward's persistent launch misses a workgroup: time-out
+    torch.cuda.synchronize()
+    assert not np.isfinite(float(loss)) and m.gru_status() != 0
+    assert torch.equal(m.flat_parameters(), p0) and torch.equal(tr.exp_avg, m0) and torch.equal(tr.exp_avg_sq, v0)
+    loss = tr.step(img, pos, neg)                           # the next step clears the word by itself and trains
+    torch.cuda.synchronize()
+    assert np.isfinite(float(loss))
+    assert bool(torch.isfinite(m.flat_parameters()).all()) and not torch.equal(m.flat_parameters(), p0)
+    assert m.gru_status() & 0x40000000                      # the earlier time-out stays on record (sticky word)
+    # the training loop reports it once and takes the per-step launches from there on
+    logs = []
+    assert ctx.lib.var_debug_ithor_gru_drop_workgroup(ctx.handle) == 0
+    losses = var_amd.train_representation(m, lambda: iter([(img, pos, neg, None)] * 3), epochs=2, log=lambda *a: logs.append(a))
+    assert all(np.isfinite(v) for v in losses)
+    assert any("timed out" in str(a[0]) for a in logs)
+    assert bool(torch.isfinite(m.flat_parameters()).all())

@@ -82,7 +82,7 @@ int var_destroy(var_ctx* c) {
     mfcc_any_forget(c);
     ithor_free(c);
     armnet_free(c);
-    if (c->ws) (void)hipFree(c->ws);
+    for (auto& sl : c->ws_slot) if (sl.base) (void)hipFree(sl.base);
     for (int i = 0; i < c->n_retired; i++) (void)hipFree(c->retired[i]);
     free(c->retired);
     if (c->default_w.data) (void)hipFree(c->default_w.data);
@@ -161,18 +161,8 @@ static int check_weights(var_ctx* c, const float* params, const char* who) {
     return VAR_OK;
 }
 
-int var_plan(var_ctx* c, int max_batch, int img_hw) {
-    CHECK_CTX(c);
-    if (max_batch <= 0 || (img_hw != 84 && img_hw != 96)) {
-        VAR_SET_ERR(c, "var_plan: batch %d / image size %d unsupported (size must be 84 or 96)", max_batch, img_hw);
-        return VAR_ERR_ARG;
-    }
-    SET_DEVICE(c);
-    if (c->ws && c->maxB >= max_batch && c->H == img_hw) return VAR_OK;
-    // A superseded workspace is retired, not freed: HIP graphs captured against it (VARTrainer.capture_*,
-    // IntrinsicReward.capture) keep replaying on their own, still valid, buffers.  Freed in var_destroy.
-    if (c->ws) { int rc = retire_block(c, c->ws); if (rc != VAR_OK) return rc; c->ws = nullptr; }
-    c->plan_gen++;
+// Carve the workspace block `base` (or, with base == nullptr, only size it) for (B, img_hw) and point the context at it.
+static size_t plan_layout(var_ctx* c, char* base, int max_batch, int img_hw) {
     const size_t B = (size_t)max_batch;
     int hs[6];
     hs[0] = img_hw;
@@ -197,8 +187,8 @@ int var_plan(var_ctx* c, int max_batch, int img_hw) {
     const size_t o_slab = carve(n_img_slab + n_snd_slab);
     const size_t o_mfcc = carve(2 * B * VAR_MFCC_FRAMES * VAR_MFCC_COEFFS);
     const size_t o_relu1 = carve(B * hs[1] * hs[1]);          // 2 halves x u16 per pixel
-    VAR_HIP_CHECK(c, hipMalloc((void**)&c->ws, off));
-    VAR_HIP_CHECK(c, hipMemset(c->ws, 0, off));
+    if (!base) return off;
+    c->ws = base;
     c->ws_bytes = off;
     auto P = [&](size_t o) { return (float*)(c->ws + o); };
     for (int l = 1; l <= 5; l++) { c->act[l] = P(o_act[l]); c->gact[l] = P(o_gact[l]); }
@@ -215,6 +205,35 @@ int var_plan(var_ctx* c, int max_batch, int img_hw) {
     c->H = img_hw;
     for (int i = 0; i < 6; i++) c->hs[i] = hs[i];
     c->saved_B = 0;
+    return off;
+}
+
+int var_plan(var_ctx* c, int max_batch, int img_hw) {
+    CHECK_CTX(c);
+    if (max_batch <= 0 || (img_hw != 84 && img_hw != 96)) {
+        VAR_SET_ERR(c, "var_plan: batch %d / image size %d unsupported (size must be 84 or 96)", max_batch, img_hw);
+        return VAR_ERR_ARG;
+    }
+    SET_DEVICE(c);
+    if (c->ws && c->maxB >= max_batch && c->H == img_hw) return VAR_OK;
+    // One workspace per image size, each only ever growing: two models of different image size alternating on one context
+    // switch between their two blocks instead of allocating a fresh one per switch (round 2 replaced the block on every
+    // change of size: hundreds of MB each time, none released before var_destroy).  A block that must GROW is retired, not
+    // freed: HIP graphs captured against it (VARTrainer.capture_*, IntrinsicReward.capture) keep replaying on their own,
+    // still valid, buffers.  Freed in var_destroy.
+    var_ctx::WsSlot& slot = c->ws_slot[img_hw == 84 ? 0 : 1];
+    if (!slot.base || slot.maxB < max_batch) {
+        if (slot.base) { int rc = retire_block(c, slot.base); if (rc != VAR_OK) return rc; slot.base = nullptr; }
+        if (c->ws && c->H == img_hw) c->ws = nullptr;          // (the active block was this slot's: just retired)
+        const int Bn = slot.maxB > max_batch ? slot.maxB : max_batch;
+        const size_t bytes = plan_layout(c, nullptr, Bn, img_hw);
+        char* blk = nullptr;
+        VAR_HIP_CHECK(c, hipMalloc((void**)&blk, bytes));
+        VAR_HIP_CHECK(c, hipMemset(blk, 0, bytes));
+        slot.base = blk; slot.maxB = Bn;
+    }
+    c->plan_gen++;                                              // the workspace pointers change: saved forwards are gone
+    plan_layout(c, slot.base, slot.maxB, img_hw);
     return VAR_OK;
 }
 

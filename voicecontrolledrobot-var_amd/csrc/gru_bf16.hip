@@ -629,9 +629,19 @@ int gru_bf16_step_bwd(var_ctx* c, hipStream_t s, float* DH, const float* Hb, con
 // The sequence kernels need every workgroup of the grid resident at once (one 512-thread workgroup per CU): return 1, and
 // the caller takes the per-step launches, when the grid is larger than the device.
 static int seq_fits(var_ctx* c, int nclips) {
-    static int cus = 0;
-    if (!cus && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) cus = 1;
-    return 2 * NJS * ((nclips + 63) / 64) <= cus;
+    // workgroups the device can hold at once: CUs x what the occupancy query grants the larger of the two sequence kernels
+    // (registers, LDS), not just the CU count -- a kernel that stops fitting one workgroup per CU must not be launched this way
+    static int slots = 0;
+    if (!slots) {
+        int cus = 0, f = 0, b = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&f, (const void*)gru_seq_fwd_kernel, 512, kFwdLds + 16) != hipSuccess) f = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (const void*)gru_seq_bwd_kernel, 512, kBwdLds + 16) != hipSuccess) b = 0;
+        const int per = f < b ? f : b;
+        slots = cus * (per > 1 ? 1 : per);        // one workgroup per CU is what the hand-off timing was measured for
+        if (slots < 1) slots = -1;
+    }
+    return slots > 0 && 2 * NJS * ((nclips + 63) / 64) <= slots;
 }
 
 int gru_bf16_reset_timeout(var_ctx* c, hipStream_t s, int maxclips, void* ws) {
@@ -673,8 +683,25 @@ int gru_bf16_poison_on_timeout(var_ctx* c, hipStream_t s, float* grads, int n, i
     return VAR_OK;
 }
 
-// blocking: the time-out word (0 = every hand-off of every sequence launch so far completed)
+// The status words (gru_sync(ws)[0..3]): [0] = code of a time-out in the CURRENT step (what Adam's guard and the poison kernel
+// read), [1] = number of earlier steps that timed out, [2] = the code of the last of them.
+__global__ void gru_step_begin_kernel(unsigned* __restrict__ w) {
+    if (w[0]) { w[1] += 1; w[2] = w[0]; w[0] = 0; }
+}
+
+int gru_bf16_step_begin(var_ctx* c, hipStream_t s, int maxclips, void* ws) {
+    hipLaunchKernelGGL(gru_step_begin_kernel, dim3(1), dim3(1), 0, s, gru_sync(ws, maxclips));
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}
+
+const unsigned* gru_bf16_timeout_ptr(int maxclips, void* ws) { return gru_sync(ws, maxclips); }
+
+// blocking: the time-out word (0 = every hand-off of every sequence launch so far completed); a time-out of an earlier
+// step reads as 0x40000000 | its code
 int gru_bf16_timeout_word(var_ctx* c, int maxclips, void* ws, unsigned* out) {
-    VAR_HIP_CHECK(c, hipMemcpy(out, gru_sync(ws, maxclips), 4, hipMemcpyDeviceToHost));
+    unsigned w[4] = {0, 0, 0, 0};
+    VAR_HIP_CHECK(c, hipMemcpy(w, gru_sync(ws, maxclips), 16, hipMemcpyDeviceToHost));
+    *out = w[0] ? w[0] : (w[1] ? (0x40000000u | w[2]) : 0u);
     return VAR_OK;
 }

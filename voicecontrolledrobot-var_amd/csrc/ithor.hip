@@ -89,6 +89,8 @@ static inline ithor_state* ith(var_ctx* c) { return (ithor_state*)c->ith; }
 template <int KC = GG_KC, class P>
 static int gg(var_ctx* c, hipStream_t s, const P& p, int batches = 1);
 
+static void ithor_update_guard(var_ctx* c);
+
 void ithor_free(var_ctx* c) {
     ithor_state* st = ith(c);
     if (!st) return;
@@ -96,6 +98,7 @@ void ithor_free(var_ctx* c) {
     free(st->folds);
     delete st;
     c->ith = nullptr;
+    c->adam_guard = nullptr; c->adam_guard_n = 0;
 }
 
 template <int KC, class P>
@@ -755,6 +758,8 @@ static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* imag
     st->image = image; st->is_u8 = is_u8; st->bstride = bstride; st->pos = pos; st->neg = neg;
     const int nclips = (pos ? B : 0) + (neg ? B : 0);
     st->nclips = nclips;
+    // a time-out of the PREVIOUS step stops guarding Adam here (it stays visible in var_ithor_gru_status' sticky words)
+    if (st->bf16 && st->gru_seq) RUN(gru_bf16_step_begin(c, s, 2 * st->maxB, st->gruws));
     if (image) {
         st->img_packed = false;
         if (st->bf16 && hs[0] == 96) {      // the eight filter tables of layers 2-5 (forward and data gradient) in one launch
@@ -1274,6 +1279,7 @@ int var_ithor_plan(var_ctx* c, int max_batch, int img_hw) {
     st->raw = w + oraw; st->graw = w + ograw; st->emb = w + oemb; st->gemb = w + ogemb; st->loss = w + oloss;
     RUN(gru_bf16_reset_timeout(c, nullptr, (int)C2, st->gruws));
     VAR_HIP_CHECK(c, hipStreamSynchronize(nullptr));
+    ithor_update_guard(c);
     return VAR_OK;
 }
 
@@ -1282,6 +1288,14 @@ static int ithor_check(var_ctx* c, int B, int H, const char* who) {
     if (!st || B > st->maxB || H != st->H) { VAR_SET_ERR(c, "%s: var_ithor_plan(%d, %d) first", who, B, H); return VAR_ERR_PLAN; }
     if (B < 1) { VAR_SET_ERR(c, "%s: empty batch", who); return VAR_ERR_ARG; }
     return VAR_OK;
+}
+
+// Adam over this model's arena skips its update while the current step's time-out word is set (pack_adam.hip)
+static void ithor_update_guard(var_ctx* c) {
+    ithor_state* st = ith(c);
+    const bool on = st && st->bf16 && st->gru_seq && st->gruws;
+    c->adam_guard = on ? gru_bf16_timeout_ptr(2 * st->maxB, st->gruws) : nullptr;
+    c->adam_guard_n = on ? (long)st->L.total : 0;
 }
 
 static int copy_out(var_ctx* c, hipStream_t s, const float* src, float* dst, long n) {
@@ -1296,7 +1310,7 @@ int var_ithor_set_bf16(var_ctx* c, int on) {
     ithor_state* st = ith(c);
     if (!st) { VAR_SET_ERR(c, "var_ithor_set_bf16: var_ithor_plan first"); return VAR_ERR_PLAN; }
     const int old = st->bf16 ? (st->keep32 ? 2 : 1) : 0;
-    if (on >= 0) { st->bf16 = on != 0; st->keep32 = on == 2; }
+    if (on >= 0) { st->bf16 = on != 0; st->keep32 = on == 2; ithor_update_guard(c); }
     return old;
 }
 
@@ -1310,6 +1324,7 @@ int var_ithor_set_gru_sequence(var_ctx* c, int on) {
         VAR_HIP_CHECK(c, hipSetDevice(c->device));
         RUN(gru_bf16_reset_timeout(c, nullptr, 2 * st->maxB, st->gruws));      // (setting the form also clears the status word)
         VAR_HIP_CHECK(c, hipStreamSynchronize(nullptr));
+        ithor_update_guard(c);
     }
     return old;
 }

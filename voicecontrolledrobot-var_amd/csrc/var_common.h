@@ -109,7 +109,8 @@ struct var_ctx {
     // plan
     int maxB = 0, H = 0;
     int hs[6] = {0};
-    char* ws = nullptr;           // one hipMalloc, carved below
+    char* ws = nullptr;           // the ACTIVE workspace block (= ws_slot[..].base of the planned image size), carved below
+    struct WsSlot { char* base = nullptr; int maxB = 0; } ws_slot[2];   // one block per image size (84, 96), each only grows
     size_t ws_bytes = 0;
     float* wpack = nullptr;       // = bound->data: the packed image the launchers read (var_weights_bind)
     var_weights default_w;        // the context's own image, bound until the host binds a per-model one
@@ -161,6 +162,8 @@ struct var_ctx {
     void* comm = nullptr; int comm_rank = 0, comm_size = 1;   // RCCL communicator (comm.hip), created by var_comm_init
     void* arm = nullptr;                  // actor-critic state (armnet.hip), created by var_armnet_plan
     void* ith = nullptr;                  // iTHOR model state (ithor.hip), created by var_ithor_plan
+    const unsigned* adam_guard = nullptr; // device word: non-zero = the gradient of this step is invalid (a persistent GRU launch timed
+    long adam_guard_n = 0;                // out): Adam launches over adam_guard_n parameters leave parameters, moments and step alone
 };
 
 #define VAR_SET_ERR(ctx, ...) do { if (ctx) snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__); } while (0)
@@ -318,6 +321,9 @@ int gru_bf16_seq_bwd(var_ctx* c, hipStream_t s, float* DH, const float* Hb, cons
                      const float* GHN, float* DGI, float* DGH, int nclips, int maxclips, long dirGI, long dirH, long dirS, long dirDGH,
                      void* ws, int store32);      // store32 = 0: DGI / DGH (fp32) are not written, only their bf16 copies
 int gru_bf16_reset_timeout(var_ctx* c, hipStream_t s, int maxclips, void* ws);
+// start of a step: a time-out left by the PREVIOUS step moves to the sticky words (count, last code) and the current word clears
+int gru_bf16_step_begin(var_ctx* c, hipStream_t s, int maxclips, void* ws);
+const unsigned* gru_bf16_timeout_ptr(int maxclips, void* ws);
 int gru_bf16_poison_on_timeout(var_ctx* c, hipStream_t s, float* grads, int n, int maxclips, void* ws);
 int gru_bf16_timeout_word(var_ctx* c, int maxclips, void* ws, unsigned* out);
 

@@ -231,9 +231,10 @@ class IthorTrainer:
         self.exp_avg_sq = torch.zeros_like(flat)
         self.step_count = 0
         self.pg = process_group
-        self.world = 1
+        self.world, self.rank = 1, 0
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
+            self.rank = torch.distributed.get_rank(process_group)
 
     @property
     def grads(self):
@@ -270,7 +271,7 @@ class IthorTrainer:
     def use_rccl(self, comm):
         """Route the all-reduce through the C ABI (comm.RcclComm) instead of torch.distributed."""
         self.rccl = comm
-        self.world = comm.size
+        self.world, self.rank = comm.size, comm.rank
         return self
 
     def allreduce(self):
@@ -289,6 +290,10 @@ class IthorTrainer:
                 "var_adam_step")
 
     def step(self, image, pos, neg, global_batch=None):
+        """One optimisation step.  bf16 mode with the persistent GRU launches: if a launch of this step timed out (its grid
+        was not fully resident -- another process on the GPU) the loss reads NaN and the Adam kernel leaves parameters,
+        moments and step count alone (a device-side guard word, csrc/pack_adam.hip); the next step clears the word and
+        trains normally; gru_status() keeps a sticky record.  Nothing to check per step on the host."""
         self.loss_and_grads(image, pos, neg, global_batch)
         self.allreduce()
         self.adam()

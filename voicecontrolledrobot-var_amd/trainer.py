@@ -524,6 +524,30 @@ class VARTrainer:
             raise VarHipError("image must be u8/f32 and MFCC f32")
 
 
+def _save_outputs(tr, model, save_dir, fname, log):
+    """Checkpoints and progress.csv are written by rank 0 only (every replica holds the same parameters; concurrent
+    torch.save calls on one path can leave a corrupt file), with a barrier behind the write."""
+    rank = getattr(tr, "rank", 0)
+    dist = getattr(tr, "world", 1) > 1 and torch.distributed.is_available() and torch.distributed.is_initialized()
+    if rank == 0:
+        os.makedirs(save_dir, exist_ok=True)
+        torch.save(model.state_dict(), fname, _use_new_zipfile_serialization=False)   # legacy format, pretext_VAR.py:79
+        log('Model saved to ' + fname)
+    if dist:
+        torch.distributed.barrier(group=getattr(tr, "pg", None))
+
+
+def _save_progress(tr, save_dir, loss_list):
+    if getattr(tr, "rank", 0) != 0:
+        return
+    os.makedirs(save_dir, exist_ok=True)
+    with open(os.path.join(save_dir, 'progress.csv'), 'w', newline='') as f:
+        w = csv.writer(f)
+        w.writerow(['avg_loss'])
+        for v in loss_list:
+            w.writerow([v])
+
+
 def train_representation(model, batches, epochs, lr=1e-4, weight_decay=1e-6, milestones=None, gamma=0.2,
                          margin=1.0, save_dir=None, save_interval=10, start_ep=0, log=print):
     """The loop of VAR/pretext_VAR.py:44-91.  `batches()` yields (image, sound_positive, sound_negative, gt)
@@ -545,21 +569,26 @@ def train_representation(model, batches, epochs, lr=1e-4, weight_decay=1e-6, mil
         for image, sp, sn, _gt in batches():
             tr.step(image.contiguous(), sp.float().contiguous(), sn.float().contiguous())
             losses.append(tr.loss.clone())
-        avg = float(torch.stack(losses).sum().item() / len(losses))      # np.sum(loss_ep)/len(loss_ep), :82
+        stack = torch.stack(losses).reshape(-1)
+        if is_ithor and model.gru_status():
+            # bf16 mode: a persistent GRU launch did not get its whole grid resident (another process on the GPU) and timed
+            # out.  Those steps carry a NaN loss and were SKIPPED by the optimiser (csrc/pack_adam.hip: Adam's guard word),
+            # so parameters and moments are intact: take the per-step launches from here on and average the steps that ran.
+            bad = int((~torch.isfinite(stack)).sum().item())
+            log(f'persistent GRU launch timed out in {bad} step(s) of epoch {start_ep + ep} (status '
+                f'{model.gru_status():#x}): skipped by the optimiser; switching to per-step GRU launches')
+            model.set_gru_sequence(False)
+            model._ensure_plan(tr.ctx, int(image.shape[0]))                # applies the form and clears the status words
+            stack = stack[torch.isfinite(stack)]
+            if stack.numel() == 0:
+                raise VarHipError("every step of the epoch timed out in the persistent GRU launches")
+        avg = float(stack.sum().item() / stack.numel())                   # np.sum(loss_ep)/len(loss_ep), :82
         loss_list.append(avg)
         log('average loss', avg)
         if save_dir and ((ep + 1) % save_interval == 0 or ep + 1 == epochs):
-            os.makedirs(save_dir, exist_ok=True)
-            fname = os.path.join(save_dir, str(start_ep + ep) + '.pt')
-            torch.save(model.state_dict(), fname, _use_new_zipfile_serialization=False)   # legacy format, :79
-            log('Model saved to ' + fname)
+            _save_outputs(tr, model, save_dir, os.path.join(save_dir, str(start_ep + ep) + '.pt'), log)
     if save_dir:
-        os.makedirs(save_dir, exist_ok=True)
-        with open(os.path.join(save_dir, 'progress.csv'), 'w', newline='') as f:
-            w = csv.writer(f)
-            w.writerow(['avg_loss'])
-            for v in loss_list:
-                w.writerow([v])
+        _save_progress(tr, save_dir, loss_list)
     model.eval()
     return loss_list
 
@@ -598,16 +627,8 @@ def train_representation_from_pool(model, pool, epochs, batch, lr=1e-4, weight_d
         loss_list.append(avg)
         log('average loss', avg)
         if save_dir and ((ep + 1) % save_interval == 0 or ep + 1 == epochs):
-            os.makedirs(save_dir, exist_ok=True)
-            fname = os.path.join(save_dir, str(start_ep + ep) + '.pt')
-            torch.save(model.state_dict(), fname, _use_new_zipfile_serialization=False)
-            log('Model saved to ' + fname)
+            _save_outputs(tr, model, save_dir, os.path.join(save_dir, str(start_ep + ep) + '.pt'), log)
     if save_dir:
-        os.makedirs(save_dir, exist_ok=True)
-        with open(os.path.join(save_dir, 'progress.csv'), 'w', newline='') as f:
-            w = csv.writer(f)
-            w.writerow(['avg_loss'])
-            for v in loss_list:
-                w.writerow([v])
+        _save_progress(tr, save_dir, loss_list)
     model.eval()
     return loss_list
