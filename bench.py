@@ -222,19 +222,18 @@ def main_ithor(args, rank, local_rank, world, dev):
             ach = flops / (best[1] * 1e-3) / 1e12
             traffic = None
             try:                                                # HBM bytes per launch from the committed PMC passes
-                if B == 256 and args.dtype == "f32":
-                    with open(os.path.join(ROOT, "profiles", "r01_ithor_pmc.json")) as f:
-                        k = json.load(f)["kernels"]
-                    k = k.get(names[best[0]]) or k[{"forward": "gg_kernel<ConvFwdP<11x5 s2>>", "data gradient": "gg_kernel<ConvDgradS2P<11x5 s2>>",
-                                                    "weight gradient": "gg_kernel<ConvWgradP<11x5 s2>>"}[names[best[0]].split("s2 ")[1]]]
-                    traffic = k["fetch_bytes"] + k["write_bytes"]
-                elif B == 256:                                  # tools/pmc_traffic.sh r02_ithor_bf16 --workload ithor --dtype bf16
-                    with open(os.path.join(ROOT, "profiles", "r02_ithor_bf16_pmc_hbm_traffic.json")) as f:
+                if B == 256 and args.dtype == "f32":             # tools/pmc_traffic.sh r03_ithor_f32 --workload ithor
+                    with open(newest_profile("ithor_f32_pmc_hbm_traffic.json")) as f:
+                        pm = json.load(f)
+                    want = {"forward": "ConvFwdP<", "data gradient": "ConvDgradS2P<", "weight gradient": "ConvWgradP<"}[names[best[0]].split("s2 ")[1]]
+                    traffic = max(v["hbm_bytes_fetch_x2_plus_write"] for kk, v in pm.items() if want in kk and "11x5" in kk)
+                elif B == 256:                                  # tools/pmc_traffic.sh r03_ithor_bf16 --workload ithor --dtype bf16
+                    with open(newest_profile("ithor_bf16_pmc_hbm_traffic.json")) as f:
                         pm = json.load(f)
                     want = {"forward": ("snd_fwd_kernel", "Geo2"), "data gradient": ("snd_dgrad_kernel", "DGeo2"),
                             "weight gradient": ("snd_wgrad_kernel", "WGeo2")}[names[best[0]].split("s2 ")[1]]
                     traffic = [v["hbm_bytes_fetch_x2_plus_write"] for kk, v in pm.items() if want[0] in kk and want[1] in kk][0]
-            except (OSError, KeyError, ValueError, IndexError):
+            except (OSError, KeyError, ValueError, IndexError, TypeError):
                 pass
             roof = {"bound": "mfma", "kernel": names[best[0]], "achieved": round(ach, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
@@ -246,11 +245,15 @@ def main_ithor(args, rank, local_rank, world, dev):
     for _ in range(args.warmup):
         step()
     barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for _ in range(args.steps):
         step()
+    ev1.record()
     barrier()
     dt = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -259,7 +262,8 @@ def main_ithor(args, rank, local_rank, world, dev):
         value = args.steps * B * world / dt
         out = {"metric": "pretext triplets/sec (iTHOR model: 96x96 RGB + 16 kHz/6 s audio)", "value": round(value, 1),
                "unit": "triplets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(1e3 * dt / args.steps, 3), "ms_per_step_device": round(dev_ms / args.steps, 3),
+               "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "n_ranks_seen": args.n_ranks_seen,
                "config": {"workload": "iTHOR pretext step (BASELINE.json configs[3] shapes), batch per GPU as given: u8 "
                                       "96x96 image + 2 int16 clips of up to 6 s resident in HBM -> python_speech_features "
@@ -299,16 +303,28 @@ def tag_flops(tag):
     return LAYER_FLOPS[tag % 5]
 
 
+def newest_profile(suffix):
+    """profiles/rNN_<suffix> of the highest round NN present (the PMC passes are re-taken per round), or None."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r[0-9][0-9]_" + suffix)):
+        m = re.match(r"r(\d\d)_", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    return best[1] if best else None
+
+
 def pmc_traffic(tag_name, hw):
     """HBM bytes per launch of the dominant kernel, from the committed PMC pass of THIS round's kernels (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction: FETCH_SIZE x 2; tools/pmc_traffic.sh ->
-    profiles/r02_pmc_hbm_traffic.json; batch 256, 84 x 84 only).
+    profiles/rNN_pmc_hbm_traffic.json, the newest round present; batch 256, 84 x 84 only).
     PMC counters cannot be collected from inside this process, so this is the figure of that pass
     (same workload, same kernel); None when the file or the kernel is not in it."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_hbm_traffic.json")
-    if hw != 84:
+    path = newest_profile("pmc_hbm_traffic.json")
+    if hw != 84 or path is None:
         return None
-    want = {"img_fwd_head_kernel[0+1]": "img_fwd_head_kernel<HeadCfg<%d," % (hw // 2),
+    want = {"img_fwd_head_kernel[0+1]": "img_head2_kernel<",
             "img_fwd_mid_kernel[2+3+4+head]": "img_fwd_mid_kernel<",
             "img_bwd_last_kernel[wgrad1+dgrad1+wgrad0]": "img_bwd_last_kernel<",
             "img_bwd_pair_kernel[wgrad2+dgrad2]": "img_bwd_pair_kernel<WgCfg<32, 64,",
@@ -553,11 +569,15 @@ def main():
         step()
 
     barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for _ in range(args.steps):
         step()
+    ev1.record()
     barrier()
     dt = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)          # the same K steps between two HIP events on the launch stream: no host launch / sync cost
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -570,7 +590,8 @@ def main():
         out = {
             "metric": f"pretext triplets/sec ({HW}x{HW} RGB + 16 kHz/1 s audio)",
             "value": round(value, 1), "unit": "triplets/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "ms_per_step_device": round(dev_ms / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "n_ranks_seen": args.n_ranks_seen,
             **({"rehearsal": "all ranks on ONE device, gloo exchange: code-path check, not a scaling number"}
@@ -583,6 +604,8 @@ def main():
             "mfma_frac_whole_step": round(value / world * FLOPS_PER_TRIPLET / 1e12 / F32_MFMA_PEAK, 4),
         }
         out["config"]["launch"] = "hip-graph replay" if use_graph else "eager"
+        if getattr(tr, "dp_graphs_per_step", None):              # data-parallel step: 1 = the collective is captured in the step's graph
+            out["config"]["dp_graph_launches_per_step"] = tr.dp_graphs_per_step
         out["config"]["head"] = args.head
         if dom_tag is not None and roof_n and iso_n:
             # `achieved` is priced on the kernel's own duration (HIP events around it with every launch of the step

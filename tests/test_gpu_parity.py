@@ -345,9 +345,18 @@ def test_data_parallel_replay_path_equals_eager_steps(var_amd, golden_dir):
         tb = var_amd.VARTrainer(mb, lr=1e-3, weight_decay=1e-6)
         tb.force_collective = True
         replay, load_table = tb.capture_epoch_steps(pool.images, pool.clips, B, table)
+        assert tb.dp_graphs_per_step == 1                       # round 3: the collective is captured, one graph launch per step
         losses_b = [float(replay().item()) for _ in range(4)]
         pb = mb.flat_parameters().cpu().numpy().copy()
         assert int(tb._g_step.item()) == 4
+        # the three-graph form of round 2 (graphs around an eager collective): bit-identical losses and parameters
+        mc = make_model(var_amd, sd, 84)
+        tc = var_amd.VARTrainer(mc, lr=1e-3, weight_decay=1e-6)
+        tc.force_collective, tc.dp_one_graph = True, False
+        replay_c, _ = tc.capture_epoch_steps(pool.images, pool.clips, B, table)
+        assert tc.dp_graphs_per_step == 3
+        losses_c = [float(replay_c().item()) for _ in range(4)]
+        assert losses_c == losses_b and torch.equal(mc.flat_parameters(), mb.flat_parameters())
     finally:
         if created:
             dist.destroy_process_group()
@@ -392,6 +401,22 @@ def test_rccl_collectives_through_the_c_abi(var_amd, golden_dir):
             assert torch.equal(flat, prev)
         prev = flat
     assert losses[0] == losses[1]
+    # the replayed data-parallel step with the C ABI's own communicator: the collective is recorded into the step's graph
+    # (ONE graph launch per step), and the replays equal the single-process replays bit for bit
+    pool = var_amd.SyntheticTripletPool(64, hw=84, seed=12, clips_per_class=4).freeze_pairs()
+    table = pool.index_table(16, 3)[:3].contiguous()
+    finals = []
+    for use in (False, True):
+        m = make_model(var_amd, sd, 84)
+        tr = var_amd.VARTrainer(m, lr=1e-3)
+        if use:
+            tr.use_rccl(comm)
+        replay, _ = tr.capture_epoch_steps(pool.images, pool.clips, 16, table)
+        ls = [float(replay().item()) for _ in range(4)]
+        finals.append((ls, m.flat_parameters().clone()))
+        if use:
+            assert tr.dp_graphs_per_step == 1
+    assert finals[0][0] == finals[1][0] and torch.equal(finals[0][1], finals[1][1])
     comm.destroy()
     with pytest.raises(var_amd.VarHipError):
         comm.allreduce(x)

@@ -268,13 +268,13 @@ class VARTrainer:
             load_table(table)
             return replay, load_table
 
-        # ---- data parallel.  The gradient all-reduce (eager between graphs) has nothing to overlap with inside the
-        # step -- every gradient is complete only at the end of the backward -- but the audio front-end of the NEXT
-        # step does not depend on the weights: per step
-        #     graph [gather + fwd + loss + bwd, MFCC features of this step precomputed]
-        #     -> all_reduce(async) || MFCC of the next step (graph, on the caller's stream)
-        #     -> wait -> graph [Adam + re-pack + row fetch]
-        # so up to an MFCC kernel's worth (60 us) of collective latency is hidden.
+        # ---- data parallel.  The gradient all-reduce has nothing to overlap with inside the step -- every gradient is
+        # complete only at the end of the backward -- but the audio front-end of the NEXT step does not depend on the
+        # weights: per step
+        #     [gather + fwd + loss + bwd, MFCC features of this step precomputed]
+        #     -> all_reduce || MFCC of the next step
+        #     -> [Adam + re-pack + row fetch]
+        # so up to an MFCC kernel's worth (45 us) of collective latency is hidden (body_step below: one graph).
         flat = self.model.flat_parameters()
         self._g_mfcc = torch.zeros(2 * B, 1, 100, 40, dtype=torch.float32, device=self.dev)
         cur, nxt = self._g_idx[:row_ints], self._g_idx[row_ints:]
@@ -300,9 +300,52 @@ class VARTrainer:
             return body
 
         body_front(B)()                                    # warm-up outside capture
-        g_grad = [c.capture([[body_grad(Bs, gb)]])[0] for Bs, gb in sizes]
-        g_front = [c.capture([[body_front(Bs)]])[0] for Bs, _ in sizes]
-        g_adam = c.capture([[adam]])[0]
+        g_front = [c.capture([[body_front(Bs)]])[0] for Bs, _ in sizes]      # (features of row 0, load_table)
+
+        # ONE graph per step (round 3): [gather + fwd + loss + bwd] -> { the collective on the capturing stream || MFCC of
+        # the NEXT step on a forked stream } -> [Adam + re-pack + row fetch].  RCCL collectives are capturable, so the
+        # replay is one graph launch -- round 2 ran three graphs, an eager collective and a host-side work.wait() per step
+        # (1.08x the single-process step in the one-rank rehearsal).  One graph per (size of this batch, size of the next)
+        # pair that the table can produce.
+        def body_step(Bs, gb, Bn):
+            grad, front = body_grad(Bs, gb), body_front(Bn)
+
+            def body():
+                grad()
+                if self.dev.type == "cuda":
+                    main = torch.cuda.current_stream(self.dev)
+                    aux = self._aux_stream()
+                    aux.wait_stream(main)                  # fork (a graph edge under capture)
+                    with torch.cuda.stream(aux):
+                        front()                            # next step's features: independent of the weights
+                    self.allreduce()                       # in flight beside the front-end
+                    main.wait_stream(aux)                  # join
+                else:                                      # (host rehearsal of the schedule, tests/_oracle_ctx.py)
+                    self.allreduce()
+                    front()
+                adam()
+            return body
+
+        def pairs():
+            out = {(0, 0)}
+            if tail_batch:
+                out |= {(0, 1), (1, 0)} if steps_per_epoch > 1 else {(1, 1)}
+            return sorted(out)
+        # capturable: RCCL (the C ABI's communicator, or torch.distributed's nccl backend); a gloo group on CUDA tensors
+        # stages through the host and cannot be recorded -- it keeps the three-graph form (the 2-ranks-on-one-device test)
+        one_graph = getattr(self, "dp_one_graph", True) and (
+            self.dev.type != "cuda" or self.rccl is not None or
+            (torch.distributed.is_initialized() and torch.distributed.get_backend(self.pg) == "nccl"))
+        g_step = {}
+        if one_graph:
+            for a, b in pairs():
+                (Bs, gb), (Bn, _) = sizes[a], sizes[b]
+                g_step[(a, b)] = c.capture([[body_step(Bs, gb, Bn)]])[0]
+        g_grad = g_adam = None
+        if not one_graph:
+            g_grad = [c.capture([[body_grad(Bs, gb)]])[0] for Bs, gb in sizes]
+            g_adam = c.capture([[adam]])[0]
+        self.dp_graphs_per_step = 1 if one_graph else 3
 
         def load_table(t):
             assert t.shape == self._g_table.shape
@@ -317,17 +360,27 @@ class VARTrainer:
         def replay():
             row = state["row"]
             self._bind()
-            g_grad[1 if is_tail(row) else 0]()
-            work = self.allreduce(async_op=True)
-            g_front[1 if is_tail((row + 1) % rows) else 0]()   # MFCC of the next step while the collective is in flight
-            if work is not None:
-                work.wait()                                # the caller's stream waits for the collective
-            g_adam()                                       # ... and fetches the rows of the steps after
+            a, b = (1 if is_tail(row) else 0), (1 if is_tail((row + 1) % rows) else 0)
+            if one_graph:
+                g_step[(a, b)]()
+            else:
+                g_grad[a]()
+                work = self.allreduce(async_op=True)
+                g_front[b]()                               # MFCC of the next step while the collective is in flight
+                if work is not None:
+                    work.wait()                            # the caller's stream waits for the collective
+                g_adam()                                   # ... and fetches the rows of the steps after
             state["row"] = (row + 1) % rows
             self.step_count += 1
             return self.loss
         load_table(table)
         return replay, load_table
+
+    def _aux_stream(self):
+        """The stream the next step's front-end is forked onto inside the captured data-parallel step."""
+        if getattr(self, "_aux", None) is None:
+            self._aux = torch.cuda.Stream(device=self.dev)
+        return self._aux
 
     def set_lr(self, lr):
         self.lr = lr
