@@ -171,7 +171,10 @@ static size_t plan_layout(var_ctx* c, char* base, int max_batch, int img_hw) {
     auto carve = [&](size_t nfloats) { size_t o = off; off += (nfloats * 4 + 255) & ~(size_t)255; return o; };
     size_t o_act[6], o_gact[6], o_sact[5], o_gsact[5];
     for (int l = 1; l <= 5; l++) {
-        const size_t n = B * kImgCh[l] * hs[l] * hs[l];
+        size_t n = B * kImgCh[l] * hs[l] * hs[l];
+        // 84 x 84: act1 lives band by band in the forward head's LDS tile layout (img_head2.hip / img_tail2.hip):
+        // [image][7 bands][32 channels][300 floats]; its gradient never exists in HBM (gact[1] is var_debug_buffer's scratch)
+        if (l == 1 && img_hw == 84) n = B * kAct1TiledFloats;
         o_act[l] = carve(n);
         o_gact[l] = carve(n);
     }
@@ -605,7 +608,16 @@ int var_debug_buffer(var_ctx* c, const char* name, void** ptr, long* nfloats) {
         char a[16], g[16];
         snprintf(a, sizeof a, "act%d", l); snprintf(g, sizeof g, "gact%d", l);
         const long n = (long)(B * kImgCh[l] * c->hs[l] * c->hs[l]);
-        if (!strcmp(name, a)) { *ptr = c->act[l]; *nfloats = n; return VAR_OK; }
+        if (!strcmp(name, a)) {
+            *ptr = c->act[l]; *nfloats = n;
+            if (l == 1 && c->H == 84) {          // the tiled form -> NCHW, into the (otherwise unused) gact[1] block
+                int rc = launch_act1_untile(c, nullptr, (int)B);
+                if (rc != VAR_OK) return rc;
+                VAR_HIP_CHECK(c, hipStreamSynchronize(nullptr));
+                *ptr = c->gact[1];
+            }
+            return VAR_OK;
+        }
         if (!strcmp(name, g)) { *ptr = c->gact[l]; *nfloats = n; return VAR_OK; }
     }
     for (int l = 1; l <= 4; l++) {

@@ -493,7 +493,7 @@ int launch_img_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads,
         if (rc != VAR_OK) return rc;
     }
     if (H == 84) {
-        rc = c->saved_u8 ? launch_last<W84_1, T84u>(c, s, B) : launch_last<W84_1, T84f>(c, s, B);
+        rc = launch_img_bwd_tail2(c, s, B);      // wgrad 1 + dgrad 1 + wgrad 0 in one role-specialised kernel (img_tail2.hip; act1 band-tiled)
     } else {
         if ((rc = launch_img_wgrad1_96(c, s, xin[1], bs[1], c->gact[2], B)) != VAR_OK) return rc;
         rc = launch_img_bwd_tail(c, s, B);

@@ -10,12 +10,9 @@ int launch_img_fwd(var_ctx* c, hipStream_t s, const float* params, const void* i
         VAR_SET_ERR(c, "unsupported image size %d (84 or 96)", c->H);
         return VAR_ERR_ARG;
     }
-#ifdef VAR_HEAD1
-    int rc = launch_img_fwd_head(c, s, params, image, is_u8, bstride, image_index, B);
-#else
+    // 84 x 84: the role-specialised head (img_head2.hip), act1 band-tiled for img_tail2.hip; 96 x 96: round 2's kernels (NCHW act1)
     int rc = c->H == 84 ? launch_img_fwd_head2(c, s, params, image, is_u8, bstride, image_index, B)
                         : launch_img_fwd_head(c, s, params, image, is_u8, bstride, image_index, B);
-#endif
     if (rc != VAR_OK) return rc;
     c->head_in_mid = true;
     return launch_img_fwd_mid(c, s, params, B, true);

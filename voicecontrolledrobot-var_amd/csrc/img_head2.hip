@@ -58,12 +58,11 @@ struct Head2Cfg {
     static constexpr int LDS_FLOATS = BIA + 64;
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
     static constexpr int NLD = 3 * IRI * (HI / 4);            // 4-pixel groups of an image band
-    static constexpr int NCO = CH * (IR1 - 1) * W1 / 4;       // float4 of the act1 rows a band owns
-    static constexpr int LPT = (NLD + NTA - 1) / NTA;         // per lane of role A
+        static constexpr int LPT = (NLD + NTA - 1) / NTA;         // per lane of role A
     static_assert(HO2 % R2 == 0 && HI % 4 == 0, "whole bands, 4-pixel groups");
     static_assert(NT2 == 4 && NBW == 8, "role B: one (conv-2 pixel tile, channel half) per wave");
     static_assert((A1ROW0 + W1) % 4 == 0 && PLANE_1 % 4 == 0 && (BIA % 4) == 0 && (IMG_FLOATS % 4) == 0 && PWI % 4 == 0, "16-byte aligned runs");
-    static_assert(((IR1 - 1) * W1) % 4 == 0, "the owned rows are whole float4");
+    static_assert(A1_FLOATS % 4 == 0, "the tile is whole float4");
     static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 };
 
@@ -98,57 +97,38 @@ img_head2_kernel(const void* __restrict__ image, long bstride, const int* __rest
     if (tid < 256) lds[C::LUT + tid] = (float)tid / 255.f;
     if (tid < 32) { lds[C::BIA + tid] = bias1[tid]; lds[C::BIA + 32 + tid] = bias2[tid]; }
     for (int e = tid; e < 2 * 3 * C::IRI; e += C::NT) lds[C::IMS + e * C::PWI + 3] = 0.f;                     // pad column x = -1
+    for (int e = tid; e < 2 * C::CH; e += C::NT) {              // pad cells of the act1 tiles (they travel to HBM with the tile)
+        float* pl = lds + C::A1S + e * C::PLANE_1;
+        pl[0] = 0.f; pl[1] = 0.f;
+        for (int k = C::A1ROW0 + C::IR1 * C::W1; k < C::PLANE_1; ++k) pl[k] = 0.f;
+    }
     __syncthreads();
     PHR(0);
 
-    // act1 tile j (complete since the last barrier) -> HBM: the rows the band owns are one contiguous run per channel, in
-    // LDS and in HBM alike (16 bytes per lane and store); then their ReLU bit patterns for img_bwd_tail.hip (u16 per pixel
-    // and channel half h, bit r <-> channel (r & 3) + 8 (r >> 2) + 4 h)
+    // act1 tile j (complete since the last barrier) -> HBM.  act1 lives in HBM band by band in EXACTLY the tile's LDS layout
+    // ([image][band][channel][PLANE_1]: row 0 = the halo row the band shares with the one above, rows 1.. = the rows it
+    // owns): one contiguous 38 KB block per band, copied 16 bytes per lane -- and read back the same way by the backward
+    // kernel that is its only consumer (img_tail2.hip), which needs exactly these 2 R2 + 1 rows per band.  The NCHW form
+    // (57.8 MB in 1 KB runs per channel and band) cost the forward 6 us and the backward its staging's index arithmetic.
     auto copy_out = [&](int j, int atid) {
         const int band = j % C::NB, b = tile_img(j);
-        const float* a1 = lds + C::A1S + (j & 1) * C::A1_FLOATS + C::A1ROW0 + C::W1;
-        constexpr int RUN = (C::IR1 - 1) * C::W1;                     // floats per channel
+        const float* a1 = lds + C::A1S + (j & 1) * C::A1_FLOATS;
         constexpr int NTC = 64 * C::NBW;                              // lanes of the role that runs the copy
-        float* yb = y1 + ((size_t)b * C::CH * C::H1 + 2 * C::R2 * band) * C::W1;
+        float* yb = y1 + (size_t)b * kAct1TiledFloats + (size_t)band * C::A1_FLOATS;
         // (the LDS reads of a group are issued before its first store: left alone hipcc emits read - wait - store chains)
-        constexpr int NF4 = (C::NCO + NTC - 1) / NTC;
+        constexpr int NF4 = (C::A1_FLOATS / 4 + NTC - 1) / NTC;
+        f32x4h cv[NF4];
 #pragma unroll
-        for (int i0 = 0; i0 < NF4; i0 += 2) {
-            f32x4h cv[2];
-#pragma unroll
-            for (int i = i0; i < i0 + 2 && i < NF4; ++i) {
-                int e = atid + NTC * i;
-                if (e >= C::NCO) e = 0;
-                const int ch = e / (RUN / 4), g = e - ch * (RUN / 4);
-                cv[i - i0] = *(const f32x4h*)(a1 + ch * C::PLANE_1 + 4 * g);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = i0; i < i0 + 2 && i < NF4; ++i) {
-                const int e = atid + NTC * i;
-                if (e < C::NCO) {
-                    const int ch = e / (RUN / 4), g = e - ch * (RUN / 4);
-                    *(f32x4h*)(yb + (size_t)ch * C::H1 * C::W1 + 4 * g) = cv[i - i0];
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < NF4; ++i) {
+            int e = atid + NTC * i;
+            if (e >= C::A1_FLOATS / 4) e = 0;
+            cv[i] = *(const f32x4h*)(a1 + 4 * e);
         }
-        uint16_t* rb = relu_bits + (size_t)b * 2 * C::H1 * C::W1 + 2 * C::R2 * band * C::W1;
-        static_assert(2 * RUN <= NTC, "one (pixel, channel half) per lane");
-        {
-            const int e = atid < 2 * RUN ? atid : 0;
-            const int h = e / RUN, f = e - h * RUN;
-            uint32_t bits = 0;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r0 = 0; r0 < 16; r0 += 8) {
-                float bvv[8];
-#pragma unroll
-                for (int r = 0; r < 8; ++r) bvv[r] = a1[(((r0 + r) & 3) + 8 * ((r0 + r) >> 2) + 4 * h) * C::PLANE_1 + f];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r = 0; r < 8; ++r) bits |= bvv[r] > 0.f ? (1u << (r0 + r)) : 0u;
-            }
-            if (atid < 2 * RUN) rb[(size_t)h * C::H1 * C::W1 + f] = (uint16_t)bits;
+        for (int i = 0; i < NF4; ++i) {
+            const int e = atid + NTC * i;
+            if (e < C::A1_FLOATS / 4) *(f32x4h*)(yb + 4 * e) = cv[i];
         }
     };
     if (wave < C::NA) {
@@ -381,7 +361,25 @@ int launch_head2(var_ctx* c, hipStream_t s, const void* image, long bstride, con
 }
 }  // namespace
 
-// conv 1 + conv 2 of the image CNN at 84 x 84; leaves act[1], relu1 and act[2]
+// var_debug_buffer("act1") at 84 x 84: the band-tiled act1 back to NCHW (rows 1.. of every band), into gact[1]
+__global__ void __launch_bounds__(256) act1_untile_kernel(const float* __restrict__ t, float* __restrict__ y, long n) {
+    using C = H2_84u;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int x = (int)(i % C::W1), r1 = (int)((i / C::W1) % C::H1), ch = (int)((i / (C::W1 * C::H1)) % C::CH);
+    const long b = i / ((long)C::W1 * C::H1 * C::CH);
+    const int band = r1 / (2 * C::R2), rl = r1 - band * 2 * C::R2 + 1;
+    y[i] = t[b * kAct1TiledFloats + (long)band * C::A1_FLOATS + ch * C::PLANE_1 + C::A1ROW0 + rl * C::W1 + x];
+}
+
+int launch_act1_untile(var_ctx* c, hipStream_t s, int B) {
+    const long n = (long)B * H2_84u::CH * H2_84u::H1 * H2_84u::W1;
+    hipLaunchKernelGGL(act1_untile_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->act[1], c->gact[1], n);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}
+
+// conv 1 + conv 2 of the image CNN at 84 x 84; leaves act[1] (band-tiled) and act[2]
 int launch_img_fwd_head2(var_ctx* c, hipStream_t s, const float* params, const void* image, int is_u8, long bstride,
                          const int* image_index, int B) {
     return is_u8 ? launch_head2<H2_84u>(c, s, image, bstride, image_index, params, B)

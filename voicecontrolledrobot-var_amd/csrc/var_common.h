@@ -255,6 +255,10 @@ int launch_img_fwd_mid(var_ctx* c, hipStream_t s, const float* params, int B, bo
 // down more than the overlap gains -- only the small sound kernels are worth forking.
 static constexpr int kDefaultStreams = 3;
 static constexpr int kTailG = 256;    // workgroups (= layer-0 slabs) of the fused backward tail
+static constexpr long kAct1TiledFloats = 7L * 32 * 300 + 128;   // act1 of one 84 x 84 image, band-tiled (+ slack for whole-KiB reads)
+int launch_act1_untile(var_ctx* c, hipStream_t s, int B);      // img_head2.hip: tiled act1 -> NCHW in gact[1] (var_debug_buffer)
+static constexpr int kTail2G = 256;   // persistent workgroups (= layer-0 and layer-1 slabs) of img_tail2_kernel: one image each
+int launch_img_bwd_tail2(var_ctx* c, hipStream_t s, int B);   // img_tail2.hip: wgrad 2 + dgrad 2 + wgrad 1 at 84 x 84
 int launch_img_bwd_tail(var_ctx* c, hipStream_t s, int B);
 int launch_img_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads, int B);
 int launch_snd_fwd(var_ctx* c, hipStream_t s, const float* params, const float* pos, const float* neg, int B);
