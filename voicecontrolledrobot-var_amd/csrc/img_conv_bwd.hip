@@ -444,6 +444,47 @@ static int launch_last(var_ctx* c, hipStream_t s, int B) {
     return VAR_OK;
 }
 
+// The weight gradients of conv 5, 4 and 3 in ONE grid (84 x 84): their inputs -- gact[5..3] left by img_chain_kernel, act[4..2]
+// -- are all there before it starts, and none of the three fills the GPU by itself (128 split-K workgroups each).  Longest first.
+template <class W2, class W3, class W4>
+__global__ void __launch_bounds__(768)
+img_wgrad345_kernel(const float* __restrict__ x2, const float* __restrict__ x3, const float* __restrict__ x4,
+                    const float* __restrict__ gy3, const float* __restrict__ gy4, const float* __restrict__ gy5,
+                    float* __restrict__ slabs2, float* __restrict__ slabs3, float* __restrict__ slabs4, int G2, int G3, int G4, int B) {
+    static_assert(W2::NW * 64 == 768 && W3::NW * 64 == 768 && W4::NW * 64 == 768, "12 waves each");
+    int id = blockIdx.x;
+    const int n2 = G2 * W2::NCOMBO, n3 = G3 * W3::NCOMBO;
+    if (id < n2) { img_wgrad_body<W2>(x2, 32L * 21 * 21, nullptr, gy3, slabs2, B, id % G2, id / G2, G2); return; }
+    id -= n2;
+    if (id < n3) { img_wgrad_body<W3>(x3, 64L * 11 * 11, nullptr, gy4, slabs3, B, id % G3, id / G3, G3); return; }
+    id -= n3;
+    img_wgrad_body<W4>(x4, 64L * 6 * 6, nullptr, gy5, slabs4, B, id % G4, id / G4, G4);
+}
+
+static int launch_wgrad345(var_ctx* c, hipStream_t s, int B) {
+    using W2 = W84_2; using W3 = W84_3; using W4 = W84_4;
+    ProfScope prof(c, s, TAG_IMG_WGRAD0 + 2);
+    constexpr int LDS_BYTES = W2::LDS_BYTES > W3::LDS_BYTES ? (W2::LDS_BYTES > W4::LDS_BYTES ? W2::LDS_BYTES : W4::LDS_BYTES)
+                                                           : (W3::LDS_BYTES > W4::LDS_BYTES ? W3::LDS_BYTES : W4::LDS_BYTES);
+    static bool attr_set = false;
+    if (!attr_set) {
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)img_wgrad345_kernel<W2, W3, W4>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_set = true;
+    }
+    auto groups = [&](int layer, int nb, int nu) {
+        const int need = (B * nb + nu - 1) / nu, gmax = img_wgrad_groups(layer);
+        return need < gmax ? need : gmax;
+    };
+    const int G2 = groups(2, W2::NB, W2::NU), G3 = groups(3, W3::NB, W3::NU), G4 = groups(4, W4::NB, W4::NU);
+    c->wg_groups[2] = G2; c->wg_groups[3] = G3; c->wg_groups[4] = G4;
+    hipLaunchKernelGGL((img_wgrad345_kernel<W2, W3, W4>), dim3(G2 * W2::NCOMBO + G3 * W3::NCOMBO + G4 * W4::NCOMBO), dim3(768),
+                       LDS_BYTES, s, c->act[2], c->act[3], c->act[4], c->gact[3], c->gact[4], c->gact[5],
+                       c->slabs + img_slab_offset(2), c->slabs + img_slab_offset(3), c->slabs + img_slab_offset(4), G2, G3, G4, B);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}
+
 // weight gradient of layer l and data gradient of layer l in one grid (84 x 84 inputs, layers 2..4)
 template <class WC, class DC, bool D16>
 static int launch_pair(var_ctx* c, hipStream_t s, int layer, const void* wx, long wbstride, const float* gy,
@@ -478,18 +519,18 @@ int launch_img_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads,
                         64L * c->hs[3] * c->hs[3], 64L * c->hs[4] * c->hs[4]};
     const void* xin[5] = {c->saved_image, c->act[1], c->act[2], c->act[3], c->act[4]};
     if (H != 84 && H != 96) { VAR_SET_ERR(c, "unsupported image size %d (84 or 96)", H); return VAR_ERR_ARG; }
-    for (int l = 4; l >= 2; --l) {
+    if (H == 84) {
+        // data gradients of conv 5 -> 4 -> 3 as one per-image chain (img_chain.hip), then their three weight gradients in one grid
+        if ((rc = launch_img_bwd_chain(c, s, B)) != VAR_OK) return rc;
+        if ((rc = launch_wgrad345(c, s, B)) != VAR_OK) return rc;
+    }
+    for (int l = 4; l >= 2 && H != 84; --l) {
         const float* gyl = c->gact[l + 1];
         const float* wdl = c->wpack + K.img_d[l];
-        if (H == 84) {
-            if (l == 4) rc = launch_pair<W84_4, D84_4, false>(c, s, 4, xin[4], bs[4], gyl, wdl, c->act[4], c->gact[4], B);
-            else if (l == 3) rc = launch_pair<W84_3, G84_3, true>(c, s, 3, xin[3], bs[3], gyl, wdl, c->act[3], c->gact[3], B);
-            else rc = launch_pair<W84_2, D84_2, false>(c, s, 2, xin[2], bs[2], gyl, wdl, c->act[2], c->gact[2], B);
-        } else {
-            if (l == 4) rc = launch_pair<W96_4, D96_4, false>(c, s, 4, xin[4], bs[4], gyl, wdl, c->act[4], c->gact[4], B);
-            else if (l == 3) rc = launch_pair<W96_3, G96_3, true>(c, s, 3, xin[3], bs[3], gyl, wdl, c->act[3], c->gact[3], B);
-            else rc = launch_pair<W96_2, D96_2p, false>(c, s, 2, xin[2], bs[2], gyl, wdl, c->act[2], c->gact[2], B);
-        }
+        // (96 x 96: round 2's paired grids, weight gradient || data gradient of a layer)
+        if (l == 4) rc = launch_pair<W96_4, D96_4, false>(c, s, 4, xin[4], bs[4], gyl, wdl, c->act[4], c->gact[4], B);
+        else if (l == 3) rc = launch_pair<W96_3, G96_3, true>(c, s, 3, xin[3], bs[3], gyl, wdl, c->act[3], c->gact[3], B);
+        else rc = launch_pair<W96_2, D96_2p, false>(c, s, 2, xin[2], bs[2], gyl, wdl, c->act[2], c->gact[2], B);
         if (rc != VAR_OK) return rc;
     }
     if (H == 84) {

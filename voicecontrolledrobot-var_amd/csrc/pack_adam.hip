@@ -11,21 +11,28 @@ struct PackSeg {
     int src;        // offset of the source tensor in the parameter arena
     int cin, cout, taps;
     int kvalid;     // cin*taps (rows beyond it are zero padding)
-    int type;       // 0: F image/1-D conv  [k=tap*cin+c][n] ; 1: D [tap][n][c] ; 2: F with source [n][tap][c]
+    int type;       // 0: F image/1-D conv  [k=tap*cin+c][n] ; 1: D [tap][n][c] ; 2: F with source [n][tap][c] ;
+                    // 3: D in MFMA A-fragment order [tap][c/16][n/16][16 (n&3) + (c&15)][(n>>2)&3]  (var_common.h: img_a)
 };
-struct PackTable { PackSeg seg[20]; int nseg; };
+struct PackTable { PackSeg seg[24]; int nseg; };
 
 __global__ void __launch_bounds__(256) pack_weights_kernel(PackTable T, const float* __restrict__ params,
                                                             float* __restrict__ wpack, int total) {
     for (int j = blockIdx.x * 256 + threadIdx.x; j < total; j += gridDim.x * 256) {
         int si = 0;
 #pragma unroll
-        for (int i = 1; i < 20; ++i) if (i < T.nseg && j >= T.seg[i].dst) si = i;
+        for (int i = 1; i < 24; ++i) if (i < T.nseg && j >= T.seg[i].dst) si = i;
         const PackSeg S = T.seg[si];
         const int e = j - S.dst;
         float v = 0.f;
         if (S.type == 1) {
             const int c = e % S.cin, n = (e / S.cin) % S.cout, tap = e / (S.cin * S.cout);
+            v = params[S.src + (n * S.cin + c) * S.taps + tap];
+        } else if (S.type == 3) {
+            const int jj = e & 3, ln = (e >> 2) & 63, grp = e >> 8;
+            const int nsg = S.cout / 16, nct = S.cin / 16;
+            const int sg = grp % nsg, ct = (grp / nsg) % nct, tap = grp / (nsg * nct);
+            const int n = 16 * sg + 4 * jj + (ln >> 4), c = 16 * ct + (ln & 15);
             v = params[S.src + (n * S.cin + c) * S.taps + tap];
         } else {
             const int n = e % S.cout, k = e / S.cout;
@@ -52,12 +59,14 @@ static PackTable make_pack_table(var_ctx* c) {
         add(K.img_f[i], Kp * kImgCh[i + 1], L.img_w[i], kImgCh[i], kImgCh[i + 1], 9, 0);
     }
     for (int i = 1; i < 5; i++) add(K.img_d[i], 9 * kImgCh[i + 1] * kImgCh[i], L.img_w[i], kImgCh[i], kImgCh[i + 1], 9, 1);
+    // (segments must stay sorted by dst for the gather kernel's search: img_a sits between the sound images and the heads in PackLayout)
     add(K.snd_f[0], 200 * 32, L.snd_w[0], 40, 32, 5, 2);
     for (int i = 1; i < 4; i++) add(K.snd_f[i], 96 * 32, L.snd_w[i], 32, 32, 3, 0);
     for (int i = 1; i < 4; i++) add(K.snd_d[i], 96 * 32, L.snd_w[i], 32, 32, 3, 1);
+    for (int i = 2; i < 5; i++) add(K.img_a[i], 9 * kImgCh[i + 1] * kImgCh[i], L.img_w[i], kImgCh[i], kImgCh[i + 1], 9, 3);
     add(K.ih_w0t, kImgFeat * kHid, L.ih_w0, kImgFeat, kHid, 1, 0);   // plain transpose
     add(K.sh_w0t, kSndFeat * kHid, L.sh_w0, kSndFeat, kHid, 1, 0);
-    T.nseg = n;   // 18
+    T.nseg = n;   // 21
     return T;
 }
 
@@ -131,7 +140,7 @@ adam_pack_dev_kernel(const PackSeg* __restrict__ segs, int nseg, float* __restri
     }
     // segment table -> LDS (one copy per block); each wave then finds the segments that touch its 64 consecutive
     // elements with ONE ballot (lane q tests segment q) instead of scanning the table per element
-    __shared__ PackSeg ssegs[20];
+    __shared__ PackSeg ssegs[24];
     if (wpack) {
         for (int e = threadIdx.x; e < nseg * (int)(sizeof(PackSeg) / 4); e += 256) ((int*)ssegs)[e] = ((const int*)segs)[e];
         __syncthreads();
@@ -173,7 +182,10 @@ adam_pack_dev_kernel(const PackSeg* __restrict__ segs, int nseg, float* __restri
                 int c, tap, nn, rest;
                 if (S.type == 2) { divmod(e, S.cin, rest, c); divmod(rest, S.taps, nn, tap); }
                 else { divmod(e, S.taps, rest, tap); divmod(rest, S.cin, nn, c); }
-                const int d = S.type == 1 ? (tap * S.cout + nn) * S.cin + c : (tap * S.cin + c) * S.cout + nn;
+                int d;
+                if (S.type == 3)
+                    d = ((((tap * (S.cin / 16) + (c >> 4)) * (S.cout / 16) + (nn >> 4)) * 64 + 16 * (nn & 3) + (c & 15)) << 2) + ((nn >> 2) & 3);
+                else d = S.type == 1 ? (tap * S.cout + nn) * S.cin + c : (tap * S.cin + c) * S.cout + nn;
                 wpack[S.dst + d] = pn;
             }
         }

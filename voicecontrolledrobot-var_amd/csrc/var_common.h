@@ -53,6 +53,7 @@ inline ParamLayout make_param_layout() {
 struct PackLayout {
     int img_f[5];
     int img_d[5];     // [0] unused
+    int img_a[5];     // [0], [1] unused: Wd of layers 2..4 in MFMA A-fragment order (img_chain.hip), see below
     int snd_f[4];
     int snd_d[4];     // [0] unused
     int ih_w0t;       // image head Linear(576,128) weight transposed: [k][j]
@@ -73,6 +74,10 @@ inline PackLayout make_pack_layout() {
     for (int i = 0; i < 4; i++) { P.snd_f[i] = o; o += snd_k[i] * 32; }
     P.snd_d[0] = -1;
     for (int i = 1; i < 4; i++) { P.snd_d[i] = o; o += 96 * 32; }
+    // A-fragment order of the transposed filter, for v_mfma_f32_16x16x4_f32 with D[c][pixel]: [tap][c tile][group of 4 k-steps]
+    // [lane = 16 q + l15][j]: W[tap][n = 16 sg + 4 j + q][c = 16 ct + l15] -- one 16-byte load per lane = its A operands of 4 k-steps
+    P.img_a[0] = P.img_a[1] = -1;
+    for (int i = 2; i < 5; i++) { P.img_a[i] = o; o += 9 * kImgCh[i + 1] * kImgCh[i]; }
     P.ih_w0t = o; o += kImgFeat * kHid;
     P.sh_w0t = o; o += kSndFeat * kHid;
     P.total = o;
@@ -257,6 +262,7 @@ static constexpr int kDefaultStreams = 3;
 static constexpr int kTailG = 256;    // workgroups (= layer-0 slabs) of the fused backward tail
 static constexpr long kAct1TiledFloats = 7L * 32 * 300 + 128;   // act1 of one 84 x 84 image, band-tiled (+ slack for whole-KiB reads)
 int launch_act1_untile(var_ctx* c, hipStream_t s, int B);      // img_head2.hip: tiled act1 -> NCHW in gact[1] (var_debug_buffer)
+int launch_img_bwd_chain(var_ctx* c, hipStream_t s, int B);   // img_chain.hip: dgrad 4 -> 3 -> 2 (conv 5, 4, 3) per image, gradients resident in LDS
 static constexpr int kTail2G = 256;   // persistent workgroups (= layer-0 and layer-1 slabs) of img_tail2_kernel: one image each
 int launch_img_bwd_tail2(var_ctx* c, hipStream_t s, int B);   // img_tail2.hip: wgrad 2 + dgrad 2 + wgrad 1 at 84 x 84
 int launch_img_bwd_tail(var_ctx* c, hipStream_t s, int B);
