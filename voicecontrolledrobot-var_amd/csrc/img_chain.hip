@@ -187,19 +187,27 @@ img_chain_kernel(const float* __restrict__ g5, const float* __restrict__ wa5, co
     // ---- conv 3: classes of 121 / 110 / 110 / 100 pixels (8 / 7 / 7 / 7 tiles) x 2 channel tiles; per channel tile 8 waves:
     //      even-even 8 tiles in two passes of 4 (16 k-steps each), even-odd and odd-even 4 + 3, odd-odd 3 + 2 + 2 ----
     {
-        const int ct = wave >> 3, w = wave & 7;
+        // Item sizes in MFMAs: ee 128 (two passes of 4 tiles x 16 k-steps), eo / oe 128 + 96, oo 192 + 128 + 128.  Waves w and w + 4
+        // share a SIMD (wave -> SIMD is cyclic): channel tile 0 pairs them (oo_a, eo_b) 288, (ee, oo_b) 256, (eo_a, oo_c) 256,
+        // (oe_a, oe_b) 224 on SIMDs 0..3, channel tile 1 takes the same pairs on SIMDs 3, 2, 1, 0 -- 512 MFMAs on every SIMD.
+        const int ct = wave >> 3, w8 = wave & 7;
+        const int simd = ct ? 3 - (w8 & 3) : (w8 & 3), second = w8 >> 2;
+        // item of (simd slot, second): {oo_a, ee, eo_a, oe_a} then {eo_b, oo_b, oo_c, oe_b}
+        const int item = second * 4 + simd;
         const float* xa = act2 + b * 32 * 441;
         float* go = g2 + b * 32 * 441;
-        if (w == 0) {
-            chain_item<L3, 4>(lds + kW3, lds + kG3, xa, go, nullptr, 0, 0, 0, ct, 0, lane);
-            chain_item<L3, 4>(lds + kW3, lds + kG3, xa, go, nullptr, 0, 0, 0, ct, 4, lane);
-        } else if (w <= 4) {
-            const int cls = 1 + ((w - 1) >> 1), second = (w - 1) & 1;
-            chain_dispatch<L3>(second ? 3 : 4, lds + kW3, lds + kG3, xa, go, nullptr, 0, 0, cls, ct, second ? 4 : 0, lane);
-        } else {
-            const int k = w - 5;                                // 0, 1, 2 -> tiles [0,3) [3,5) [5,7)
-            chain_dispatch<L3>(k == 0 ? 3 : 2, lds + kW3, lds + kG3, xa, go, nullptr, 0, 0, 3, ct, k == 0 ? 0 : (k == 1 ? 3 : 5), lane);
-        }
+        const float* wa = lds + kW3;
+        const float* gs = lds + kG3;
+        if (item == 1) {                                        // ee: 8 tiles
+            chain_item<L3, 4>(wa, gs, xa, go, nullptr, 0, 0, 0, ct, 0, lane);
+            chain_item<L3, 4>(wa, gs, xa, go, nullptr, 0, 0, 0, ct, 4, lane);
+        } else if (item == 2) chain_item<L3, 4>(wa, gs, xa, go, nullptr, 0, 0, 1, ct, 0, lane);      // eo tiles [0, 4)
+        else if (item == 4) chain_item<L3, 3>(wa, gs, xa, go, nullptr, 0, 0, 1, ct, 4, lane);       // eo tiles [4, 7)
+        else if (item == 3) chain_item<L3, 4>(wa, gs, xa, go, nullptr, 0, 0, 2, ct, 0, lane);       // oe tiles [0, 4)
+        else if (item == 7) chain_item<L3, 3>(wa, gs, xa, go, nullptr, 0, 0, 2, ct, 4, lane);       // oe tiles [4, 7)
+        else if (item == 0) chain_item<L3, 3>(wa, gs, xa, go, nullptr, 0, 0, 3, ct, 0, lane);       // oo tiles [0, 3)
+        else if (item == 5) chain_item<L3, 2>(wa, gs, xa, go, nullptr, 0, 0, 3, ct, 3, lane);       // oo tiles [3, 5)
+        else chain_item<L3, 2>(wa, gs, xa, go, nullptr, 0, 0, 3, ct, 5, lane);                      // oo tiles [5, 7)
     }
     PHR(5);
     PHR_FLUSH();
