@@ -294,3 +294,50 @@ def test_gru_time_out_skips_the_optimiser_step_and_clears_itself(var_amd):
     assert all(np.isfinite(v) for v in losses)
     assert any("timed out" in str(a[0]) for a in logs)
     assert bool(torch.isfinite(m.flat_parameters()).all())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# iTHOR model over an HBM-resident pool: replayed ragged epochs = eager steps on the same rows
+# ------------------------------------------------------------------------------------------------------------------
+def test_ithor_replayed_ragged_epochs_over_a_pool_equal_eager_steps(var_amd, tmp_path):
+    """The reference's iTHOR default is 500 triplets at batch 128 (128 / 128 / 128 / 116, Envs/ai2thor/config.py:24,41);
+    here the same shape in small: 22 triplets at batch 8 (8 / 8 / 6), clips of up to 1.5 s with ragged lengths, two epochs
+    through IthorTrainer.capture_epoch_steps (gather of the row from the resident pool, then the captured step -- a second
+    graph for the short batch) against eager step_from_pcm calls on the rows.  Run twice in one
+    process (graph lifetimes: var_amd._lib.new_graph)."""
+    pool = var_amd.SyntheticTripletPool(22, hw=96, seed=5, clips_per_class=3, n_samples=24000, ragged_lens=True).freeze_pairs()
+    B, spe, bt = 8, pool.steps_per_epoch(8), pool.tail_batch(8)
+    assert (spe, bt) == (3, 6)
+    table = pool.index_table(B, 2 * spe, drop_last=False)
+    torch.manual_seed(977)
+    sd = IthorNetCPU().state_dict()
+    out = []
+    for mode in ("replay", "eager", "replay"):
+        m = var_amd.IthorVARPretextNet(icfg(96))
+        m.load_state_dict(sd)
+        m = m.to("cuda")
+        tr = var_amd.IthorTrainer(m, lr=1e-3)
+        losses = []
+        if mode == "replay":
+            replay, _ = tr.capture_epoch_steps(pool.images, pool.clips, B, table, steps_per_epoch=spe, tail_batch=bt)
+            assert torch.equal(m.flat_parameters().cpu(), torch.cat([v.reshape(-1) for v in sd.values()]))   # capture trains nothing
+            losses = [float(replay().item()) for _ in range(2 * spe)]
+        else:
+            for row in range(2 * spe):
+                Bs = bt if row % spe == spe - 1 else B
+                r = table[row]
+                img = pool.images[r[:Bs].long()].contiguous()
+                pcm = pool.clips[r[Bs:3 * Bs].long()].contiguous()
+                losses.append(float(tr.step_from_pcm(img, pcm, r[3 * Bs:5 * Bs].contiguous()).item()))
+        out.append((losses, m.flat_parameters().clone(), tr.step_count))
+    assert out[0][2] == out[1][2] == out[2][2] == 6
+    assert out[0][0] == out[2][0] and torch.equal(out[0][1], out[2][1])
+    assert np.allclose(out[0][0], out[1][0], rtol=0, atol=2e-6), (out[0][0], out[1][0])
+    d = (out[0][1] - out[1][1]).abs()
+    assert float((d < 2e-6).float().mean()) > 0.995 and float(d.max()) < 5e-3      # (host-side vs device-side Adam scalars)
+    # and the training loop of VAR/pretext_VAR.py over the pool, with the model's own milestones
+    m = var_amd.IthorVARPretextNet(icfg(96)).to("cuda")
+    losses = var_amd.train_representation_from_pool(m, pool, epochs=2, batch=8, lr=1e-3, save_dir=str(tmp_path), save_interval=1,
+                                                    log=lambda *a: None)
+    assert len(losses) == 2 and all(np.isfinite(v) for v in losses)
+    assert sorted(p.name for p in tmp_path.iterdir()) == ['0.pt', '1.pt', 'progress.csv']

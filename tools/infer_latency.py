@@ -70,7 +70,7 @@ for _ in range(n):
 torch.cuda.synchronize()
 print(f"{'actor-critic act()':34s} {1e6 * (time.perf_counter() - t0) / n:8.1f} us per step (B={B}, eager, incl. sampling)")
 # the same forward as a replayed graph over static buffers
-g = torch.cuda.CUDAGraph()
+g = var_amd._lib.new_graph()
 side = torch.cuda.Stream()
 side.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(side):

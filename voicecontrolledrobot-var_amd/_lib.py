@@ -103,6 +103,25 @@ def load_library():
     return _lib
 
 
+_LIVE_GRAPHS = []
+
+
+def new_graph():
+    """A torch.cuda.CUDAGraph for the package's captures, made safe against two hazards measured on this stack (ROCm 7.2
+    runtime under torch 2.10, MI355X; tools/graph_lifetime_check.py reproduces both):
+      * torch destroys the captured hipGraph_t right after instantiating its exec; the runtime frees that memory lazily,
+        and after a hipStreamSynchronize(NULL) (var_ithor_plan and other set-up calls of the C ABI issue one) the exec's
+        replays read recycled memory: a step then returns loss == margin with all-zero gradients.  keep_graph=True keeps
+        the hipGraph_t for the life of the exec (instantiation moves to the first replay).
+      * destroying an exec AFTER a later one was instantiated corrupts the later one's replays the same way; Python's
+        collection order is not ours to arrange, so graphs are retired to a process-lifetime list instead of destroyed.
+    The cost is host memory for the nodes (a few hundred KB per step graph)."""
+    import torch
+    g = torch.cuda.CUDAGraph(keep_graph=True)
+    _LIVE_GRAPHS.append(g)
+    return g
+
+
 class Context:
     """One var_ctx per (process, device)."""
     _by_device = {}
@@ -145,7 +164,7 @@ class Context:
         graphs = []
         with torch.cuda.stream(side):
             for bodies in groups:
-                g = torch.cuda.CUDAGraph()
+                g = new_graph()
                 # thread-local capture: the RCCL watchdog thread of torch.distributed may query events meanwhile
                 with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                     for body in bodies:

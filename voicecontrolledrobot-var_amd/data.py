@@ -242,15 +242,23 @@ class TripletPool:
 
 
 class SyntheticTripletPool(TripletPool):
-    """Synthetic pool: U{0..255} images, sine+noise 1 s clips, 20 % "empty" positives."""
+    """Synthetic pool: U{0..255} images, sine+noise clips, 20 % "empty" positives.  n_samples: clip length
+    (16 000 = 1 s, the Kuka / GoogleCommand shape; up to 96 000 = the iTHOR / FluentSpeech 6 s clips,
+    Envs/ai2thor/config.py:119); ragged_lens: draw each clip's valid length in [n_samples / 2, n_samples]."""
 
-    def __init__(self, n_items, hw=84, task_num=4, clips_per_class=64, seed=0, device="cuda", empty_frac=0.2):
+    def __init__(self, n_items, hw=84, task_num=4, clips_per_class=64, seed=0, device="cuda", empty_frac=0.2,
+                 n_samples=16000, ragged_lens=False):
         g = np.random.default_rng(seed)
         images = g.integers(0, 256, size=(n_items, 3, hw, hw), dtype=np.uint8)
         gt = g.integers(0, task_num, size=n_items)
         gt[g.random(n_items) < empty_frac] = task_num          # 20 % "empty" positives
         sn = np.array([choose_negative_id(a, task_num, rand_int=lambda lo, hi: int(g.integers(lo, hi))) for a in gt])
-        clips = synth_clips(task_num * clips_per_class, seed=seed + 1)   # (task_num*cpc, 16000) int16, class-major
-        super().__init__(images, gt, sn, clips, np.full(clips.shape[0], clips.shape[1], dtype=np.int32),
+        clips = synth_clips(task_num * clips_per_class, seed=seed + 1, n_samples=n_samples)   # (task_num*cpc, n) int16, class-major
+        lens = np.full(clips.shape[0], clips.shape[1], dtype=np.int32)
+        if ragged_lens:
+            lens = g.integers(n_samples // 2, n_samples + 1, size=clips.shape[0]).astype(np.int32)
+            for i, n in enumerate(lens):
+                clips[i, n:] = 0
+        super().__init__(images, gt, sn, clips, lens,
                          np.arange(task_num) * clips_per_class, np.full(task_num, clips_per_class), task_num,
                          seed=seed, device=device)

@@ -6,7 +6,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ._lib import Context, VarHipError, current_stream_handle, ptr
+from ._lib import Context, VarHipError, current_stream_handle, new_graph, ptr
 
 
 class _IthorFn(torch.autograd.Function):
@@ -304,14 +304,14 @@ class IthorTrainer:
         if getattr(self, "_g_lr", None) is not None:
             self._g_lr.fill_(float(lr))
 
-    def capture_step(self, image, pcm, lens, global_batch=None):
+    def capture_step(self, image, pcm, lens, global_batch=None, _ctx=None, _shared_scalars=False):
         """Capture step_from_pcm over STATIC CUDA tensors (image u8|f32 (B,3,H,H), pcm int16 (2B,n), lens int32 (2B)) into
         a HIP graph and return replay(): the step's ~700 launches (2 x 73 dependent recurrent products and gate kernels
         in each direction of time) then cost one graph launch.  The caller refreshes the static tensors in place between
         replays (e.g. TripletPool.gather(..., out_img=, out_pcm=, out_len=)).  Step count and learning rate live on the
         device (var_adam_step_dev; set_lr updates the latter).  Under data parallelism the all-reduce stays eager
         between two graphs."""
-        m, c = self.model, self.ctx
+        m, c = self.model, (_ctx or self.ctx)
         flat = m.flat_parameters()
         B = image.shape[0]
         for t in (image, pcm, lens):
@@ -320,12 +320,25 @@ class IthorTrainer:
         if pcm.dtype != torch.int16 or lens.dtype != torch.int32 or image.dtype not in (torch.uint8, torch.float32):
             raise VarHipError("capture_step: image u8|f32, pcm int16, lens int32")
         frames = m.config.sound_dim[1]
-        self.step_from_pcm(image, pcm, lens, global_batch)          # eager once: workspace plan, front-end tables
-        self._g_feats = torch.empty((2 * B, 1, frames, 40), dtype=torch.float32, device=self.dev)
-        self._g_lr = torch.full((1,), float(self.lr), dtype=torch.float32, device=self.dev)
-        self._g_step = torch.full((1,), int(self.step_count), dtype=torch.int32, device=self.dev)
+        if _ctx is None:
+            self.step_from_pcm(image, pcm, lens, global_batch)      # eager once: workspace plan, front-end tables
+        else:                                                       # (capture_epoch_steps: same warm-up on the given context, no optimiser step)
+            m._ensure_plan(c, B)
+            warm = torch.empty((2 * B, 1, frames, 40), dtype=torch.float32, device=self.dev)
+            c.check(c.lib.var_mfcc_psf(c.handle, current_stream_handle(), ptr(pcm), ptr(lens), None, 2 * B, pcm.shape[1], frames,
+                                       ptr(warm)), "var_mfcc_psf")
+            c.check(c.lib.var_ithor_loss_grad(c.handle, current_stream_handle(), ptr(flat), ptr(image),
+                                              int(image.dtype == torch.uint8), image.stride(0), ptr(warm[:B]), ptr(warm[B:]), B,
+                                              m.config.img_dim[1], float(self.margin), 1.0, ptr(self.gbuf),
+                                              self.gbuf.data_ptr() + 4 * self.n, None), "var_ithor_loss_grad")
+            torch.cuda.synchronize()
+            del warm
+        feats = torch.empty((2 * B, 1, frames, 40), dtype=torch.float32, device=self.dev)
+        self._g_feats = feats
+        if not (_shared_scalars and getattr(self, "_g_step", None) is not None):
+            self._g_lr = torch.full((1,), float(self.lr), dtype=torch.float32, device=self.dev)
+            self._g_step = torch.full((1,), int(self.step_count), dtype=torch.int32, device=self.dev)
         gb = B * self.world if global_batch is None else global_batch
-        feats = self._g_feats
 
         def body_grad():
             s = current_stream_handle()
@@ -348,13 +361,14 @@ class IthorTrainer:
         graphs = []
         with torch.cuda.stream(side):
             for bodies in ((body_grad,), (body_adam,)) if collective else ((body_grad, body_adam),):
-                g = torch.cuda.CUDAGraph()
+                g = new_graph()
                 with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                     for b in bodies:
                         b()
                 graphs.append(g)
         torch.cuda.current_stream().wait_stream(side)
-        self._keep = (image, pcm, lens, graphs)
+        self._keep = getattr(self, "_keep_all", []) + [(image, pcm, lens, feats, graphs)]
+        self._keep_all = self._keep
 
         def replay():
             graphs[0].replay()
@@ -364,6 +378,61 @@ class IthorTrainer:
             self.step_count += 1
             return self.loss
         return replay
+
+    def capture_epoch_steps(self, images, pcm, batch, table, global_batch=None, steps_per_epoch=None, tail_batch=0,
+                            tail_global_batch=None):
+        """The replayed step over an HBM-resident dataset (TripletPool: u8 images (N,3,H,H), int16 clips (M,n)), the
+        iTHOR counterpart of VARTrainer.capture_epoch_steps: `table` is an int32 (rows, 5*batch) tensor of step rows
+        [image_index | clip_index (2B) | lens (2B)] (TripletPool.index_table / epoch_index_table).  A replay gathers the row
+        into static buffers (three small eager launches: ~30 us against a step of 6-40 ms) and launches the captured step
+        (capture_step: python_speech_features front-end, forward, triplet loss, backward, [collective,] Adam).  Ragged epochs
+        (the reference's iTHOR default is 500 triplets at batch 128: 128 / 128 / 128 / 116, Envs/ai2thor/config.py:24,41): with
+        `tail_batch` every `steps_per_epoch`-th row is the short last batch, packed at the head of its row; a second graph
+        over the same workspace runs it.  Returns (replay, load_table)."""
+        m = self.model
+        B = int(batch)
+        rows, row_ints = int(table.shape[0]), int(table.shape[1])
+        if row_ints != 5 * B or table.dtype != torch.int32 or table.device != self.dev or not table.is_contiguous():
+            raise VarHipError("index table must be a contiguous int32 (rows, 5*batch) tensor on the trainer's device")
+        tail_batch = int(tail_batch)
+        if tail_batch and (not (0 < tail_batch < B) or not steps_per_epoch or rows % steps_per_epoch):
+            raise VarHipError("ragged table: need 0 < tail_batch < batch and rows a multiple of steps_per_epoch")
+        if not (images.is_cuda and images.dtype == torch.uint8 and pcm.is_cuda and pcm.dtype == torch.int16
+                and images.is_contiguous() and pcm.is_contiguous()):
+            raise VarHipError("capture_epoch_steps needs the pool's contiguous CUDA tensors: u8 images, int16 clips")
+        sizes = [(B, B * self.world if global_batch is None else int(global_batch))]
+        if tail_batch:
+            sizes.append((tail_batch, tail_batch * self.world if tail_global_batch is None else int(tail_global_batch)))
+        ctxs = [self.ctx, self.ctx]                           # both graphs run on the trainer's workspace (planned for `batch`)
+        self._g_step = None                                    # both graphs share ONE device-side step count / learning rate
+        plans = []
+        for (Bs, gb), cx in zip(sizes, ctxs):
+            img = torch.zeros((Bs,) + tuple(images.shape[1:]), dtype=torch.uint8, device=self.dev)
+            clp = torch.zeros((2 * Bs, pcm.shape[1]), dtype=torch.int16, device=self.dev)
+            lns = torch.zeros(2 * Bs, dtype=torch.int32, device=self.dev)
+            idx = torch.zeros(3 * Bs, dtype=torch.int64, device=self.dev)
+            plans.append((Bs, img, clp, lns, idx, self.capture_step(img, clp, lns, global_batch=gb, _ctx=cx, _shared_scalars=True)))
+        state = {"row": 0, "table": table.clone()}
+
+        def is_tail(r):
+            return bool(tail_batch) and r % steps_per_epoch == steps_per_epoch - 1
+
+        def load_table(t):
+            assert t.shape == state["table"].shape
+            state["table"].copy_(t, non_blocking=True)
+            state["row"] = 0
+
+        def replay():
+            Bs, img, clp, lns, idx, run = plans[1 if is_tail(state["row"]) else 0]
+            r = state["table"][state["row"]]
+            idx.copy_(r[:3 * Bs])                              # int32 -> int64: [image ids | clip ids]
+            torch.index_select(images, 0, idx[:Bs], out=img)
+            torch.index_select(pcm, 0, idx[Bs:], out=clp)
+            lns.copy_(r[3 * Bs:5 * Bs])
+            run()
+            state["row"] = (state["row"] + 1) % rows
+            return self.loss
+        return replay, load_table
 
     def step_from_pcm(self, image, pcm, lens, global_batch=None):
         """The step with the data-loader's audio work folded in (dataset.py:64-89 + Envs/audioLoader.py:158-161,

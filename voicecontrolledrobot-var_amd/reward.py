@@ -89,7 +89,7 @@ class IntrinsicReward:
         image + goal sound (first step of an episode) and image only (later steps: the goal embedding is reused) --
         over static device buffers.  Weights are packed once here: call again after loading another checkpoint.
         Returns self; then use step()."""
-        from ._lib import Context, current_stream_handle, ptr
+        from ._lib import Context, current_stream_handle, new_graph, ptr
         m = self.model
         flat = m.flat_parameters()
         dev = flat.device
@@ -119,7 +119,7 @@ class IntrinsicReward:
         with torch.cuda.stream(side):
             for with_goal in (True, False):
                 body(with_goal)                                  # warm-up outside capture (lazy kernel attributes)
-                g = torch.cuda.CUDAGraph()
+                g = new_graph()
                 with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                     body(with_goal)
                 self._graphs[with_goal] = g

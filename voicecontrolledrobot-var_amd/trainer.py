@@ -646,7 +646,7 @@ def train_representation(model, batches, epochs, lr=1e-4, weight_decay=1e-6, mil
     return loss_list
 
 
-def train_representation_from_pool(model, pool, epochs, batch, lr=1e-4, weight_decay=1e-6, milestones=(10, 30, 50),
+def train_representation_from_pool(model, pool, epochs, batch, lr=1e-4, weight_decay=1e-6, milestones=None,
                                    gamma=0.2, margin=1.0, save_dir=None, save_interval=10, start_ep=0, log=print,
                                    drop_last=False, _ctx=None):
     """The loop of VAR/pretext_VAR.py:44-91 over a TripletPool resident in HBM (u8 images, int16 clips, frozen pairs =
@@ -654,8 +654,18 @@ def train_representation_from_pool(model, pool, epochs, batch, lr=1e-4, weight_d
     drop_last=False incl. the short last batch) walked by the replayed step -- gather, MFCC front-end, forward, triplet
     loss, backward, Adam in one graph launch per step; MultiStepLR per epoch (utils.py:42-46); average loss per epoch =
     sum of the step losses / number of steps (:82), accumulated on the device (no per-step host sync); legacy-format
-    checkpoints every `save_interval` epochs and at the end (:75-80), progress.csv (:87-91).  Kuka model."""
-    tr = VARTrainer(model, lr=lr, weight_decay=weight_decay, margin=margin, _ctx=_ctx)
+    checkpoints every `save_interval` epochs and at the end (:75-80), progress.csv (:87-91).
+    Both models: the Kuka one (1 s clips, torchaudio-flavour MFCC, milestones [10, 30, 50]) and the iTHOR one (clips of up
+    to 6 s, python_speech_features MFCC of 600 frames, milestones [20, 30] -- its reference default of 500 triplets at batch
+    128 runs as 128 / 128 / 128 / 116, Envs/ai2thor/config.py:24,41-48)."""
+    from .ithor import IthorTrainer, IthorVARPretextNet
+    is_ithor = isinstance(model, IthorVARPretextNet)
+    if milestones is None:
+        milestones = (20, 30) if is_ithor else (10, 30, 50)
+    if is_ithor:
+        tr = IthorTrainer(model, lr=lr, weight_decay=weight_decay, margin=margin)
+    else:
+        tr = VARTrainer(model, lr=lr, weight_decay=weight_decay, margin=margin, _ctx=_ctx)
     if getattr(pool, "clip_tab", None) is None:
         pool.freeze_pairs()
     model.train()
