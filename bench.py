@@ -226,7 +226,7 @@ def main_ithor(args, rank, local_rank, world, dev):
                     with open(newest_profile("ithor_f32_pmc_hbm_traffic.json")) as f:
                         pm = json.load(f)
                     want = {"forward": "ConvFwdP<", "data gradient": "ConvDgradS2P<", "weight gradient": "ConvWgradP<"}[names[best[0]].split("s2 ")[1]]
-                    traffic = max(v["hbm_bytes_fetch_x2_plus_write"] for kk, v in pm.items() if want in kk and "11x5" in kk)
+                    traffic = max(v["hbm_bytes_fetch_x2_plus_write"] for kk, v in pm.items() if want in kk and "Geo<11, 5," in kk)
                 elif B == 256:                                  # tools/pmc_traffic.sh r03_ithor_bf16 --workload ithor --dtype bf16
                     with open(newest_profile("ithor_bf16_pmc_hbm_traffic.json")) as f:
                         pm = json.load(f)
@@ -286,21 +286,34 @@ def main_ithor(args, rank, local_rank, world, dev):
         torch.distributed.destroy_process_group()
 
 
+def tag_kernel(tag, hw):
+    """The kernel a profiled conv tag stands for at image size `hw` (its name as rocprofv3 prints it)."""
+    if hw == 84:
+        return {1: "img_head2_kernel<", 2: "img_fwd_mid_kernel<", 7: "img_wgrad345_kernel<", 11: "img_tail2_kernel<",
+                12: "img_chain_kernel", 15: "img_wgrad_reduce_kernel"}.get(tag)
+    return {1: "img_fwd_head_kernel<", 2: "img_fwd_mid_kernel<", 6: "img_wgrad_kernel<", 7: "img_bwd_pair_kernel<WgCfg<32, 64,",
+            8: "img_bwd_pair_kernel<WgCfg<64, 64, 12,", 9: "img_bwd_pair_kernel<WgCfg<64, 64, 6,", 11: "img_bwd_last_kernel<",
+            15: "img_wgrad_reduce_kernel"}.get(tag)
+
+
 def tag_flops(tag):
-    """Algorithmic FLOPs per triplet of a profiled conv kernel family (tags: 0-4 forward, 5-9 weight
-    gradient, 11-14 data gradient of layer tag % 5) in the default (fused) configuration: tag 1 = forward head
-    (conv 1 + conv 2), tag 2 = conv 3 + 4 + 5 (+ image head, not counted), tags 7-9 = weight + data gradient of
-    layers 2-4 in one grid, tag 11 = weight gradient of conv 2 + data gradient of conv 2 + weight gradient of conv 1.
+    """Algorithmic FLOPs per triplet of a profiled conv launch (csrc/api.hip kTagNames).  84 x 84: tag 1 = conv 1 + conv 2
+    forward, 2 = conv 3 + 4 + 5 forward (+ image head, not counted), 7 = the weight gradients of conv 3-5, 11 = data gradient
+    of conv 2 + weight gradients of conv 2 and conv 1, 12 = the data gradients of conv 5, 4, 3.  96 x 96: 6 = weight gradient
+    of conv 2, 7-9 = weight + data gradient of one layer, 11 = data gradient of conv 2 + weight gradient of conv 1.
     Halo recomputation inside the fused kernels is not counted."""
+    L = LAYER_FLOPS
     if tag == 1:
-        return LAYER_FLOPS[0] + LAYER_FLOPS[1]
+        return L[0] + L[1]
     if tag == 2:
-        return LAYER_FLOPS[2] + LAYER_FLOPS[3] + LAYER_FLOPS[4]
+        return L[2] + L[3] + L[4]
+    if HW == 84:
+        return {7: L[2] + L[3] + L[4], 11: 2 * L[1] + L[0], 12: L[2] + L[3] + L[4]}.get(tag, 0)
     if tag in (7, 8, 9):
-        return 2 * LAYER_FLOPS[tag - 5]
-    if tag == 11:                             # 84: wgrad 1 + tail in one grid; 96: the tail alone (wgrad 1 = tag 6)
-        return (2 if HW == 84 else 1) * LAYER_FLOPS[1] + LAYER_FLOPS[0]
-    return LAYER_FLOPS[tag % 5]
+        return 2 * L[tag - 5]
+    if tag == 11:
+        return L[1] + L[0]
+    return L[tag % 5]
 
 
 def newest_profile(suffix):
@@ -315,7 +328,7 @@ def newest_profile(suffix):
     return best[1] if best else None
 
 
-def pmc_traffic(tag_name, hw):
+def pmc_traffic(tag, hw):
     """HBM bytes per launch of the dominant kernel, from the committed PMC pass of THIS round's kernels (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction: FETCH_SIZE x 2; tools/pmc_traffic.sh ->
     profiles/rNN_pmc_hbm_traffic.json, the newest round present; batch 256, 84 x 84 only).
@@ -324,11 +337,7 @@ def pmc_traffic(tag_name, hw):
     path = newest_profile("pmc_hbm_traffic.json")
     if hw != 84 or path is None:
         return None
-    want = {"img_fwd_head_kernel[0+1]": "img_head2_kernel<",
-            "img_fwd_mid_kernel[2+3+4+head]": "img_fwd_mid_kernel<",
-            "img_bwd_last_kernel[wgrad1+dgrad1+wgrad0]": "img_bwd_last_kernel<",
-            "img_bwd_pair_kernel[wgrad2+dgrad2]": "img_bwd_pair_kernel<WgCfg<32, 64,",
-            "img_bwd_pair_kernel[wgrad3+dgrad3]": "img_bwd_pair_kernel<WgCfg<64, 64, %d," % (11 if hw == 84 else 12)}.get(tag_name)
+    want = tag_kernel(tag, hw)
     if want is None or not os.path.exists(path):
         return None
     with open(path) as f:
@@ -347,6 +356,14 @@ def algorithmic_bytes(tag, B, hw):
     act = [B * _CH[l] * h[l] * h[l] * 4 for l in range(6)]     # act[0] as f32; the u8 image is act[0] / 4
     img = act[0] // 4
     bits = B * h[1] * h[1] * 4
+    if hw == 84:
+        act1 = B * (7 * 32 * 300 + 128) * 4                      # act1 in its band-tiled layout (csrc/var_common.h kAct1TiledFloats)
+        return {1: img + act1 + act[2],                          # image in; act1 (tiles), act2 out
+                2: act[2] + act[3] + act[4] + act[5],
+                7: act[2] + 2 * (act[3] + act[4]) + act[5],      # x of conv 3-5 (act2-4) and their output gradients (gact3-5)
+                11: act1 + act[2] + img,                         # act1 tiles (ReLU gate + conv 2's x), gact2, image
+                12: act[5] + 2 * (act[4] + act[3]) + 2 * act[2]  # gact5 in; act4, act3, act2 (ReLU gates) in; gact4, gact3, gact2 out
+                }.get(tag)
     if tag == 1:
         return img + act[1] + act[2] + bits
     if tag == 2:
@@ -354,8 +371,8 @@ def algorithmic_bytes(tag, B, hw):
     if tag in (7, 8, 9):                      # wgrad l (x, gy) || dgrad l (gy, mask x, gx)
         l = tag - 5
         return 2 * act[l + 1] + 3 * act[l]
-    if tag == 11:                             # wgrad 1 (act1, gact2) || tail (gact2, bits, image)
-        return act[1] + 2 * act[2] + bits + img
+    if tag == 11:                             # tail (gact2, bits, image); the weight gradient of conv 2 is tag 6 at this size
+        return act[2] + bits + img
     return None
 
 
@@ -616,9 +633,9 @@ def main():
             flops = tag_flops(dom_tag) * B
             us = 1e3 * iso_ms / iso_n
             ach = flops / (us * 1e-6) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": names[dom_tag], "achieved": round(ach, 2),
+            out["roofline"] = {"bound": "mfma", "kernel": (tag_kernel(dom_tag, HW) or "").rstrip("<,") + " [" + names[dom_tag] + "]", "achieved": round(ach, 2),
                                "peak": F32_MFMA_PEAK, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK, 4),
-                               "traffic": pmc_traffic(names[dom_tag], HW) if B == 256 else None,
+                               "traffic": pmc_traffic(dom_tag, HW) if B == 256 else None,
                                "algorithmic_bytes": algorithmic_bytes(dom_tag, B, HW),
                                "avg_us": round(us, 2), "launches": iso_n,
                                "with_side_stream_us": round(1e3 * roof_ms / roof_n, 2),

@@ -538,11 +538,13 @@ int var_mfcc_ex(var_ctx* c, void* stream, const int16_t* pcm, const int* lens, c
                            hop_length, out);
 }
 
+// what each profiled launch computes (both image sizes; bench.py maps (tag, image size) to the kernel's name)
 static const char* kTagNames[TAG_COUNT] = {
-    "(unused)", "img_fwd_head_kernel[0+1]", "img_fwd_mid_kernel[2+3+4+head]", "(unused)",
-    "(unused)", "(unused)", "img_wgrad_kernel[1] (96x96 only)", "img_bwd_pair_kernel[wgrad2+dgrad2]",
-    "img_bwd_pair_kernel[wgrad3+dgrad3]", "img_bwd_pair_kernel[wgrad4+dgrad4]", "(unused)", "img_bwd_last_kernel[wgrad1+dgrad1+wgrad0]",
-    "(unused)", "(unused)", "(unused)", "img_wgrad_reduce_kernel",
+    "(unused)", "img conv1+conv2 forward", "img conv3+4+5 forward + image head", "(unused)",
+    "(unused)", "(unused)", "img conv2 weight gradient (96x96)", "img conv3+4+5 weight gradients (84x84) / conv3 weight+data gradient (96x96)",
+    "img conv4 weight+data gradient (96x96)", "img conv5 weight+data gradient (96x96)", "(unused)",
+    "img conv2 data gradient + conv2, conv1 weight gradients (84x84) / conv2 data + conv1 weight gradient (96x96)",
+    "img conv5-4-3 data gradient chain (84x84)", "(unused)", "(unused)", "img weight-gradient slab fold",
     "snd_fwd_kernel", "snd_dgrad_kernel", "snd_wgrad_kernel", "snd_reduce_kernel", "heads_fwd_kernel",
     "heads_bwd_rows_kernel", "heads_bwd_gemm_kernel", "triplet_kernel", "adam_kernel", "pack_weights_kernel",
     "mfcc_kernel", "ithor conv 11x5 s2 forward", "ithor conv 11x5 s2 data gradient", "ithor conv 11x5 s2 weight gradient"};
