@@ -522,7 +522,7 @@ int launch_img_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads,
     if (H == 84) {
         // data gradients of conv 5 -> 4 -> 3 as one per-image chain (img_chain.hip), then their three weight gradients in one grid
         if ((rc = launch_img_bwd_chain(c, s, B)) != VAR_OK) return rc;
-        if ((rc = launch_img_wg345(c, s, B)) != VAR_OK) return rc;
+        if ((rc = launch_wgrad345(c, s, B)) != VAR_OK) return rc;
     }
     for (int l = 4; l >= 2 && H != 84; --l) {
         const float* gyl = c->gact[l + 1];

@@ -266,54 +266,48 @@ using W96_4 = WgCfg<64, 64, 6, false, 3, 4, 4>;
 struct RedSeg { int slab_off; int slab_sz; int G; int ncombo; int cblk; int cin; int smallc; int gw; int gb; };
 struct RedTable { RedSeg seg[5]; int start[6]; };
 
-// 128 consecutive slab elements (four per lane, 16-byte loads) x 8 slices of the workgroup index per block: each lane sums
-// every 8th slab (loads unrolled), the 8 partial sums are folded in a fixed order through LDS.
+// 32 consecutive slab elements x 8 slices of the workgroup index per block: each lane sums every 8th
+// slab (loads unrolled), the 8 partial sums are folded in a fixed order through LDS.
 __global__ void __launch_bounds__(256)
 img_wgrad_reduce_kernel(RedTable T, const float* __restrict__ slabs, float* __restrict__ grads) {
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    __shared__ f4 part[8][33];
+    __shared__ float part[8][33];
     const int lane32 = threadIdx.x & 31, gs = threadIdx.x >> 5;
-    const int j = (blockIdx.x * 32 + lane32) * 4;
+    const int j = blockIdx.x * 32 + lane32;
     const bool live = j < T.start[5];
     int l = 0;
 #pragma unroll
     for (int i = 1; i < 5; ++i) if (j >= T.start[i] && T.start[i + 1] > T.start[i]) l = i;
     const RedSeg S = T.seg[l];
-    const int e = live ? j - T.start[l] : 0;         // first of four elements of the (combo, slab) space of this layer
+    const int e = live ? j - T.start[l] : 0;         // element of the (combo, slab) space of this layer
     const float* p = slabs + S.slab_off + e;
     const size_t gstride = (size_t)S.ncombo * S.slab_sz;
-    f4 s = {0.f, 0.f, 0.f, 0.f};
+    float s = 0.f;
     if (live) {
 #pragma unroll 8
-        for (int g = gs; g < S.G; g += 8) s += *(const f4*)(p + (size_t)g * gstride);
+        for (int g = gs; g < S.G; g += 8) s += p[(size_t)g * gstride];
     }
     part[gs][lane32] = s;
     __syncthreads();
     if (gs != 0 || !live) return;
     s = ((part[0][lane32] + part[1][lane32]) + (part[2][lane32] + part[3][lane32])) +
         ((part[4][lane32] + part[5][lane32]) + (part[6][lane32] + part[7][lane32]));
-    const int combo = e / S.slab_sz, i0 = e - combo * S.slab_sz;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i = i0 + k;
-        const float v = s[k];
-        if (S.smallc) {
-            if (i >= 1024) { grads[S.gb + (i - 1024)] = v; continue; }
-            const int n = i / 32, col = i % 32;
-            if (col < S.cin * 9) {
-                const int tap = col / S.cin, c = col - tap * S.cin;
-                grads[S.gw + (n * S.cin + c) * 9 + tap] = v;
-            }
-            continue;
+    const int combo = e / S.slab_sz, i = e - combo * S.slab_sz;
+    if (S.smallc) {
+        if (i >= 1024) { grads[S.gb + (i - 1024)] = s; return; }
+        const int n = i / 32, col = i % 32;
+        if (col < S.cin * 9) {
+            const int tap = col / S.cin, c = col - tap * S.cin;
+            grads[S.gw + (n * S.cin + c) * 9 + tap] = s;
         }
-        const int nb = combo / S.cblk, cb = combo - nb * S.cblk;
-        if (i >= 9216) {
-            if (cb == 0) grads[S.gb + nb * 32 + (i - 9216)] = v;
-            continue;
-        }
-        const int c = i % 32, tap = (i / 32) % 9, n = i / 288;
-        grads[S.gw + ((nb * 32 + n) * S.cin + cb * 32 + c) * 9 + tap] = v;
+        return;
     }
+    const int nb = combo / S.cblk, cb = combo - nb * S.cblk;
+    if (i >= 9216) {
+        if (cb == 0) grads[S.gb + nb * 32 + (i - 9216)] = s;
+        return;
+    }
+    const int c = i % 32, tap = (i / 32) % 9, n = i / 288;
+    grads[S.gw + ((nb * 32 + n) * S.cin + cb * 32 + c) * 9 + tap] = s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -321,20 +315,18 @@ img_wgrad_reduce_kernel(RedTable T, const float* __restrict__ slabs, float* __re
 // ------------------------------------------------------------------------------------------
 // split-K workgroups (grid.x) per layer; grid.y = channel-block combos.  Also sizes the slab workspace.
 static const int kWgG[5] = {512, 256, 64, 32, 32};     // layer 0: the fused tail (kTailG <= 512)
-static const int kWgG84[5] = {512, 256, 64, 48, 16};   // 84 x 84: img_wg345.hip splits the CUs between layers 2-4 by their work (two workgroups per group)
-static const int kSlabCap[5] = {512, 256, 64, 48, 32};  // slab workspace: the larger of the two per layer
 static const int kCombo[5] = {1, 1, 2, 4, 4};
 static const int kSlabSz[5] = {32 * 32 + 32, 9248, 9248, 9248, 9248};
 
 size_t img_slab_floats() {
     size_t t = 0;
-    for (int i = 0; i < 5; i++) t += (size_t)kSlabCap[i] * kCombo[i] * kSlabSz[i];
+    for (int i = 0; i < 5; i++) t += (size_t)kWgG[i] * kCombo[i] * kSlabSz[i];
     return t;
 }
 
 static size_t slab_offset(int layer) {
     size_t o = 0;
-    for (int i = 0; i < layer; i++) o += (size_t)kSlabCap[i] * kCombo[i] * kSlabSz[i];
+    for (int i = 0; i < layer; i++) o += (size_t)kWgG[i] * kCombo[i] * kSlabSz[i];
     return o;
 }
 
@@ -378,13 +370,12 @@ int launch_img_wgrad_reduce(var_ctx* c, hipStream_t s, float* grads, int lo, int
     }
     T.start[5] = st;
     ProfScope prof(c, s, TAG_IMG_WREDUCE);
-    hipLaunchKernelGGL(img_wgrad_reduce_kernel, dim3((st / 4 + 31) / 32), dim3(256), 0, s, T, c->slabs, grads);     // (st: a multiple of 4)
+    hipLaunchKernelGGL(img_wgrad_reduce_kernel, dim3((st + 31) / 32), dim3(256), 0, s, T, c->slabs, grads);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }
 
 // workgroups per layer / slab workspace offsets, for the fused launches of img_conv_bwd.hip
 int img_wgrad_groups(int layer) { return kWgG[layer]; }
-int img_wgrad_groups84(int layer) { return kWgG84[layer]; }
 size_t img_slab_offset(int layer) { return slab_offset(layer); }
 #endif  // VAR_WGRAD_DEVICE_ONLY

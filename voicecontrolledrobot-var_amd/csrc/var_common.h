@@ -234,7 +234,6 @@ void comm_free(var_ctx* c);
 int pack_table_upload(var_ctx* c);
 size_t img_slab_floats();
 int img_wgrad_groups(int layer);
-int img_wgrad_groups84(int layer);                            // caps of img_wg345.hip (84 x 84)
 size_t img_slab_offset(int layer);
 int launch_img_wgrad1_96(var_ctx* c, hipStream_t s, const void* x, long bstride, const float* gy, int B);
 int launch_img_wgrad_reduce(var_ctx* c, hipStream_t s, float* grads, int lo, int hi);
@@ -263,7 +262,6 @@ static constexpr int kDefaultStreams = 3;
 static constexpr int kTailG = 256;    // workgroups (= layer-0 slabs) of the fused backward tail
 static constexpr long kAct1TiledFloats = 7L * 32 * 300 + 128;   // act1 of one 84 x 84 image, band-tiled (+ slack for whole-KiB reads)
 int launch_act1_untile(var_ctx* c, hipStream_t s, int B);      // img_head2.hip: tiled act1 -> NCHW in gact[1] (var_debug_buffer)
-int launch_img_wg345(var_ctx* c, hipStream_t s, int B);       // img_wg345.hip: weight gradients of conv 3, 4, 5 in one grid (84 x 84)
 int launch_img_bwd_chain(var_ctx* c, hipStream_t s, int B);   // img_chain.hip: dgrad 4 -> 3 -> 2 (conv 5, 4, 3) per image, gradients resident in LDS
 static constexpr int kTail2G = 256;   // persistent workgroups (= layer-0 and layer-1 slabs) of img_tail2_kernel: one image each
 int launch_img_bwd_tail2(var_ctx* c, hipStream_t s, int B);   // img_tail2.hip: wgrad 2 + dgrad 2 + wgrad 1 at 84 x 84
