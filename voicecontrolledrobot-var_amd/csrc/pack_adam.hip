@@ -105,7 +105,8 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
 // counter tells which one that is), so the launch can be captured into a HIP graph without a "tick" kernel.
 // Block 0 also copies the next row of the epoch's index table into the row buffer the step's kernels read,
 // so a replay needs no host-side copy at all.
-__global__ void __launch_bounds__(256)
+constexpr int kAdamT = 1024;      // threads per block: one element per thread at this model's size, one round of loads
+__global__ void __launch_bounds__(kAdamT)
 adam_pack_dev_kernel(const PackSeg* __restrict__ segs, int nseg, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                      float* __restrict__ v, long n, const float* __restrict__ lr_dev, float b1, float b2, float eps,
                      float wd, int* __restrict__ step_dev, unsigned* __restrict__ done_ctr, float* __restrict__ wpack,
@@ -131,7 +132,7 @@ adam_pack_dev_kernel(const PackSeg* __restrict__ segs, int nseg, float* __restri
         if (next >= n_rows) next = 0;
         int next2 = next + 1;                                // ahead: a second copy, one row further on, behind the first
         if (next2 >= n_rows) next2 = 0;
-        for (int e = threadIdx.x; e < row_ints; e += 256) {
+        for (int e = threadIdx.x; e < row_ints; e += kAdamT) {
             idx_row[e] = idx_table[(size_t)next * row_ints + e];
             if (ahead_from > 0) idx_row[row_ints + e] = idx_table[(size_t)next2 * row_ints + e];
         }
@@ -142,11 +143,11 @@ adam_pack_dev_kernel(const PackSeg* __restrict__ segs, int nseg, float* __restri
     // elements with ONE ballot (lane q tests segment q) instead of scanning the table per element
     __shared__ PackSeg ssegs[24];
     if (wpack) {
-        for (int e = threadIdx.x; e < nseg * (int)(sizeof(PackSeg) / 4); e += 256) ((int*)ssegs)[e] = ((const int*)segs)[e];
+        for (int e = threadIdx.x; e < nseg * (int)(sizeof(PackSeg) / 4); e += kAdamT) ((int*)ssegs)[e] = ((const int*)segs)[e];
         __syncthreads();
     }
     const int lane = threadIdx.x & 63;
-    for (long w0 = (long)blockIdx.x * 256 + (threadIdx.x - lane); w0 < n; w0 += (long)gridDim.x * 256) {   // wave-uniform
+    for (long w0 = (long)blockIdx.x * kAdamT + (threadIdx.x - lane); w0 < n; w0 += (long)gridDim.x * kAdamT) {   // wave-uniform
         const long i = w0 + lane;
         float pn = 0.f;
         if (i < n) {
@@ -211,10 +212,10 @@ int launch_adam_dev(var_ctx* c, hipStream_t s, float* p, const float* g, float* 
                     const float* lr_dev, float b1, float b2, float eps, float wd, int* step_dev, bool repack,
                     const int* idx_table, int row_ints, int n_rows, int* cursor, int* idx_row, int ahead_from) {
     ProfScope prof(c, s, TAG_ADAM);
-    // few blocks (4 elements per thread): every block ends with one device-scope atomic on the same word
-    int grid = (int)((n + 1023) / 1024);
+    // few blocks: every block ends with one device-scope atomic on the same word
+    int grid = (int)((n + kAdamT - 1) / kAdamT);
     if (grid > 256) grid = 256;
-    hipLaunchKernelGGL(adam_pack_dev_kernel, dim3(grid), dim3(256), 0, s, (const PackSeg*)c->pack_segs_dev, c->pack_nseg, p, g, m, v, n, lr_dev,
+    hipLaunchKernelGGL(adam_pack_dev_kernel, dim3(grid), dim3(kAdamT), 0, s, (const PackSeg*)c->pack_segs_dev, c->pack_nseg, p, g, m, v, n, lr_dev,
                        b1, b2, eps, wd, step_dev, c->done_ctr, repack ? c->wpack : nullptr, idx_table, row_ints, n_rows,
                        cursor, idx_row, ahead_from, (c->adam_guard && n == c->adam_guard_n) ? c->adam_guard : nullptr);
     VAR_HIP_CHECK(c, hipGetLastError());
