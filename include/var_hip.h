@@ -91,7 +91,9 @@ int var_pack_weights(var_ctx* ctx, void* stream, const float* params);
  *   mfcc_pos/neg     (B,1,100,40) f32, either may be NULL
  *   outputs          any may be NULL: image_feat/pos_feat/neg_feat (B,3),
  *                    image_raw (B,576) = image_feat_raw, pos_raw (B,160) = pos_sound_raw
- *   save_for_bwd     keep activations in the workspace for var_arm_encoder_bwd
+ *   save_for_bwd     1: keep activations in the workspace for var_arm_encoder_bwd; 0: do not; 2: do not, and a batch of
+ *                    <= 64 images takes the kernels that minimise the latency of a small batch (the RL stage's 8 envs;
+ *                    Envs/vec_env/vec_pretext_normalize.py:82-101) -- equal to the training forward within rounding, not bitwise
  */
 int var_arm_encoder_fwd(var_ctx* ctx, void* stream, const float* params,
                         const void* image, int image_is_u8, long image_bstride,

@@ -90,3 +90,27 @@ def test_sampling_and_rejections(var_amd, fx):
     with pytest.raises(var_amd.VarHipError):
         var_amd.ArmNetPolicy(None, Box(2), config=types.SimpleNamespace(img_dim=(3, 84, 84), representationDim=3, robotStateDim=2),
                              base='arm_VAR', base_kwargs=KW)
+
+
+@pytest.mark.parametrize("B", [1, 5, 8])
+def test_fused_small_batch_chain_equals_the_per_layer_path(var_amd, fx, B):
+    """B <= 8 (the RL stage's envs) takes the one-launch MLP chain after the convolutions (csrc/armnet.hip:
+    armnet_chain_kernel); larger batches take one launch per layer.  The same rows through both: a batch of B alone, and
+    as the first B rows of a batch of 12.  Two consecutive steps (the second from the first's hidden state)."""
+    ref = armnet_seeded(int(fx["seed"]))
+    m = make(var_amd, ref)
+    g = torch.Generator().manual_seed(5)
+    big = {'image': torch.randint(0, 256, (12, 3, 96, 96), dtype=torch.uint8, generator=g).cuda(),
+           'image_feat': torch.randn(12, 3, generator=g).cuda(), 'robot_pose': torch.randn(12, 2, generator=g).cuda(),
+           'goal_sound_feat': torch.randn(12, 3, generator=g).cuda()}
+    hxs = torch.randn(12, 512, generator=g).cuda() * 0.3
+    masks = torch.tensor([[1.], [0.], [1.], [1.], [0.], [1.], [1.], [1.], [1.], [0.], [1.], [1.]]).cuda()
+    small = {k: v[:B].contiguous() for k, v in big.items()}
+    v1, a1, _, h1 = m.act(small, hxs[:B].contiguous(), masks[:B].contiguous(), deterministic=True)
+    v2, a2, _, h2 = m.act(big, hxs, masks, deterministic=True)
+    for got, want in ((v1, v2), (a1, a2), (h1, h2)):
+        np.testing.assert_allclose(got.cpu().numpy(), want[:B].cpu().numpy(), rtol=0, atol=2e-5)
+    v3, a3, _, h3 = m.act(small, h1, torch.ones(B, 1, device="cuda"), deterministic=True)
+    v4, a4, _, h4 = m.act(big, h2, torch.ones(12, 1, device="cuda"), deterministic=True)
+    for got, want in ((v3, v4), (a3, a4), (h3, h4)):
+        np.testing.assert_allclose(got.cpu().numpy(), want[:B].cpu().numpy(), rtol=0, atol=5e-5)

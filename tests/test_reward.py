@@ -56,10 +56,11 @@ def test_intrinsic_reward_on_hip_encoder(golden_dir):
     # later steps of the episode: the goal sound is not embedded again
     image_feat2, goal_feat2, _ = r.embeddings(img, None)
     assert np.array_equal(goal_feat2, goal_feat) and np.array_equal(image_feat2, image_feat)
-    # the graph-captured latency path gives the same numbers
+    # the graph-captured latency path gives the same numbers (the image branch through the small-batch kernels,
+    # include/var_hip.h: save_for_bwd = 2 -- equal within rounding; the sound branch bit for bit)
     r.capture(img.shape[0])
     f1, g1, dot1 = r.step(torch.from_numpy(img).cuda(), torch.from_numpy(goal).cuda())
-    assert np.array_equal(f1.cpu().numpy(), image_feat) and np.array_equal(g1.cpu().numpy(), goal_feat)
+    assert np.max(np.abs(f1.cpu().numpy() - image_feat)) < 1e-6 and np.array_equal(g1.cpu().numpy(), goal_feat)
     assert np.max(np.abs(dot1.cpu().numpy() - fx["d.reward"])) < 1e-4
     f2, g2, dot2 = r.step(torch.from_numpy(img).cuda(), None)
-    assert np.array_equal(f2.cpu().numpy(), image_feat) and np.array_equal(g2.cpu().numpy(), goal_feat)
+    assert np.array_equal(f2.cpu().numpy(), f1.cpu().numpy()) and np.array_equal(g2.cpu().numpy(), goal_feat)

@@ -340,8 +340,11 @@ int var_arm_encoder_fwd(var_ctx* c, void* stream, const float* params, const voi
     if ((rc = check_weights(c, params, "var_arm_encoder_fwd")) != VAR_OK) return rc;
     SET_DEVICE(c);
     hipStream_t s = (hipStream_t)stream;
-    if ((rc = encoder_fwd(c, s, params, image, image_is_u8, image_bstride, nullptr, mfcc_pos, mfcc_neg, nullptr, B)) != VAR_OK) return rc;
-    if (!save_for_bwd) c->saved_B = 0;
+    c->fwd_only = save_for_bwd == 2;                // inference with the small-batch kernels (img_conv_fwd.hip)
+    rc = encoder_fwd(c, s, params, image, image_is_u8, image_bstride, nullptr, mfcc_pos, mfcc_neg, nullptr, B);
+    c->fwd_only = false;
+    if (rc != VAR_OK) return rc;
+    if (save_for_bwd != 1) c->saved_B = 0;
     CopySegs S{};
     auto seg = [&](float* dst, const float* src, int n) { S.dst[S.count] = dst; S.src[S.count] = src; S.n[S.count] = n; S.count++; };
     if (image && image_feat) seg(image_feat, c->emb, 3 * B);
@@ -612,7 +615,7 @@ int var_debug_buffer(var_ctx* c, const char* name, void** ptr, long* nfloats) {
         const long n = (long)(B * kImgCh[l] * c->hs[l] * c->hs[l]);
         if (!strcmp(name, a)) {
             *ptr = c->act[l]; *nfloats = n;
-            if (l == 1 && c->H == 84) {          // the tiled form -> NCHW, into the (otherwise unused) gact[1] block
+            if (l == 1 && c->H == 84 && c->act1_tiled) {          // the tiled form -> NCHW, into the (otherwise unused) gact[1] block
                 int rc = launch_act1_untile(c, nullptr, (int)B);
                 if (rc != VAR_OK) return rc;
                 VAR_HIP_CHECK(c, hipStreamSynchronize(nullptr));

@@ -9,6 +9,17 @@
 #include "gg.h"
 
 namespace {
+PH_DECL();
+}
+#ifdef VAR_PHASES
+extern "C" int var_debug_phases_armchain(unsigned long long* out) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
+
+namespace {
 constexpr int kCh[9] = {3, 32, 32, 64, 64, 128, 128, 256, 128};
 constexpr int kRepr = 3, kRobot = 2, kRin = 128, kRh = 512, kAct = 128, kActions = 2, kFlat = 1152;
 
@@ -51,6 +62,8 @@ struct arm_state {
     float *t0 = nullptr, *t1 = nullptr, *t2 = nullptr, *t3 = nullptr;   // (B,512) scratch rows
     float* slab = nullptr;
     float *flat_img = nullptr, *motor = nullptr, *sound = nullptr, *fusion = nullptr, *h0 = nullptr, *gi = nullptr, *gh = nullptr;
+    float* chain = nullptr;        // the fused small-batch MLP chain's vectors (armnet_chain_kernel)
+    unsigned* sync = nullptr;      // its grid barrier: [0] arrivals, [1] finished workgroups, [2] time-out (sticky)
 };
 
 static __global__ void an_pool_kernel(const float* __restrict__ x, float* __restrict__ y, long n, int H, int HP) {
@@ -90,6 +103,269 @@ static __global__ void an_gru_cell_kernel(const float* __restrict__ gi, const fl
     const float v = (1.f - z) * n + z * h[i];
     out[i] = v;
     if (out2) out2[i] = v;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Small batches (the RL stage's 8 envs): everything after the convolutions as ONE persistent launch.
+// 22 Linear layers + the GRU step are 12 dependent stages of tiny products (8 rows x K <= 1152 x N <= 1536): as separate
+// launches they cost ~4 us each whatever they compute (45 launches, 240 us of the 435-us forward).  Here kChainG workgroups
+// stay resident; a stage's inputs (<= 57 KB for 8 rows) are staged into every workgroup's LDS, a wave takes blocks of four
+// output features (lanes split K: coalesced 256-B reads of the weight rows in their state_dict() layout, 8 rows x 4
+// outputs of partial sums per lane, a 31-shuffle butterfly leaves one (output, row) sum per lane), and stages are separated
+// by a grid barrier in the guide's hand-off form (MI355X_MICROARCH.md, inter-workgroup visibility, third table row): every
+// handed-off float is stored and loaded sc1 (agent-scope relaxed atomics), each wave drains its stores, one lane per
+// workgroup adds to the counter behind a workgroup barrier and polls it; a workgroup barrier stands between the poll and
+// the loads.  The poll is bounded: a grid that is not resident sets sync[2] and every workgroup leaves (outputs NaN).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kChainG = 128, kChainT = 256, kChainRows = 8, kChainNB = 4;
+enum { IN_PLAIN = 0, IN_SUM, IN_CAT, IN_MASK, IN_GRU };
+struct ChainJob { int w, b, K, N, kind, in0, in1, cat0, out, relu, wg0, nwg; };
+struct ChainStage { int job0, njobs; };
+constexpr int kChainMaxJobs = 28, kChainMaxStages = 12, kChainBufs = 36;
+struct ChainDesc {
+    const float* P;
+    float* buf[kChainBufs];
+    ChainJob job[kChainMaxJobs];
+    ChainStage stage[kChainMaxStages];
+    int nstages, B, H;
+    int b_hxs, b_mask, b_hout;           // buffer ids the GRU input kind needs besides in0 (gi) / in1 (gh)
+    unsigned* sync;
+};
+typedef __attribute__((address_space(1))) float gf32;
+typedef __attribute__((address_space(1))) unsigned gu32c;
+__device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load((gf32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store((gf32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+typedef float f32x4c __attribute__((ext_vector_type(4)));
+// 16 bytes of a handed-off vector, read around the L1 (sc1): element offset `e` (a multiple of 4) of buffer p
+__device__ __forceinline__ f32x4c ld4_sc1(const float* p, int e) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7fffffff, 0x00020000);
+    return __builtin_bit_cast(f32x4c, __builtin_amdgcn_raw_buffer_load_b128(r, e * 4, 0, 16));
+}
+
+__global__ void __launch_bounds__(kChainT) armnet_chain_kernel(ChainDesc D) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int ok_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = D.B, H = D.H;
+    bool alive = true;
+    PHR_INIT(5, 0);
+    // this workgroup's job of a stage (jobs own ranges of workgroups, sized by their weight volume)
+    auto job_of = [&](int si) {
+        const ChainStage S = D.stage[si];
+        int q = 0;
+#pragma unroll 1
+        for (int t = 1; t < S.njobs; ++t) if ((int)blockIdx.x >= D.job[S.job0 + t].wg0) q = t;
+        return D.job[S.job0 + q];
+    };
+    // The weights do not depend on the activations: the first eight k-chunks of this wave's first item of the NEXT stage (all
+    // of them for every layer but the 1152-wide one) and its bias are requested BEFORE the grid barrier and land behind it.
+    const int lidx = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+    float pw[8][kChainNB], pbias = 0.f;
+    auto load_w = [&](const ChainJob& J, int o0, int kc0, float (&wv)[8][kChainNB]) {
+        const float* W = D.P + J.w;
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) {
+            const int k = kc0 + c8 * 64 + lane;
+#pragma unroll
+            for (int o = 0; o < kChainNB; ++o) {                               // (unconditional, clamped: see the staging below)
+                const int kk = k < J.K ? k : J.K - 1, oo = o0 + o < J.N ? o0 + o : J.N - 1;
+                wv[c8][o] = W[(long)oo * J.K + kk];
+            }
+        }
+    };
+    auto prefetch = [&](const ChainJob& J) {
+        const int jw = ((int)blockIdx.x - J.wg0) * (kChainT / 64) + wave;
+        if (jw * kChainNB < J.N) {
+            load_w(J, jw * kChainNB, 0, pw);
+            const int oo = jw * kChainNB + lidx / kChainRows;
+            pbias = D.P[J.b + (oo < J.N ? oo : J.N - 1)];
+        }
+    };
+    ChainJob J = job_of(0);
+    prefetch(J);
+#pragma unroll 1
+    for (int si = 0; si < D.nstages; ++si) {
+        PHR(0);
+        const int Kp = (J.K + 63) & ~63;
+        // ---- the job's input -> LDS [row][Kp], zero-padded; 16-byte sc1 loads, four in flight per thread ----
+        {
+            const float* a = D.buf[J.in0];
+            const float* b2 = J.in1 >= 0 ? D.buf[J.in1] : nullptr;
+            if (J.kind == IN_GRU) {
+                // torch.nn.GRU cell (gate order r, z, n) from gi (in0) and gh (in1): the new state is this layer's input.  A rolled
+                // loop on purpose: the kernel's code runs once per stage, and what does not fit the instruction cache is fetched again
+                const int kq = J.K >> 2, n4 = B * kq;
+#pragma unroll 1
+                for (int e = tid; e < n4; e += kChainT) {
+                    const int r = e / kq, k = 4 * (e - r * kq);
+                    const f32x4c hx = ld4_sc1(D.buf[D.b_hxs], r * H + k);
+                    const float hm = ld_sc1(D.buf[D.b_mask] + r);
+                    f32x4c g3[6];
+#pragma unroll
+                    for (int gte = 0; gte < 3; ++gte) { g3[gte] = ld4_sc1(a, r * 3 * H + gte * H + k); g3[3 + gte] = ld4_sc1(b2, r * 3 * H + gte * H + k); }
+                    f32x4c o;
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        const float h = hx[c4] * hm;
+                        const float rr = 1.f / (1.f + expf(-(g3[0][c4] + g3[3][c4])));
+                        const float z = 1.f / (1.f + expf(-(g3[1][c4] + g3[4][c4])));
+                        const float n = tanhf(g3[2][c4] + rr * g3[5][c4]);
+                        o[c4] = (1.f - z) * n + z * h;
+                    }
+                    if (blockIdx.x == J.wg0) *(f32x4c*)(D.buf[D.b_hout] + r * H + k) = o;       // rnn_hxs_out (later launches read it)
+                    *(f32x4c*)(lds + r * Kp + k) = o;
+                }
+                for (int e = tid; e < (kChainRows - B) * Kp; e += kChainT) lds[B * Kp + e] = 0.f;
+            } else if ((J.K & 3) == 0) {
+                const int kq = J.K >> 2, n4 = kChainRows * kq;                  // vec4 elements of the [8][K] input
+#pragma unroll 1
+                for (int e0 = tid; e0 < n4; e0 += 8 * kChainT) {
+                    // all loads first (unconditional: addresses clamped into the buffers, values selected afterwards -- a load behind
+                    // a per-lane condition becomes a branch with a wait of its own, i.e. a chain of memory latencies)
+                    f32x4c v[8], u[8];
+                    float hm[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        int e = e0 + i * kChainT;
+                        e = e < n4 ? e : n4 - 1;
+                        int r = e / kq;
+                        const int k = 4 * (e - r * kq);
+                        r = r < B ? r : B - 1;
+                        v[i] = ld4_sc1(a, r * J.K + k);
+                        u[i] = J.kind == IN_SUM ? ld4_sc1(b2, r * J.K + k) : f32x4c{0.f, 0.f, 0.f, 0.f};
+                        hm[i] = J.kind == IN_MASK ? ld_sc1(b2 + r) : 1.f;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int e = e0 + i * kChainT;
+                        if (e >= n4) continue;
+                        const int r = e / kq, k = 4 * (e - r * kq);
+                        f32x4c o = (v[i] + u[i]) * hm[i];
+                        if (r >= B) o = f32x4c{0.f, 0.f, 0.f, 0.f};
+                        *(f32x4c*)(lds + r * Kp + k) = o;
+                    }
+                }
+            } else {                                                            // the two tiny first layers (K = 5: [image_feat | robot_pose], K = 3)
+                for (int e = tid; e < kChainRows * Kp; e += kChainT) {
+                    const int r = e / Kp, k = e - r * Kp;
+                    float v = 0.f;
+                    if (r < B && k < J.K) {
+                        if (J.kind == IN_CAT) v = k < J.cat0 ? ld_sc1(a + r * J.cat0 + k) : ld_sc1(b2 + r * (J.K - J.cat0) + k - J.cat0);
+                        else v = ld_sc1(a + r * J.K + k);
+                    }
+                    lds[e] = v;
+                }
+            }
+        }
+        PHR(1);
+        __syncthreads();
+        PHR(2);
+        // ---- items: blocks of kChainNB outputs, dealt to the waves of the job's workgroups ----
+        {
+            const int jw = ((int)blockIdx.x - J.wg0) * (kChainT / 64) + wave, jnw = J.nwg * (kChainT / 64);
+            const int nitems = (J.N + kChainNB - 1) / kChainNB;
+            bool first = true;
+#pragma unroll 1
+            for (int it = jw; it < nitems; it += jnw) {
+                const int o0 = it * kChainNB;
+                float acc[kChainNB][kChainRows];
+#pragma unroll
+                for (int o = 0; o < kChainNB; ++o)
+#pragma unroll
+                    for (int r = 0; r < kChainRows; ++r) acc[o][r] = 0.f;
+                float bias = pbias;
+                if (!first) { const int oo = o0 + lidx / kChainRows; bias = D.P[J.b + (oo < J.N ? oo : J.N - 1)]; }
+                // weight rows stream from HBM: eight k-chunks (32 loads) in flight per wave
+#pragma unroll 1
+                for (int kc0 = 0; kc0 < Kp; kc0 += 8 * 64) {
+                    float wv[8][kChainNB];
+                    if (first && kc0 == 0) {
+#pragma unroll
+                        for (int c8 = 0; c8 < 8; ++c8)
+#pragma unroll
+                            for (int o = 0; o < kChainNB; ++o) wv[c8][o] = pw[c8][o];
+                    } else load_w(J, o0, kc0, wv);
+#pragma unroll
+                    for (int c8 = 0; c8 < 8; ++c8) {
+                        const int k = kc0 + c8 * 64 + lane;
+                        if (kc0 + c8 * 64 < Kp) {
+#pragma unroll
+                            for (int r = 0; r < kChainRows; ++r) {
+                                const float xv = lds[r * Kp + k];
+#pragma unroll
+                                for (int o = 0; o < kChainNB; ++o) acc[o][r] = fmaf(wv[c8][o], xv, acc[o][r]);      // (padding k: xv == 0)
+                            }
+                        }
+                    }
+                }
+                // butterfly over the 64 lanes: 32 values -> lane L ends with value idx(L) = o * 8 + r
+                float v[32];
+#pragma unroll
+                for (int o = 0; o < kChainNB; ++o)
+#pragma unroll
+                    for (int r = 0; r < kChainRows; ++r) v[o * kChainRows + r] = acc[o][r];
+                // (each step with compile-time constants: a loop over (half, bit) is not unrolled by hipcc, and the array then
+                //  becomes 32-way select chains -- 6 K instructions)
+#define CHAIN_FOLD(HALF, BIT)                                                                         \
+                {                                                                                     \
+                    const bool up = (lane & (BIT)) != 0;                                              \
+                    _Pragma("unroll") for (int i = 0; i < (HALF); ++i) {                             \
+                        const float keep = up ? v[i + (HALF)] : v[i], give = up ? v[i] : v[i + (HALF)]; \
+                        v[i] = keep + __shfl_xor(give, (BIT), 64);                                   \
+                    }                                                                                 \
+                }
+                CHAIN_FOLD(16, 32) CHAIN_FOLD(8, 16) CHAIN_FOLD(4, 8) CHAIN_FOLD(2, 4) CHAIN_FOLD(1, 2)
+#undef CHAIN_FOLD
+                const float sum = v[0] + __shfl_xor(v[0], 1, 64);
+                const int o = lidx / kChainRows, r = lidx % kChainRows;
+                first = false;
+                if ((lane & 1) == 0 && r < B && o0 + o < J.N) {
+                    float y = sum + bias;
+                    if (J.relu) y = fmaxf(y, 0.f);
+                    if (!alive) y = __builtin_nanf("");
+                    st_sc1(D.buf[J.out] + r * J.N + o0 + o, y);
+                }
+            }
+        }
+        PHR(3);
+        if (si + 1 == D.nstages) break;
+        // ---- grid barrier ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's sc1 stores have left
+        J = job_of(si + 1);
+        prefetch(J);                                                // (in flight across the barrier)
+        __syncthreads();
+        PHR(4);
+        if (tid == 0) {
+            int ok = 1;
+            if (alive) {
+                const unsigned want = (unsigned)(si + 1) * gridDim.x;
+                __hip_atomic_fetch_add((gu32c*)D.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned spins = 0;
+                while (__hip_atomic_load((gu32c*)D.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    if (++spins > (1u << 18)) { ok = 0; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (!ok) __hip_atomic_store((gu32c*)(D.sync + 2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else ok = 0;
+            ok_s = ok;
+        }
+        __syncthreads();
+        alive = ok_s != 0;
+        PHR(5);
+    }
+    PHR_FLUSH();
+    // the last workgroup to finish re-arms the counter for the next launch (nobody polls it any more)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned d = __hip_atomic_fetch_add((gu32c*)(D.sync + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (d == gridDim.x - 1) {
+            __hip_atomic_store((gu32c*)D.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store((gu32c*)(D.sync + 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 inline dim3 g1(long n) { return dim3((unsigned)((n + 255) / 256)); }
@@ -132,6 +408,95 @@ int linear(var_ctx* c, hipStream_t s, arm_state* st, const float* P, const Lin& 
 }
 }  // namespace
 
+
+namespace {
+int chain_forward(var_ctx* c, hipStream_t s, arm_state* st, const float* P, const float* image_feat, const float* robot_pose,
+                  const float* goal, const float* hxs, const float* masks, int B, float* value, float* actor_features, float* action_mean,
+                  float* hxs_out) {
+    const ArmLayout& L = st->L;
+    ChainDesc D{};
+    D.P = P; D.B = B; D.H = kRh; D.sync = st->sync;
+    enum { A8, IMGF, POSE, GOAL, HXS, MASK, HOUT, VALUE, AFEAT, MEAN, CNN0, FLAT, M0, M1, MOTOR, S0, S1, SOUND, GH, IM0, X, F0, FUSION, GI, IMR,
+           ALL0, ALL1, C0, C1, A0, NBUF };
+    static_assert(NBUF <= kChainBufs, "buffer table");
+    float* sc = st->chain;
+    auto scratch = [&](int width) { float* p = sc; sc += kChainRows * width; return p; };
+    D.buf[A8] = st->a[8]; D.buf[IMGF] = (float*)image_feat; D.buf[POSE] = (float*)robot_pose; D.buf[GOAL] = (float*)goal;
+    D.buf[HXS] = (float*)hxs; D.buf[MASK] = (float*)masks; D.buf[HOUT] = hxs_out; D.buf[VALUE] = value; D.buf[AFEAT] = actor_features;
+    D.buf[MEAN] = action_mean ? action_mean : scratch(kActions);
+    const int widths[][2] = {{CNN0, 512}, {FLAT, 256}, {M0, 256}, {M1, 512}, {MOTOR, 256}, {S0, 128}, {S1, 256}, {SOUND, 256}, {GH, 3 * kRh},
+                             {IM0, 256}, {X, kRin}, {F0, 512}, {FUSION, 256}, {GI, 3 * kRh}, {IMR, 256}, {ALL0, 256}, {ALL1, 128}, {C0, 128},
+                             {C1, 128}, {A0, 128}};
+    for (auto& wd : widths) D.buf[wd[0]] = scratch(wd[1]);
+    D.b_hxs = HXS; D.b_mask = MASK; D.b_hout = HOUT;
+    int nj = 0, ns = 0;
+    long lds_max = 0, lds_cur = 0;
+    auto stage = [&]() { D.stage[ns].job0 = nj; D.stage[ns].njobs = 0; lds_cur = 0; return ns++; };
+    auto job = [&](const Lin& l, int kind, int in0, int in1, int cat0, int out, int relu) {
+        D.job[nj] = ChainJob{l.w, l.b, l.in, l.out, kind, in0, in1, cat0, out, relu, 0, 0};
+        D.stage[ns - 1].njobs++;
+        nj++;
+        lds_cur = (long)kChainRows * ((l.in + 63) & ~63);              // a workgroup stages the input of ITS job only
+        if (lds_cur > lds_max) lds_max = lds_cur;
+    };
+    // workgroup ranges of a stage's jobs, proportional to their weight volume (every job at least one workgroup)
+    auto split = [&]() {
+        ChainStage& S = D.stage[ns - 1];
+        double tot = 0;
+        for (int q = 0; q < S.njobs; ++q) tot += (double)D.job[S.job0 + q].K * D.job[S.job0 + q].N;
+        int left = kChainG, wg0 = 0;
+        for (int q = 0; q < S.njobs; ++q) {
+            ChainJob& J = D.job[S.job0 + q];
+            int n = q + 1 == S.njobs ? left : (int)((double)J.K * J.N / tot * kChainG + 0.5);
+            if (n < 1) n = 1;
+            if (n > left - (S.njobs - 1 - q)) n = left - (S.njobs - 1 - q);
+            J.wg0 = wg0; J.nwg = n;
+            wg0 += n; left -= n;
+        }
+    };
+    const Lin ih{L.g_wih, L.g_bih, kRin, 3 * kRh}, hh{L.g_whh, L.g_bhh, kRh, 3 * kRh};
+    stage(); job(L.cnn[0], IN_PLAIN, A8, -1, 0, CNN0, 1); job(L.motor[0], IN_CAT, IMGF, POSE, kRepr, M0, 1);
+             job(L.snd[0], IN_PLAIN, GOAL, -1, 0, S0, 1); job(hh, IN_MASK, HXS, MASK, 0, GH, 0);
+    split();
+    stage(); job(L.cnn[1], IN_PLAIN, CNN0, -1, 0, FLAT, 1); job(L.motor[1], IN_PLAIN, M0, -1, 0, M1, 1); job(L.snd[1], IN_PLAIN, S0, -1, 0, S1, 1);
+    split();
+    stage(); job(L.motor[2], IN_PLAIN, M1, -1, 0, MOTOR, 1); job(L.snd[2], IN_PLAIN, S1, -1, 0, SOUND, 1);
+    split();
+    stage(); job(L.im[0], IN_SUM, FLAT, MOTOR, 0, IM0, 1); job(L.fus[0], IN_SUM, SOUND, FLAT, 0, F0, 1);
+    split();
+    stage(); job(L.im[1], IN_PLAIN, IM0, -1, 0, X, 1); job(L.fus[1], IN_PLAIN, F0, -1, 0, FUSION, 1);
+    split();
+    stage(); job(ih, IN_PLAIN, X, -1, 0, GI, 0);
+    split();
+    stage(); job(L.im2, IN_GRU, GI, GH, 0, IMR, 1);                                   // the GRU cell is its input transform
+    split();
+    stage(); job(L.all[0], IN_SUM, FUSION, IMR, 0, ALL0, 1);
+    split();
+    stage(); job(L.all[1], IN_PLAIN, ALL0, -1, 0, ALL1, 1);
+    split();
+    stage(); job(L.critic[0], IN_PLAIN, ALL1, -1, 0, C0, 1); job(L.actor[0], IN_PLAIN, ALL1, -1, 0, A0, 1);
+    split();
+    stage(); job(L.critic[1], IN_PLAIN, C0, -1, 0, C1, 1); job(L.actor[1], IN_PLAIN, A0, -1, 0, AFEAT, 1);
+    split();
+    stage(); job(L.clin, IN_PLAIN, C1, -1, 0, VALUE, 0); job(L.mean, IN_PLAIN, AFEAT, -1, 0, MEAN, 0);
+    split();
+    D.nstages = ns;
+    if (ns > kChainMaxStages || nj > kChainMaxJobs || sc - st->chain > kChainRows * 8192) {
+        VAR_SET_ERR(c, "armnet chain: table overflow");
+        return VAR_ERR_ARG;
+    }
+    const int lds_bytes = (int)lds_max * 4;
+    static bool attr = false;
+    if (!attr) {
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)armnet_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL(armnet_chain_kernel, dim3(kChainG), dim3(kChainT), lds_bytes, s, D);
+    AN_CHECK(c);
+    return VAR_OK;
+}
+}  // namespace
+
 void armnet_free(var_ctx* c) {
     arm_state* st = (arm_state*)c->arm;
     if (!st) return;
@@ -170,6 +535,7 @@ int var_armnet_plan(var_ctx* c, int max_batch) {
     const long ot0 = take(B * 512), ot1 = take(B * 512), ot2 = take(B * 512), ot3 = take(B * 512);
     const long ofl = take(B * 256), omo = take(B * 256), osn = take(B * 256), ofu = take(B * 256), oh0 = take(B * kRh);
     const long ogi = take(B * 3 * kRh), ogh = take(B * 3 * kRh), oslab = take(kSlab);
+    const long ochain = take(kChainRows * 8192), osync = take(64);
     VAR_HIP_CHECK(c, hipMalloc((void**)&st->ws, (size_t)total * sizeof(float)));
     float* w = st->ws;
     for (int l = 1; l <= 8; ++l) st->a[l] = w + oa[l];
@@ -177,6 +543,8 @@ int var_armnet_plan(var_ctx* c, int max_batch) {
     st->t0 = w + ot0; st->t1 = w + ot1; st->t2 = w + ot2; st->t3 = w + ot3;
     st->flat_img = w + ofl; st->motor = w + omo; st->sound = w + osn; st->fusion = w + ofu; st->h0 = w + oh0;
     st->gi = w + ogi; st->gh = w + ogh; st->slab = w + oslab;
+    st->chain = w + ochain; st->sync = (unsigned*)(w + osync);
+    VAR_HIP_CHECK(c, hipMemset(st->sync, 0, 64 * sizeof(float)));
     return VAR_OK;
 }
 
@@ -225,6 +593,9 @@ int var_armnet_forward(var_ctx* c, void* stream, const float* params, const void
     RUN(pool(st->a[6], st->p[3], 128, 24));
     RUN((conv<S2P0, false>(c, s, st, dims(7, 12, 2, 0), st->p[3], P + L.cw[6], P + L.cb[6], st->a[7])));
     RUN((conv<S1P0, false>(c, s, st, dims(8, 5, 1, 0), st->a[7], P + L.cw[7], P + L.cb[7], st->a[8])));
+    if (B <= kChainRows)      // the RL stage's batch: everything after the convolutions in one persistent launch
+        return chain_forward(c, s, st, P, image_feat, robot_pose, goal_sound_feat, rnn_hxs, masks, B, value, actor_features, action_mean,
+                             rnn_hxs_out);
     // image_flatten = cnnMlp(flatten)
     RUN(linear(c, s, st, P, L.cnn[0], st->a[8], st->t0, B, 1));
     RUN(linear(c, s, st, P, L.cnn[1], st->t0, st->flat_img, B, 1));

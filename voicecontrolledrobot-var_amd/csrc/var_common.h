@@ -158,6 +158,8 @@ struct var_ctx {
     const float* saved_neg = nullptr;
     const int* saved_index = nullptr;     // optional image gather index of the saved forward
     // side stream for the sound branch (runs beside the image branch) and its fork/join events
+    bool act1_tiled = false;              // the last image forward left act1 band-tiled (img_head2.hip) rather than NCHW
+    bool fwd_only = false;                // the running forward saves nothing for a backward (var_arm_encoder_fwd, save_for_bwd = 0)
     bool serial = false;                  // var_set_streams(0): everything on the caller's stream (per-kernel profiling)
     int streams = 0;              // bit mask, see var_init
     hipStream_t side = nullptr;

@@ -110,7 +110,7 @@ class IntrinsicReward:
             c.check(c.lib.var_arm_encoder_fwd(c.handle, current_stream_handle(), ptr(flat), ptr(self._img), 1,
                                               self._img.stride(0), ptr(self._goal) if with_goal else None, None, B, hw,
                                               ptr(self._image_feat), ptr(self._goal_feat) if with_goal else None,
-                                              None, None, None, 0), "var_arm_encoder_fwd")
+                                              None, None, None, 2), "var_arm_encoder_fwd")      # 2: inference, small-batch kernels
             torch.sum(self._image_feat * self._goal_feat, dim=1, out=self._reward)    # <image_feat, goal_feat>
 
         side = torch.cuda.Stream(device=dev)
