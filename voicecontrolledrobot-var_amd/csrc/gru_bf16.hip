@@ -355,6 +355,7 @@ __global__ void __launch_bounds__(512) gru_seq_fwd_kernel(const float* __restric
         PH(3);
         __syncthreads();
         PH(4);
+        float4 o, rr, zz, nn, gg;
         if (clip < nclips) {
             float gh[3][4];
 #pragma unroll
@@ -367,9 +368,7 @@ __global__ void __launch_bounds__(512) gru_seq_fwd_kernel(const float* __restric
                 }
                 gh[g][0] = v.x; gh[g][1] = v.y; gh[g][2] = v.z; gh[g][3] = v.w;
             }
-            float* hnext = Hb + dir * dirH + (long)(step + 1) * nclips * GH + (long)clip * GH + j;
-            const long so = dir * dirS + (long)step * nclips * GH + (long)clip * GH + j;
-            float4 o, rr, zz, nn, gg;
+
 #define GRU_LANE(c, e)                                                     \
     {                                                                      \
         const float r_ = sigmoidf_(gr.c + (gh[0][e] + br.c));              \
@@ -384,8 +383,6 @@ __global__ void __launch_bounds__(512) gru_seq_fwd_kernel(const float* __restric
             u32x2_t o16;
             o16.x = pack2(o.x, o.y); o16.y = pack2(o.z, o.w);
             __builtin_amdgcn_raw_buffer_store_b64(o16, hr, stoff, rows + nclips * (GH * 2), kSc1);
-            *(float4*)hnext = o;
-            if (save) { *(float4*)(R + so) = rr; *(float4*)(Z + so) = zz; *(float4*)(Nn + so) = nn; *(float4*)(GHN + so) = gg; }
             hp = o;
         }
         PH(5);
@@ -394,6 +391,14 @@ __global__ void __launch_bounds__(512) gru_seq_fwd_kernel(const float* __restric
         __syncthreads();
         PH(7);
         if (tid == 0) __hip_atomic_fetch_add((gu32*)(cnt + step + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // what only LATER launches read (the fp32 state, the saved gates) is stored behind the hand-off: the drain above then
+        // waits for the one bf16 row the next step needs, not for five more 16-byte stores per lane
+        if (clip < nclips) {
+            float* hnext = Hb + dir * dirH + (long)(step + 1) * nclips * GH + (long)clip * GH + j;
+            const long so = dir * dirS + (long)step * nclips * GH + (long)clip * GH + j;
+            *(float4*)hnext = o;
+            if (save) { *(float4*)(R + so) = rr; *(float4*)(Z + so) = zz; *(float4*)(Nn + so) = nn; *(float4*)(GHN + so) = gg; }
+        }
     }
 }
 
@@ -461,10 +466,10 @@ __global__ void __launch_bounds__(512) gru_seq_bwd_kernel(float* __restrict__ DH
                 dp[0] += p.x; dp[1] += p.y; dp[2] += p.z; dp[3] += p.w;
             }
         }
+        float4 dr, dz, dn, dnr;
+        u32x2_t pr, pz, pn;
         if (clip < nclips) {
-            float* dgi = DGI + dir * dirGI + ((long)clip * SEQ + t) * G3 + j;
-            float* dgh = DGH + dir * dirDGH + ((long)step * nclips + clip) * G3 + j;
-            float4 dr, dz, dn, dnr, dd;
+            float4 dd;
 #define GRU_LANE(c, e)                                                     \
     {                                                                      \
         const float dh_ = d4.c + dp[e];                                    \
@@ -475,20 +480,12 @@ __global__ void __launch_bounds__(512) gru_seq_bwd_kernel(float* __restrict__ DH
     }
             GRU_LANE(x, 0) GRU_LANE(y, 1) GRU_LANE(z, 2) GRU_LANE(w, 3)
 #undef GRU_LANE
-            u32x2_t pr, pz, pn;
             pr.x = pack2(dr.x, dr.y); pr.y = pack2(dr.z, dr.w);
             pz.x = pack2(dz.x, dz.y); pz.y = pack2(dz.z, dz.w);
             pn.x = pack2(dnr.x, dnr.y); pn.y = pack2(dnr.z, dnr.w);
             __builtin_amdgcn_raw_buffer_store_b64(pr, gr, stoff, rows, kSc1);
             __builtin_amdgcn_raw_buffer_store_b64(pz, gr, stoff + GH * 2, rows, kSc1);
             __builtin_amdgcn_raw_buffer_store_b64(pn, gr, stoff + 2 * GH * 2, rows, kSc1);
-            if (store32) {      // (the fp32 arrays: nothing reads them when the products take the bf16 copies and the bias sums are formed here)
-                *(float4*)dgi = dr; *(float4*)(dgi + GH) = dz; *(float4*)(dgi + 2 * GH) = dn;
-                *(float4*)dgh = dr; *(float4*)(dgh + GH) = dz; *(float4*)(dgh + 2 * GH) = dnr;
-            }
-            uint2* i16 = DGI16 + ((long)dir * SEQ * nclips + (long)clip * SEQ + t) * (G3 / 4) + 8 * js + jq;
-            i16[0] = make_uint2(pr.x, pr.y); i16[GH / 4] = make_uint2(pz.x, pz.y);
-            i16[2 * GH / 4] = make_uint2(pack2(dn.x, dn.y), pack2(dn.z, dn.w));
             d4 = dd;
             sr.x += dr.x; sr.y += dr.y; sr.z += dr.z; sr.w += dr.w;
             sz.x += dz.x; sz.y += dz.y; sz.z += dz.z; sz.w += dz.w;
@@ -501,6 +498,18 @@ __global__ void __launch_bounds__(512) gru_seq_bwd_kernel(float* __restrict__ DH
         __syncthreads();
         PH(17);
         if (tid == 0) __hip_atomic_fetch_add((gu32*)(cnt + step), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (as in the forward pass: what later launches read is stored behind the hand-off)
+        if (clip < nclips) {
+            if (store32) {      // (the fp32 arrays: nothing reads them when the products take the bf16 copies and the bias sums are formed here)
+                float* dgi = DGI + dir * dirGI + ((long)clip * SEQ + t) * G3 + j;
+                float* dgh = DGH + dir * dirDGH + ((long)step * nclips + clip) * G3 + j;
+                *(float4*)dgi = dr; *(float4*)(dgi + GH) = dz; *(float4*)(dgi + 2 * GH) = dn;
+                *(float4*)dgh = dr; *(float4*)(dgh + GH) = dz; *(float4*)(dgh + 2 * GH) = dnr;
+            }
+            uint2* i16 = DGI16 + ((long)dir * SEQ * nclips + (long)clip * SEQ + t) * (G3 / 4) + 8 * js + jq;
+            i16[0] = make_uint2(pr.x, pr.y); i16[GH / 4] = make_uint2(pz.x, pz.y);
+            i16[2 * GH / 4] = make_uint2(pack2(dn.x, dn.y), pack2(dn.z, dn.w));
+        }
     }
     if (clip < nclips) *(float4*)dh = d4;
     // bias gradients: b_ih = sum over (clip, t) of (dr, dz, dn), b_hh of (dr, dz, dn r) -- this workgroup's 64 clips summed
