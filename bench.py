@@ -526,6 +526,29 @@ def main():
 
     for _ in range(max(2, args.warmup // 2)):                  # eager warm-up: lazy kernel attributes, workspace plan
         eager_step()
+    # Capture FIRST, measure the eager legs after it: the capture leaves the GPU idle for ~9 ms, and the clocks then take ~40
+    # steps (13 ms) to come back (tools/ramp_check.py: 0.330 -> 0.309 ms per replay over the first 40 replays after a capture,
+    # with a zero learning rate too; 0.308 from the second replay on when eager steps ran in between).  With the eager legs
+    # between capture and replays the timed region starts at the sustained clock, as a training run is after its first
+    # milliseconds.
+    if use_graph:
+        # the captured step walks a device-resident table of shuffled epochs by itself (no host copy per step);
+        # the host installs the next epochs' table when this one is used up
+        trows = 256
+        if args.head == "inbatch":
+            replay, load_table = tr.capture_inbatch_epoch_steps(pool.images, pool.clips, B,
+                                                                pool.index_table(B, trows)[:trows].contiguous(), tau=0.1)
+        else:
+            replay, load_table = tr.capture_epoch_steps(pool.images, pool.clips, B, pool.index_table(B, trows)[:trows].contiguous(),
+                                                        global_batch=B * world)
+        gstate = {"left": trows}
+
+        def step():
+            if gstate["left"] == 0:
+                load_table(pool.index_table(B, trows)[:trows].contiguous())
+                gstate["left"] = trows
+            gstate["left"] -= 1
+            replay()
     # pick the dominant conv kernel family by the kernel's OWN duration (three profiled eager steps per candidate with every
     # launch on one stream: what the rocprofv3 kernel-stats average reads too; beside the side stream's kernels the event
     # bracket of whichever kernel runs next to the MFCC reads longest, which says nothing about that kernel)
@@ -565,23 +588,7 @@ def main():
         ctx.profile_select(-1)
 
     if use_graph:
-        # the captured step walks a device-resident table of shuffled epochs by itself (no host copy per step);
-        # the host installs the next epochs' table when this one is used up
-        trows = 256
-        if args.head == "inbatch":
-            replay, load_table = tr.capture_inbatch_epoch_steps(pool.images, pool.clips, B,
-                                                                pool.index_table(B, trows)[:trows].contiguous(), tau=0.1)
-        else:
-            replay, load_table = tr.capture_epoch_steps(pool.images, pool.clips, B, pool.index_table(B, trows)[:trows].contiguous(),
-                                                        global_batch=B * world)
-        gstate = {"left": trows}
-
-        def step():
-            if gstate["left"] == 0:
-                load_table(pool.index_table(B, trows)[:trows].contiguous())
-                gstate["left"] = trows
-            gstate["left"] -= 1
-            replay()
+        tr.sync_device_scalars()                     # (the eager legs above advanced the optimiser's step count)
     for _ in range(args.warmup):
         step()
 

@@ -304,7 +304,7 @@ def test_ithor_replayed_ragged_epochs_over_a_pool_equal_eager_steps(var_amd, tmp
     here the same shape in small: 22 triplets at batch 8 (8 / 8 / 6), clips of up to 1.5 s with ragged lengths, two epochs
     through IthorTrainer.capture_epoch_steps (gather of the row from the resident pool, then the captured step -- a second
     graph for the short batch) against eager step_from_pcm calls on the rows.  Run twice in one
-    process (graph lifetimes: var_amd._lib.new_graph)."""
+    process."""
     pool = var_amd.SyntheticTripletPool(22, hw=96, seed=5, clips_per_class=3, n_samples=24000, ragged_lens=True).freeze_pairs()
     B, spe, bt = 8, pool.steps_per_epoch(8), pool.tail_batch(8)
     assert (spe, bt) == (3, 6)
@@ -341,3 +341,28 @@ def test_ithor_replayed_ragged_epochs_over_a_pool_equal_eager_steps(var_amd, tmp
                                                     log=lambda *a: None)
     assert len(losses) == 2 and all(np.isfinite(v) for v in losses)
     assert sorted(p.name for p in tmp_path.iterdir()) == ['0.pt', '1.pt', 'progress.csv']
+
+
+def test_ithor_replays_survive_synchronises_between_them(var_amd):
+    """Regression: with memset nodes in the captured step (hipMemsetAsync for the GRU's initial state, the gradient arena, ...)
+    a replay after a device or stream synchronise filled those buffers with garbage in about half of the processes (loss ==
+    margin, zero gradients).  The library now zeroes by kernel.  Zero learning rate: every replay of the
+    same batch must return the same loss and the same gradient, whatever is synchronised in between."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    pool = var_amd.SyntheticTripletPool(22, hw=96, seed=5, clips_per_class=3, n_samples=24000, ragged_lens=True).freeze_pairs()
+    B = 8
+    row = pool.index_table(B, 1, drop_last=True)[0]
+    img, pcm, lens = pool.images[row[:B].long()].contiguous(), pool.clips[row[B:3 * B].long()].contiguous(), row[3 * B:5 * B].contiguous()
+    torch.manual_seed(977)
+    m = var_amd.IthorVARPretextNet(icfg(96)).to("cuda")
+    tr = var_amd.IthorTrainer(m, lr=0.0)
+    replay = tr.capture_step(img, pcm, lens, _ctx=tr.ctx)
+    l0 = float(replay().item())
+    g0 = tr.grads.clone()
+    assert np.isfinite(l0) and abs(l0 - 1.0) > 1e-3 and float(g0.abs().max()) > 1e-3
+    for sync in (lambda: hip.hipStreamSynchronize(None), torch.cuda.synchronize, lambda: torch.cuda.default_stream().synchronize()):
+        sync()
+        for _ in range(2):
+            assert float(replay().item()) == l0
+            assert torch.equal(tr.grads, g0)

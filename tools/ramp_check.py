@@ -6,7 +6,7 @@ B = 256
 cfg = types.SimpleNamespace(img_dim=(3, 84, 84), sound_dim=(1, 100, 40), representationDim=3)
 torch.manual_seed(453)
 m = var_amd.VARPretextNet(cfg).to("cuda")
-tr = var_amd.VARTrainer(m)
+tr = var_amd.VARTrainer(m, lr=float(os.environ.get("RAMP_LR", "1e-4")))
 pool = var_amd.SyntheticTripletPool(4096, hw=84, seed=0, clips_per_class=32).freeze_pairs()
 for _ in range(60):
     i, c, l = pool.next_batch_indices(B)
@@ -17,10 +17,12 @@ replay, _ = tr.capture_epoch_steps(pool.images, pool.clips, B, pool.index_table(
 torch.cuda.synchronize()
 print("capture took %.1f ms" % (1e3 * (time.perf_counter() - t0)))
 mode = sys.argv[1] if len(sys.argv) > 1 else "plain"
-if mode == "busy":          # keep the GPU busy with eager steps right before the replays
+if mode.startswith("busy"):  # keep the GPU busy with eager steps right before the replays ("busy_sync": one step in flight)
     for _ in range(60):
         i, c, l = pool.next_batch_indices(B)
         tr.step_from_dataset(pool.images, i, pool.clips, c, l)
+        if mode == "busy_sync":
+            torch.cuda.synchronize()
 n = 80
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
 ev[0].record()

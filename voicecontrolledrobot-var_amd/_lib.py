@@ -103,23 +103,18 @@ def load_library():
     return _lib
 
 
-_LIVE_GRAPHS = []
-
-
 def new_graph():
-    """A torch.cuda.CUDAGraph for the package's captures, made safe against two hazards measured on this stack (ROCm 7.2
-    runtime under torch 2.10, MI355X; tools/graph_lifetime_check.py reproduces both):
-      * torch destroys the captured hipGraph_t right after instantiating its exec; the runtime frees that memory lazily,
-        and after a hipStreamSynchronize(NULL) (var_ithor_plan and other set-up calls of the C ABI issue one) the exec's
-        replays read recycled memory: a step then returns loss == margin with all-zero gradients.  keep_graph=True keeps
-        the hipGraph_t for the life of the exec (instantiation moves to the first replay).
-      * destroying an exec AFTER a later one was instantiated corrupts the later one's replays the same way; Python's
-        collection order is not ours to arrange, so graphs are retired to a process-lifetime list instead of destroyed.
-    The cost is host memory for the nodes (a few hundred KB per step graph)."""
+    """The torch.cuda.CUDAGraph of the package's captures (one place to change how they are made).
+
+    History, so that it is not repeated: captured iTHOR steps used to return loss == margin with all-zero gradients -- always
+    from some replay after a device or stream synchronise, in about half the processes.  The initial GRU state, which the step
+    zeroed with hipMemsetAsync, was then full of 16-byte patterns of host pointers: on this stack (ROCm 7.2 runtime under torch
+    2.10, MI355X) a memset NODE of a captured graph can lose its fill pattern across a synchronise.  keep_graph=True and never
+    destroying graphs hid it for a while (they moved the instantiation); the cure is that the library enqueues kernels only
+    (csrc/var_common.h: var_zero_async / var_copy_async) -- plain graphs, destroyed whenever Python likes, are fine then
+    (tools/graph_replay_check.py runs the sequences that used to fail)."""
     import torch
-    g = torch.cuda.CUDAGraph(keep_graph=True)
-    _LIVE_GRAPHS.append(g)
-    return g
+    return torch.cuda.CUDAGraph()
 
 
 class Context:

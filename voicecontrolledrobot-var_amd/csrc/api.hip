@@ -368,7 +368,7 @@ static int encoder_bwd(var_ctx* c, hipStream_t s, const float* params, float* gr
     int rc;
     if (!c->saved_image || !c->saved_pos || !c->saved_neg) {
         // a branch that did not run contributes zero gradient
-        VAR_HIP_CHECK(c, hipMemsetAsync(grads, 0, sizeof(float) * VAR_N_PARAMS, s));
+        if ((rc = var_zero_async(c, s, grads, sizeof(float) * VAR_N_PARAMS)) != VAR_OK) return rc;
     }
     const int snd_lo = c->saved_pos ? 0 : B, snd_hi = c->saved_neg ? 2 * B : B;
     // streams: s = image head + the image backward chain, side = sound head + sound CNN backward + loss value
@@ -397,8 +397,8 @@ int var_arm_encoder_bwd(var_ctx* c, void* stream, const float* params, const flo
     const size_t e = sizeof(float) * 3 * (size_t)B;
     const float* g[3] = {g_image_feat, g_pos_feat, g_neg_feat};
     for (int i = 0; i < 3; i++) {
-        if (g[i]) VAR_HIP_CHECK(c, hipMemcpyAsync(c->gemb + 3 * B * i, g[i], e, hipMemcpyDeviceToDevice, s));
-        else VAR_HIP_CHECK(c, hipMemsetAsync(c->gemb + 3 * B * i, 0, e, s));
+        const int rz = g[i] ? var_copy_async(c, s, c->gemb + 3 * B * i, g[i], e) : var_zero_async(c, s, c->gemb + 3 * B * i, e);
+        if (rz != VAR_OK) return rz;
     }
     return encoder_bwd(c, s, params, grads);
 }
@@ -430,7 +430,7 @@ static int loss_grad_impl(var_ctx* c, hipStream_t s, const float* params, const 
     if ((rc = launch_triplet(c, s, c->emb, c->emb + 3 * B, c->emb + 6 * B, B, margin, inv_count, loss_out,
                              c->gemb, c->gemb + 3 * B, c->gemb + 6 * B)) != VAR_OK) return rc;
     if (feats_out)
-        VAR_HIP_CHECK(c, hipMemcpyAsync(feats_out, c->emb, sizeof(float) * 9 * (size_t)B, hipMemcpyDeviceToDevice, s));
+        if ((rc = var_copy_async(c, s, feats_out, c->emb, sizeof(float) * 9 * (size_t)B)) != VAR_OK) return rc;
     return encoder_bwd(c, s, params, grads);
 }
 

@@ -654,7 +654,7 @@ static int seq_fits(var_ctx* c, int nclips) {
 }
 
 int gru_bf16_reset_timeout(var_ctx* c, hipStream_t s, int maxclips, void* ws) {
-    VAR_HIP_CHECK(c, hipMemsetAsync(gru_sync(ws, maxclips), 0, 16, s));
+    { const int rz = var_zero_async(c, s, gru_sync(ws, maxclips), 16); if (rz != VAR_OK) return rz; }
     return VAR_OK;
 }
 
@@ -677,7 +677,7 @@ int gru_bf16_seq_bwd(var_ctx* c, hipStream_t s, float* DH, const float* Hb, cons
     if (!seq_fits(c, nclips)) return 1;
     unsigned* sync = gru_sync(ws, maxclips);
     unsigned* cnt = sync + 4 + sync_counters(maxclips);
-    VAR_HIP_CHECK(c, hipMemsetAsync(cnt, 0, 4L * sync_counters(maxclips), s));
+    { const int rz = var_zero_async(c, s, cnt, 4L * sync_counters(maxclips)); if (rz != VAR_OK) return rz; }
     hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3(NJS, (nclips + 63) / 64, 2), dim3(512), kBwdLds + 16, s, DH, Hb,
                        (const uint4*)((const char*)ws + kWfBytes), (uint2*)gru_bf16_dgh16(ws, maxclips),
                        (uint2*)gru_bf16_dgi16(ws, maxclips), R, Z, Nn, GHN, DGI, DGH, nclips, dirGI, dirH, dirS, dirDGH, cnt, sync,

@@ -838,7 +838,7 @@ static int ithor_fwd(var_ctx* c, hipStream_t s, const float* P, const void* imag
             RUN(gg(c, s, p, 2));
         }
         if (!st->bf16)      // (bf16 mode: gru_bf16_pack zeroed the initial states)
-            for (int d = 0; d < 2; ++d) VAR_HIP_CHECK(c, hipMemsetAsync(st->Hb + d * dirH, 0, sizeof(float) * nclips * kGh, s));
+            for (int d = 0; d < 2; ++d) RUN(var_zero_async(c, s, st->Hb + d * dirH, sizeof(float) * nclips * kGh));
         int whole = 0;       // the 73 steps in one launch
         if (st->bf16 && st->gru_seq) {
             const int r = gru_bf16_seq_fwd(c, s, st->GI, st->Hb, P + L.b_hh[0], dirP, st->R, st->Z, st->Nn, st->GHN, nclips, 2 * st->maxB,
@@ -890,7 +890,7 @@ static int ithor_bwd(var_ctx* c, hipStream_t s, const float* P, float* G) {
     const int* hs = st->hs;
     const int B = st->B, nclips = st->nclips;
     const long mB = st->maxB;
-    VAR_HIP_CHECK(c, hipMemsetAsync(G, 0, sizeof(float) * L.total, s));
+    RUN(var_zero_async(c, s, G, sizeof(float) * L.total));
     st->bs_used = 0;                                           // the pass's bias partials and their folds (flush_folds at its end)
     if (!st->folds) st->folds = calloc(1, sizeof(FoldJobs));
     if (st->folds) ((FoldJobs*)st->folds)->count = 0;
@@ -1156,6 +1156,11 @@ int ithor_debug_buffer(var_ctx* c, const char* name, void** ptr, long* nfloats) 
             if (!strcmp(name, g)) { *ptr = st->gp[l]; *nfloats = n; return VAR_OK; }
         }
     }
+    if (!strcmp(name, "emb")) { *ptr = st->emb; *nfloats = 9L * st->maxB; return VAR_OK; }
+    if (!strcmp(name, "sraw")) { *ptr = st->sraw; *nfloats = C2 * kSRaw; return VAR_OK; }
+    if (!strcmp(name, "hb")) { *ptr = st->Hb; *nfloats = 2L * (kSeq + 1) * C2 * kGh; return VAR_OK; }
+    if (!strcmp(name, "gh")) { *ptr = st->GH; *nfloats = 2L * (C2 + 2048) * kG3; return VAR_OK; }
+    if (!strcmp(name, "gi")) { *ptr = st->GI; *nfloats = 2L * C2 * kSeq * kG3; return VAR_OK; }
     VAR_SET_ERR(c, "var_debug_buffer: unknown iTHOR buffer '%s'", name);
     return VAR_ERR_ARG;
 }
@@ -1399,7 +1404,7 @@ int var_ithor_encoder_bwd(var_ctx* c, void* stream, const float* params, const f
     if (!params || !grads) { VAR_SET_ERR(c, "var_ithor_encoder_bwd: NULL argument"); return VAR_ERR_ARG; }
     hipStream_t s = (hipStream_t)stream;
     const long mB = st->maxB; const int B = st->B;
-    VAR_HIP_CHECK(c, hipMemsetAsync(st->gemb, 0, sizeof(float) * 9 * mB, s));
+    RUN(var_zero_async(c, s, st->gemb, sizeof(float) * 9 * mB));
     if (st->has_img && g_image_feat) RUN(copy_out(c, s, g_image_feat, st->gemb, 3L * B));
     int off = 0;
     if (st->has_pos) { if (g_pos_feat) RUN(copy_out(c, s, g_pos_feat, st->gemb + 3 * mB, 3L * B)); off = B; }

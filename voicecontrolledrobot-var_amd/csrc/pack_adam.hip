@@ -5,6 +5,29 @@
 
 #include "var_common.h"
 
+// ---- zero / copy by kernel (var_common.h: why not hipMemsetAsync / hipMemcpyAsync) ----
+__global__ void __launch_bounds__(256) zero_words_kernel(unsigned* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+__global__ void __launch_bounds__(256) copy_words_kernel(unsigned* __restrict__ d, const unsigned* __restrict__ s, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) d[i] = s[i];
+}
+static inline int words_grid(size_t n) { const size_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g)); }
+int var_zero_async(var_ctx* c, hipStream_t s, void* p, size_t bytes) {
+    if (!bytes) return VAR_OK;
+    if ((bytes & 3) || ((uintptr_t)p & 3)) { VAR_SET_ERR(c, "var_zero_async: %zu bytes at %p are not whole aligned words", bytes, p); return VAR_ERR_ARG; }
+    hipLaunchKernelGGL(zero_words_kernel, dim3(words_grid(bytes / 4)), dim3(256), 0, s, (unsigned*)p, bytes / 4);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}
+int var_copy_async(var_ctx* c, hipStream_t s, void* dst, const void* src, size_t bytes) {
+    if (!bytes) return VAR_OK;
+    if ((bytes & 3) || ((uintptr_t)dst & 3) || ((uintptr_t)src & 3)) { VAR_SET_ERR(c, "var_copy_async: not whole aligned words"); return VAR_ERR_ARG; }
+    hipLaunchKernelGGL(copy_words_kernel, dim3(words_grid(bytes / 4)), dim3(256), 0, s, (unsigned*)dst, (const unsigned*)src, bytes / 4);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}
+
 struct PackSeg {
     int dst;        // offset in wpack
     int count;      // elements in this segment

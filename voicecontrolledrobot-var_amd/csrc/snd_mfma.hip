@@ -466,7 +466,7 @@ int launch_snd_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads,
     const PackLayout& K = c->kl;
     const int lo = c->saved_pos ? 0 : B, hi = c->saved_neg ? 2 * B : B;
     if (hi <= lo) {
-        VAR_HIP_CHECK(c, hipMemsetAsync(grads + L.snd_w[0], 0, sizeof(float) * SND_SLICE, s));
+        { const int rz = var_zero_async(c, s, grads + L.snd_w[0], sizeof(float) * SND_SLICE); if (rz != VAR_OK) return rz; }
         return VAR_OK;
     }
     {

@@ -247,6 +247,13 @@ int launch_img_fwd(var_ctx* c, hipStream_t s, const float* params, const void* i
                    long bstride, const int* image_index, int B);
 int launch_img_fwd_head(var_ctx* c, hipStream_t s, const float* params, const void* image, int is_u8, long bstride,
                         const int* image_index, int B);
+// Zero / copy device memory with a KERNEL instead of hipMemsetAsync / hipMemcpyAsync.  Measured on ROCm 7.2 (MI355X): a memset
+// node of a captured graph takes its fill pattern from runtime-owned staging memory that is recycled at the next device or
+// stream synchronise -- the replays after that fill with whatever is there (the iTHOR step's initial GRU state then read
+// 16-byte patterns of host pointers: loss == margin, zero gradients; tools/graph_replay_check.py).  Everything the library
+// enqueues may end up in a caller's graph, so it enqueues kernels only.  bytes % 4 == 0, 4-byte aligned.
+int var_zero_async(var_ctx* c, hipStream_t s, void* p, size_t bytes);
+int var_copy_async(var_ctx* c, hipStream_t s, void* dst, const void* src, size_t bytes);
 int launch_img_fwd_head2(var_ctx* c, hipStream_t s, const float* params, const void* image, int is_u8, long bstride,
                          const int* image_index, int B);      // img_head2.hip: the 84 x 84 form, two small workgroups per CU
 #ifndef VAR_HEAD2_G

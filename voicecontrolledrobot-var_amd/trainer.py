@@ -154,6 +154,13 @@ class VARTrainer:
         self._g_lr = torch.full((1,), float(self.lr), dtype=torch.float32, device=dev)
         self._g_step = torch.full((1,), int(self.step_count), dtype=torch.int32, device=dev)
 
+    def sync_device_scalars(self):
+        """After eager steps taken between a capture and its replays: the replayed optimiser reads its step count and
+        learning rate from device memory, where the capture put them."""
+        if getattr(self, "_g_step", None) is not None:
+            self._g_step.fill_(int(self.step_count))
+            self._g_lr.fill_(float(self.lr))
+
     def _body_grad_pcm(self, images, pcm, idx, Bs, gb):
         """Closure enqueueing gather + MFCC + fwd + loss + bwd for `Bs` samples whose indices sit PACKED at the head of
         `idx`: [image_index (Bs) | clip_index (2 Bs) | lens (2 Bs)] (a full row is exactly that with Bs = batch; the short
