@@ -530,7 +530,7 @@ class VARTrainer:
             self._bind()
             c.check(c.lib.var_arm_encoder_bwd(c.handle, c.stream(), ptr(flat), ptr(ga), ptr(mine[:B]), ptr(mine[B:]),
                                               ptr(self.gbuf)), "var_arm_encoder_bwd")
-            self.gbuf[N_PARAMS:].copy_(loss1)
+            torch.mul(loss1, 1.0, out=self.gbuf[N_PARAMS:])          # (a kernel, not a memcpy node: _lib.new_graph)
 
         adam = self._body_adam(self._g_table, rows, row_ints, 0)
         body_fwd()                                                  # warm-up outside capture (torch's lazy initialisations)
