@@ -51,7 +51,10 @@ __device__ __forceinline__ void stage_clip(float* dst, const float* __restrict__
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-constexpr int FNC = 2, FNW = 3, FNT = FNW * 64;
+// 4 clips and 6 waves per workgroup (round 3; was 2 and 3): 128 fat workgroups keep fewer CUs away from the one-workgroup-
+// per-CU image kernels they run beside than 256 thin ones -- step 0.3061-0.3082 -> 0.3004-0.3023 ms (1 clip: 0.311; 5: no better)
+constexpr int FNC = 4, FNW = 6, FNT = FNW * 64;
+static_assert(FNC * 48 == FNW * 32, "layer 0: one 32-pixel block of the FNC x 48 (clip, t) pixels per wave");
 constexpr int P1 = 49, P2 = 23, P3 = 11;         // LDS row strides of y1,y2,y3 ([c][t])
 constexpr int F_XS = 0, F_Y1 = FNC * XCLIP, F_Y2 = F_Y1 + FNC * 32 * P1, F_Y3 = F_Y2 + FNC * 32 * P2,
               F_END = F_Y3 + FNC * 32 * P3;
@@ -115,7 +118,7 @@ snd_fwd_kernel(const float* __restrict__ pos, const float* __restrict__ neg, int
         stage_clip<FNT>(lds + F_XS + c * XCLIP, valid ? src : pos, valid, tid);
     }
     __syncthreads();
-    {   // layer 0: 96 (clip,t) pixels = 3 blocks, one per wave; K = 200 = 5 blocks of 20 k-pairs
+    {   // layer 0: FNC x 48 (clip,t) pixels = FNW blocks of 32, one per wave; K = 200 = 5 blocks of 20 k-pairs
         const int p = wave * 32 + l31;
         const int cl = p / T1, t = p - cl * T1;
         const float* bp = lds + F_XS + cl * XCLIP + 2 * t * XROW + half;
