@@ -322,12 +322,9 @@ img_bwd_tail_kernel(const float* __restrict__ gy, const float* __restrict__ wd, 
 }
 
 //                    H    U8   RI NU
-using T84u = TailCfg<42, true, 6, 2>;      // 2 bands: 4 pixel blocks x 3 K parts = 12 waves, 3 per SIMD
-using T84f = TailCfg<42, false, 6, 2>;
 using T96u = TailCfg<48, true, 8, 1>;      // 1 band: 3 pixel blocks x 3 K parts = 9 waves
 using T96f = TailCfg<48, false, 8, 1>;
 
-#ifndef VAR_TAIL_DEVICE_ONLY       // img_conv_bwd.hip includes this file for the device code above only
 template <class C>
 static int launch_tail(var_ctx* c, hipStream_t s, int B) {
     ProfScope prof(c, s, TAG_IMG_DGRAD0 + 1);
@@ -350,7 +347,5 @@ static int launch_tail(var_ctx* c, hipStream_t s, int B) {
 // dgrad of image conv 2 fused with the weight gradient of image conv 1; leaves layer 0's slabs
 // (slab workspace offset 0, c->wg_groups[0] of them) for launch_img_wgrad_reduce
 int launch_img_bwd_tail(var_ctx* c, hipStream_t s, int B) {
-    if (c->H == 84) return c->saved_u8 ? launch_tail<T84u>(c, s, B) : launch_tail<T84f>(c, s, B);
     return c->saved_u8 ? launch_tail<T96u>(c, s, B) : launch_tail<T96f>(c, s, B);
 }
-#endif  // VAR_TAIL_DEVICE_ONLY

@@ -17,9 +17,6 @@
 #define VAR_WGRAD_DEVICE_ONLY
 #include "img_wgrad.hip"             // WgCfg, img_wgrad_body, the W84_* / W96_* configurations (device code only)
 #undef VAR_WGRAD_DEVICE_ONLY
-#define VAR_TAIL_DEVICE_ONLY
-#include "img_bwd_tail.hip"          // TailCfg, img_bwd_tail_body, T84* (device code only)
-#undef VAR_TAIL_DEVICE_ONLY
 
 // ------------------------------------------------------------------------------------------
 // dgrad
@@ -398,51 +395,9 @@ img_bwd_pair_kernel(const void* __restrict__ wx, long wbstride, const float* __r
 // host side
 // ------------------------------------------------------------------------------------------
 //                 CIN COUT  H  RI NU NW
-using D84_2 = DgCfg<32, 64, 21, 22, 1, 4, 1>;     // 4 items x 3 slices          -> 12 waves
-using D84_4 = DgCfg<64, 64, 6, 6, 3, 2, 2>;       // 3 images, 2 items x 6 slices -> 12 waves
-using G84_3 = Dg16Cfg<64, 64, 11, 12>;            // conv 4's data gradient on 16-wide tiles: 3 pair tiles x 4 channel tiles
 using G96_3 = Dg16Cfg<64, 64, 12, 12>;
 using D96_2p = DgCfg<32, 64, 24, 10, 2, 4, 1>;    // 12-wave form for the paired grid: 2 bands of 10 rows, 4 items x 3 slices
 using D96_4 = DgCfg<64, 64, 6, 6, 3, 2, 2>;
-
-// The last two kernels of the image backward in one grid: the weight gradient of conv 2 (blocks [0, Gw)) and the
-// fused tail (data gradient of conv 2 + weight gradient of conv 1, the blocks after).  Both consume gact2 only.
-template <class WC, class TC>
-__global__ void __launch_bounds__(768)
-img_bwd_last_kernel(const void* __restrict__ wx, long wbstride, const float* __restrict__ gy, float* __restrict__ wslabs,
-                    int Gw, const float* __restrict__ wd, const uint16_t* __restrict__ relu_bits,
-                    const void* __restrict__ image, long ibstride, const int* __restrict__ bidx,
-                    float* __restrict__ tslabs, int Gt, int B) {
-    static_assert(WC::NW * 64 == 768 && TC::NT == 768 && WC::NCOMBO == 1, "both halves run 12 waves");
-    const int id = blockIdx.x;
-    if (id < Gw) img_wgrad_body<WC>(wx, wbstride, nullptr, gy, wslabs, B, id, 0, Gw);
-    else img_bwd_tail_body<TC>(gy, wd, relu_bits, image, ibstride, bidx, tslabs, B, id - Gw, Gt);
-}
-
-template <class WC, class TC>
-static int launch_last(var_ctx* c, hipStream_t s, int B) {
-    ProfScope prof(c, s, TAG_IMG_DGRAD0 + 1);
-    constexpr int LDS_BYTES = WC::LDS_BYTES > TC::LDS_BYTES ? WC::LDS_BYTES : TC::LDS_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)img_bwd_last_kernel<WC, TC>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set = true;
-    }
-    const int need = (B * WC::NB + WC::NU - 1) / WC::NU;
-    const int gmax = img_wgrad_groups(1);
-    const int Gw = need < gmax ? need : gmax;
-    c->wg_groups[1] = Gw;
-    const int ntiles = (B * TC::NB + TC::NU - 1) / TC::NU;
-    const int Gt = ntiles < kTailG ? ntiles : kTailG;
-    c->wg_groups[0] = Gt;
-    hipLaunchKernelGGL((img_bwd_last_kernel<WC, TC>), dim3(Gw + Gt), dim3(768), LDS_BYTES, s, c->act[1],
-                       32L * c->hs[1] * c->hs[1], c->gact[2], c->slabs + img_slab_offset(1), Gw,
-                       c->wpack + c->kl.img_d[1], c->relu1, c->saved_image, c->saved_bstride, c->saved_index,
-                       c->slabs, Gt, B);
-    VAR_HIP_CHECK(c, hipGetLastError());
-    return VAR_OK;
-}
 
 // The weight gradients of conv 5, 4 and 3 in ONE grid (84 x 84): their inputs -- gact[5..3] left by img_chain_kernel, act[4..2]
 // -- are all there before it starts, and none of the three fills the GPU by itself (128 split-K workgroups each).  Longest first.

@@ -248,7 +248,6 @@ img_wgrad_kernel(const void* __restrict__ xin, long bstride, const int* __restri
 //                   CIN COUT  H   U8    R  NU KS
 using W84_0u = WgCfg<3, 32, 84, true, 6, 1, 4>;
 using W84_0f = WgCfg<3, 32, 84, false, 6, 1, 4>;
-using W84_1 = WgCfg<32, 32, 42, false, 3, 1, 4, true>;
 using W84_2 = WgCfg<32, 64, 21, false, 11, 1, 4>;
 using W84_3 = WgCfg<64, 64, 11, false, 6, 1, 4>;
 using W84_4 = WgCfg<64, 64, 6, false, 3, 4, 4>;
