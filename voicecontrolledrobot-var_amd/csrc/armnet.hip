@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include "gg.h"
+#include "c3f.h"
 
 namespace {
 PH_DECL();
@@ -64,7 +65,17 @@ struct arm_state {
     float *flat_img = nullptr, *motor = nullptr, *sound = nullptr, *fusion = nullptr, *h0 = nullptr, *gi = nullptr, *gh = nullptr;
     float* chain = nullptr;        // the fused small-batch MLP chain's vectors (armnet_chain_kernel)
     unsigned* sync = nullptr;      // its grid barrier: [0] arrivals, [1] finished workgroups, [2] time-out (sticky)
+    c3f::f32x4* wpk = nullptr;     // conv 2..6 filters in MFMA A-fragment order (c3f.h), re-packed per forward
+    c3f::PackDesc pack{};
 };
+
+// conv 2..6 of the 96x96 stack as band kernels (c3f.h): bands / channel groups chosen for ~192-256 workgroups at 8 images
+using ArmC2 = c3f::Cfg<32, 32, 96, 4, 2, 1, true>;
+using ArmC3 = c3f::Cfg<32, 64, 48, 6, 1, 1, false>;
+using ArmC4 = c3f::Cfg<64, 64, 48, 6, 1, 1, true>;
+using ArmC5 = c3f::Cfg<64, 128, 24, 8, 1, 1, false>;
+using ArmC6 = c3f::Cfg<128, 128, 24, 4, 2, 2, true>;
+constexpr int kBandMaxB = 64;      // beyond this the gather-GEMM's big tiles win
 
 static __global__ void an_pool_kernel(const float* __restrict__ x, float* __restrict__ y, long n, int H, int HP) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -536,6 +547,19 @@ int var_armnet_plan(var_ctx* c, int max_batch) {
     const long ofl = take(B * 256), omo = take(B * 256), osn = take(B * 256), ofu = take(B * 256), oh0 = take(B * kRh);
     const long ogi = take(B * 3 * kRh), ogh = take(B * 3 * kRh), oslab = take(kSlab);
     const long ochain = take(kChainRows * 8192), osync = take(64);
+    {
+        c3f::PackDesc& d = st->pack;
+        d.n_layers = 5;
+        int f4 = 0;
+        for (int i = 0; i < 5; ++i) {
+            const int l = i + 1;                          // conv l+1: kCh[l] -> kCh[l + 1]
+            d.w_off[i] = st->L.cw[l]; d.cin[i] = kCh[l]; d.cout[i] = kCh[l + 1];
+            d.wp_off[i] = f4; d.first[i] = f4;
+            f4 += kCh[l] * kCh[l + 1] * 9 / 4;
+        }
+        d.first[5] = f4;
+    }
+    const long owpk = take(4L * st->pack.first[5]);
     VAR_HIP_CHECK(c, hipMalloc((void**)&st->ws, (size_t)total * sizeof(float)));
     float* w = st->ws;
     for (int l = 1; l <= 8; ++l) st->a[l] = w + oa[l];
@@ -544,6 +568,7 @@ int var_armnet_plan(var_ctx* c, int max_batch) {
     st->flat_img = w + ofl; st->motor = w + omo; st->sound = w + osn; st->fusion = w + ofu; st->h0 = w + oh0;
     st->gi = w + ogi; st->gh = w + ogh; st->slab = w + oslab;
     st->chain = w + ochain; st->sync = (unsigned*)(w + osync);
+    st->wpk = (c3f::f32x4*)(w + owpk);
     VAR_HIP_CHECK(c, hipMemset(st->sync, 0, 64 * sizeof(float)));
     return VAR_OK;
 }
@@ -583,14 +608,25 @@ int var_armnet_forward(var_ctx* c, void* stream, const float* params, const void
         if (image_is_u8) RUN((conv<S1, true>(c, s, st, d, image, P + L.cw[0], P + L.cb[0], st->a[1])));
         else RUN((conv<S1, false>(c, s, st, d, image, P + L.cw[0], P + L.cb[0], st->a[1])));
     }
-    RUN((conv<S1, false>(c, s, st, dims(2, 96, 1, 1), st->a[1], P + L.cw[1], P + L.cb[1], st->a[2])));
-    RUN(pool(st->a[2], st->p[1], 32, 96));
-    RUN((conv<S1, false>(c, s, st, dims(3, 48, 1, 1), st->p[1], P + L.cw[2], P + L.cb[2], st->a[3])));
-    RUN((conv<S1, false>(c, s, st, dims(4, 48, 1, 1), st->a[3], P + L.cw[3], P + L.cb[3], st->a[4])));
-    RUN(pool(st->a[4], st->p[2], 64, 48));
-    RUN((conv<S1, false>(c, s, st, dims(5, 24, 1, 1), st->p[2], P + L.cw[4], P + L.cb[4], st->a[5])));
-    RUN((conv<S1, false>(c, s, st, dims(6, 24, 1, 1), st->a[5], P + L.cw[5], P + L.cb[5], st->a[6])));
-    RUN(pool(st->a[6], st->p[3], 128, 24));
+    if (B <= kBandMaxB) {
+        const c3f::PackDesc& d = st->pack;
+        hipLaunchKernelGGL(c3f::c3f_pack_kernel, g1(d.first[5]), dim3(256), 0, s, P, st->wpk, d);
+        AN_CHECK(c);
+        RUN(c3f::launch<ArmC2>(c, s, st->a[1], st->wpk + d.wp_off[0], P + L.cb[1], st->p[1], B));
+        RUN(c3f::launch<ArmC3>(c, s, st->p[1], st->wpk + d.wp_off[1], P + L.cb[2], st->a[3], B));
+        RUN(c3f::launch<ArmC4>(c, s, st->a[3], st->wpk + d.wp_off[2], P + L.cb[3], st->p[2], B));
+        RUN(c3f::launch<ArmC5>(c, s, st->p[2], st->wpk + d.wp_off[3], P + L.cb[4], st->a[5], B));
+        RUN(c3f::launch<ArmC6>(c, s, st->a[5], st->wpk + d.wp_off[4], P + L.cb[5], st->p[3], B));
+    } else {
+        RUN((conv<S1, false>(c, s, st, dims(2, 96, 1, 1), st->a[1], P + L.cw[1], P + L.cb[1], st->a[2])));
+        RUN(pool(st->a[2], st->p[1], 32, 96));
+        RUN((conv<S1, false>(c, s, st, dims(3, 48, 1, 1), st->p[1], P + L.cw[2], P + L.cb[2], st->a[3])));
+        RUN((conv<S1, false>(c, s, st, dims(4, 48, 1, 1), st->a[3], P + L.cw[3], P + L.cb[3], st->a[4])));
+        RUN(pool(st->a[4], st->p[2], 64, 48));
+        RUN((conv<S1, false>(c, s, st, dims(5, 24, 1, 1), st->p[2], P + L.cw[4], P + L.cb[4], st->a[5])));
+        RUN((conv<S1, false>(c, s, st, dims(6, 24, 1, 1), st->a[5], P + L.cw[5], P + L.cb[5], st->a[6])));
+        RUN(pool(st->a[6], st->p[3], 128, 24));
+    }
     RUN((conv<S2P0, false>(c, s, st, dims(7, 12, 2, 0), st->p[3], P + L.cw[6], P + L.cb[6], st->a[7])));
     RUN((conv<S1P0, false>(c, s, st, dims(8, 5, 1, 0), st->a[7], P + L.cw[7], P + L.cb[7], st->a[8])));
     if (B <= kChainRows)      // the RL stage's batch: everything after the convolutions in one persistent launch

@@ -1,0 +1,202 @@
+// fp32 3x3 / stride 1 / pad 1 convolution + bias + ReLU (+ 2x2 max pool) for SMALL batches: the five big layers of the
+// actor-critic's image stack (models/RL/arm_RL_model.py:20-31, conv 2..6 of the 96x96 branch) at the RL stage's 8 envs.
+// The gather-GEMM of gg.h computes im2col addresses per element and, at 8 images, needs split-K slabs, a finish launch
+// and a pool launch per layer (199 us for these five layers).  Here a workgroup owns a BAND of TR rows of one image and
+// 16 * NCBW output channels:
+//   * the input band (TR + 2 rows, every input channel, zero halo) is staged ONCE into LDS with 16-byte loads; a tap is
+//     an immediate offset of a `ds_read_b32`, the plane pitch is 16 mod 32 floats so that the 16 pixels x 4 channels of
+//     a B operand hit 64 distinct banks;
+//   * v_mfma_f32_16x16x4_f32, A = filter (16 output channels x 4 input channels), B = 16 consecutive pixels of the band;
+//     a wave keeps NPB pixel blocks x NCB channel blocks of accumulators (4 VGPRs each), so one A operand feeds NPB and one
+//     B read feeds NCB matrix instructions;
+//   * the filter comes from L2 in MFMA A-fragment order (c3f_pack_kernel: one 16-byte load = the A operands of four
+//     k-steps), fetched one tap ahead;
+//   * the epilogue adds the bias, applies ReLU and either stores NCHW or goes through an LDS tile for the 2x2 max pool (the
+//     un-pooled map is never written: the acting path has no backward).
+#pragma once
+#include "var_common.h"
+
+namespace c3f {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int CIN_, int COUT_, int H_, int TR_, int NCBW_, int WCB_, bool POOL_>
+struct Cfg {
+    static constexpr int CIN = CIN_, COUT = COUT_, H = H_, W = H_, TR = TR_, NCBW = NCBW_, WCB = WCB_;
+    static constexpr bool POOL = POOL_;
+    static constexpr int PW = W + 8, ROWS = TR + 2;                     // pixel x of a row sits at float 4 + x
+    static constexpr int PLANE0 = ROWS * PW;
+    static constexpr int PLANE = PLANE0 + (48 - PLANE0 % 32) % 32;      // == 16 (mod 32)
+    static constexpr int NPX = TR * W, PBT = NPX / 16;                  // pixel blocks of the band
+    static constexpr int WPB = 4 / WCB;                                 // waves along the pixel blocks
+    static constexpr int NPB = (PBT + WPB - 1) / WPB, NCB = NCBW / WCB;
+    static constexpr int KG = CIN / 16;
+    static constexpr int BAND = CIN * PLANE;
+    static constexpr int OP = NPX + 4;                                  // pool tile pitch: 4 (mod 8)
+    static constexpr int OUTT = POOL ? 16 * NCBW * OP : 0;
+    static constexpr int LDSF = BAND > OUTT ? BAND : OUTT;
+    static constexpr int BANDS = H / TR, CBG = COUT / (16 * NCBW);
+    static constexpr int WFLOATS = COUT * CIN * 9;
+    static_assert(PLANE % 32 == 16 && PLANE % 4 == 0, "plane pitch");
+    static_assert(CIN % 16 == 0 && COUT % (16 * NCBW) == 0 && H % TR == 0 && NPX % 16 == 0 && W % 4 == 0, "c3f shape");
+    static_assert(NCBW % WCB == 0 && 4 % WCB == 0 && (!POOL || TR % 2 == 0), "c3f wave split");
+    static_assert(LDSF * 4 <= 160 * 1024, "c3f LDS");
+    static_assert((12 * PLANE + 2 * PW + 5) * 4 < 65536, "ds_read immediate offset");
+};
+
+// wp[((cb * KG + kg) * 9 + tap) * 64 + lane] = { w[16 cb + (lane & 15)][16 kg + 4 j + (lane >> 4)][tap] : j = 0..3 }, all layers of
+// a stack in one launch (the parameters may change between two forwards -- PPO updates them in PyTorch --, so the acting path
+// re-packs per call: 1.1 MB, one launch)
+constexpr int kMaxLayers = 8;
+struct PackDesc {
+    int n_layers;
+    int w_off[kMaxLayers], wp_off[kMaxLayers] /* float4 units */, cin[kMaxLayers], cout[kMaxLayers], first[kMaxLayers + 1];
+};
+__global__ void __launch_bounds__(256) c3f_pack_kernel(const float* __restrict__ params, f32x4* __restrict__ wp, PackDesc d) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.first[d.n_layers]) return;
+    int l = 0;
+    while (i >= d.first[l + 1]) ++l;
+    i -= d.first[l];
+    const int CIN = d.cin[l], KG = CIN / 16;
+    const int lane = i & 63, tap = (i >> 6) % 9, kg = (i / (64 * 9)) % KG, cb = i / (64 * 9 * KG);
+    const float* q = params + d.w_off[l] + ((long)(16 * cb + (lane & 15)) * CIN + 16 * kg + (lane >> 4)) * 9 + tap;
+    wp[d.wp_off[l] + i] = f32x4{q[0], q[4 * 9], q[8 * 9], q[12 * 9]};
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) c3f_kernel(const float* __restrict__ x, const f32x4* __restrict__ wp, const float* __restrict__ bias,
+                                                 float* __restrict__ y, int B) {
+    constexpr int CIN = C::CIN, COUT = C::COUT, H = C::H, W = C::W, TR = C::TR, PW = C::PW, ROWS = C::ROWS, PLANE = C::PLANE;
+    constexpr int NPB = C::NPB, NCB = C::NCB, KG = C::KG, PBT = C::PBT;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lk = lane >> 4;
+    const int tile = blockIdx.x % (B * C::BANDS), cbg = blockIdx.x / (B * C::BANDS);
+    const int b = tile / C::BANDS, r0 = (tile - b * C::BANDS) * TR;
+    const int wc = wave % C::WCB, wpb = wave / C::WCB;
+    const int cb0 = cbg * C::NCBW + wc * NCB;                      // first 16-channel block of this wave
+
+    // ---- filter: the first tap's A operands are on their way while the band is staged
+    const f32x4* wa = wp + (size_t)cb0 * KG * 9 * 64 + lane;
+    f32x4 a_cur[NCB], a_nxt[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) a_cur[cb] = wa[(size_t)cb * KG * 9 * 64];
+
+    // ---- stage the band: rows r0 - 1 .. r0 + TR of every input channel, zeros outside the image
+    {
+        constexpr int Q = W / 4, SLOTS = CIN * ROWS * Q, RND = 8;
+        const float* xb = x + (size_t)b * CIN * H * W;
+#pragma unroll 1
+        for (int e0 = tid; e0 < SLOTS; e0 += 256 * RND) {
+            float4 v[RND];
+#pragma unroll
+            for (int u = 0; u < RND; ++u) {
+                int e = e0 + 256 * u;
+                e = e < SLOTS ? e : SLOTS - 1;
+                const int ch = e / (ROWS * Q), rem = e - ch * (ROWS * Q), br = rem / Q, q = rem - br * Q;
+                const int ir = r0 - 1 + br, irc = ir < 0 ? 0 : (ir >= H ? H - 1 : ir);
+                v[u] = *(const float4*)(xb + ((size_t)ch * H + irc) * W + 4 * q);
+                if (ir != irc) v[u] = float4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < RND; ++u) {
+                const int e = e0 + 256 * u;
+                if (e < SLOTS) {
+                    const int ch = e / (ROWS * Q), rem = e - ch * (ROWS * Q), br = rem / Q, q = rem - br * Q;
+                    *(float4*)(lds + ch * PLANE + br * PW + 4 + 4 * q) = v[u];
+                }
+            }
+        }
+        for (int e = tid; e < CIN * ROWS; e += 256) {
+            const int ch = e / ROWS, br = e - ch * ROWS;
+            lds[ch * PLANE + br * PW + 3] = 0.f;
+            lds[ch * PLANE + br * PW + 4 + W] = 0.f;
+        }
+    }
+    // lane constants: where this lane's pixel of each block sits in the band (row-major over TR x W), plus its k plane
+    int va[NPB];
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+        int pb = wpb * NPB + i;
+        pb = pb < PBT ? pb : PBT - 1;
+        const int p = pb * 16 + l15, row = p / W, col = p - row * W;
+        va[i] = lk * PLANE + row * PW + col + 3;
+    }
+    f32x4 acc[NPB][NCB];
+#pragma unroll
+    for (int i = 0; i < NPB; ++i)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) acc[i][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    // ---- products: K = (16 input channels) x (9 taps) per outer step
+#pragma unroll 1
+    for (int kg = 0; kg < KG; ++kg) {
+        const float* xk = lds + kg * 16 * PLANE;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            {
+                int nx = kg * 9 + tap + 1;
+                if (tap == 8) nx = kg + 1 < KG ? nx : nx - 1;          // the last fetch of the stream re-reads its own entry
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) a_nxt[cb] = wa[((size_t)cb * KG * 9 + nx) * 64];
+            }
+            const int dy = tap / 3, dx = tap - 3 * dy;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float bv[NPB];
+#pragma unroll
+                for (int i = 0; i < NPB; ++i) bv[i] = xk[va[i] + 4 * j * PLANE + dy * PW + dx];
+#pragma unroll
+                for (int i = 0; i < NPB; ++i)
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb)
+                        acc[i][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[cb][j], bv[i], acc[i][cb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) a_cur[cb] = a_nxt[cb];
+        }
+    }
+
+    // ---- epilogue: D[channel 4 (lane >> 4) + r][pixel lane & 15]
+    if (C::POOL) __syncthreads();                                   // every wave is done with the band: the pool tile reuses it
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+        const int pb = wpb * NPB + i;
+        if (pb >= PBT) continue;                                    // wave-uniform
+        const int p = pb * 16 + l15, row = p / W, col = p - row * W;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = 16 * (cb0 + cb) + 4 * lk + r;
+                float v = acc[i][cb][r] + bias[co];
+                v = v > 0.f ? v : 0.f;
+                if (C::POOL) lds[(16 * (wc * NCB + cb) + 4 * lk + r) * C::OP + p] = v;
+                else y[(((size_t)b * COUT + co) * H + r0 + row) * W + col] = v;
+            }
+    }
+    if (C::POOL) {
+        __syncthreads();
+        constexpr int HP = H / 2, WP = W / 2, TP = TR / 2, NOUT = 16 * C::NCBW * TP * WP;
+        for (int e = tid; e < NOUT; e += 256) {
+            const int cl = e / (TP * WP), rem = e - cl * (TP * WP), pr = rem / WP, pc = rem - pr * WP;
+            const float* q = lds + cl * C::OP + (2 * pr) * W + 2 * pc;
+            const float m = fmaxf(fmaxf(q[0], q[1]), fmaxf(q[W], q[W + 1]));
+            y[(((size_t)b * COUT + 16 * cbg * C::NCBW + cl) * HP + r0 / 2 + pr) * WP + pc] = m;
+        }
+    }
+}
+
+template <class C>
+int launch(var_ctx* c, hipStream_t s, const float* x, const f32x4* wp, const float* bias, float* y, int B) {
+    static bool attr = false;
+    if (!attr) {
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)c3f_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDSF * 4));
+        attr = true;
+    }
+    hipLaunchKernelGGL(c3f_kernel<C>, dim3(B * C::BANDS * C::CBG), dim3(256), C::LDSF * 4, s, x, wp, bias, y, B);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}
+}  // namespace c3f

@@ -501,7 +501,16 @@ static __global__ void gg_finish_kernel(float* __restrict__ out, const float* __
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float v = bias ? bias[(i / plane) % C] : 0.f;
-    for (int s = 0; s < nsplit; ++s) v += slabs[s * stride + i];
+    // eight loads in flight, added in slab order (a rolled loop waits for every load: 72 slabs took 18 us)
+    int s = 0;
+    for (; s + 8 <= nsplit; s += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = slabs[(s + u) * stride + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; s < nsplit; ++s) v += slabs[s * stride + i];
     out[i] = relu ? (v > 0.f ? v : 0.f) : v;
 }
 
