@@ -7,11 +7,11 @@
 #include <string.h>
 
 #include "gg.h"
-#include "c3f.h"
 
 namespace {
 PH_DECL();
 }
+#include "c3f.h"
 #ifdef VAR_PHASES
 extern "C" int var_debug_phases_armchain(unsigned long long* out) {
     unsigned long long z[32] = {0};

@@ -9,12 +9,17 @@
 //   * v_mfma_f32_16x16x4_f32, A = filter (16 output channels x 4 input channels), B = 16 consecutive pixels of the band;
 //     a wave keeps NPB pixel blocks x NCB channel blocks of accumulators (4 VGPRs each), so one A operand feeds NPB and one
 //     B read feeds NCB matrix instructions;
-//   * the filter comes from L2 in MFMA A-fragment order (c3f_pack_kernel: one 16-byte load = the A operands of four
-//     k-steps), fetched one tap ahead;
+//   * the filter is packed in MFMA A-fragment order (c3f_pack_kernel: 16 bytes = the A operands of four k-steps) and travels
+//     through LDS in 16-channel chunks beside the band's (a wave streaming it from L2 one tap ahead waited ~20 cycles per
+//     matrix instruction: 55 instead of 32 cycles each);
 //   * the epilogue adds the bias, applies ReLU and either stores NCHW or goes through an LDS tile for the 2x2 max pool (the
 //     un-pooled map is never written: the acting path has no backward).
 #pragma once
 #include "var_common.h"
+#ifndef VAR_PH_C3F_CIN
+#define VAR_PH_C3F_CIN 128      // which layer `make phases` times (tools/phases_arm.py, phases 16..21)
+#define VAR_PH_C3F_COUT 128
+#endif
 
 namespace c3f {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -33,7 +38,9 @@ struct Cfg {
     static constexpr int BAND = CIN * PLANE;
     static constexpr int OP = NPX + 4;                                  // pool tile pitch: 4 (mod 8)
     static constexpr int OUTT = POOL ? 16 * NCBW * OP : 0;
-    static constexpr int LDSF = BAND > OUTT ? BAND : OUTT;
+    static constexpr int ACH = NCBW * 9 * 64 * 4;                       // floats of one 16-channel filter chunk (A fragments)
+    static constexpr int BOT = BAND > OUTT ? BAND : OUTT;               // band, later the pool tile
+    static constexpr int LDSF = BOT + 2 * ACH;                          // + two filter chunks (double buffer)
     static constexpr int BANDS = H / TR, CBG = COUT / (16 * NCBW);
     static constexpr int WFLOATS = COUT * CIN * 9;
     static_assert(PLANE % 32 == 16 && PLANE % 4 == 0, "plane pitch");
@@ -75,44 +82,62 @@ __global__ void __launch_bounds__(256) c3f_kernel(const float* __restrict__ x, c
     const int b = tile / C::BANDS, r0 = (tile - b * C::BANDS) * TR;
     const int wc = wave % C::WCB, wpb = wave / C::WCB;
     const int cb0 = cbg * C::NCBW + wc * NCB;                      // first 16-channel block of this wave
+    PHR_INIT(0, 0);
 
-    // ---- filter: the first tap's A operands are on their way while the band is staged
-    const f32x4* wa = wp + (size_t)cb0 * KG * 9 * 64 + lane;
-    f32x4 a_cur[NCB], a_nxt[NCB];
+    // ---- stage the band: rows r0 - 1 .. r0 + TR, zeros outside the image, in chunks of 16 input channels (= one outer step
+    //      of the product loop): chunk 0 before the loop, chunk kg + 1 is in flight (registers) during the products of chunk kg
+    //      The filter chunk of the same 16 channels (9 taps x NCBW channel blocks of A fragments, shared by the four waves)
+    //      travels with it into one of two LDS buffers.
+    constexpr int Q = W / 4, CSLOTS = 16 * ROWS * Q, NLD = (CSLOTS + 255) / 256;
+    constexpr int ASLOTS = C::NCBW * 9 * 64, NLA = (ASLOTS + 255) / 256;
+    const float* xb = x + (size_t)b * CIN * H * W;
+    float* aw = lds + C::BOT;
+    float4 sv[NLD];
+    f32x4 sa[NLA];
+    auto issue = [&](int kg) {
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) a_cur[cb] = wa[(size_t)cb * KG * 9 * 64];
-
-    // ---- stage the band: rows r0 - 1 .. r0 + TR of every input channel, zeros outside the image
-    {
-        constexpr int Q = W / 4, SLOTS = CIN * ROWS * Q, RND = 8;
-        const float* xb = x + (size_t)b * CIN * H * W;
-#pragma unroll 1
-        for (int e0 = tid; e0 < SLOTS; e0 += 256 * RND) {
-            float4 v[RND];
+        for (int u = 0; u < NLA; ++u) {
+            int e = tid + 256 * u;
+            e = e < ASLOTS ? e : ASLOTS - 1;
+            const int cbl = e / 576, rem = e - cbl * 576;
+            sa[u] = wp[((size_t)(cbg * C::NCBW + cbl) * KG + kg) * 576 + rem];
+        }
 #pragma unroll
-            for (int u = 0; u < RND; ++u) {
-                int e = e0 + 256 * u;
-                e = e < SLOTS ? e : SLOTS - 1;
-                const int ch = e / (ROWS * Q), rem = e - ch * (ROWS * Q), br = rem / Q, q = rem - br * Q;
-                const int ir = r0 - 1 + br, irc = ir < 0 ? 0 : (ir >= H ? H - 1 : ir);
-                v[u] = *(const float4*)(xb + ((size_t)ch * H + irc) * W + 4 * q);
-                if (ir != irc) v[u] = float4{0.f, 0.f, 0.f, 0.f};
-            }
+        for (int u = 0; u < NLD; ++u) {
+            int e = tid + 256 * u;
+            e = e < CSLOTS ? e : CSLOTS - 1;
+            const int cl = e / (ROWS * Q), rem = e - cl * (ROWS * Q), br = rem / Q, q = rem - br * Q;
+            const int ir = r0 - 1 + br, irc = ir < 0 ? 0 : (ir >= H ? H - 1 : ir);
+            sv[u] = *(const float4*)(xb + ((size_t)(16 * kg + cl) * H + irc) * W + 4 * q);     // rows outside the image: zeroed in commit()
+        }
+    };
+    auto commit = [&](int kg) {
 #pragma unroll
-            for (int u = 0; u < RND; ++u) {
-                const int e = e0 + 256 * u;
-                if (e < SLOTS) {
-                    const int ch = e / (ROWS * Q), rem = e - ch * (ROWS * Q), br = rem / Q, q = rem - br * Q;
-                    *(float4*)(lds + ch * PLANE + br * PW + 4 + 4 * q) = v[u];
-                }
+        for (int u = 0; u < NLA; ++u) {
+            const int e = tid + 256 * u;
+            if (e < ASLOTS) *(f32x4*)(aw + (kg & 1) * C::ACH + 4 * e) = sa[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int e = tid + 256 * u;
+            if (e < CSLOTS) {
+                const int cl = e / (ROWS * Q), rem = e - cl * (ROWS * Q), br = rem / Q, q = rem - br * Q;
+                const int ir = r0 - 1 + br;
+                // (selecting the zeros where the load is issued would make issue() wait for its own loads)
+                *(float4*)(lds + (16 * kg + cl) * PLANE + br * PW + 4 + 4 * q) = (ir < 0 || ir >= H) ? float4{0.f, 0.f, 0.f, 0.f} : sv[u];
             }
         }
-        for (int e = tid; e < CIN * ROWS; e += 256) {
-            const int ch = e / ROWS, br = e - ch * ROWS;
-            lds[ch * PLANE + br * PW + 3] = 0.f;
-            lds[ch * PLANE + br * PW + 4 + W] = 0.f;
-        }
+    };
+    issue(0);
+    for (int e = tid; e < CIN * ROWS; e += 256) {                  // halo columns x = -1 and x = W of every row
+        const int ch = e / ROWS, br = e - ch * ROWS;
+        lds[ch * PLANE + br * PW + 3] = 0.f;
+        lds[ch * PLANE + br * PW + 4 + W] = 0.f;
     }
+    commit(0);
+    PHR(0);
+    if (KG > 1) issue(1);
+    __builtin_amdgcn_sched_barrier(0);
     // lane constants: where this lane's pixel of each block sits in the band (row-major over TR x W), plus its k plane
     int va[NPB];
 #pragma unroll
@@ -128,18 +153,24 @@ __global__ void __launch_bounds__(256) c3f_kernel(const float* __restrict__ x, c
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) acc[i][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
+    PHR(1);
 
     // ---- products: K = (16 input channels) x (9 taps) per outer step
 #pragma unroll 1
     for (int kg = 0; kg < KG; ++kg) {
         const float* xk = lds + kg * 16 * PLANE;
+        const f32x4* ak = (const f32x4*)(aw + (kg & 1) * C::ACH) + (wc * NCB) * 576 + lane;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            {
-                int nx = kg * 9 + tap + 1;
-                if (tap == 8) nx = kg + 1 < KG ? nx : nx - 1;          // the last fetch of the stream re-reads its own entry
+            f32x4 a[NCB];
 #pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) a_nxt[cb] = wa[((size_t)cb * KG * 9 + nx) * 64];
+            for (int cb = 0; cb < NCB; ++cb) a[cb] = ak[cb * 576 + tap * 64];
+            if (tap == 3 && kg + 1 < KG) {
+                // the next chunk (in registers since the middle of the previous block) goes to LDS and the one after it leaves
+                // for the registers HERE, between matrix instructions that are already queued, not at the block's barrier
+                commit(kg + 1);
+                if (kg + 2 < KG) issue(kg + 2);
+                __builtin_amdgcn_sched_barrier(0);
             }
             const int dy = tap / 3, dx = tap - 3 * dy;
 #pragma unroll
@@ -151,11 +182,13 @@ __global__ void __launch_bounds__(256) c3f_kernel(const float* __restrict__ x, c
                 for (int i = 0; i < NPB; ++i)
 #pragma unroll
                     for (int cb = 0; cb < NCB; ++cb)
-                        acc[i][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[cb][j], bv[i], acc[i][cb], 0, 0, 0);
+                        acc[i][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb][j], bv[i], acc[i][cb], 0, 0, 0);
             }
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) a_cur[cb] = a_nxt[cb];
         }
+        PHR(2);
+        // LDS-only barrier: __syncthreads() also drains vmcnt, i.e. waits for the chunk that has just been requested
+        if (kg + 1 < KG) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        PHR(3);
     }
 
     // ---- epilogue: D[channel 4 (lane >> 4) + r][pixel lane & 15]
@@ -176,6 +209,7 @@ __global__ void __launch_bounds__(256) c3f_kernel(const float* __restrict__ x, c
                 else y[(((size_t)b * COUT + co) * H + r0 + row) * W + col] = v;
             }
     }
+    PHR(4);
     if (C::POOL) {
         __syncthreads();
         constexpr int HP = H / 2, WP = W / 2, TP = TR / 2, NOUT = 16 * C::NCBW * TP * WP;
@@ -186,6 +220,11 @@ __global__ void __launch_bounds__(256) c3f_kernel(const float* __restrict__ x, c
             y[(((size_t)b * COUT + 16 * cbg * C::NCBW + cl) * HP + r0 / 2 + pr) * WP + pc] = m;
         }
     }
+    PHR(5);
+#ifdef VAR_PHASES
+    if (ph_on && CIN == VAR_PH_C3F_CIN && COUT == VAR_PH_C3F_COUT)
+        for (int i_ = 0; i_ < 8; ++i_) g_phase[16 + i_] += ph_a[i_];
+#endif
 }
 
 template <class C>
