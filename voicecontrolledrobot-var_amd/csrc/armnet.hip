@@ -75,6 +75,8 @@ using ArmC3 = c3f::Cfg<32, 64, 48, 6, 1, 1, false>;
 using ArmC4 = c3f::Cfg<64, 64, 48, 6, 1, 1, true>;
 using ArmC5 = c3f::Cfg<64, 128, 24, 8, 1, 1, false>;
 using ArmC6 = c3f::Cfg<128, 128, 24, 4, 2, 2, true>;
+using ArmC7 = c3f::SmallCfg<128, 256, 12, 2, 5>;
+using ArmC8 = c3f::SmallCfg<256, 128, 5, 1, 3>;
 constexpr int kBandMaxB = 64;      // beyond this the gather-GEMM's big tiles win
 
 static __global__ void an_pool_kernel(const float* __restrict__ x, float* __restrict__ y, long n, int H, int HP) {
@@ -549,17 +551,17 @@ int var_armnet_plan(var_ctx* c, int max_batch) {
     const long ochain = take(kChainRows * 8192), osync = take(64);
     {
         c3f::PackDesc& d = st->pack;
-        d.n_layers = 5;
+        d.n_layers = 7;
         int f4 = 0;
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < 7; ++i) {
             const int l = i + 1;                          // conv l+1: kCh[l] -> kCh[l + 1]
             d.w_off[i] = st->L.cw[l]; d.cin[i] = kCh[l]; d.cout[i] = kCh[l + 1];
             d.wp_off[i] = f4; d.first[i] = f4;
             f4 += kCh[l] * kCh[l + 1] * 9 / 4;
         }
-        d.first[5] = f4;
+        d.first[7] = f4;
     }
-    const long owpk = take(4L * st->pack.first[5]);
+    const long owpk = take(4L * st->pack.first[7]);
     VAR_HIP_CHECK(c, hipMalloc((void**)&st->ws, (size_t)total * sizeof(float)));
     float* w = st->ws;
     for (int l = 1; l <= 8; ++l) st->a[l] = w + oa[l];
@@ -610,7 +612,7 @@ int var_armnet_forward(var_ctx* c, void* stream, const float* params, const void
     }
     if (B <= kBandMaxB) {
         const c3f::PackDesc& d = st->pack;
-        hipLaunchKernelGGL(c3f::c3f_pack_kernel, g1(d.first[5]), dim3(256), 0, s, P, st->wpk, d);
+        hipLaunchKernelGGL(c3f::c3f_pack_kernel, g1(d.first[7]), dim3(256), 0, s, P, st->wpk, d);
         AN_CHECK(c);
         RUN(c3f::launch<ArmC2>(c, s, st->a[1], st->wpk + d.wp_off[0], P + L.cb[1], st->p[1], B));
         RUN(c3f::launch<ArmC3>(c, s, st->p[1], st->wpk + d.wp_off[1], P + L.cb[2], st->a[3], B));
@@ -627,8 +629,13 @@ int var_armnet_forward(var_ctx* c, void* stream, const float* params, const void
         RUN((conv<S1, false>(c, s, st, dims(6, 24, 1, 1), st->a[5], P + L.cw[5], P + L.cb[5], st->a[6])));
         RUN(pool(st->a[6], st->p[3], 128, 24));
     }
-    RUN((conv<S2P0, false>(c, s, st, dims(7, 12, 2, 0), st->p[3], P + L.cw[6], P + L.cb[6], st->a[7])));
-    RUN((conv<S1P0, false>(c, s, st, dims(8, 5, 1, 0), st->a[7], P + L.cw[7], P + L.cb[7], st->a[8])));
+    if (B <= kBandMaxB) {
+        RUN(c3f::launch_small<ArmC7>(c, s, st->p[3], st->wpk + st->pack.wp_off[5], P + L.cb[6], st->a[7], B));
+        RUN(c3f::launch_small<ArmC8>(c, s, st->a[7], st->wpk + st->pack.wp_off[6], P + L.cb[7], st->a[8], B));
+    } else {
+        RUN((conv<S2P0, false>(c, s, st, dims(7, 12, 2, 0), st->p[3], P + L.cw[6], P + L.cb[6], st->a[7])));
+        RUN((conv<S1P0, false>(c, s, st, dims(8, 5, 1, 0), st->a[7], P + L.cw[7], P + L.cb[7], st->a[8])));
+    }
     if (B <= kChainRows)      // the RL stage's batch: everything after the convolutions in one persistent launch
         return chain_forward(c, s, st, P, image_feat, robot_pose, goal_sound_feat, rnn_hxs, masks, B, value, actor_features, action_mean,
                              rnn_hxs_out);

@@ -238,4 +238,111 @@ int launch(var_ctx* c, hipStream_t s, const float* x, const f32x4* wp, const flo
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }
+
+// ---- the two last layers of the stack (conv 7: 128 -> 256, 3x3 stride 2 pad 0, 12x12 -> 5x5; conv 8: 256 -> 128, 3x3, 5x5 -> 3x3):
+// a quarter of a GFLOP, 2.4 MB of filter.  A workgroup = (image, 16 output channels): the image's input (<= 74 KB) is staged in
+// LDS, the four waves split K (16-channel groups dealt round-robin), every wave requests ALL of its filter share before the
+// staging (<= 36 16-byte loads in flight per lane), the four partial tiles are folded through LDS in wave order.  Replaces a
+// split-K gather-GEMM launch and its finish launch per layer.
+template <int CIN_, int COUT_, int HIN_, int S_, int HOUT_>
+struct SmallCfg {
+    static constexpr int CIN = CIN_, COUT = COUT_, HIN = HIN_, S = S_, HOUT = HOUT_;
+    static constexpr int NPX = HOUT * HOUT, NPB = (NPX + 15) / 16, KG = CIN / 16, KGW = KG / 4;
+    static constexpr int PL0 = HIN * HIN, PL = PL0 + (48 - PL0 % 32) % 32;       // == 16 (mod 32)
+    static constexpr int IMG = CIN * PL, RED = 4 * NPB * 4 * 64;
+    static constexpr int LDSF = IMG + RED;
+    static_assert(KG % 4 == 0 && COUT % 16 == 0 && (CIN * PL0) % 4 == 0 && LDSF * 4 <= 160 * 1024, "small conv shape");
+    static_assert((HOUT - 1) * S + 3 <= HIN, "valid convolution (no padding)");
+};
+
+template <class C>
+__global__ void __launch_bounds__(256) c3s_kernel(const float* __restrict__ x, const f32x4* __restrict__ wp, const float* __restrict__ bias,
+                                                 float* __restrict__ y, int B) {
+    constexpr int CIN = C::CIN, COUT = C::COUT, HIN = C::HIN, S = C::S, HOUT = C::HOUT, NPX = C::NPX, NPB = C::NPB, KG = C::KG, PL = C::PL;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* red = lds + C::IMG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lk = lane >> 4;
+    const int b = blockIdx.x % B, cb = blockIdx.x / B;
+    // this wave's share of the filter: groups kg = wave, wave + 4, ...
+    f32x4 a[C::KGW][9];
+    const f32x4* wa = wp + (size_t)cb * KG * 576 + lane;
+#pragma unroll
+    for (int g = 0; g < C::KGW; ++g)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) a[g][tap] = wa[((wave + 4 * g) * 9 + tap) * 64];
+    // the image -> LDS [channel][PL]
+    {
+        constexpr int N4 = CIN * C::PL0 / 4;
+        const float4* src = (const float4*)(x + (size_t)b * CIN * C::PL0);
+#pragma unroll 1
+        for (int e0 = tid; e0 < N4; e0 += 256 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = e0 + 256 * u; v[u] = src[e < N4 ? e : N4 - 1]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + 256 * u;
+                if (e < N4) {
+                    const float t[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int idx = 4 * e + q, ch = idx / C::PL0, pos = idx - ch * C::PL0;
+                        lds[ch * PL + pos] = t[q];
+                    }
+                }
+            }
+        }
+    }
+    int va[NPB];
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+        int p = i * 16 + l15;
+        p = p < NPX ? p : NPX - 1;
+        const int oy = p / HOUT, ox = p - oy * HOUT;
+        va[i] = lk * PL + oy * S * HIN + ox * S;
+    }
+    f32x4 acc[NPB];
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < C::KGW; ++g) {
+        const float* xk = lds + (wave + 4 * g) * 16 * PL;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap - 3 * dy;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < NPB; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][tap][j], xk[va[i] + 4 * j * PL + dy * HIN + dx], acc[i], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NPB; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((wave * NPB + i) * 4 + r) * 64 + lane] = acc[i][r];
+    __syncthreads();
+    for (int e = tid; e < NPB * 4 * 64; e += 256) {
+        const int l = e & 63, r = (e >> 6) & 3, i = e >> 8;
+        const float sum = ((red[e] + red[NPB * 256 + e]) + red[2 * NPB * 256 + e]) + red[3 * NPB * 256 + e];
+        const int co = 16 * cb + 4 * (l >> 4) + r, px = i * 16 + (l & 15);
+        if (px < NPX) {
+            const float v = sum + bias[co];
+            y[((size_t)b * COUT + co) * NPX + px] = v > 0.f ? v : 0.f;
+        }
+    }
+}
+
+template <class C>
+int launch_small(var_ctx* c, hipStream_t s, const float* x, const f32x4* wp, const float* bias, float* y, int B) {
+    static bool attr = false;
+    if (!attr) {
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)c3s_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDSF * 4));
+        attr = true;
+    }
+    hipLaunchKernelGGL(c3s_kernel<C>, dim3(B * (C::COUT / 16)), dim3(256), C::LDSF * 4, s, x, wp, bias, y, B);
+    VAR_HIP_CHECK(c, hipGetLastError());
+    return VAR_OK;
+}
 }  // namespace c3f
