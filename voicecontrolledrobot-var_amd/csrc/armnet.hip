@@ -604,7 +604,15 @@ int var_armnet_forward(var_ctx* c, void* stream, const float* params, const void
         return VAR_OK;
     };
     // imgCNN
-    {
+    if (B <= kBandMaxB) {      // conv 1 and the filter pack of conv 2..8 in one launch (c3f.h)
+        const c3f::PackDesc& d = st->pack;
+        const int nconv = B * c3f::C1_BANDS, npack = (d.first[7] + 255) / 256;
+        if (image_is_u8) hipLaunchKernelGGL(c3f::c1f_pack_kernel<true>, dim3(nconv + npack), dim3(256), 0, s, image, image_bstride, P, L.cw[0],
+                                            L.cb[0], st->a[1], nconv, st->wpk, d);
+        else hipLaunchKernelGGL(c3f::c1f_pack_kernel<false>, dim3(nconv + npack), dim3(256), 0, s, image, image_bstride, P, L.cw[0], L.cb[0],
+                                st->a[1], nconv, st->wpk, d);
+        AN_CHECK(c);
+    } else {
         ConvDims d = dims(1, 96, 1, 1);
         d.xb = image_bstride;
         if (image_is_u8) RUN((conv<S1, true>(c, s, st, d, image, P + L.cw[0], P + L.cb[0], st->a[1])));
@@ -612,8 +620,6 @@ int var_armnet_forward(var_ctx* c, void* stream, const float* params, const void
     }
     if (B <= kBandMaxB) {
         const c3f::PackDesc& d = st->pack;
-        hipLaunchKernelGGL(c3f::c3f_pack_kernel, g1(d.first[7]), dim3(256), 0, s, P, st->wpk, d);
-        AN_CHECK(c);
         RUN(c3f::launch<ArmC2>(c, s, st->a[1], st->wpk + d.wp_off[0], P + L.cb[1], st->p[1], B));
         RUN(c3f::launch<ArmC3>(c, s, st->p[1], st->wpk + d.wp_off[1], P + L.cb[2], st->a[3], B));
         RUN(c3f::launch<ArmC4>(c, s, st->a[3], st->wpk + d.wp_off[2], P + L.cb[3], st->p[2], B));

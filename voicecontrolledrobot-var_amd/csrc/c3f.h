@@ -9,7 +9,7 @@
 //   * v_mfma_f32_16x16x4_f32, A = filter (16 output channels x 4 input channels), B = 16 consecutive pixels of the band;
 //     a wave keeps NPB pixel blocks x NCB channel blocks of accumulators (4 VGPRs each), so one A operand feeds NPB and one
 //     B read feeds NCB matrix instructions;
-//   * the filter is packed in MFMA A-fragment order (c3f_pack_kernel: 16 bytes = the A operands of four k-steps) and travels
+//   * the filter is packed in MFMA A-fragment order (pack_item(): 16 bytes = the A operands of four k-steps) and travels
 //     through LDS in 16-channel chunks beside the band's (a wave streaming it from L2 one tap ahead waited ~20 cycles per
 //     matrix instruction: 55 instead of 32 cycles each);
 //   * the epilogue adds the bias, applies ReLU and either stores NCHW or goes through an LDS tile for the 2x2 max pool (the
@@ -58,8 +58,7 @@ struct PackDesc {
     int n_layers;
     int w_off[kMaxLayers], wp_off[kMaxLayers] /* float4 units */, cin[kMaxLayers], cout[kMaxLayers], first[kMaxLayers + 1];
 };
-__global__ void __launch_bounds__(256) c3f_pack_kernel(const float* __restrict__ params, f32x4* __restrict__ wp, PackDesc d) {
-    int i = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void pack_item(const float* __restrict__ params, f32x4* __restrict__ wp, const PackDesc& d, int i) {
     if (i >= d.first[d.n_layers]) return;
     int l = 0;
     while (i >= d.first[l + 1]) ++l;
@@ -68,6 +67,79 @@ __global__ void __launch_bounds__(256) c3f_pack_kernel(const float* __restrict__
     const int lane = i & 63, tap = (i >> 6) % 9, kg = (i / (64 * 9)) % KG, cb = i / (64 * 9 * KG);
     const float* q = params + d.w_off[l] + ((long)(16 * cb + (lane & 15)) * CIN + 16 * kg + (lane >> 4)) * 9 + tap;
     wp[d.wp_off[l] + i] = f32x4{q[0], q[4 * 9], q[8 * 9], q[12 * 9]};
+}
+
+// ---- conv 1 of the stack (3 -> 32, 3x3 pad 1, 96x96; u8 / 255 or float input) + the filter pack of the later layers in ONE launch:
+// workgroups [0, nconv) own bands of two image rows (K = 27 padded to 28 = 7 steps of v_mfma_f32_16x16x4_f32, the filter read in
+// place from its state_dict() layout, a per-lane table turns k = 4 j + (lane >> 4) into its (channel, tap) offset in the LDS
+// band), the rest run pack_item().  The layer is a 9.4-MB write: the point is one launch instead of two on a dependent chain.
+constexpr int C1_H = 96, C1_TR = 2, C1_PW = C1_H + 8, C1_ROWS = C1_TR + 2, C1_PLANE = C1_ROWS * C1_PW, C1_BANDS = C1_H / C1_TR;
+template <bool U8>
+__global__ void __launch_bounds__(256) c1f_pack_kernel(const void* __restrict__ image, long bstride, const float* __restrict__ params, int w_off,
+                                                      int b_off, float* __restrict__ y, int nconv, f32x4* __restrict__ wp, PackDesc d) {
+    if ((int)blockIdx.x >= nconv) { pack_item(params, wp, d, ((int)blockIdx.x - nconv) * 256 + threadIdx.x); return; }
+    constexpr int H = C1_H, W = C1_H, PW = C1_PW, ROWS = C1_ROWS, PLANE = C1_PLANE, NPB = (C1_TR * W / 16) / 4;
+    __shared__ float band[3 * PLANE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lk = lane >> 4;
+    const int b = blockIdx.x / C1_BANDS, r0 = (blockIdx.x - b * C1_BANDS) * C1_TR;
+    const float* w = params + w_off;
+    // A operands: a[cb][j] = w[16 cb + l15][k = 4 j + lk], zero for the padding k = 27; B offsets of the same k
+    float a[2][7];
+    int off[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int k = 4 * j + lk, kc = k < 27 ? k : 26;
+        const int ch = kc / 9, tap = kc - 9 * ch, dy = tap / 3, dx = tap - 3 * dy;
+        off[j] = ch * PLANE + dy * PW + dx + 3;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) { const float v = w[(16 * cb + l15) * 27 + kc]; a[cb][j] = k < 27 ? v : 0.f; }
+    }
+    // band: rows r0 - 1 .. r0 + TR of the three channels, zeros outside the image
+    {
+        constexpr int N = 3 * ROWS * W, PER = (N + 255) / 256;
+        float v[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            int e = tid + 256 * u;
+            e = e < N ? e : N - 1;
+            const int ch = e / (ROWS * W), rem = e - ch * (ROWS * W), br = rem / W, col = rem - br * W;
+            const int ir = r0 - 1 + br, irc = ir < 0 ? 0 : (ir >= H ? H - 1 : ir);
+            const long o = (long)b * bstride + ((long)ch * H + irc) * W + col;
+            v[u] = U8 ? (float)((const uint8_t*)image)[o] / 255.f : ((const float*)image)[o];          // dataset.py:67-68
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int e = tid + 256 * u;
+            if (e < N) {
+                const int ch = e / (ROWS * W), rem = e - ch * (ROWS * W), br = rem / W, col = rem - br * W;
+                const int ir = r0 - 1 + br;
+                band[ch * PLANE + br * PW + 4 + col] = (ir < 0 || ir >= H) ? 0.f : v[u];
+            }
+        }
+        if (tid < 3 * ROWS) { band[(tid / ROWS) * PLANE + (tid % ROWS) * PW + 3] = 0.f; band[(tid / ROWS) * PLANE + (tid % ROWS) * PW + 4 + W] = 0.f; }
+    }
+    __syncthreads();
+    const float* bias = params + b_off;
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+        const int p = (wave * NPB + i) * 16 + l15, row = p / W, col = p - row * W;
+        const float* xp = band + row * PW + col;
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const float bv = xp[off[j]];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb][j], bv, acc[cb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = 16 * cb + 4 * lk + r;
+                const float v = acc[cb][r] + bias[co];
+                y[(((size_t)b * 32 + co) * H + r0 + row) * W + col] = v > 0.f ? v : 0.f;
+            }
+    }
 }
 
 template <class C>
