@@ -114,3 +114,30 @@ def test_fused_small_batch_chain_equals_the_per_layer_path(var_amd, fx, B):
     v4, a4, _, h4 = m.act(big, h2, torch.ones(12, 1, device="cuda"), deterministic=True)
     for got, want in ((v3, v4), (a3, a4), (h3, h4)):
         np.testing.assert_allclose(got.cpu().numpy(), want[:B].cpu().numpy(), rtol=0, atol=5e-5)
+
+
+def test_band_convolutions_equal_the_gather_gemm_path(var_amd, fx):
+    """Up to 64 images the image stack runs on the LDS-band kernels of csrc/c3f.h (conv 1 + filter pack, conv 2..6 with the
+    pools fused, conv 7/8 with K split over a workgroup's waves); larger batches keep the gather-GEMM + split-K finish + pool
+    launches.  The same 8 rows through both: alone (band kernels, fused chain) and as the first rows of a batch of 66."""
+    ref = armnet_seeded(int(fx["seed"]))
+    m = make(var_amd, ref)
+    g = torch.Generator().manual_seed(11)
+    n = 66
+    big = {'image': torch.randint(0, 256, (n, 3, 96, 96), dtype=torch.uint8, generator=g).cuda(),
+           'image_feat': torch.randn(n, 3, generator=g).cuda(), 'robot_pose': torch.randn(n, 2, generator=g).cuda(),
+           'goal_sound_feat': torch.randn(n, 3, generator=g).cuda()}
+    hxs = torch.randn(n, 512, generator=g).cuda() * 0.3
+    masks = (torch.rand(n, 1, generator=g) > 0.2).float().cuda()
+    for B in (8, 40):                                      # 40: band kernels + per-layer MLP
+        small = {k: v[:B].contiguous() for k, v in big.items()}
+        v1, a1, _, h1 = m.act(small, hxs[:B].contiguous(), masks[:B].contiguous(), deterministic=True)
+        v2, a2, _, h2 = m.act(big, hxs, masks, deterministic=True)
+        for got, want in ((v1, v2), (a1, a2), (h1, h2)):
+            np.testing.assert_allclose(got.cpu().numpy(), want[:B].cpu().numpy(), rtol=0, atol=2e-5)
+    # float images take the same kernels' other instantiation
+    fl = {k: (v[:8].float() / 255. if k == 'image' else v[:8].contiguous()) for k, v in big.items()}
+    v3, a3, _, h3 = m.act(fl, hxs[:8].contiguous(), masks[:8].contiguous(), deterministic=True)
+    v4, a4, _, h4 = m.act({k: v[:8].contiguous() for k, v in big.items()}, hxs[:8].contiguous(), masks[:8].contiguous(), deterministic=True)
+    for got, want in ((v3, v4), (a3, a4), (h3, h4)):
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=0, atol=2e-5)
