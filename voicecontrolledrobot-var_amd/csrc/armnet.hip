@@ -2,8 +2,10 @@
 // models/RL/arm_RL_model.py:7-134 `armNet_VAR` (96x96 branch: 8 convolutions / 3 max pools -> 1152, the motor /
 // image / sound MLPs, one GRU(128 -> 512) step through NNBase._forward_gru's acting path, models/ppo/model.py:116-121,
 // fusion and the actor / critic trunks) followed by DiagGaussian's mean layer (models/ppo/distributions.py:65-84), i.e.
-// everything of Policy.act up to the sampling.  Inference only (the PPO update stays in PyTorch); every product is
-// an instance of the gather-GEMM of gg.h, parameters are used in place in their state_dict() layouts.
+// everything of Policy.act up to the sampling.  Inference only (the PPO update stays in PyTorch).  Up to 64 images the
+// convolutions run on the LDS-band kernels of c3f.h (filters re-packed per call inside conv 1's launch) and, up to 8 rows, the
+// 22 Linear layers + GRU step on the one-launch chain below; larger batches take the gather-GEMM of gg.h layer by layer with
+// the parameters in place in their state_dict() layouts.
 #include <string.h>
 
 #include "gg.h"
