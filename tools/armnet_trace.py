@@ -37,18 +37,22 @@ def run():
     torch.cuda.synchronize()
 
 
-def show(d):
+def show(d, n_avg=40):
     f = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
     names = [r["Kernel_Name"] for r in rows]
-    last = max(i for i, n in enumerate(names) if "armnet_chain" in n)
-    prev = max(i for i, n in enumerate(names[:last]) if "armnet_chain" in n)
-    step = rows[prev + 1:last + 1]
-    t0 = int(step[0]["Start_Timestamp"])
-    for r in step:
-        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-        print(f"{(s - t0) / 1e3:8.1f} {(e - s) / 1e3:7.1f}  grid {r.get('Grid_Size_X', '?'):>7}x{r.get('Grid_Size_Y', '?')}x{r.get('Grid_Size_Z', '?')}  {r['Kernel_Name'][:110]}")
-    print(f"span {(int(step[-1]['End_Timestamp']) - t0) / 1e3:.1f} us, {len(step)} launches")
+    ends = [i for i, n in enumerate(names) if "armnet_chain" in n]          # the chain kernel closes a forward
+    steps = [rows[a + 1:b + 1] for a, b in zip(ends[:-1], ends[1:])][-n_avg:]
+    steps = [st for st in steps if len(st) == len(steps[-1])]
+    k = len(steps[-1])
+    mean = lambda xs: sum(xs) / len(xs)
+    start = [mean([(int(st[i]["Start_Timestamp"]) - int(st[0]["Start_Timestamp"])) / 1e3 for st in steps]) for i in range(k)]
+    dur = [mean([(int(st[i]["End_Timestamp"]) - int(st[i]["Start_Timestamp"])) / 1e3 for st in steps]) for i in range(k)]
+    for i in range(k):
+        r = steps[-1][i]
+        print(f"{start[i]:8.1f} {dur[i]:7.1f}  grid {r.get('Grid_Size_X', '?'):>7}x{r.get('Grid_Size_Y', '?')}x{r.get('Grid_Size_Z', '?')}  {r['Kernel_Name'][:110]}")
+    span = mean([(int(st[-1]["End_Timestamp"]) - int(st[0]["Start_Timestamp"])) / 1e3 for st in steps])
+    print(f"span {span:.1f} us, {k} launches (mean of the last {len(steps)} replays)")
 
 
 if __name__ == "__main__":

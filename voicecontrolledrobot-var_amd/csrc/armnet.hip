@@ -8,6 +8,8 @@
 // the parameters in place in their state_dict() layouts.
 #include <string.h>
 
+#include <type_traits>
+
 #include "gg.h"
 
 namespace {
@@ -127,15 +129,14 @@ static __global__ void an_gru_cell_kernel(const float* __restrict__ gi, const fl
 // launches they cost ~4 us each whatever they compute (45 launches, 240 us of the 435-us forward).  Here kChainG workgroups
 // stay resident; a stage's inputs (<= 57 KB for 8 rows) are staged into every workgroup's LDS, a wave takes blocks of four
 // output features (lanes split K: coalesced 256-B reads of the weight rows in their state_dict() layout, 8 rows x 4
-// outputs of partial sums per lane, a 31-shuffle butterfly leaves one (output, row) sum per lane), and stages are separated
-// by a grid barrier in the guide's hand-off form (MI355X_MICROARCH.md, inter-workgroup visibility, third table row): every
-// handed-off float is stored and loaded sc1 (agent-scope relaxed atomics), each wave drains its stores, one lane per
-// workgroup adds to the counter behind a workgroup barrier and polls it; a workgroup barrier stands between the poll and
-// the loads.  The poll is bounded: a grid that is not resident sets sync[2] and every workgroup leaves (outputs NaN).
+// outputs of partial sums per lane, a 31-shuffle butterfly leaves one (output, row) sum per lane).  Stages are NOT separated
+// by a grid barrier (round 3's first form: sc1 stores drained, counter add, counter poll, sc1 loads -- four dependent trips
+// through the fabric, ~8 us per stage): the handed-off vectors carry a tag, see st_pair() below.  The polls are bounded: a
+// grid that is not resident sets sync[2], every workgroup stops waiting and the outputs are NaN.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kChainG = 128, kChainT = 256, kChainRows = 8, kChainNB = 4;
 enum { IN_PLAIN = 0, IN_SUM, IN_CAT, IN_MASK, IN_GRU };
-struct ChainJob { int w, b, K, N, kind, in0, in1, cat0, out, relu, wg0, nwg; };
+struct ChainJob { int w, b, K, N, kind, in0, in1, cat0, out, relu, wg0, nwg, out2; };   // out2: a second, plain copy of the output (or -1)
 struct ChainStage { int job0, njobs; };
 constexpr int kChainMaxJobs = 28, kChainMaxStages = 12, kChainBufs = 36;
 struct ChainDesc {
@@ -145,25 +146,31 @@ struct ChainDesc {
     ChainStage stage[kChainMaxStages];
     int nstages, B, H;
     int b_hxs, b_mask, b_hout;           // buffer ids the GRU input kind needs besides in0 (gi) / in1 (gh)
-    unsigned* sync;
+    unsigned long long tagged;           // bit i: buffer i is handed over inside the launch as (value, tag) pairs
+    unsigned* sync;                      // [1] finished workgroups, [2] time-out (sticky), [3] epoch of the next launch
 };
 typedef __attribute__((address_space(1))) float gf32;
 typedef __attribute__((address_space(1))) unsigned gu32c;
-__device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load((gf32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store((gf32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-typedef float f32x4c __attribute__((ext_vector_type(4)));
-// 16 bytes of a handed-off vector, read around the L1 (sc1): element offset `e` (a multiple of 4) of buffer p
-__device__ __forceinline__ f32x4c ld4_sc1(const float* p, int e) {
-    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7fffffff, 0x00020000);
-    return __builtin_bit_cast(f32x4c, __builtin_amdgcn_raw_buffer_load_b128(r, e * 4, 0, 16));
+// Hand-over without a barrier: every float a stage hands to a later one travels as an 8-byte (value, tag) pair written by ONE
+// 64-bit sc1 store; the tag is the launch's epoch (a device counter the last workgroup of a launch bumps: captured graphs replay
+// with frozen arguments).  A consumer polls its INPUT until every pair carries the epoch -- one trip through the fabric after the
+// producer's store lands, instead of drain + counter add + counter poll + load (four), and a workgroup whose inputs are complete
+// runs ahead of the others.  Every internal vector is written once per launch, so the epoch alone identifies it.
+typedef __attribute__((address_space(1))) unsigned long long gu64c;
+__device__ __forceinline__ void st_pair(float* buf, int e, float v, unsigned tag) {
+    const unsigned long long q = (unsigned long long)__builtin_bit_cast(unsigned, v) | ((unsigned long long)tag << 32);
+    __hip_atomic_store((gu64c*)(buf + 2 * e), q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+constexpr unsigned kChainSpinMax = 1u << 17;
 
 __global__ void __launch_bounds__(kChainT) armnet_chain_kernel(ChainDesc D) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ int ok_s;
+    __shared__ int dead_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = D.B, H = D.H;
+    const unsigned epoch = __hip_atomic_load((gu32c*)(D.sync + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) dead_s = 0;
     bool alive = true;
     PHR_INIT(5, 0);
     // this workgroup's job of a stage (jobs own ranges of workgroups, sized by their weight volume)
@@ -175,16 +182,19 @@ __global__ void __launch_bounds__(kChainT) armnet_chain_kernel(ChainDesc D) {
         return D.job[S.job0 + q];
     };
     // The weights do not depend on the activations: the first eight k-chunks of this wave's first item of the NEXT stage (all
-    // of them for every layer but the 1152-wide one) and its bias are requested BEFORE the grid barrier and land behind it.
+    // of them for every layer but the 1152-wide one) and its bias are requested before the stage's input is polled.
+    // lane -> (output, row) after the butterfly: value o * 8 + r in the even lanes
     const int lidx = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+    using NB4 = std::integral_constant<int, kChainNB>;
     float pw[8][kChainNB], pbias = 0.f;
-    auto load_w = [&](const ChainJob& J, int o0, int kc0, float (&wv)[8][kChainNB]) {
+    auto load_w = [&](auto nbc, const ChainJob& J, int o0, int kc0, float (&wv)[8][kChainNB]) {
+        constexpr int NB = decltype(nbc)::value;
         const float* W = D.P + J.w;
 #pragma unroll
         for (int c8 = 0; c8 < 8; ++c8) {
             const int k = kc0 + c8 * 64 + lane;
 #pragma unroll
-            for (int o = 0; o < kChainNB; ++o) {                               // (unconditional, clamped: see the staging below)
+            for (int o = 0; o < NB; ++o) {                                     // (unconditional, clamped: see the staging below)
                 const int kk = k < J.K ? k : J.K - 1, oo = o0 + o < J.N ? o0 + o : J.N - 1;
                 wv[c8][o] = W[(long)oo * J.K + kk];
             }
@@ -193,106 +203,191 @@ __global__ void __launch_bounds__(kChainT) armnet_chain_kernel(ChainDesc D) {
     auto prefetch = [&](const ChainJob& J) {
         const int jw = ((int)blockIdx.x - J.wg0) * (kChainT / 64) + wave;
         if (jw * kChainNB < J.N) {
-            load_w(J, jw * kChainNB, 0, pw);
-            const int oo = jw * kChainNB + lidx / kChainRows;
+            int oo;
+            load_w(NB4{}, J, jw * kChainNB, 0, pw); oo = jw * kChainNB + lidx / kChainRows;
             pbias = D.P[J.b + (oo < J.N ? oo : J.N - 1)];
         }
     };
+    auto give_up = [&]() {          // a producer never delivered (the grid is not resident): sticky time-out, outputs NaN
+        __hip_atomic_store((gu32c*)(D.sync + 2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dead_s = 1;
+    };
     ChainJob J = job_of(0);
     prefetch(J);
+    __syncthreads();
 #pragma unroll 1
     for (int si = 0; si < D.nstages; ++si) {
         PHR(0);
         const int Kp = (J.K + 63) & ~63;
-        // ---- the job's input -> LDS [row][Kp], zero-padded; 16-byte sc1 loads, four in flight per thread ----
+        float* xs = lds;          // two input buffers: the next stage is staged while slow waves still read this one
+        const bool t0 = (D.tagged >> J.in0) & 1;          // handed-off input(s) -- IN_SUM pairs and the GRU's gi / gh are always both
+        // ---- the job's input -> LDS [row][Kp], zero-padded ----
         {
             const float* a = D.buf[J.in0];
             const float* b2 = J.in1 >= 0 ? D.buf[J.in1] : nullptr;
             if (J.kind == IN_GRU) {
-                // torch.nn.GRU cell (gate order r, z, n) from gi (in0) and gh (in1): the new state is this layer's input.  A rolled
-                // loop on purpose: the kernel's code runs once per stage, and what does not fit the instruction cache is fetched again
-                const int kq = J.K >> 2, n4 = B * kq;
+                // torch.nn.GRU cell (gate order r, z, n) from gi (in0) and gh (in1), both handed off: the new state is this layer's
+                // input.  Two hidden units per thread and turn; a rolled loop on purpose (the code runs once per stage).
+                const int kq = J.K >> 1, n2 = B * kq;
 #pragma unroll 1
-                for (int e = tid; e < n4; e += kChainT) {
-                    const int r = e / kq, k = 4 * (e - r * kq);
-                    const f32x4c hx = ld4_sc1(D.buf[D.b_hxs], r * H + k);
-                    const float hm = ld_sc1(D.buf[D.b_mask] + r);
-                    f32x4c g3[6];
+                for (int e = tid; e < n2; e += kChainT) {
+                    const int r = e / kq, k = 2 * (e - r * kq);
+                    const float2 hx = *(const float2*)(D.buf[D.b_hxs] + r * H + k);
+                    const float hm = D.buf[D.b_mask][r];
+                    unsigned long long q[6][2];
+                    unsigned spins = 0;
+                    for (;;) {
 #pragma unroll
-                    for (int gte = 0; gte < 3; ++gte) { g3[gte] = ld4_sc1(a, r * 3 * H + gte * H + k); g3[3 + gte] = ld4_sc1(b2, r * 3 * H + gte * H + k); }
-                    f32x4c o;
+                        for (int gte = 0; gte < 3; ++gte) {
+                            const int el = r * 3 * H + gte * H + k;
+                            q[gte][0] = __hip_atomic_load((gu64c*)(a + 2 * el), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            q[gte][1] = __hip_atomic_load((gu64c*)(a + 2 * el + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            q[3 + gte][0] = __hip_atomic_load((gu64c*)(b2 + 2 * el), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            q[3 + gte][1] = __hip_atomic_load((gu64c*)(b2 + 2 * el + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        unsigned bad = 0u;
 #pragma unroll
-                    for (int c4 = 0; c4 < 4; ++c4) {
-                        const float h = hx[c4] * hm;
-                        const float rr = 1.f / (1.f + expf(-(g3[0][c4] + g3[3][c4])));
-                        const float z = 1.f / (1.f + expf(-(g3[1][c4] + g3[4][c4])));
-                        const float n = tanhf(g3[2][c4] + rr * g3[5][c4]);
-                        o[c4] = (1.f - z) * n + z * h;
+                        for (int g = 0; g < 6; ++g) bad |= ((unsigned)(q[g][0] >> 32) ^ epoch) | ((unsigned)(q[g][1] >> 32) ^ epoch);
+                        if (bad == 0u) break;
+                        if (++spins > kChainSpinMax) { give_up(); break; }
+                        __builtin_amdgcn_s_sleep(1);
                     }
-                    if (blockIdx.x == J.wg0) *(f32x4c*)(D.buf[D.b_hout] + r * H + k) = o;       // rnn_hxs_out (later launches read it)
-                    *(f32x4c*)(lds + r * Kp + k) = o;
+                    float2 g3[6];
+#pragma unroll
+                    for (int g = 0; g < 6; ++g) g3[g] = float2{__builtin_bit_cast(float, (unsigned)q[g][0]), __builtin_bit_cast(float, (unsigned)q[g][1])};
+                    const float gi_[2][3] = {{g3[0].x, g3[1].x, g3[2].x}, {g3[0].y, g3[1].y, g3[2].y}};
+                    const float gh_[2][3] = {{g3[3].x, g3[4].x, g3[5].x}, {g3[3].y, g3[4].y, g3[5].y}};
+                    const float hh[2] = {hx.x * hm, hx.y * hm};
+                    float o[2];
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) {
+                        const float rr = 1.f / (1.f + expf(-(gi_[c2][0] + gh_[c2][0])));
+                        const float z = 1.f / (1.f + expf(-(gi_[c2][1] + gh_[c2][1])));
+                        const float n = tanhf(gi_[c2][2] + rr * gh_[c2][2]);
+                        o[c2] = (1.f - z) * n + z * hh[c2];
+                    }
+                    if (blockIdx.x == J.wg0) *(float2*)(D.buf[D.b_hout] + r * H + k) = float2{o[0], o[1]};       // rnn_hxs_out
+                    *(float2*)(xs + r * Kp + k) = float2{o[0], o[1]};
                 }
-                for (int e = tid; e < (kChainRows - B) * Kp; e += kChainT) lds[B * Kp + e] = 0.f;
+                for (int e = tid; e < (kChainRows - B) * Kp; e += kChainT) xs[B * Kp + e] = 0.f;
             } else if ((J.K & 3) == 0) {
-                const int kq = J.K >> 2, n4 = kChainRows * kq;                  // vec4 elements of the [8][K] input
+                const int kq = J.K >> 1, n2 = kChainRows * kq;
+                if (!t0) {
+                    // kernel inputs (the convolutions' output, rnn_hxs * masks): nothing to poll.  All loads first, unconditional
+                    // (addresses clamped into the buffers, values selected afterwards -- a load behind a per-lane condition becomes
+                    // a branch with a wait of its own)
 #pragma unroll 1
-                for (int e0 = tid; e0 < n4; e0 += 8 * kChainT) {
-                    // all loads first (unconditional: addresses clamped into the buffers, values selected afterwards -- a load behind
-                    // a per-lane condition becomes a branch with a wait of its own, i.e. a chain of memory latencies)
-                    f32x4c v[8], u[8];
-                    float hm[8];
+                    for (int e0 = tid; e0 < n2; e0 += 8 * kChainT) {
+                        float2 v[8];
+                        float hm[8];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        int e = e0 + i * kChainT;
-                        e = e < n4 ? e : n4 - 1;
-                        int r = e / kq;
-                        const int k = 4 * (e - r * kq);
-                        r = r < B ? r : B - 1;
-                        v[i] = ld4_sc1(a, r * J.K + k);
-                        u[i] = J.kind == IN_SUM ? ld4_sc1(b2, r * J.K + k) : f32x4c{0.f, 0.f, 0.f, 0.f};
-                        hm[i] = J.kind == IN_MASK ? ld_sc1(b2 + r) : 1.f;
+                        for (int i = 0; i < 8; ++i) {
+                            int e = e0 + i * kChainT;
+                            e = e < n2 ? e : n2 - 1;
+                            int r = e / kq;
+                            const int k = 2 * (e - r * kq);
+                            r = r < B ? r : B - 1;
+                            v[i] = *(const float2*)(a + r * J.K + k);
+                            hm[i] = J.kind == IN_MASK ? b2[r] : 1.f;
+                        }
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int e = e0 + i * kChainT;
+                            if (e >= n2) continue;
+                            const int r = e / kq, k = 2 * (e - r * kq);
+                            *(float2*)(xs + r * Kp + k) = r < B ? float2{v[i].x * hm[i], v[i].y * hm[i]} : float2{0.f, 0.f};
+                        }
                     }
+                } else {
+                    // handed-off vectors ((value, tag) pairs; IN_SUM: two of them): a turn = 8 element pairs per thread, ALL of its
+                    // 64-bit atomic loads issued back to back (hipcc keeps atomic loads in program order, so anything between two of
+                    // them -- a tag compare, a branch -- makes every pair wait for the previous one), then the tags are checked; a
+                    // turn that is not complete yet is simply taken again
+                    const bool sum = J.kind == IN_SUM;
+#pragma unroll 1
+                    for (int e0 = tid; e0 < n2; e0 += 8 * kChainT) {
+                        unsigned long long qa[8][2], qb[8][2];
+                        int el[8];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int e = e0 + i * kChainT;
-                        if (e >= n4) continue;
-                        const int r = e / kq, k = 4 * (e - r * kq);
-                        f32x4c o = (v[i] + u[i]) * hm[i];
-                        if (r >= B) o = f32x4c{0.f, 0.f, 0.f, 0.f};
-                        *(f32x4c*)(lds + r * Kp + k) = o;
+                        for (int i = 0; i < 8; ++i) {
+                            int e = e0 + i * kChainT;
+                            e = e < n2 ? e : n2 - 1;
+                            el[i] = 2 * e;                                    // (rows beyond the batch are handed over too)
+                        }
+                        unsigned spins = 0;
+                        for (;;) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                qa[i][0] = __hip_atomic_load((gu64c*)(a + 2 * el[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                qa[i][1] = __hip_atomic_load((gu64c*)(a + 2 * el[i] + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            if (sum) {
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) {
+                                    qb[i][0] = __hip_atomic_load((gu64c*)(b2 + 2 * el[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    qb[i][1] = __hip_atomic_load((gu64c*)(b2 + 2 * el[i] + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) qb[i][0] = qb[i][1] = (unsigned long long)epoch << 32;      // value 0.f, tag ok
+                            }
+                            unsigned bad = 0u;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i)
+                                bad |= ((unsigned)(qa[i][0] >> 32) ^ epoch) | ((unsigned)(qa[i][1] >> 32) ^ epoch) |
+                                       ((unsigned)(qb[i][0] >> 32) ^ epoch) | ((unsigned)(qb[i][1] >> 32) ^ epoch);
+                            if (bad == 0u) break;
+                            if (++spins > kChainSpinMax) { give_up(); break; }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int e = e0 + i * kChainT;
+                            if (e >= n2) continue;
+                            const int r = e / kq, k = 2 * (e - r * kq);
+                            float2 o = float2{__builtin_bit_cast(float, (unsigned)qa[i][0]) + __builtin_bit_cast(float, (unsigned)qb[i][0]),
+                                              __builtin_bit_cast(float, (unsigned)qa[i][1]) + __builtin_bit_cast(float, (unsigned)qb[i][1])};
+                            if (r >= B) o = float2{0.f, 0.f};
+                            *(float2*)(xs + r * Kp + k) = o;
+                        }
                     }
                 }
-            } else {                                                            // the two tiny first layers (K = 5: [image_feat | robot_pose], K = 3)
+            } else {                                                            // the two tiny first layers (K = 5: [image_feat | robot_pose], K = 3): kernel inputs
                 for (int e = tid; e < kChainRows * Kp; e += kChainT) {
                     const int r = e / Kp, k = e - r * Kp;
                     float v = 0.f;
                     if (r < B && k < J.K) {
-                        if (J.kind == IN_CAT) v = k < J.cat0 ? ld_sc1(a + r * J.cat0 + k) : ld_sc1(b2 + r * (J.K - J.cat0) + k - J.cat0);
-                        else v = ld_sc1(a + r * J.K + k);
+                        if (J.kind == IN_CAT) v = k < J.cat0 ? a[r * J.cat0 + k] : b2[r * (J.K - J.cat0) + k - J.cat0];
+                        else v = a[r * J.K + k];
                     }
-                    lds[e] = v;
+                    xs[e] = v;
                 }
             }
         }
         PHR(1);
         __syncthreads();
+        alive = alive && dead_s == 0;
         PHR(2);
-        // ---- items: blocks of kChainNB outputs, dealt to the waves of the job's workgroups ----
-        {
+        // ---- items: blocks of kChainNB outputs, dealt to the waves of the job's workgroups.  (Blocks of ONE output where a job has a
+        //      wave per output -- a quarter of the serial work per wave -- measured: 97.5 vs 94.5 us for the chain, the second
+        //      instantiation's code does not pay for itself) ----
+        auto items = [&](auto nbc) {
+            constexpr int NB = decltype(nbc)::value;
             const int jw = ((int)blockIdx.x - J.wg0) * (kChainT / 64) + wave, jnw = J.nwg * (kChainT / 64);
-            const int nitems = (J.N + kChainNB - 1) / kChainNB;
+            const int nitems = (J.N + NB - 1) / NB;
+            const bool tout = (D.tagged >> J.out) & 1;
             bool first = true;
 #pragma unroll 1
             for (int it = jw; it < nitems; it += jnw) {
-                const int o0 = it * kChainNB;
-                float acc[kChainNB][kChainRows];
+                const int o0 = it * NB;
+                float acc[NB][kChainRows];
 #pragma unroll
-                for (int o = 0; o < kChainNB; ++o)
+                for (int o = 0; o < NB; ++o)
 #pragma unroll
                     for (int r = 0; r < kChainRows; ++r) acc[o][r] = 0.f;
                 float bias = pbias;
-                if (!first) { const int oo = o0 + lidx / kChainRows; bias = D.P[J.b + (oo < J.N ? oo : J.N - 1)]; }
-                // weight rows stream from HBM: eight k-chunks (32 loads) in flight per wave
+                if (!first) { const int oo = NB == 1 ? o0 : o0 + lidx / kChainRows; bias = D.P[J.b + (oo < J.N ? oo : J.N - 1)]; }
+                // weight rows stream from HBM: eight k-chunks in flight per wave
 #pragma unroll 1
                 for (int kc0 = 0; kc0 < Kp; kc0 += 8 * 64) {
                     float wv[8][kChainNB];
@@ -300,25 +395,25 @@ __global__ void __launch_bounds__(kChainT) armnet_chain_kernel(ChainDesc D) {
 #pragma unroll
                         for (int c8 = 0; c8 < 8; ++c8)
 #pragma unroll
-                            for (int o = 0; o < kChainNB; ++o) wv[c8][o] = pw[c8][o];
-                    } else load_w(J, o0, kc0, wv);
+                            for (int o = 0; o < NB; ++o) wv[c8][o] = pw[c8][o];
+                    } else load_w(nbc, J, o0, kc0, wv);
 #pragma unroll
                     for (int c8 = 0; c8 < 8; ++c8) {
                         const int k = kc0 + c8 * 64 + lane;
                         if (kc0 + c8 * 64 < Kp) {
 #pragma unroll
                             for (int r = 0; r < kChainRows; ++r) {
-                                const float xv = lds[r * Kp + k];
+                                const float xv = xs[r * Kp + k];
 #pragma unroll
-                                for (int o = 0; o < kChainNB; ++o) acc[o][r] = fmaf(wv[c8][o], xv, acc[o][r]);      // (padding k: xv == 0)
+                                for (int o = 0; o < NB; ++o) acc[o][r] = fmaf(wv[c8][o], xv, acc[o][r]);      // (padding k: xv == 0)
                             }
                         }
                     }
                 }
-                // butterfly over the 64 lanes: 32 values -> lane L ends with value idx(L) = o * 8 + r
-                float v[32];
+                // butterfly over the 64 lanes: NB x 8 values -> one (output, row) sum per lane
+                float v[NB * kChainRows];
 #pragma unroll
-                for (int o = 0; o < kChainNB; ++o)
+                for (int o = 0; o < NB; ++o)
 #pragma unroll
                     for (int r = 0; r < kChainRows; ++r) v[o * kChainRows + r] = acc[o][r];
                 // (each step with compile-time constants: a loop over (half, bit) is not unrolled by hipcc, and the array then
@@ -331,54 +426,43 @@ __global__ void __launch_bounds__(kChainT) armnet_chain_kernel(ChainDesc D) {
                         v[i] = keep + __shfl_xor(give, (BIT), 64);                                   \
                     }                                                                                 \
                 }
+                float sum;
+                int o, r;
+                bool writer;
                 CHAIN_FOLD(16, 32) CHAIN_FOLD(8, 16) CHAIN_FOLD(4, 8) CHAIN_FOLD(2, 4) CHAIN_FOLD(1, 2)
+                sum = v[0] + __shfl_xor(v[0], 1, 64);
+                o = lidx / kChainRows; r = lidx % kChainRows; writer = (lane & 1) == 0;
 #undef CHAIN_FOLD
-                const float sum = v[0] + __shfl_xor(v[0], 1, 64);
-                const int o = lidx / kChainRows, r = lidx % kChainRows;
                 first = false;
-                if ((lane & 1) == 0 && r < B && o0 + o < J.N) {
+                if (writer && o0 + o < J.N) {
                     float y = sum + bias;
                     if (J.relu) y = fmaxf(y, 0.f);
                     if (!alive) y = __builtin_nanf("");
-                    st_sc1(D.buf[J.out] + r * J.N + o0 + o, y);
+                    // rows beyond the batch are handed over too (zeros in, bias out): a consumer polls whole vectors
+                    if (tout) st_pair(D.buf[J.out], r * J.N + o0 + o, y, epoch);
+                    else if (r < B) D.buf[J.out][r * J.N + o0 + o] = y;
+                    if (J.out2 >= 0 && r < B) D.buf[J.out2][r * J.N + o0 + o] = y;
                 }
             }
-        }
+        };
+        items(NB4{});
         PHR(3);
         if (si + 1 == D.nstages) break;
-        // ---- grid barrier ----
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's sc1 stores have left
         J = job_of(si + 1);
-        prefetch(J);                                                // (in flight across the barrier)
+        prefetch(J);                                                // (in flight while the next input is polled)
         __syncthreads();
         PHR(4);
-        if (tid == 0) {
-            int ok = 1;
-            if (alive) {
-                const unsigned want = (unsigned)(si + 1) * gridDim.x;
-                __hip_atomic_fetch_add((gu32c*)D.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                unsigned spins = 0;
-                while (__hip_atomic_load((gu32c*)D.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-                    if (++spins > (1u << 18)) { ok = 0; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (!ok) __hip_atomic_store((gu32c*)(D.sync + 2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else ok = 0;
-            ok_s = ok;
-        }
-        __syncthreads();
-        alive = ok_s != 0;
-        PHR(5);
     }
     PHR_FLUSH();
-    // the last workgroup to finish re-arms the counter for the next launch (nobody polls it any more)
+    // the last workgroup to finish opens the next launch's epoch (its stores are drained first: nothing of this launch can
+    // carry the new tag)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
         const unsigned d = __hip_atomic_fetch_add((gu32c*)(D.sync + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (d == gridDim.x - 1) {
-            __hip_atomic_store((gu32c*)D.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store((gu32c*)(D.sync + 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store((gu32c*)(D.sync + 3), epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -432,41 +516,56 @@ int chain_forward(var_ctx* c, hipStream_t s, arm_state* st, const float* P, cons
     ChainDesc D{};
     D.P = P; D.B = B; D.H = kRh; D.sync = st->sync;
     enum { A8, IMGF, POSE, GOAL, HXS, MASK, HOUT, VALUE, AFEAT, MEAN, CNN0, FLAT, M0, M1, MOTOR, S0, S1, SOUND, GH, IM0, X, F0, FUSION, GI, IMR,
-           ALL0, ALL1, C0, C1, A0, NBUF };
+           ALL0, ALL1, C0, C1, A0, AFT, NBUF };
     static_assert(NBUF <= kChainBufs, "buffer table");
     float* sc = st->chain;
-    auto scratch = [&](int width) { float* p = sc; sc += kChainRows * width; return p; };
+    auto scratch = [&](int width) { float* p = sc; sc += kChainRows * width * 2; return p; };     // (value, tag) pairs
     D.buf[A8] = st->a[8]; D.buf[IMGF] = (float*)image_feat; D.buf[POSE] = (float*)robot_pose; D.buf[GOAL] = (float*)goal;
     D.buf[HXS] = (float*)hxs; D.buf[MASK] = (float*)masks; D.buf[HOUT] = hxs_out; D.buf[VALUE] = value; D.buf[AFEAT] = actor_features;
     D.buf[MEAN] = action_mean ? action_mean : scratch(kActions);
     const int widths[][2] = {{CNN0, 512}, {FLAT, 256}, {M0, 256}, {M1, 512}, {MOTOR, 256}, {S0, 128}, {S1, 256}, {SOUND, 256}, {GH, 3 * kRh},
                              {IM0, 256}, {X, kRin}, {F0, 512}, {FUSION, 256}, {GI, 3 * kRh}, {IMR, 256}, {ALL0, 256}, {ALL1, 128}, {C0, 128},
-                             {C1, 128}, {A0, 128}};
-    for (auto& wd : widths) D.buf[wd[0]] = scratch(wd[1]);
+                             {C1, 128}, {A0, 128}, {AFT, kAct}};
+    for (auto& wd : widths) { D.buf[wd[0]] = scratch(wd[1]); D.tagged |= 1ull << wd[0]; }      // handed over inside the launch
     D.b_hxs = HXS; D.b_mask = MASK; D.b_hout = HOUT;
     int nj = 0, ns = 0;
     long lds_max = 0, lds_cur = 0;
     auto stage = [&]() { D.stage[ns].job0 = nj; D.stage[ns].njobs = 0; lds_cur = 0; return ns++; };
-    auto job = [&](const Lin& l, int kind, int in0, int in1, int cat0, int out, int relu) {
-        D.job[nj] = ChainJob{l.w, l.b, l.in, l.out, kind, in0, in1, cat0, out, relu, 0, 0};
+    auto job = [&](const Lin& l, int kind, int in0, int in1, int cat0, int out, int relu, int out2 = -1) {
+        D.job[nj] = ChainJob{l.w, l.b, l.in, l.out, kind, in0, in1, cat0, out, relu, 0, 0, out2};
         D.stage[ns - 1].njobs++;
         nj++;
         lds_cur = (long)kChainRows * ((l.in + 63) & ~63);              // a workgroup stages the input of ITS job only
         if (lds_cur > lds_max) lds_max = lds_cur;
     };
-    // workgroup ranges of a stage's jobs, proportional to their weight volume (every job at least one workgroup)
+    // Workgroup ranges of a stage's jobs.  What a stage costs is its slowest wave's chain of dependent weight fetches (a block
+    // of outputs = ceil(K / 512) batches of loads, ~2 us each from HBM; only a wave's first batch is requested ahead), NOT its
+    // weight volume: sized by volume, the two tiny first layers (K = 5 and 3) got one workgroup each and their 64 / 32 blocks
+    // took 35 us, a third of the whole chain, behind which everything else waited.  Greedy: every job starts with one
+    // workgroup, the job with the longest per-wave chain gets the next one.
     auto split = [&]() {
         ChainStage& S = D.stage[ns - 1];
-        double tot = 0;
-        for (int q = 0; q < S.njobs; ++q) tot += (double)D.job[S.job0 + q].K * D.job[S.job0 + q].N;
-        int left = kChainG, wg0 = 0;
+        auto chain_len = [&](const ChainJob& J, int nwg) {
+            const int blocks = (J.N + kChainNB - 1) / kChainNB, waves = nwg * (kChainT / 64);
+            return ((blocks + waves - 1) / waves) * ((J.K + 511) / 512);
+        };
+        int nwg[kChainMaxJobs] = {0};
+        for (int q = 0; q < S.njobs; ++q) nwg[q] = 1;
+        for (int left = kChainG - S.njobs; left > 0; --left) {
+            int worst = 0;
+            for (int q = 1; q < S.njobs; ++q) {
+                const int cq = chain_len(D.job[S.job0 + q], nwg[q]), cw = chain_len(D.job[S.job0 + worst], nwg[worst]);
+                // ties: the job with more weight per workgroup (bandwidth is the second-order cost)
+                if (cq > cw || (cq == cw && (double)D.job[S.job0 + q].K * D.job[S.job0 + q].N / nwg[q] >
+                                                (double)D.job[S.job0 + worst].K * D.job[S.job0 + worst].N / nwg[worst])) worst = q;
+            }
+            ++nwg[worst];
+        }
+        int wg0 = 0;
         for (int q = 0; q < S.njobs; ++q) {
             ChainJob& J = D.job[S.job0 + q];
-            int n = q + 1 == S.njobs ? left : (int)((double)J.K * J.N / tot * kChainG + 0.5);
-            if (n < 1) n = 1;
-            if (n > left - (S.njobs - 1 - q)) n = left - (S.njobs - 1 - q);
-            J.wg0 = wg0; J.nwg = n;
-            wg0 += n; left -= n;
+            J.wg0 = wg0; J.nwg = nwg[q];
+            wg0 += nwg[q];
         }
     };
     const Lin ih{L.g_wih, L.g_bih, kRin, 3 * kRh}, hh{L.g_whh, L.g_bhh, kRh, 3 * kRh};
@@ -491,12 +590,12 @@ int chain_forward(var_ctx* c, hipStream_t s, arm_state* st, const float* P, cons
     split();
     stage(); job(L.critic[0], IN_PLAIN, ALL1, -1, 0, C0, 1); job(L.actor[0], IN_PLAIN, ALL1, -1, 0, A0, 1);
     split();
-    stage(); job(L.critic[1], IN_PLAIN, C0, -1, 0, C1, 1); job(L.actor[1], IN_PLAIN, A0, -1, 0, AFEAT, 1);
+    stage(); job(L.critic[1], IN_PLAIN, C0, -1, 0, C1, 1); job(L.actor[1], IN_PLAIN, A0, -1, 0, AFT, 1, AFEAT);
     split();
-    stage(); job(L.clin, IN_PLAIN, C1, -1, 0, VALUE, 0); job(L.mean, IN_PLAIN, AFEAT, -1, 0, MEAN, 0);
+    stage(); job(L.clin, IN_PLAIN, C1, -1, 0, VALUE, 0); job(L.mean, IN_PLAIN, AFT, -1, 0, MEAN, 0);
     split();
     D.nstages = ns;
-    if (ns > kChainMaxStages || nj > kChainMaxJobs || sc - st->chain > kChainRows * 8192) {
+    if (ns > kChainMaxStages || nj > kChainMaxJobs || sc - st->chain > kChainRows * 16384) {
         VAR_SET_ERR(c, "armnet chain: table overflow");
         return VAR_ERR_ARG;
     }
@@ -550,7 +649,7 @@ int var_armnet_plan(var_ctx* c, int max_batch) {
     const long ot0 = take(B * 512), ot1 = take(B * 512), ot2 = take(B * 512), ot3 = take(B * 512);
     const long ofl = take(B * 256), omo = take(B * 256), osn = take(B * 256), ofu = take(B * 256), oh0 = take(B * kRh);
     const long ogi = take(B * 3 * kRh), ogh = take(B * 3 * kRh), oslab = take(kSlab);
-    const long ochain = take(kChainRows * 8192), osync = take(64);
+    const long ochain = take(kChainRows * 16384), osync = take(64);
     {
         c3f::PackDesc& d = st->pack;
         d.n_layers = 7;
@@ -573,7 +672,12 @@ int var_armnet_plan(var_ctx* c, int max_batch) {
     st->gi = w + ogi; st->gh = w + ogh; st->slab = w + oslab;
     st->chain = w + ochain; st->sync = (unsigned*)(w + osync);
     st->wpk = (c3f::f32x4*)(w + owpk);
-    VAR_HIP_CHECK(c, hipMemset(st->sync, 0, 64 * sizeof(float)));
+    VAR_HIP_CHECK(c, hipMemset(st->chain, 0, (size_t)kChainRows * 16384 * sizeof(float)));       // no tag of any launch yet
+    {
+        const unsigned init[4] = {0u, 0u, 0u, 1u};                  // [3]: the first launch's epoch
+        VAR_HIP_CHECK(c, hipMemset(st->sync, 0, 64 * sizeof(float)));
+        VAR_HIP_CHECK(c, hipMemcpy(st->sync, init, sizeof(init), hipMemcpyHostToDevice));
+    }
     return VAR_OK;
 }
 
