@@ -213,10 +213,18 @@ __global__ void __launch_bounds__(kChainT) armnet_chain_kernel(ChainDesc D) {
         dead_s = 1;
     };
     ChainJob J = job_of(0);
-    prefetch(J);
+    bool mine = (int)blockIdx.x < J.wg0 + J.nwg;          // a stage may leave workgroups without a job (see split())
+    if (mine) prefetch(J);
     __syncthreads();
 #pragma unroll 1
     for (int si = 0; si < D.nstages; ++si) {
+        if (!mine) {                                      // (workgroup-uniform; nothing to wait for: stages are not fenced)
+            if (si + 1 == D.nstages) break;
+            J = job_of(si + 1);
+            mine = (int)blockIdx.x < J.wg0 + J.nwg;
+            if (mine) prefetch(J);
+            continue;
+        }
         PHR(0);
         const int Kp = (J.K + 63) & ~63;
         float* xs = lds;          // two input buffers: the next stage is staged while slow waves still read this one
@@ -449,7 +457,8 @@ __global__ void __launch_bounds__(kChainT) armnet_chain_kernel(ChainDesc D) {
         PHR(3);
         if (si + 1 == D.nstages) break;
         J = job_of(si + 1);
-        prefetch(J);                                                // (in flight while the next input is polled)
+        mine = (int)blockIdx.x < J.wg0 + J.nwg;
+        if (mine) prefetch(J);                                      // (in flight while the next input is polled)
         __syncthreads();
         PHR(4);
     }
@@ -551,9 +560,17 @@ int chain_forward(var_ctx* c, hipStream_t s, arm_state* st, const float* P, cons
         };
         int nwg[kChainMaxJobs] = {0};
         for (int q = 0; q < S.njobs; ++q) nwg[q] = 1;
+        // (a job is never given more waves than it has blocks: an extra workgroup would only poll and stage the input once more
+        //  -- the GRU stage's 196 KB per workgroup -- and the leftover workgroups skip the stage)
+        auto full = [&](int q) { return nwg[q] * (kChainT / 64) >= (D.job[S.job0 + q].N + kChainNB - 1) / kChainNB; };
         for (int left = kChainG - S.njobs; left > 0; --left) {
-            int worst = 0;
-            for (int q = 1; q < S.njobs; ++q) {
+            bool any = false;
+            for (int q = 0; q < S.njobs; ++q) any = any || !full(q);
+            if (!any) break;
+            int worst = -1;
+            for (int q = 0; q < S.njobs; ++q) {
+                if (full(q)) continue;
+                if (worst < 0) { worst = q; continue; }
                 const int cq = chain_len(D.job[S.job0 + q], nwg[q]), cw = chain_len(D.job[S.job0 + worst], nwg[worst]);
                 // ties: the job with more weight per workgroup (bandwidth is the second-order cost)
                 if (cq > cw || (cq == cw && (double)D.job[S.job0 + q].K * D.job[S.job0 + q].N / nwg[q] >
