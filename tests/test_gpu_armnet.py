@@ -141,3 +141,53 @@ def test_band_convolutions_equal_the_gather_gemm_path(var_amd, fx):
     v4, a4, _, h4 = m.act({k: v[:8].contiguous() for k, v in big.items()}, hxs[:8].contiguous(), masks[:8].contiguous(), deterministic=True)
     for got, want in ((v3, v4), (a3, a4), (h3, h4)):
         np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=0, atol=2e-5)
+
+
+def test_replayed_forward_is_stable_and_sees_new_inputs_and_weights(var_amd, fx):
+    """The chain's workgroups hand vectors over as (value, epoch) pairs and poll their inputs: the epoch lives on the device
+    because a captured graph replays with frozen arguments.  200 replays of one captured forward must return the first replay's
+    bits every time (a stale pair accepted once would show), follow the static input buffers when they change, and follow the
+    parameters when they change in place (the filters are re-packed inside every forward)."""
+    ref = armnet_seeded(int(fx["seed"]))
+    m = make(var_amd, ref)
+    obs = {k: v.clone() for k, v in obs_of(fx, True).items()}
+    hxs, masks = cuda(fx['rnn_hxs']).clone(), cuda(fx['masks']).clone()
+    eager = [t.clone() for t in m._base_forward(obs, hxs, masks)]
+    g = var_amd._lib.new_graph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        m._base_forward(obs, hxs, masks)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=side):
+            outs = m._base_forward(obs, hxs, masks)
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    first = [t.clone() for t in outs]
+    for a, b in zip(first, eager):
+        assert torch.equal(a, b)
+    for i in range(200):
+        g.replay()
+        if i % 50 == 49:
+            torch.cuda.synchronize()
+            for a, b in zip(outs, first):
+                assert torch.equal(a, b), f"replay {i}"
+    # new inputs through the same static buffers
+    obs['robot_pose'].add_(0.25)
+    obs['image'].copy_(torch.flip(obs['image'], dims=[3]))
+    want = [t.clone() for t in m._base_forward(obs, hxs, masks)]
+    g.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(outs, want):
+        assert torch.equal(a, b)
+    assert not torch.equal(outs[0], first[0])
+    # parameters changed in place (a PPO update between two acting steps)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.01)
+    want = [t.clone() for t in m._base_forward(obs, hxs, masks)]
+    g.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(outs, want):
+        assert torch.equal(a, b)
