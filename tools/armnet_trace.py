@@ -45,14 +45,14 @@ def show(d, n_avg=40):
     steps = [rows[a + 1:b + 1] for a, b in zip(ends[:-1], ends[1:])][-n_avg:]
     steps = [st for st in steps if len(st) == len(steps[-1])]
     k = len(steps[-1])
-    mean = lambda xs: sum(xs) / len(xs)
+    mean = lambda xs: sorted(xs)[len(xs) // 2]           # the median: a replay that waited for the profiler's flush does not count
     start = [mean([(int(st[i]["Start_Timestamp"]) - int(st[0]["Start_Timestamp"])) / 1e3 for st in steps]) for i in range(k)]
     dur = [mean([(int(st[i]["End_Timestamp"]) - int(st[i]["Start_Timestamp"])) / 1e3 for st in steps]) for i in range(k)]
     for i in range(k):
         r = steps[-1][i]
         print(f"{start[i]:8.1f} {dur[i]:7.1f}  grid {r.get('Grid_Size_X', '?'):>7}x{r.get('Grid_Size_Y', '?')}x{r.get('Grid_Size_Z', '?')}  {r['Kernel_Name'][:110]}")
     span = mean([(int(st[-1]["End_Timestamp"]) - int(st[0]["Start_Timestamp"])) / 1e3 for st in steps])
-    print(f"span {span:.1f} us, {k} launches (mean of the last {len(steps)} replays)")
+    print(f"span {span:.1f} us, {k} launches (medians of the last {len(steps)} replays)")
 
 
 if __name__ == "__main__":
