@@ -425,21 +425,38 @@ __global__ void __launch_bounds__(kChainT) armnet_chain_kernel(ChainDesc D) {
 #pragma unroll
                     for (int r = 0; r < kChainRows; ++r) v[o * kChainRows + r] = acc[o][r];
                 // (each step with compile-time constants: a loop over (half, bit) is not unrolled by hipcc, and the array then
-                //  becomes 32-way select chains -- 6 K instructions)
-#define CHAIN_FOLD(HALF, BIT)                                                                         \
+                //  becomes 32-way select chains -- 6 K instructions.)  The two wide steps are gfx950's lane-swap instructions
+                //  (v_permlane32_swap: lanes 32-63 of one register <-> lanes 0-31 of the other, v_permlane16_swap the same for the odd /
+                //  even 16-lane rows): a step is one swap + one add per pair instead of two selects + a ds_bpermute + an add; xor 8 / 2 / 1
+                //  are DPP moves (row_ror:8, quad_perm); only the two xor-4 exchanges go through the LDS crossbar.
+                const auto fb = [](float x) { return __builtin_bit_cast(unsigned, x); };
+                const auto bf = [](unsigned x) { return __builtin_bit_cast(float, x); };
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { const auto q = __builtin_amdgcn_permlane32_swap(fb(v[i]), fb(v[i + 16]), false, false); v[i] = bf(q[0]) + bf(q[1]); }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const auto q = __builtin_amdgcn_permlane16_swap(fb(v[i]), fb(v[i + 8]), false, false); v[i] = bf(q[0]) + bf(q[1]); }
+#define CHAIN_FOLD(HALF, BIT, XCHG)                                                                   \
                 {                                                                                     \
                     const bool up = (lane & (BIT)) != 0;                                              \
                     _Pragma("unroll") for (int i = 0; i < (HALF); ++i) {                             \
                         const float keep = up ? v[i + (HALF)] : v[i], give = up ? v[i] : v[i + (HALF)]; \
-                        v[i] = keep + __shfl_xor(give, (BIT), 64);                                   \
+                        v[i] = keep + XCHG(give);                                                     \
                     }                                                                                 \
                 }
+#define X_ROR8(x) bf((unsigned)__builtin_amdgcn_update_dpp(0, (int)fb(x), 0x128, 0xf, 0xf, false))
+#define X_XOR4(x) __shfl_xor(x, 4, 64)
+#define X_XOR2(x) bf((unsigned)__builtin_amdgcn_update_dpp(0, (int)fb(x), 0x4e, 0xf, 0xf, false))
+#define X_XOR1(x) bf((unsigned)__builtin_amdgcn_update_dpp(0, (int)fb(x), 0xb1, 0xf, 0xf, false))
+                CHAIN_FOLD(4, 8, X_ROR8) CHAIN_FOLD(2, 4, X_XOR4) CHAIN_FOLD(1, 2, X_XOR2)
                 float sum;
                 int o, r;
                 bool writer;
-                CHAIN_FOLD(16, 32) CHAIN_FOLD(8, 16) CHAIN_FOLD(4, 8) CHAIN_FOLD(2, 4) CHAIN_FOLD(1, 2)
-                sum = v[0] + __shfl_xor(v[0], 1, 64);
+                sum = v[0] + X_XOR1(v[0]);
                 o = lidx / kChainRows; r = lidx % kChainRows; writer = (lane & 1) == 0;
+#undef X_ROR8
+#undef X_XOR4
+#undef X_XOR2
+#undef X_XOR1
 #undef CHAIN_FOLD
                 first = false;
                 if (writer && o0 + o < J.N) {
