@@ -101,6 +101,11 @@ int var_arm_encoder_fwd(var_ctx* ctx, void* stream, const float* params,
                         float* image_feat, float* pos_feat, float* neg_feat,
                         float* image_raw, float* pos_raw, int save_for_bwd);
 
+/* out[r] = sum_k a[r][k] * b[r][k], rows x dim f32 (dim <= 64): the intrinsic reward <image_feat, goal_sound_feat> of
+ * Envs/vec_env/vec_pretext_normalize.py:96-101 (`calcReward`: torch.sum(a * b, dim=1)) as ONE launch on `stream`; the sum
+ * runs over k in index order in fp32. */
+int var_row_dot(var_ctx* ctx, void* stream, const float* a, const float* b, int rows, int dim, float* out);
+
 /* autograd backward of the encoder (loss.backward(), VAR/pretext_VAR.py:68) from the
  * gradients of the three embeddings; writes d(loss)/d(param) for all 213478
  * parameters into `grads` (overwrites; arena layout).  Any g_* may be NULL (= zeros). */

@@ -45,6 +45,7 @@ _SIGNATURES = {
     "var_pack_weights": (_i, [_vp, _vp, _vp]),
     "var_arm_encoder_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i]),
     "var_arm_encoder_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "var_row_dot": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "var_triplet_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp]),
     "var_arm_loss_grad": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
     "var_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i]),

@@ -341,15 +341,15 @@ int var_arm_encoder_fwd(var_ctx* c, void* stream, const float* params, const voi
     SET_DEVICE(c);
     hipStream_t s = (hipStream_t)stream;
     c->fwd_only = save_for_bwd == 2;                // inference with the small-batch kernels (img_conv_fwd.hip)
+    // the normalised embeddings go to the caller's buffers from the heads' finish kernels themselves
+    c->out_img = image ? image_feat : nullptr; c->out_pos = mfcc_pos ? pos_feat : nullptr; c->out_neg = mfcc_neg ? neg_feat : nullptr;
     rc = encoder_fwd(c, s, params, image, image_is_u8, image_bstride, nullptr, mfcc_pos, mfcc_neg, nullptr, B);
     c->fwd_only = false;
+    c->out_img = c->out_pos = c->out_neg = nullptr;
     if (rc != VAR_OK) return rc;
     if (save_for_bwd != 1) c->saved_B = 0;
     CopySegs S{};
     auto seg = [&](float* dst, const float* src, int n) { S.dst[S.count] = dst; S.src[S.count] = src; S.n[S.count] = n; S.count++; };
-    if (image && image_feat) seg(image_feat, c->emb, 3 * B);
-    if (mfcc_pos && pos_feat) seg(pos_feat, c->emb + 3 * B, 3 * B);
-    if (mfcc_neg && neg_feat) seg(neg_feat, c->emb + 6 * B, 3 * B);
     if (image && image_raw) seg(image_raw, c->act[5], kImgFeat * B);
     if (mfcc_pos && pos_raw) seg(pos_raw, c->sact[4], kSndFeat * B);
     if (S.count) {
@@ -357,6 +357,24 @@ int var_arm_encoder_fwd(var_ctx* c, void* stream, const float* params, const voi
         hipLaunchKernelGGL(copy_out_kernel, dim3(grid < 1024 ? grid : 1024), dim3(256), 0, s, S);
         VAR_HIP_CHECK(c, hipGetLastError());
     }
+    return VAR_OK;
+}
+
+__global__ void __launch_bounds__(256) row_dot_kernel(const float* __restrict__ a, const float* __restrict__ b, int rows, int dim,
+                                                      float* __restrict__ out) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    float s = 0.f;
+    for (int k = 0; k < dim; ++k) s += a[(size_t)r * dim + k] * b[(size_t)r * dim + k];
+    out[r] = s;
+}
+
+int var_row_dot(var_ctx* c, void* stream, const float* a, const float* b, int rows, int dim, float* out) {
+    CHECK_CTX(c);
+    if (!a || !b || !out || rows < 1 || dim < 1 || dim > 64) { VAR_SET_ERR(c, "var_row_dot: bad argument (rows %d, dim %d)", rows, dim); return VAR_ERR_ARG; }
+    SET_DEVICE(c);
+    hipLaunchKernelGGL(row_dot_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, b, rows, dim, out);
+    VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }
 

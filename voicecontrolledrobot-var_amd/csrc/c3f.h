@@ -311,41 +311,66 @@ int launch(var_ctx* c, hipStream_t s, const float* x, const f32x4* wp, const flo
     return VAR_OK;
 }
 
-// ---- the two last layers of the stack (conv 7: 128 -> 256, 3x3 stride 2 pad 0, 12x12 -> 5x5; conv 8: 256 -> 128, 3x3, 5x5 -> 3x3):
-// a quarter of a GFLOP, 2.4 MB of filter.  A workgroup = (image, 16 output channels): the image's input (<= 74 KB) is staged in
-// LDS, the four waves split K (16-channel groups dealt round-robin), every wave requests ALL of its filter share before the
-// staging (<= 36 16-byte loads in flight per lane), the four partial tiles are folded through LDS in wave order.  Replaces a
-// split-K gather-GEMM launch and its finish launch per layer.
-template <int CIN_, int COUT_, int HIN_, int S_, int HOUT_>
+// ---- small convolutions of a small batch: the actor-critic's two last layers (conv 7: 128 -> 256, 3x3 stride 2 pad 0, 12x12 ->
+// 5x5; conv 8: 256 -> 128, 3x3, 5x5 -> 3x3: a quarter of a GFLOP, 2.4 MB of filter) and conv 3..5 of the Kuka encoder when it runs
+// frozen on the RL stage's 8 images (3x3 stride 2 pad 1, 21 -> 11 -> 6 -> 3).  A workgroup = (image, 16 output channels): the
+// image's input (<= 74 KB, zero halo for PAD = 1) is staged in LDS, the four waves split K in 16-channel groups (WK ways) and the
+// pixel blocks (4 / WK ways), every wave requests ALL of its filter share before the staging (<= 36 loads in flight per lane;
+// RAW: read in place from the state_dict() layout, four 4-byte loads instead of one packed 16-byte load), the WK partial tiles
+// are folded through LDS in wave order.  Replaces a split-K gather-GEMM launch + finish per layer (actor-critic) / the
+// one-workgroup-per-image conv 3-5 kernel whose time is the per-image latency (frozen encoder: 34 us at 8 images).
+template <int CIN_, int COUT_, int HIN_, int S_, int HOUT_, int PAD_ = 0, bool RAW_ = false>
 struct SmallCfg {
-    static constexpr int CIN = CIN_, COUT = COUT_, HIN = HIN_, S = S_, HOUT = HOUT_;
-    static constexpr int NPX = HOUT * HOUT, NPB = (NPX + 15) / 16, KG = CIN / 16, KGW = KG / 4;
-    static constexpr int PL0 = HIN * HIN, PL = PL0 + (48 - PL0 % 32) % 32;       // == 16 (mod 32)
+    static constexpr int CIN = CIN_, COUT = COUT_, HIN = HIN_, S = S_, HOUT = HOUT_, PAD = PAD_;
+    static constexpr bool RAW = RAW_;
+    static constexpr int NPX = HOUT * HOUT, NPBT = (NPX + 15) / 16, KG = CIN / 16;
+    static constexpr int WK = KG >= 4 ? 4 : KG, WP = 4 / WK;              // waves along K / along the pixel blocks
+    static constexpr int KGW = KG / WK, NPB = (NPBT + WP - 1) / WP;
+    static constexpr int HP = HIN + 2 * PAD;                               // padded input side
+    static constexpr int PL0 = HP * HP, PL = PL0 + (48 - PL0 % 32) % 32;   // == 16 (mod 32)
     static constexpr int IMG = CIN * PL, RED = 4 * NPB * 4 * 64;
     static constexpr int LDSF = IMG + RED;
-    static_assert(KG % 4 == 0 && COUT % 16 == 0 && (CIN * PL0) % 4 == 0 && LDSF * 4 <= 160 * 1024, "small conv shape");
-    static_assert((HOUT - 1) * S + 3 <= HIN, "valid convolution (no padding)");
+    static_assert(KG % WK == 0 && 4 % WK == 0 && COUT % 16 == 0 && LDSF * 4 <= 160 * 1024, "small conv shape");
+    static_assert((HOUT - 1) * S + 3 <= HP, "taps stay inside the (padded) input");
 };
 
 template <class C>
-__global__ void __launch_bounds__(256) c3s_kernel(const float* __restrict__ x, const f32x4* __restrict__ wp, const float* __restrict__ bias,
+__global__ void __launch_bounds__(256) c3s_kernel(const float* __restrict__ x, const void* __restrict__ wsrc, const float* __restrict__ bias,
                                                  float* __restrict__ y, int B) {
     constexpr int CIN = C::CIN, COUT = C::COUT, HIN = C::HIN, S = C::S, HOUT = C::HOUT, NPX = C::NPX, NPB = C::NPB, KG = C::KG, PL = C::PL;
+    constexpr int HP = C::HP, PAD = C::PAD, WK = C::WK;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* red = lds + C::IMG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lk = lane >> 4;
     const int b = blockIdx.x % B, cb = blockIdx.x / B;
-    // this wave's share of the filter: groups kg = wave, wave + 4, ...
+    const int wk = wave % WK, wp = wave / WK;
+    // this wave's share of the filter: groups kg = wk, wk + WK, ...
     f32x4 a[C::KGW][9];
-    const f32x4* wa = wp + (size_t)cb * KG * 576 + lane;
+    if (C::RAW) {
+        const float* w = (const float*)wsrc + ((long)(16 * cb + l15) * CIN + lk) * 9;
 #pragma unroll
-    for (int g = 0; g < C::KGW; ++g)
+        for (int g = 0; g < C::KGW; ++g)
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) a[g][tap] = wa[((wave + 4 * g) * 9 + tap) * 64];
-    // the image -> LDS [channel][PL]
+            for (int tap = 0; tap < 9; ++tap) {
+                const float* q = w + (16 * (wk + WK * g)) * 9 + tap;
+                a[g][tap] = f32x4{q[0], q[4 * 9], q[8 * 9], q[12 * 9]};
+            }
+    } else {
+        const f32x4* wa = (const f32x4*)wsrc + (size_t)cb * KG * 576 + lane;
+#pragma unroll
+        for (int g = 0; g < C::KGW; ++g)
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) a[g][tap] = wa[((wk + WK * g) * 9 + tap) * 64];
+    }
+    // the image -> LDS [channel][PL] (padded side HP; the halo is zeroed first)
+    if (PAD) {
+        for (int e = tid; e < CIN * C::PL0; e += 256) { const int ch = e / C::PL0; lds[ch * PL + (e - ch * C::PL0)] = 0.f; }
+        __syncthreads();
+    }
     {
-        constexpr int N4 = CIN * C::PL0 / 4;
-        const float4* src = (const float4*)(x + (size_t)b * CIN * C::PL0);
+        constexpr int P0 = HIN * HIN, N4 = CIN * P0 / 4;
+        static_assert((CIN * P0) % 4 == 0, "16-byte loads over an image");
+        const float4* src = (const float4*)(x + (size_t)b * CIN * P0);
 #pragma unroll 1
         for (int e0 = tid; e0 < N4; e0 += 256 * 8) {
             float4 v[8];
@@ -358,8 +383,8 @@ __global__ void __launch_bounds__(256) c3s_kernel(const float* __restrict__ x, c
                     const float t[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int idx = 4 * e + q, ch = idx / C::PL0, pos = idx - ch * C::PL0;
-                        lds[ch * PL + pos] = t[q];
+                        const int idx = 4 * e + q, ch = idx / P0, pos = idx - ch * P0, yy = pos / HIN, xx = pos - yy * HIN;
+                        lds[ch * PL + (yy + PAD) * HP + xx + PAD] = t[q];
                     }
                 }
             }
@@ -368,10 +393,10 @@ __global__ void __launch_bounds__(256) c3s_kernel(const float* __restrict__ x, c
     int va[NPB];
 #pragma unroll
     for (int i = 0; i < NPB; ++i) {
-        int p = i * 16 + l15;
+        int p = (wp * NPB + i) * 16 + l15;
         p = p < NPX ? p : NPX - 1;
         const int oy = p / HOUT, ox = p - oy * HOUT;
-        va[i] = lk * PL + oy * S * HIN + ox * S;
+        va[i] = lk * PL + oy * S * HP + ox * S;
     }
     f32x4 acc[NPB];
 #pragma unroll
@@ -379,7 +404,7 @@ __global__ void __launch_bounds__(256) c3s_kernel(const float* __restrict__ x, c
     __syncthreads();
 #pragma unroll
     for (int g = 0; g < C::KGW; ++g) {
-        const float* xk = lds + (wave + 4 * g) * 16 * PL;
+        const float* xk = lds + (wk + WK * g) * 16 * PL;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap - 3 * dy;
@@ -387,7 +412,7 @@ __global__ void __launch_bounds__(256) c3s_kernel(const float* __restrict__ x, c
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int i = 0; i < NPB; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][tap][j], xk[va[i] + 4 * j * PL + dy * HIN + dx], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][tap][j], xk[va[i] + 4 * j * PL + dy * HP + dx], acc[i], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -395,10 +420,13 @@ __global__ void __launch_bounds__(256) c3s_kernel(const float* __restrict__ x, c
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[((wave * NPB + i) * 4 + r) * 64 + lane] = acc[i][r];
     __syncthreads();
-    for (int e = tid; e < NPB * 4 * 64; e += 256) {
-        const int l = e & 63, r = (e >> 6) & 3, i = e >> 8;
-        const float sum = ((red[e] + red[NPB * 256 + e]) + red[2 * NPB * 256 + e]) + red[3 * NPB * 256 + e];
-        const int co = 16 * cb + 4 * (l >> 4) + r, px = i * 16 + (l & 15);
+    // fold the WK partial tiles of a pixel block (waves wp * WK .. + WK - 1) in wave order
+    for (int e = tid; e < C::WP * NPB * 4 * 64; e += 256) {
+        const int l = e & 63, r = (e >> 6) & 3, i = (e >> 8) % NPB, wq = e / (256 * NPB);
+        float sum = red[(((wq * WK) * NPB + i) * 4 + r) * 64 + l];
+#pragma unroll
+        for (int k = 1; k < WK; ++k) sum += red[(((wq * WK + k) * NPB + i) * 4 + r) * 64 + l];
+        const int co = 16 * cb + 4 * (l >> 4) + r, px = (wq * NPB + i) * 16 + (l & 15);
         if (px < NPX) {
             const float v = sum + bias[co];
             y[((size_t)b * COUT + co) * NPX + px] = v > 0.f ? v : 0.f;
@@ -407,13 +435,13 @@ __global__ void __launch_bounds__(256) c3s_kernel(const float* __restrict__ x, c
 }
 
 template <class C>
-int launch_small(var_ctx* c, hipStream_t s, const float* x, const f32x4* wp, const float* bias, float* y, int B) {
+int launch_small(var_ctx* c, hipStream_t s, const float* x, const void* wsrc, const float* bias, float* y, int B) {
     static bool attr = false;
     if (!attr) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)c3s_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDSF * 4));
         attr = true;
     }
-    hipLaunchKernelGGL(c3s_kernel<C>, dim3(B * (C::COUT / 16)), dim3(256), C::LDSF * 4, s, x, wp, bias, y, B);
+    hipLaunchKernelGGL(c3s_kernel<C>, dim3(B * (C::COUT / 16)), dim3(256), C::LDSF * 4, s, x, wsrc, bias, y, B);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }

@@ -383,7 +383,7 @@ heads_fwd_split_kernel(const float* __restrict__ x, int R, const float* __restri
 // emb_raw = b1 + ((part0 + part1) + (part2 + part3)); emb = emb_raw / max(||emb_raw||, 1e-12)
 __global__ void __launch_bounds__(256)
 heads_finish_kernel(const float* __restrict__ part, const float* __restrict__ b1, int R, float* __restrict__ emb_raw,
-                    float* __restrict__ emb) {
+                    float* __restrict__ emb, float* __restrict__ out0, float* __restrict__ out1, int split) {
     const int row = blockIdx.x * 256 + threadIdx.x;
     if (row >= R) return;
     const float4* p = (const float4*)(part + (size_t)row * 16);
@@ -395,12 +395,15 @@ heads_finish_kernel(const float* __restrict__ part, const float* __restrict__ b1
     const float den = nrm > 1e-12f ? nrm : 1e-12f;
     emb_raw[row * 3 + 0] = a; emb_raw[row * 3 + 1] = b; emb_raw[row * 3 + 2] = c;
     emb[row * 3 + 0] = a / den; emb[row * 3 + 1] = b / den; emb[row * 3 + 2] = c / den;
+    // the caller's copy of the normalised embedding (var_arm_encoder_fwd): rows [0, split) -> out0, the rest -> out1
+    float* o = row < split ? (out0 ? out0 + 3 * row : nullptr) : (out1 ? out1 + 3 * (row - split) : nullptr);
+    if (o) { o[0] = a / den; o[1] = b / den; o[2] = c / den; }
 }
 
 template <int K>
 static int run_heads_fwd(var_ctx* c, hipStream_t s, const float* x, int R, const float* w0t, const float* b0,
                          const float* w1, const float* b1, float* hid, float* emb_raw, float* emb, float* part,
-                         bool finish) {
+                         bool finish, float* out0 = nullptr, float* out1 = nullptr, int split = 0) {
     constexpr int A1 = 32 * (K + 1) * 4, A2 = 5 * 32 * 33 * 4;
     constexpr int LDS_BYTES = A1 > A2 ? A1 : A2;
     static bool attr_set = false;
@@ -410,7 +413,7 @@ static int run_heads_fwd(var_ctx* c, hipStream_t s, const float* x, int R, const
         attr_set = true;
     }
     hipLaunchKernelGGL(heads_fwd_split_kernel<K>, dim3((R + 31) / 32, 4), dim3(256), LDS_BYTES, s, x, R, w0t, b0, w1, hid, part);
-    if (finish) hipLaunchKernelGGL(heads_finish_kernel, dim3((R + 255) / 256), dim3(256), 0, s, part, b1, R, emb_raw, emb);
+    if (finish) hipLaunchKernelGGL(heads_finish_kernel, dim3((R + 255) / 256), dim3(256), 0, s, part, b1, R, emb_raw, emb, out0, out1, split);
     return VAR_OK;
 }
 
@@ -422,18 +425,19 @@ int launch_heads_fwd(var_ctx* c, hipStream_t s, hipStream_t ss, const float* par
     if (has_img && c->head_in_mid) {
         // the fused conv 3-5 kernel already left hid_i and the 128 -> 3 partials of every image
         if (finish) hipLaunchKernelGGL(heads_finish_kernel, dim3((B + 255) / 256), dim3(256), 0, s, c->head_part,
-                                       params + L.ih_b1, B, c->emb_raw, c->emb);
+                                       params + L.ih_b1, B, c->emb_raw, c->emb, c->out_img, (float*)nullptr, B);
     } else if (has_img) {
         ProfScope prof(c, s, TAG_HEADS_FWD);
         if ((rc = run_heads_fwd<kImgFeat>(c, s, c->act[5], B, c->wpack + K.ih_w0t, params + L.ih_b0, params + L.ih_w1,
-                                          params + L.ih_b1, c->hid_i, c->emb_raw, c->emb, c->head_part, finish)) != VAR_OK) return rc;
+                                          params + L.ih_b1, c->hid_i, c->emb_raw, c->emb, c->head_part, finish, c->out_img, nullptr, B)) != VAR_OK) return rc;
     }
     if (has_pos || has_neg) {
         const int lo = has_pos ? 0 : B, hi = has_neg ? 2 * B : B;
         if ((rc = run_heads_fwd<kSndFeat>(c, ss, c->sact[4] + (size_t)lo * kSndFeat, hi - lo, c->wpack + K.sh_w0t,
                                           params + L.sh_b0, params + L.sh_w1, params + L.sh_b1,
                                           c->hid_s + (size_t)lo * kHid, c->emb_raw + 3 * (B + lo),
-                                          c->emb + 3 * (B + lo), c->head_part + 16 * (size_t)(B + lo), finish)) != VAR_OK) return rc;
+                                          c->emb + 3 * (B + lo), c->head_part + 16 * (size_t)(B + lo), finish,
+                                          lo == 0 ? c->out_pos : nullptr, c->out_neg, lo == 0 ? B : 0)) != VAR_OK) return rc;
     }
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;

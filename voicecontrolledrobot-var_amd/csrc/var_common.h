@@ -149,6 +149,8 @@ struct var_ctx {
     int prof_n = 0;               // pairs recorded since select
     hipEvent_t* prof_ev = nullptr;
     // saved forward
+    // var_arm_encoder_fwd's embedding outputs: the finish kernels of the heads write them directly (no copy launch afterwards)
+    float *out_img = nullptr, *out_pos = nullptr, *out_neg = nullptr;
     bool head_in_mid = false;             // the last image forward also ran the image head (img_fwd_mid.hip)
     int saved_B = 0;
     const void* saved_image = nullptr;

@@ -111,7 +111,9 @@ class IntrinsicReward:
                                               self._img.stride(0), ptr(self._goal) if with_goal else None, None, B, hw,
                                               ptr(self._image_feat), ptr(self._goal_feat) if with_goal else None,
                                               None, None, None, 2), "var_arm_encoder_fwd")      # 2: inference, small-batch kernels
-            torch.sum(self._image_feat * self._goal_feat, dim=1, out=self._reward)    # <image_feat, goal_feat>
+            # <image_feat, goal_feat> (calcReward's torch.sum(a * b, dim=1): one launch instead of a product and a reduction)
+            c.check(c.lib.var_row_dot(c.handle, current_stream_handle(), ptr(self._image_feat), ptr(self._goal_feat), B,
+                                      self._image_feat.shape[1], ptr(self._reward)), "var_row_dot")
 
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
