@@ -64,3 +64,23 @@ def test_intrinsic_reward_on_hip_encoder(golden_dir):
     assert np.max(np.abs(dot1.cpu().numpy() - fx["d.reward"])) < 1e-4
     f2, g2, dot2 = r.step(torch.from_numpy(img).cuda(), None)
     assert np.array_equal(f2.cpu().numpy(), f1.cpu().numpy()) and np.array_equal(g2.cpu().numpy(), goal_feat)
+
+
+@pytest.mark.gpu
+def test_row_dot_is_calc_reward_and_rejects_bad_arguments():
+    """var_row_dot = calcReward's torch.sum(a * b, dim=1) (vec_pretext_normalize.py:96-101) in one launch."""
+    import torch
+    import var_amd
+    from var_amd._lib import Context, VarHipError, current_stream_handle, ptr
+    c = Context.get(0)
+    g = torch.Generator().manual_seed(3)
+    for rows, dim in ((8, 3), (300, 3), (5, 64)):
+        a, b = torch.randn(rows, dim, generator=g).cuda(), torch.randn(rows, dim, generator=g).cuda()
+        out = torch.empty(rows, device="cuda")
+        c.check(c.lib.var_row_dot(c.handle, current_stream_handle(), ptr(a), ptr(b), rows, dim, ptr(out)), "var_row_dot")
+        want = (a.double() * b.double()).sum(1)
+        np.testing.assert_allclose(out.cpu().numpy(), want.cpu().numpy(), rtol=0, atol=1e-6 * dim)
+    with pytest.raises(VarHipError):
+        c.check(c.lib.var_row_dot(c.handle, current_stream_handle(), ptr(a), ptr(b), 5, 65, ptr(out)), "var_row_dot")
+    with pytest.raises(VarHipError):
+        c.check(c.lib.var_row_dot(c.handle, current_stream_handle(), None, ptr(b), 5, 3, ptr(out)), "var_row_dot")
