@@ -283,7 +283,12 @@ int var_allgather_emb(var_ctx* ctx, void* stream, const float* local, float* glo
  * fusionMlp, mlp_all, actor, critic, critic_linear, dist.fc_mean, dist.logstd._bias): var_armnet_param_count() floats.
  *   image (B,3,96,96) u8 (divided by 255) or f32; image_feat (B,3), robot_pose (B,2), goal_sound_feat (B,3),
  *   rnn_hxs (B,512), masks (B,1)  ->  value (B,1), actor_features (B,128), action_mean (B,2, may be NULL),
- *   rnn_hxs_out (B,512).  Sampling / log-probabilities (a handful of flops) stay with the caller. */
+ *   rnn_hxs_out (B,512).  Sampling / log-probabilities (a handful of flops) stay with the caller.
+ * Kernel paths (same results within 2e-5): B <= 64 images run the convolutions on LDS-band kernels with the pools fused, the
+ * filters re-packed inside the first launch of every call (parameters updated in place between two calls are picked up);
+ * B <= 8 rows (the RL stage's envs) run the 22 Linear layers + GRU step as one persistent launch whose workgroups hand their
+ * vectors over as (value, epoch) pairs -- it needs its 128 workgroups co-resident; if they are not, every wait times out
+ * (bounded) and the outputs are NaN.  Captured into a HIP graph the call replays as 9 kernel nodes. */
 int var_armnet_param_count(void);
 int var_armnet_plan(var_ctx* ctx, int max_batch);
 int var_armnet_forward(var_ctx* ctx, void* stream, const float* params, const void* image, int image_is_u8,
