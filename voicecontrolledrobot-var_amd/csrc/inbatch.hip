@@ -69,9 +69,26 @@ __global__ void __launch_bounds__(256) inbatch_rows_kernel(const float* __restri
 }
 
 // columns: gradient wrt candidate j from the B local rows (partial under data parallelism)
+// (the block after the last column block adds the row losses up in a fixed order: the sum only needs the rows kernel, and a
+//  launch of its own cost 6 us on the step's critical path)
+__device__ __forceinline__ void inbatch_loss_sum(const float* __restrict__ rowloss, int B, float* __restrict__ out) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < B; i += 256) acc += rowloss[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
 __global__ void __launch_bounds__(256) inbatch_cols_kernel(const float* __restrict__ a, const float* __restrict__ cand,
                                                           const int* __restrict__ target, const float* __restrict__ lse, int B,
-                                                          int M, float inv_tau, float inv_count, float* __restrict__ gc) {
+                                                          int M, float inv_tau, float inv_count, float* __restrict__ gc,
+                                                          const float* __restrict__ rowloss, float* __restrict__ loss_out) {
+    if ((int)blockIdx.x == (M + 3) / 4) { inbatch_loss_sum(rowloss, B, loss_out); return; }
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (j >= M) return;
     const float* cj = cand + 3 * j;
@@ -87,18 +104,6 @@ __global__ void __launch_bounds__(256) inbatch_cols_kernel(const float* __restri
     if (lane == 0) { gc[3 * j] = gx; gc[3 * j + 1] = gy; gc[3 * j + 2] = gz; }
 }
 
-__global__ void __launch_bounds__(256) inbatch_loss_sum_kernel(const float* __restrict__ rowloss, int B, float* __restrict__ out) {
-    __shared__ float red[256];
-    float acc = 0.f;
-    for (int i = threadIdx.x; i < B; i += 256) acc += rowloss[i];
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[0] = red[0];
-}
 }  // namespace
 
 extern "C" int var_inbatch_loss_fwd_bwd(var_ctx* c, void* stream, const float* anchor, const float* cand, const int* target,
@@ -116,10 +121,8 @@ extern "C" int var_inbatch_loss_fwd_bwd(var_ctx* c, void* stream, const float* a
     hipLaunchKernelGGL(inbatch_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, s, anchor, cand, target, B, M, 1.f / tau, inv_count,
                        lse, rowloss, g_anchor);
     VAR_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(inbatch_cols_kernel, dim3((M + 3) / 4), dim3(256), 0, s, anchor, cand, target, lse, B, M, 1.f / tau,
-                       inv_count, g_cand);
-    VAR_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(inbatch_loss_sum_kernel, dim3(1), dim3(256), 0, s, rowloss, B, loss_out);
+    hipLaunchKernelGGL(inbatch_cols_kernel, dim3((M + 3) / 4 + 1), dim3(256), 0, s, anchor, cand, target, lse, B, M, 1.f / tau,
+                       inv_count, g_cand, rowloss, loss_out);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }

@@ -425,9 +425,8 @@ class IthorTrainer:
         def replay():
             Bs, img, clp, lns, idx, run = plans[1 if is_tail(state["row"]) else 0]
             r = state["table"][state["row"]]
-            idx.copy_(r[:3 * Bs])                              # int32 -> int64: [image ids | clip ids]
-            torch.index_select(images, 0, idx[:Bs], out=img)
-            torch.index_select(pcm, 0, idx[Bs:], out=clp)
+            torch.index_select(images, 0, r[:Bs], out=img)     # (int32 indices as they are: [image ids | clip ids])
+            torch.index_select(pcm, 0, r[Bs:3 * Bs], out=clp)
             lns.copy_(r[3 * Bs:5 * Bs])
             run()
             state["row"] = (state["row"] + 1) % rows

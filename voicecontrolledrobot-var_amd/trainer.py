@@ -498,7 +498,6 @@ class VARTrainer:
         self._g_cursor = torch.zeros(1, dtype=torch.int32, device=dev)
         self._g_idx = torch.zeros(row_ints, dtype=torch.int32, device=dev)
         self._device_scalars(B)
-        idx64 = torch.zeros(B, dtype=torch.int64, device=dev)
         img = torch.zeros((B,) + tuple(images.shape[1:]), dtype=images.dtype, device=dev)
         feats = torch.zeros((2 * B, 1, 100, 40), dtype=torch.float32, device=dev)
         emb = torch.zeros((3, B, 3), dtype=torch.float32, device=dev)            # [image | pos | neg]
@@ -509,12 +508,11 @@ class VARTrainer:
         scratch = torch.zeros(2 * B, dtype=torch.float32, device=dev)
         mine = gc[rank * 2 * B:(rank + 1) * 2 * B]
         clip_idx, lens = self._g_idx[B:3 * B], self._g_idx[3 * B:5 * B]
-        self._keep_inbatch = (idx64, img, feats, emb, cand, target, loss1, ga, gc, scratch)
+        self._keep_inbatch = (img, feats, emb, cand, target, loss1, ga, gc, scratch)
 
         def body_fwd():
             self._bind()
-            idx64.copy_(self._g_idx[:B])
-            torch.index_select(images, 0, idx64, out=img)
+            torch.index_select(images, 0, self._g_idx[:B], out=img)     # (int32 indices: no widening launch in front)
             c.check(c.lib.var_mfcc(c.handle, c.stream(), ptr(pcm), ptr(lens), ptr(clip_idx), 2 * B, pcm.stride(0), 100,
                                    ptr(feats)), "var_mfcc")
             c.check(c.lib.var_arm_encoder_fwd(c.handle, c.stream(), ptr(flat), ptr(img), int(img.dtype == torch.uint8),
