@@ -362,10 +362,15 @@ __global__ void __launch_bounds__(256) c3s_kernel(const float* __restrict__ x, c
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) a[g][tap] = wa[((wk + WK * g) * 9 + tap) * 64];
     }
-    // the image -> LDS [channel][PL] (padded side HP; the halo is zeroed first)
-    if (PAD) {
-        for (int e = tid; e < CIN * C::PL0; e += 256) { const int ch = e / C::PL0; lds[ch * PL + (e - ch * C::PL0)] = 0.f; }
-        __syncthreads();
+    // the image -> LDS [channel][PL] (padded side HP with a zero ring)
+    if (PAD) {      // only the one-cell ring around each plane: the interior is written below (disjoint cells, one barrier for both)
+        constexpr int RING = 4 * HP - 4;
+        for (int e = tid; e < CIN * RING; e += 256) {
+            const int ch = e / RING, q = e - ch * RING;
+            const int yy = q < HP ? 0 : (q < 2 * HP ? HP - 1 : 1 + (q - 2 * HP) / 2);
+            const int xx = q < HP ? q : (q < 2 * HP ? q - HP : ((q - 2 * HP) & 1 ? HP - 1 : 0));
+            lds[ch * PL + yy * HP + xx] = 0.f;
+        }
     }
     {
         constexpr int P0 = HIN * HIN, N4 = CIN * P0 / 4;
