@@ -289,9 +289,9 @@ def main_ithor(args, rank, local_rank, world, dev):
 def tag_kernel(tag, hw):
     """The kernel a profiled conv tag stands for at image size `hw` (its name as rocprofv3 prints it)."""
     if hw == 84:
-        return {1: "img_head2_kernel<", 2: "img_fwd_mid_kernel<", 7: "img_wgrad345_kernel<", 11: "img_tail2_kernel<",
+        return {1: "img_head2_kernel<", 2: "img_mid3_kernel<", 7: "img_wgrad345_kernel<", 11: "img_tail2_kernel<",
                 12: "img_chain_kernel", 15: "img_wgrad_reduce_kernel"}.get(tag)
-    return {1: "img_fwd_head_kernel<", 2: "img_fwd_mid_kernel<", 6: "img_wgrad_kernel<", 7: "img_bwd_pair_kernel<WgCfg<32, 64,",
+    return {1: "img_fwd_head_kernel<", 2: "img_mid3_kernel<", 6: "img_wgrad_kernel<", 7: "img_bwd_pair_kernel<WgCfg<32, 64,",
             8: "img_bwd_pair_kernel<WgCfg<64, 64, 12,", 9: "img_bwd_pair_kernel<WgCfg<64, 64, 6,", 11: "img_bwd_last_kernel<",
             15: "img_wgrad_reduce_kernel"}.get(tag)
 

@@ -1,6 +1,6 @@
 // Data gradients of conv 5 -> conv 4 -> conv 3 of the image CNN in ONE kernel, one workgroup per image (autograd of
 // models/pretext/arm_pretext_model.py:13-18 under loss.backward(), VAR/pretext_VAR.py:68): the mirror image of the fused
-// forward img_fwd_mid.hip.  From the third conv on an image's gradients are small (gact5 2 KB, gact4 9 KB, gact3 31 KB):
+// forward img_mid3.hip.  From the third conv on an image's gradients are small (gact5 2 KB, gact4 9 KB, gact3 31 KB):
 // they stay in LDS between the layers (and also go to HBM, for the weight gradients), so the three dependent launches of
 // round 2 -- each bound by its own per-image latency, 13 + 26 + 27 us alone -- become one chain without launch boundaries,
 // restaging or index arithmetic per layer.

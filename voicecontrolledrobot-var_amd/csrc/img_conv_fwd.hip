@@ -1,6 +1,6 @@
 // Image CNN forward of the Kuka VARPretextNet (models/pretext/arm_pretext_model.py:9-18): two fused launches,
 //   img_fwd_head.hip : conv 1 + conv 2 (the first activation map stays in LDS between them)
-//   img_fwd_mid.hip  : conv 3 + conv 4 + conv 5 + the image head's first Linear, one workgroup per image
+//   img_mid3.hip     : conv 3 + conv 4 + conv 5 + the image head's first Linear, one workgroup per image
 // leaving act[1..5], the ReLU bits of act1 and the image head's hidden layer / partials in the workspace.
 #include "var_common.h"
 
@@ -10,7 +10,7 @@ PH_DECL();      // (c3f.h's band kernel carries phase marks for `make phases`)
 #include "c3f.h"
 
 // conv 3..5 at 84 x 84 for a small inference-only batch (c3f.h: one (image, 16 output channels) workgroup per tile, the filter
-// read in place): img_fwd_mid keeps an image inside ONE workgroup -- right for 256 images on 256 CUs, 34 us of per-image latency
+// read in place): img_mid3 keeps an image inside ONE workgroup -- right for 256 images on 256 CUs, 34 us of per-image latency
 // at the RL stage's 8
 using KukaS3 = c3f::SmallCfg<32, 64, 21, 2, 11, 1, true>;
 using KukaS4 = c3f::SmallCfg<64, 64, 11, 2, 6, 1, true>;

@@ -36,6 +36,9 @@ struct PackSeg {
     int kvalid;     // cin*taps (rows beyond it are zero padding)
     int type;       // 0: F image/1-D conv  [k=tap*cin+c][n] ; 1: D [tap][n][c] ; 2: F with source [n][tap][c] ;
                     // 3: D in MFMA A-fragment order [tap][c/16][n/16][16 (n&3) + (c&15)][(n>>2)&3]  (var_common.h: img_a)
+                    // 4, 5: F in MFMA A-fragment order for D[n][pixel] (img_mid3.hip): [G][n/16][lane = 16 q + (n&15)][j] holds
+                    //       W[n][c = 16 cg + 4 j + q][tap] -- one 1-KiB piece per (group of 16 k, n tile), a lane's 16 bytes = its
+                    //       A operands of four k-steps; G = tap * (cin/16) + cg (type 4) or cg * 9 + tap (type 5: channel groups outermost)
 };
 struct PackTable { PackSeg seg[24]; int nseg; };
 
@@ -56,6 +59,13 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(PackTable T, const fl
             const int nsg = S.cout / 16, nct = S.cin / 16;
             const int sg = grp % nsg, ct = (grp / nsg) % nct, tap = grp / (nsg * nct);
             const int n = 16 * sg + 4 * jj + (ln >> 4), c = 16 * ct + (ln & 15);
+            v = params[S.src + (n * S.cin + c) * S.taps + tap];
+        } else if (S.type >= 4) {
+            const int jj = e & 3, ln = (e >> 2) & 63, grp = e >> 8;
+            const int nnt = S.cout / 16, ncg = S.cin / 16;
+            const int nt = grp % nnt, G = grp / nnt;
+            const int cg = S.type == 4 ? G % ncg : G / 9, tap = S.type == 4 ? G / ncg : G % 9;
+            const int n = 16 * nt + (ln & 15), c = 16 * cg + 4 * jj + (ln >> 4);
             v = params[S.src + (n * S.cin + c) * S.taps + tap];
         } else {
             const int n = e % S.cout, k = e / S.cout;
@@ -79,7 +89,8 @@ static PackTable make_pack_table(var_ctx* c) {
     };
     for (int i = 0; i < 5; i++) {
         int Kp = kImgCh[i] * 9; if (Kp & 1) Kp++;
-        add(K.img_f[i], Kp * kImgCh[i + 1], L.img_w[i], kImgCh[i], kImgCh[i + 1], 9, 0);
+        // conv 1, 2: [k][n]; conv 3..5: A-fragment pieces for img_mid3.hip (conv 3 with its channel groups outermost)
+        add(K.img_f[i], Kp * kImgCh[i + 1], L.img_w[i], kImgCh[i], kImgCh[i + 1], 9, i < 2 ? 0 : (i == 2 ? 5 : 4));
     }
     for (int i = 1; i < 5; i++) add(K.img_d[i], 9 * kImgCh[i + 1] * kImgCh[i], L.img_w[i], kImgCh[i], kImgCh[i + 1], 9, 1);
     // (segments must stay sorted by dst for the gather kernel's search: img_a sits between the sound images and the heads in PackLayout)
@@ -209,7 +220,10 @@ adam_pack_dev_kernel(const PackSeg* __restrict__ segs, int nseg, float* __restri
                 int d;
                 if (S.type == 3)
                     d = ((((tap * (S.cin / 16) + (c >> 4)) * (S.cout / 16) + (nn >> 4)) * 64 + 16 * (nn & 3) + (c & 15)) << 2) + ((nn >> 2) & 3);
-                else d = S.type == 1 ? (tap * S.cout + nn) * S.cin + c : (tap * S.cin + c) * S.cout + nn;
+                else if (S.type >= 4) {
+                    const int G = S.type == 4 ? tap * (S.cin / 16) + (c >> 4) : (c >> 4) * 9 + tap;
+                    d = (((G * (S.cout / 16) + (nn >> 4)) * 64 + 16 * (c & 3) + (nn & 15)) << 2) + ((c >> 2) & 3);
+                } else d = S.type == 1 ? (tap * S.cout + nn) * S.cin + c : (tap * S.cin + c) * S.cout + nn;
                 wpack[S.dst + d] = pn;
             }
         }

@@ -47,7 +47,8 @@ inline ParamLayout make_param_layout() {
 }
 
 // ---- packed (kernel-side) weight images, refreshed by var_pack_weights ----
-// fwd image conv l : Wf[k][n], k = tap*CIN + c (conv1: K 27 padded to 28 with a zero row)
+// fwd image conv l : conv 1, 2: Wf[k][n], k = tap*CIN + c (conv1: K 27 padded to 28 with a zero row); conv 3..5: 1-KiB MFMA
+//                    A-fragment pieces [group of 16 k][16-channel tile][lane][4] for img_mid3.hip (pack_adam.hip, types 4 / 5)
 // dX  image conv l : Wd[tap][n][c]             (layers 1..4 = second..fifth conv)
 // sound conv l     : Ws[k][n], k = kt*CINw + c  (conv0: k = kt*40 + f), and WsT[kt][n][c] for dX
 struct PackLayout {
@@ -151,7 +152,7 @@ struct var_ctx {
     // saved forward
     // var_arm_encoder_fwd's embedding outputs: the finish kernels of the heads write them directly (no copy launch afterwards)
     float *out_img = nullptr, *out_pos = nullptr, *out_neg = nullptr;
-    bool head_in_mid = false;             // the last image forward also ran the image head (img_fwd_mid.hip)
+    bool head_in_mid = false;             // the last image forward also ran the image head (img_mid3.hip)
     int saved_B = 0;
     const void* saved_image = nullptr;
     int saved_u8 = 0;
