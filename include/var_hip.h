@@ -232,6 +232,13 @@ int var_ithor_set_bf16(var_ctx* ctx, int on);
  * hipDeviceSynchronize-like wait on the null stream). */
 int var_ithor_set_gru_sequence(var_ctx* ctx, int on);
 int var_ithor_gru_status(var_ctx* ctx, unsigned* word);
+/* Data parallelism: the time-out word above is per rank, but the poisoned gradient of the rank that timed out is summed into
+ * every rank's buffer by the all-reduce.  var_ithor_guard_loss names a device float that var_adam_step / var_adam_step_dev over
+ * this model's arena read at launch time as a second guard: not finite = leave parameters, moments and step count alone.
+ * Point it at the loss slot that travels with the gradient through the all-reduce (the timed-out rank's loss is NaN, so the
+ * sum is NaN on every rank) and all replicas skip the same step.  NULL removes the guard.  The pointer is read when an Adam
+ * launch is enqueued (a captured launch keeps the one it was captured with). */
+int var_ithor_guard_loss(var_ctx* ctx, const float* loss_dev);
 int var_ithor_encoder_fwd(var_ctx* ctx, void* stream, const float* params,
                           const void* image, int image_is_u8, long image_bstride,
                           const float* snd_pos, const float* snd_neg, int B, int H,
@@ -288,13 +295,20 @@ int var_allgather_emb(var_ctx* ctx, void* stream, const float* local, float* glo
  * filters re-packed inside the first launch of every call (parameters updated in place between two calls are picked up);
  * B <= 8 rows (the RL stage's envs) run the 22 Linear layers + GRU step as one persistent launch whose workgroups hand their
  * vectors over as (value, epoch) pairs -- it needs its 128 workgroups co-resident; if they are not, every wait times out
- * (bounded) and the outputs are NaN.  Captured into a HIP graph the call replays as 9 kernel nodes. */
+ * (bounded: a workgroup gives up all its later waits at once after its first expired one) and the outputs are NaN.  The
+ * reference's Policy.act (models/ppo/model.py:57-69) has no failure mode, so this one is reported: var_armnet_status copies
+ * (blocking) 1 if the most recent chain launch timed out, 0x40000001 if an earlier one did since the last
+ * var_armnet_clear_status, else 0; a timed-out launch leaves nothing behind -- the next one is clean.  rnn_hxs_out must not
+ * overlap rnn_hxs (VAR_ERR_ARG: the chain reads the old state from all workgroups of its GRU stage while one writes the new
+ * one).  Captured into a HIP graph the call replays as 9 kernel nodes. */
 int var_armnet_param_count(void);
 int var_armnet_plan(var_ctx* ctx, int max_batch);
 int var_armnet_forward(var_ctx* ctx, void* stream, const float* params, const void* image, int image_is_u8,
                        long image_bstride, const float* image_feat, const float* robot_pose,
                        const float* goal_sound_feat, const float* rnn_hxs, const float* masks, int B,
                        float* value, float* actor_features, float* action_mean, float* rnn_hxs_out);
+int var_armnet_status(var_ctx* ctx, unsigned* word);
+int var_armnet_clear_status(var_ctx* ctx);
 
 /* The iTHOR/FSC audio front-end: python_speech_features.mfcc as called at Envs/audioLoader.py:158-161 (pre-emphasis
  * .97, 400/160 frames with a zero-padded tail, np.hamming, |rfft_512|^2/512, 40 triangles, log, orthonormal DCT-II,
@@ -331,6 +345,10 @@ int var_debug_buffer(var_ctx* ctx, const char* name, void** ptr, long* nfloats);
  * complete -- what the resident part of a grid sees when the rest is not: every wait must expire (about 0.3 s), the
  * launch must end, var_ithor_gru_status must read non-zero and the step's outputs must be NaN. */
 int var_debug_ithor_gru_drop_workgroup(var_ctx* ctx);
+/* tests: the next small-batch chain launch of var_armnet_forward runs one workgroup short: the vectors that workgroup owes never
+ * arrive, every consumer's wait must expire (about 0.3 s), the launch must end with NaN outputs, var_armnet_status must read 1,
+ * and the launch after that must be clean (status 0x40000001 until cleared). */
+int var_debug_armnet_drop_workgroup(var_ctx* ctx);
 int var_debug_ithor_dense(var_ctx* ctx, void* stream, int a_kfast, int b_kfast, const float* a, const float* b,
                           float* c, int M, int N, int K, int nsplit, int add);
 

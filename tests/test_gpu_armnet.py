@@ -191,3 +191,44 @@ def test_replayed_forward_is_stable_and_sees_new_inputs_and_weights(var_amd, fx)
     torch.cuda.synchronize()
     for a, b in zip(outs, want):
         assert torch.equal(a, b)
+
+
+def test_chain_time_out_is_reported_leaves_nothing_behind_and_clears(var_amd, fx):
+    """The reference's Policy.act (models/ppo/model.py:57-69) cannot fail; the fused small-batch chain can -- it needs its 128
+    workgroups resident at once.  Fault injection (var_debug_armnet_drop_workgroup: the next chain launch runs one
+    workgroup short, so the vectors it owes never arrive): the launch ends, its outputs are NaN, var_armnet_status reads 1;
+    the NEXT launch is bit-identical to an undisturbed one and the status says "an earlier launch"; the record clears."""
+    import ctypes
+    from var_amd._lib import Context
+    ref = armnet_seeded(int(fx["seed"]))
+    m = make(var_amd, ref)
+    obs, hxs, masks = obs_of(fx, True), cuda(fx['rnn_hxs']), cuda(fx['masks'])
+    good = [t.clone() for t in m.act(obs, hxs, masks, deterministic=True)]
+    torch.cuda.synchronize()
+    assert m.chain_status() == 0
+    ctx = Context.get(0)
+    assert ctx.lib.var_debug_armnet_drop_workgroup(ctx.handle) == 0
+    with torch.no_grad():
+        bad = m._base_forward(obs, hxs, masks)                    # (act() would raise in torch.distributions: the mean is NaN)
+    torch.cuda.synchronize()
+    assert torch.isnan(bad[0]).all() and torch.isnan(bad[2]).all(), "a timed-out chain must not return half-updated values"
+    assert m.chain_status() == 1
+    again = m.act(obs, hxs, masks, deterministic=True)
+    torch.cuda.synchronize()
+    for g, a in zip(good, again):
+        assert torch.equal(g, a)
+    assert m.chain_status() == 0x40000001
+    m.clear_chain_status()
+    assert m.chain_status() == 0
+    # in-place state update is refused (the chain reads rnn_hxs from every workgroup of its GRU stage while one writes the new state)
+    word = ctypes.c_uint(0)
+    assert ctx.lib.var_armnet_status(ctx.handle, ctypes.byref(word)) == 0 and word.value == 0
+    flat = m._flat
+    img = obs['image'].reshape(8, -1, 96, 96).contiguous()
+    f = lambda t: ctypes.c_void_p(t.data_ptr())        # noqa: E731
+    out = [torch.empty(8, n, device="cuda") for n in (1, 128, 2)]
+    h = hxs.clone().float().contiguous()
+    rc = ctx.lib.var_armnet_forward(ctx.handle, None, f(flat), f(img), 1, img.stride(0), f(obs['image_feat'].float().contiguous()),
+                                    f(obs['robot_pose'].float().contiguous()), f(obs['goal_sound_feat'].float().contiguous()),
+                                    f(h), f(masks.float().contiguous()), 8, f(out[0]), f(out[1]), f(out[2]), f(h))
+    assert rc != 0

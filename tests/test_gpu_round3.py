@@ -296,6 +296,49 @@ def test_gru_time_out_skips_the_optimiser_step_and_clears_itself(var_amd):
     assert bool(torch.isfinite(m.flat_parameters()).all())
 
 
+def test_one_replica_timing_out_makes_every_replica_skip_the_step(var_amd):
+    """Data parallelism (round-3 advisor finding): the time-out word is per rank, but the NaN gradient of the rank that timed
+    out is summed into EVERY rank's buffer.  Two replicas on one device, the all-reduce done by hand (sum of the two
+    [gradient | loss] buffers, exactly what IthorTrainer.allreduce does): replica A's persistent GRU launch times out, B's
+    runs.  Both must skip the step -- parameters, moments AND the applied-step count untouched, replicas identical -- through
+    the loss guard (var_ithor_guard_loss: B's own time-out word is clean, and A's was cleared by B's forward on the shared
+    workspace before A's Adam runs).  The step after that trains both, identically."""
+    from var_amd._lib import Context
+    B = 3
+    batches = [tuple(t.cuda() for t in _ithor_batch(B, 50 + r)) for r in range(2)]
+    reps = []
+    for r in range(2):
+        torch.manual_seed(5)
+        m = var_amd.IthorVARPretextNet(icfg(96)).to("cuda").set_precision("bf16")
+        reps.append((m, var_amd.IthorTrainer(m)))
+    ctx = Context.get(0)
+
+    def dp_step(drop_rank=None):
+        for r, (m, tr) in enumerate(reps):
+            if r == drop_rank:
+                assert ctx.lib.var_debug_ithor_gru_drop_workgroup(ctx.handle) == 0
+            tr.loss_and_grads(*batches[r], global_batch=2 * B)
+        total = reps[0][1].gbuf + reps[1][1].gbuf                # the all-reduce (SUM) of [gradients | loss]
+        for _, tr in reps:
+            tr.gbuf.copy_(total)
+            tr.adam()
+        torch.cuda.synchronize()
+        return float(total[-1])
+
+    assert np.isfinite(dp_step())                                # a good step first (moments off zero)
+    assert torch.equal(reps[0][0].flat_parameters(), reps[1][0].flat_parameters())
+    snap = [(m.flat_parameters().clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone()) for m, tr in reps]
+    assert [tr.step_count for _, tr in reps] == [1, 1]
+    assert not np.isfinite(dp_step(drop_rank=0))                 # replica A times out: the summed loss is NaN on both
+    for (m, tr), (p0, m0, v0) in zip(reps, snap):
+        assert torch.equal(m.flat_parameters(), p0) and torch.equal(tr.exp_avg, m0) and torch.equal(tr.exp_avg_sq, v0)
+        assert tr.step_count == 1                                # the bias corrections do not drift
+    assert np.isfinite(dp_step())
+    assert torch.equal(reps[0][0].flat_parameters(), reps[1][0].flat_parameters())
+    assert bool(torch.isfinite(reps[0][0].flat_parameters()).all()) and not torch.equal(reps[0][0].flat_parameters(), snap[0][0])
+    assert [tr.step_count for _, tr in reps] == [2, 2]
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # iTHOR model over an HBM-resident pool: replayed ragged epochs = eager steps on the same rows
 # ------------------------------------------------------------------------------------------------------------------

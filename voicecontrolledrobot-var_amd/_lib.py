@@ -64,12 +64,16 @@ _SIGNATURES = {
     "var_armnet_param_count": (_i, []),
     "var_armnet_plan": (_i, [_vp, _i]),
     "var_armnet_forward": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "var_armnet_status": (_i, [_vp, _vp]),
+    "var_armnet_clear_status": (_i, [_vp]),
+    "var_debug_armnet_drop_workgroup": (_i, [_vp]),
     "var_mfcc_psf": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "var_ithor_param_count": (_i, []),
     "var_ithor_plan": (_i, [_vp, _i, _i]),
     "var_ithor_set_bf16": (_i, [_vp, _i]),
     "var_ithor_set_gru_sequence": (_i, [_vp, _i]),
     "var_ithor_gru_status": (_i, [_vp, _vp]),
+    "var_ithor_guard_loss": (_i, [_vp, _vp]),
     "var_debug_ithor_gru_drop_workgroup": (_i, [_vp]),
     "var_ithor_encoder_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i]),
     "var_ithor_saved_generation": (_i, [_vp]),

@@ -158,6 +158,21 @@ class ArmNetPolicy(nn.Module):
                 "var_armnet_forward")
         return value, feats, mean, hout
 
+    def chain_status(self):
+        """Status of the small-batch (B <= 8) MLP chain launch, a persistent kernel that needs its 128 workgroups resident at
+        once: 1 = the most recent forward timed out (its outputs are NaN), 0x40000001 = an earlier one did since the last
+        clear_chain_status(), 0 = never.  Blocking.  (The reference's Policy.act, models/ppo/model.py:57-69, cannot fail;
+        a caller that shares the GPU checks this after a NaN value or once per rollout.)"""
+        import ctypes
+        c = Context.get(self._flat.device.index)
+        w = ctypes.c_uint(0)
+        c.check(c.lib.var_armnet_status(c.handle, ctypes.byref(w)), "var_armnet_status")
+        return int(w.value)
+
+    def clear_chain_status(self):
+        c = Context.get(self._flat.device.index)
+        c.check(c.lib.var_armnet_clear_status(c.handle), "var_armnet_clear_status")
+
     @staticmethod
     def _prep(t, shape):
         if not t.is_cuda:

@@ -68,7 +68,9 @@ struct arm_state {
     float* slab = nullptr;
     float *flat_img = nullptr, *motor = nullptr, *sound = nullptr, *fusion = nullptr, *h0 = nullptr, *gi = nullptr, *gh = nullptr;
     float* chain = nullptr;        // the fused small-batch MLP chain's vectors (armnet_chain_kernel)
-    unsigned* sync = nullptr;      // its grid barrier: [0] arrivals, [1] finished workgroups, [2] time-out (sticky)
+    unsigned* sync = nullptr;      // [1] finished workgroups, [2] epoch of the last launch that timed out, [3] epoch of the next launch,
+                                   // [4] sticky: some launch timed out since the last var_armnet_clear_status
+    bool drop_one = false;         // tests: the next chain launch runs one workgroup short (var_debug_armnet_drop_workgroup)
     c3f::f32x4* wpk = nullptr;     // conv 2..6 filters in MFMA A-fragment order (c3f.h), re-packed per forward
     c3f::PackDesc pack{};
 };
@@ -147,7 +149,7 @@ struct ChainDesc {
     int nstages, B, H;
     int b_hxs, b_mask, b_hout;           // buffer ids the GRU input kind needs besides in0 (gi) / in1 (gh)
     unsigned long long tagged;           // bit i: buffer i is handed over inside the launch as (value, tag) pairs
-    unsigned* sync;                      // [1] finished workgroups, [2] time-out (sticky), [3] epoch of the next launch
+    unsigned* sync;                      // [1] finished workgroups, [2] epoch of the last timed-out launch, [3] epoch of the next launch, [4] sticky
 };
 typedef __attribute__((address_space(1))) float gf32;
 typedef __attribute__((address_space(1))) unsigned gu32c;
@@ -208,10 +210,16 @@ __global__ void __launch_bounds__(kChainT) armnet_chain_kernel(ChainDesc D) {
             pbias = D.P[J.b + (oo < J.N ? oo : J.N - 1)];
         }
     };
-    auto give_up = [&]() {          // a producer never delivered (the grid is not resident): sticky time-out, outputs NaN
-        __hip_atomic_store((gu32c*)(D.sync + 2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    auto give_up = [&]() {          // a producer never delivered (the grid is not resident): outputs NaN, the event is recorded
+        if (*(volatile int*)&dead_s == 0) {
+            __hip_atomic_store((gu32c*)(D.sync + 2), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // which launch (var_armnet_status)
+            __hip_atomic_store((gu32c*)(D.sync + 4), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // sticky
+        }
         dead_s = 1;
     };
+    // (once one wait of this workgroup has expired every later one gives up at its first turn: a grid that is not resident costs
+    //  one bound, not one per poll)
+    auto expired = [&](unsigned& spins) { return ++spins > kChainSpinMax || *(volatile int*)&dead_s != 0; };
     ChainJob J = job_of(0);
     bool mine = (int)blockIdx.x < J.wg0 + J.nwg;          // a stage may leave workgroups without a job (see split())
     if (mine) prefetch(J);
@@ -257,7 +265,7 @@ __global__ void __launch_bounds__(kChainT) armnet_chain_kernel(ChainDesc D) {
 #pragma unroll
                         for (int g = 0; g < 6; ++g) bad |= ((unsigned)(q[g][0] >> 32) ^ epoch) | ((unsigned)(q[g][1] >> 32) ^ epoch);
                         if (bad == 0u) break;
-                        if (++spins > kChainSpinMax) { give_up(); break; }
+                        if (expired(spins)) { give_up(); break; }
                         __builtin_amdgcn_s_sleep(1);
                     }
                     float2 g3[6];
@@ -345,7 +353,7 @@ __global__ void __launch_bounds__(kChainT) armnet_chain_kernel(ChainDesc D) {
                                 bad |= ((unsigned)(qa[i][0] >> 32) ^ epoch) | ((unsigned)(qa[i][1] >> 32) ^ epoch) |
                                        ((unsigned)(qb[i][0] >> 32) ^ epoch) | ((unsigned)(qb[i][1] >> 32) ^ epoch);
                             if (bad == 0u) break;
-                            if (++spins > kChainSpinMax) { give_up(); break; }
+                            if (expired(spins)) { give_up(); break; }
                             __builtin_amdgcn_s_sleep(1);
                         }
 #pragma unroll
@@ -639,7 +647,9 @@ int chain_forward(var_ctx* c, hipStream_t s, arm_state* st, const float* P, cons
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)armnet_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr = true;
     }
-    hipLaunchKernelGGL(armnet_chain_kernel, dim3(kChainG), dim3(kChainT), lds_bytes, s, D);
+    const int grid = kChainG - (st->drop_one ? 1 : 0);          // (one short: its outputs never arrive, every consumer's wait expires)
+    st->drop_one = false;
+    hipLaunchKernelGGL(armnet_chain_kernel, dim3(grid), dim3(kChainT), lds_bytes, s, D);
     AN_CHECK(c);
     return VAR_OK;
 }
@@ -727,6 +737,14 @@ int var_armnet_forward(var_ctx* c, void* stream, const float* params, const void
         !actor_features || !rnn_hxs_out || B < 1) {
         VAR_SET_ERR(c, "var_armnet_forward: NULL argument");
         return VAR_ERR_ARG;
+    }
+    {   // the small-batch chain reads rnn_hxs from every workgroup of its GRU stage while one of them writes rnn_hxs_out
+        const char *a0 = (const char*)rnn_hxs, *b0 = (const char*)rnn_hxs_out;
+        const size_t n = (size_t)B * kRh * sizeof(float);
+        if (a0 < b0 + n && b0 < a0 + n) {
+            VAR_SET_ERR(c, "var_armnet_forward: rnn_hxs_out overlaps rnn_hxs (an in-place state update is not supported)");
+            return VAR_ERR_ARG;
+        }
     }
     hipStream_t s = (hipStream_t)stream;
     const ArmLayout& L = st->L;
@@ -828,6 +846,38 @@ int var_armnet_forward(var_ctx* c, void* stream, const float* params, const void
     RUN(linear(c, s, st, P, L.actor[0], st->t3, st->t0, B, 1));
     RUN(linear(c, s, st, P, L.actor[1], st->t0, actor_features, B, 1));
     if (action_mean) RUN(linear(c, s, st, P, L.mean, actor_features, action_mean, B, 0));
+    return VAR_OK;
+}
+
+int var_armnet_status(var_ctx* c, unsigned* word) {
+    if (!c) return VAR_ERR_ARG;
+    arm_state* st = (arm_state*)c->arm;
+    if (!st || !word) { VAR_SET_ERR(c, "var_armnet_status: var_armnet_plan first"); return VAR_ERR_PLAN; }
+    VAR_HIP_CHECK(c, hipSetDevice(c->device));
+    unsigned w[8] = {0};
+    VAR_HIP_CHECK(c, hipMemcpy(w, st->sync, sizeof(w), hipMemcpyDeviceToHost));       // (blocking: behind the work already enqueued)
+    // w[2]: epoch of the last launch whose waits expired; w[3]: epoch of the NEXT launch, so w[3] - 1 ran last
+    *word = (w[2] != 0u && w[2] == w[3] - 1u) ? 1u : (w[4] ? 0x40000001u : 0u);
+    return VAR_OK;
+}
+
+int var_armnet_clear_status(var_ctx* c) {
+    if (!c) return VAR_ERR_ARG;
+    arm_state* st = (arm_state*)c->arm;
+    if (!st) { VAR_SET_ERR(c, "var_armnet_clear_status: var_armnet_plan first"); return VAR_ERR_PLAN; }
+    VAR_HIP_CHECK(c, hipSetDevice(c->device));
+    VAR_HIP_CHECK(c, hipDeviceSynchronize());
+    const unsigned z = 0u;
+    VAR_HIP_CHECK(c, hipMemcpy(st->sync + 2, &z, sizeof(z), hipMemcpyHostToDevice));
+    VAR_HIP_CHECK(c, hipMemcpy(st->sync + 4, &z, sizeof(z), hipMemcpyHostToDevice));
+    return VAR_OK;
+}
+
+int var_debug_armnet_drop_workgroup(var_ctx* c) {
+    if (!c) return VAR_ERR_ARG;
+    arm_state* st = (arm_state*)c->arm;
+    if (!st) { VAR_SET_ERR(c, "var_debug_armnet_drop_workgroup: var_armnet_plan first"); return VAR_ERR_PLAN; }
+    st->drop_one = true;
     return VAR_OK;
 }
 

@@ -98,7 +98,7 @@ void ithor_free(var_ctx* c) {
     free(st->folds);
     delete st;
     c->ith = nullptr;
-    c->adam_guard = nullptr; c->adam_guard_n = 0;
+    c->adam_guard = nullptr; c->adam_guard_n = 0; c->adam_guard_loss = nullptr;
 }
 
 template <int KC, class P>
@@ -1300,7 +1300,7 @@ static void ithor_update_guard(var_ctx* c) {
     ithor_state* st = ith(c);
     const bool on = st && st->bf16 && st->gru_seq && st->gruws;
     c->adam_guard = on ? gru_bf16_timeout_ptr(2 * st->maxB, st->gruws) : nullptr;
-    c->adam_guard_n = on ? (long)st->L.total : 0;
+    c->adam_guard_n = st ? (long)st->L.total : 0;          // (also what the loss guard, var_ithor_guard_loss, applies to)
 }
 
 static int copy_out(var_ctx* c, hipStream_t s, const float* src, float* dst, long n) {
@@ -1332,6 +1332,14 @@ int var_ithor_set_gru_sequence(var_ctx* c, int on) {
         ithor_update_guard(c);
     }
     return old;
+}
+
+int var_ithor_guard_loss(var_ctx* c, const float* loss_dev) {
+    CHECK_CTX(c);
+    ithor_state* st = ith(c);
+    if (!st) { VAR_SET_ERR(c, "var_ithor_guard_loss: var_ithor_plan first"); return VAR_ERR_PLAN; }
+    c->adam_guard_loss = loss_dev;
+    return VAR_OK;
 }
 
 int var_debug_ithor_gru_drop_workgroup(var_ctx* c) {

@@ -116,8 +116,10 @@ int launch_pack_weights(var_ctx* c, hipStream_t s, const float* params) {
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, long n,
                                                     float b1, float b2, float eps, float wd,
-                                                    float step_size, float bc2_sqrt, const unsigned* __restrict__ guard) {
+                                                    float step_size, float bc2_sqrt, const unsigned* __restrict__ guard,
+                                                    const float* __restrict__ gloss) {
     if (guard && *guard) return;          // this step's gradient is invalid (var_ctx::adam_guard): leave the state alone
+    if (gloss && !(fabsf(*gloss) <= 3.4e38f)) return;      // ... or some rank's was: its NaN came in with the all-reduced loss
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const float pi = p[i];
         const float gi = g[i] + wd * pi;
@@ -145,8 +147,9 @@ adam_pack_dev_kernel(const PackSeg* __restrict__ segs, int nseg, float* __restri
                      float* __restrict__ v, long n, const float* __restrict__ lr_dev, float b1, float b2, float eps,
                      float wd, int* __restrict__ step_dev, unsigned* __restrict__ done_ctr, float* __restrict__ wpack,
                      const int* __restrict__ idx_table, int row_ints, int n_rows, int* __restrict__ cursor,
-                     int* __restrict__ idx_row, int ahead_from, const unsigned* __restrict__ guard) {
+                     int* __restrict__ idx_row, int ahead_from, const unsigned* __restrict__ guard, const float* __restrict__ gloss) {
     if (guard && *guard) return;          // (every block: no update, no step count, no cursor move)
+    if (gloss && !(fabsf(*gloss) <= 3.4e38f)) return;
     // bias corrections: double-precision pow once per block, not per thread
     __shared__ float sh_step[2];
     const int t = step_dev[0] + 1;
@@ -254,7 +257,8 @@ int launch_adam_dev(var_ctx* c, hipStream_t s, float* p, const float* g, float* 
     if (grid > 256) grid = 256;
     hipLaunchKernelGGL(adam_pack_dev_kernel, dim3(grid), dim3(kAdamT), 0, s, (const PackSeg*)c->pack_segs_dev, c->pack_nseg, p, g, m, v, n, lr_dev,
                        b1, b2, eps, wd, step_dev, c->done_ctr, repack ? c->wpack : nullptr, idx_table, row_ints, n_rows,
-                       cursor, idx_row, ahead_from, (c->adam_guard && n == c->adam_guard_n) ? c->adam_guard : nullptr);
+                       cursor, idx_row, ahead_from, (c->adam_guard && n == c->adam_guard_n) ? c->adam_guard : nullptr,
+                       n == c->adam_guard_n ? c->adam_guard_loss : nullptr);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }
@@ -269,7 +273,7 @@ int launch_adam(var_ctx* c, hipStream_t s, float* p, const float* g, float* m, f
     if (grid > 2048) grid = 2048;
     ProfScope prof(c, s, TAG_ADAM);
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, s, p, g, m, v, n, b1, b2, eps, wd, step_size, bc2_sqrt,
-                       (c->adam_guard && n == c->adam_guard_n) ? c->adam_guard : nullptr);
+                       (c->adam_guard && n == c->adam_guard_n) ? c->adam_guard : nullptr, n == c->adam_guard_n ? c->adam_guard_loss : nullptr);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }

@@ -174,6 +174,8 @@ struct var_ctx {
     void* ith = nullptr;                  // iTHOR model state (ithor.hip), created by var_ithor_plan
     const unsigned* adam_guard = nullptr; // device word: non-zero = the gradient of this step is invalid (a persistent GRU launch timed
     long adam_guard_n = 0;                // out): Adam launches over adam_guard_n parameters leave parameters, moments and step alone
+    const float* adam_guard_loss = nullptr;   // device float (the step's -- under data parallelism the all-reduced -- loss): not finite = the same
+                                              // (var_ithor_guard_loss; a rank's time-out reaches every rank through the NaN it sums in)
 };
 
 #define VAR_SET_ERR(ctx, ...) do { if (ctx) snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__); } while (0)

@@ -229,7 +229,8 @@ class IthorTrainer:
         self.gbuf = torch.zeros(self.n + 1, dtype=torch.float32, device=self.dev)   # [gradients | loss]
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
-        self.step_count = 0
+        self._host_steps = 0
+        self._g_step = self._g_lr = None
         self.pg = process_group
         self.world, self.rank = 1, 0
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
@@ -280,14 +281,40 @@ class IthorTrainer:
         elif self.world > 1:
             torch.distributed.all_reduce(self.gbuf, op=torch.distributed.ReduceOp.SUM, group=self.pg)
 
+    @property
+    def step_count(self):
+        """Optimiser steps APPLIED so far.  The count lives on the device (the Adam kernel advances it itself, and leaves it
+        alone when it skips a poisoned step); reading it here synchronises."""
+        g = getattr(self, "_g_step", None)
+        return int(g.item()) if g is not None else self._host_steps
+
+    @step_count.setter
+    def step_count(self, v):
+        self._host_steps = int(v)
+        if getattr(self, "_g_step", None) is not None:
+            self._g_step.fill_(int(v))
+
+    def _device_scalars(self):
+        if getattr(self, "_g_step", None) is None:
+            self._g_lr = torch.full((1,), float(self.lr), dtype=torch.float32, device=self.dev)
+            self._g_step = torch.full((1,), int(self._host_steps), dtype=torch.int32, device=self.dev)
+
+    def _guard(self, c):
+        # second guard of the Adam kernels: the loss slot that went through the all-reduce with the gradient.  A rank whose
+        # persistent GRU launch timed out contributes NaN to it, so EVERY rank skips that step and the replicas stay identical
+        # (the time-out word alone is per rank: the others would have applied the NaN gradient the all-reduce gave them)
+        c.check(c.lib.var_ithor_guard_loss(c.handle, self.gbuf.data_ptr() + 4 * self.n), "var_ithor_guard_loss")
+
     def adam(self):
         c = self.ctx
         flat = self.model.flat_parameters()
-        self.step_count += 1
-        c.check(c.lib.var_adam_step(c.handle, current_stream_handle(), ptr(flat), ptr(self.gbuf), ptr(self.exp_avg),
-                                    ptr(self.exp_avg_sq), self.n, float(self.lr), float(self.betas[0]),
-                                    float(self.betas[1]), float(self.eps), float(self.wd), self.step_count),
-                "var_adam_step")
+        self._device_scalars()
+        self._g_lr.fill_(float(self.lr))                       # (the eager loop assigns .lr directly, train_representation)
+        self._guard(c)
+        c.check(c.lib.var_adam_step_dev(c.handle, current_stream_handle(), ptr(flat), ptr(self.gbuf), ptr(self.exp_avg),
+                                        ptr(self.exp_avg_sq), self.n, ptr(self._g_lr), float(self.betas[0]),
+                                        float(self.betas[1]), float(self.eps), float(self.wd), ptr(self._g_step)),
+                "var_adam_step_dev")
 
     def step(self, image, pos, neg, global_batch=None):
         """One optimisation step.  bf16 mode with the persistent GRU launches: if a launch of this step timed out (its grid
@@ -335,9 +362,7 @@ class IthorTrainer:
             del warm
         feats = torch.empty((2 * B, 1, frames, 40), dtype=torch.float32, device=self.dev)
         self._g_feats = feats
-        if not (_shared_scalars and getattr(self, "_g_step", None) is not None):
-            self._g_lr = torch.full((1,), float(self.lr), dtype=torch.float32, device=self.dev)
-            self._g_step = torch.full((1,), int(self.step_count), dtype=torch.int32, device=self.dev)
+        self._device_scalars()
         gb = B * self.world if global_batch is None else global_batch
 
         def body_grad():
@@ -350,6 +375,7 @@ class IthorTrainer:
                                               self.gbuf.data_ptr() + 4 * self.n, None), "var_ithor_loss_grad")
 
         def body_adam():
+            self._guard(c)
             c.check(c.lib.var_adam_step_dev(c.handle, current_stream_handle(), ptr(flat), ptr(self.gbuf), ptr(self.exp_avg),
                                             ptr(self.exp_avg_sq), self.n, ptr(self._g_lr), float(self.betas[0]),
                                             float(self.betas[1]), float(self.eps), float(self.wd), ptr(self._g_step)),
@@ -375,7 +401,6 @@ class IthorTrainer:
             if collective:
                 self.allreduce()
                 graphs[1].replay()
-            self.step_count += 1
             return self.loss
         return replay
 
@@ -404,7 +429,7 @@ class IthorTrainer:
         if tail_batch:
             sizes.append((tail_batch, tail_batch * self.world if tail_global_batch is None else int(tail_global_batch)))
         ctxs = [self.ctx, self.ctx]                           # both graphs run on the trainer's workspace (planned for `batch`)
-        self._g_step = None                                    # both graphs share ONE device-side step count / learning rate
+        self._device_scalars()                                 # every graph of this trainer shares ONE device-side step count / learning rate
         plans = []
         for (Bs, gb), cx in zip(sizes, ctxs):
             img = torch.zeros((Bs,) + tuple(images.shape[1:]), dtype=torch.uint8, device=self.dev)

@@ -680,6 +680,7 @@ def train_representation_from_pool(model, pool, epochs, batch, lr=1e-4, weight_d
     replay = load_table = None
     loss_list = []
     acc = torch.zeros(1, dtype=torch.float32, device=tr.dev)
+    ran = torch.zeros(1, dtype=torch.float32, device=tr.dev)
     for ep in range(epochs):
         tr.set_lr(multistep_lr(lr, milestones, gamma, ep))
         table = pool.epoch_index_table(batch, drop_last)
@@ -689,9 +690,25 @@ def train_representation_from_pool(model, pool, epochs, batch, lr=1e-4, weight_d
         else:
             load_table(table)
         acc.zero_()
+        ran.zero_()
         for _ in range(spe):
-            acc += replay()
-        avg = float(acc.item()) / spe
+            l = replay()
+            ok = torch.isfinite(l)                         # (device-side: a timed-out iTHOR step reads NaN and was skipped by Adam)
+            acc += torch.where(ok, l, torch.zeros_like(l)).reshape(-1)[:1]
+            ran += ok.reshape(-1)[:1].float()
+        n_ran = int(ran.item())
+        if is_ithor and n_ran < spe:
+            # bf16 mode: a persistent GRU launch did not get its whole grid resident and timed out; the optimiser skipped those
+            # steps (the Adam kernels' guards, csrc/pack_adam.hip), parameters and moments are intact.  The captured graphs keep
+            # the persistent form: switch to per-step GRU launches and capture again for the next epoch.
+            log(f'persistent GRU launch timed out in {spe - n_ran} step(s) of epoch {start_ep + ep} (status '
+                f'{model.gru_status():#x}): skipped by the optimiser; switching to per-step GRU launches')
+            model.set_gru_sequence(False)
+            model._ensure_plan(tr.ctx, int(batch))         # applies the form and clears the status words
+            replay = None
+            if n_ran == 0:
+                raise VarHipError("every step of the epoch timed out in the persistent GRU launches")
+        avg = float(acc.item()) / max(n_ran, 1)               # np.sum(loss_ep)/len(loss_ep), :82, over the steps that ran
         loss_list.append(avg)
         log('average loss', avg)
         if save_dir and ((ep + 1) % save_interval == 0 or ep + 1 == epochs):
