@@ -292,7 +292,7 @@ def tag_kernel(tag, hw):
         return {1: "img_head2_kernel<", 2: "img_mid3_kernel<", 7: "img_wgrad345_kernel<", 11: "img_tail2_kernel<",
                 12: "img_chain_kernel", 15: "img_wgrad_reduce_kernel"}.get(tag)
     return {1: "img_fwd_head_kernel<", 2: "img_mid3_kernel<", 6: "img_wgrad_kernel<", 7: "img_bwd_pair_kernel<WgCfg<32, 64,",
-            8: "img_bwd_pair_kernel<WgCfg<64, 64, 12,", 9: "img_bwd_pair_kernel<WgCfg<64, 64, 6,", 11: "img_bwd_last_kernel<",
+            8: "img_bwd_pair_kernel<WgCfg<64, 64, 12,", 9: "img_bwd_pair_kernel<WgCfg<64, 64, 6,", 11: "img_bwd_tail_kernel<",
             15: "img_wgrad_reduce_kernel"}.get(tag)
 
 
@@ -349,7 +349,9 @@ def pmc_traffic(tag, hw):
 
 
 def algorithmic_bytes(tag, B, hw):
-    """Bytes a launch of the kernel family MUST move: inputs read once, outputs written once."""
+    """Bytes a launch of the kernel family MUST move: inputs read once, outputs written once, every
+    tensor at its own size (NCHW f32; the u8 image as bytes).  Layout padding of the build's own making -- act1's band tiles
+    at 84 x 84 hold 67 328 floats per image for 56 448 real ones -- is NOT algorithmic: it shows up in `traffic`'s excess."""
     h = [hw]
     for _ in range(5):
         h.append((h[-1] - 1) // 2 + 1)
@@ -357,11 +359,11 @@ def algorithmic_bytes(tag, B, hw):
     img = act[0] // 4
     bits = B * h[1] * h[1] * 4
     if hw == 84:
-        act1 = B * (7 * 32 * 300 + 128) * 4                      # act1 in its band-tiled layout (csrc/var_common.h kAct1TiledFloats)
-        return {1: img + act1 + act[2],                          # image in; act1 (tiles), act2 out
+        act1 = act[1]
+        return {1: img + act1 + act[2],                          # image in; act1, act2 out
                 2: act[2] + act[3] + act[4] + act[5],
                 7: act[2] + 2 * (act[3] + act[4]) + act[5],      # x of conv 3-5 (act2-4) and their output gradients (gact3-5)
-                11: act1 + act[2] + img,                         # act1 tiles (ReLU gate + conv 2's x), gact2, image
+                11: act1 + act[2] + img,                         # act1 (ReLU gate + conv 2's x), gact2, image
                 12: act[5] + 2 * (act[4] + act[3]) + 2 * act[2]  # gact5 in; act4, act3, act2 (ReLU gates) in; gact4, gact3, gact2 out
                 }.get(tag)
     if tag == 1:
@@ -587,6 +589,23 @@ def main():
         ctx.set_streams(old_mask)
         ctx.profile_select(-1)
 
+    # north_star's own number: MFMA fraction of the image CNN forward + backward = its algorithmic FLOPs / the summed durations of
+    # its kernels INSIDE a step (HIP events around each family in turn, over eager steps under the step's own stream plan: the
+    # sound branch runs beside them as it does in the replayed graph).  The rocprofv3 timeline of the replayed step under
+    # profiles/ is the reference for these durations; the event brackets read a few percent longer.
+    img_us = {}
+    if not args.no_roofline and HW in (84, 96):
+        tags = (1, 2, 12, 7, 11, 15) if HW == 84 else (1, 2, 6, 7, 8, 9, 11, 15)
+        for tag in tags:
+            ctx.profile_select(tag)
+            for _ in range(20):
+                eager_step()
+                torch.cuda.synchronize()
+            ms, n = ctx.profile_read()
+            if n:
+                img_us[tag_kernel(tag, HW).rstrip("<,")] = round(1e3 * ms / 20, 2)      # per step (a family may launch twice)
+        ctx.profile_select(-1)
+
     if use_graph:
         tr.sync_device_scalars()                     # (the eager legs above advanced the optimiser's step count)
     for _ in range(args.warmup):
@@ -647,6 +666,13 @@ def main():
                                "avg_us": round(us, 2), "launches": iso_n,
                                "with_side_stream_us": round(1e3 * roof_ms / roof_n, 2),
                                "flops_per_launch": flops}
+        if img_us:
+            img_flops = sum(LAYER_FLOPS) * 3 * B          # forward + data gradient + weight gradient of the five convolutions
+            img_flops -= LAYER_FLOPS[0] * B               # (conv 1 has no data gradient)
+            tot = sum(img_us.values())
+            out["image_cnn_mfma_frac"] = round(img_flops / (tot * 1e-6) / 1e12 / F32_MFMA_PEAK, 4)
+            out["image_cnn"] = {"flops_per_step": img_flops, "kernels_us_in_step": img_us, "sum_us": round(tot, 1),
+                                "how": "HIP events around each kernel family over eager steps with the sound branch on its side stream"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
             out["parity_vs_cpu"] = parity_vs_cpu(var_amd, model, pool)

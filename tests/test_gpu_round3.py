@@ -211,18 +211,27 @@ def test_ithor_bf16_at_the_benchmarked_batch_256(var_amd):
     assert float((f16[sl].cpu() - want).abs().max()) < 1e-2
 
 
-def test_ithor_bf16_gradient_drift_is_traced_to_routing_flips(var_amd):
-    """Where the bf16 gradient leaves the fp32 one, the cause must be visible: a ReLU gate (here: of the two wide sound
-    convolutions, whose activations the debug buffers keep) that differs between the two forwards.  Every differing gate
-    must sit at a pre-activation within bf16 rounding of zero -- the surviving side of the pair is tiny against the layer's
-    scale -- and the gates that differ are a small fraction; with them the 5-8 % L2 drift of the sound-branch gradients
-     is routing, not arithmetic."""
+def test_ithor_bf16_gradient_drift_is_accounted_for(var_amd):
+    """Where the bf16 gradient leaves the fp32 one, the cause must be visible in the workspace, tensor by tensor.
+    (a) Routing: a ReLU gate (the two wide sound convolutions, the image branch's five convolutions) that differs between the
+        two forwards must sit at a pre-activation within bf16 rounding of zero, and such units are a small fraction.
+    (b) Weight tensors: within 30 % in L2, and any drift above 3 % needs at least one differing gate.
+    (c) The image branch's BIAS gradients (32-128 sums over every pixel of the batch) drifted by up to 34 % in round 3 and the
+        bound had been widened to 50 % on the strength of a comment about pool winners.  Traced now (tools/probe/bf16_bias_trace.py):
+        the terms of those sums are the buffers ga1..ga5; split by unit, the part of the difference on units the gradient
+        reaches in only ONE of the two runs (gate / pool-winner flips) is 2-15 % of the tensor's norm -- the rest sits on
+        units BOTH runs reach and is operand rounding: the sums cancel heavily (sum |g| / |sum g| = 8 ... 270), so a
+        per-term relative perturbation of 2^-10 ... 2^-8 (bf16 operands upstream) shows up multiplied by that factor.  The
+        bound is therefore drift <= 2^-7 x (sum |g| / |sum g|), computed from the fp32 run's own terms, and the routed part
+        alone must stay under 20 %."""
     from var_amd._lib import Context
     B = 8
     img, pos, neg = (t.cuda() for t in _ithor_batch(B, 43))
     torch.manual_seed(977)
     sd = IthorNetCPU().state_dict()
-    acts, grads = {}, {}
+    side = {1: 96, 2: 96, 3: 48, 4: 24, 5: 12}                  # output map of image conv l
+    ich = [3, 32, 32, 64, 64, 128]
+    acts, grads, terms = {}, {}, {}
     for prec in ("fp32", "bf16"):
         m = var_amd.IthorVARPretextNet(icfg(96))
         m.load_state_dict(sd)
@@ -234,10 +243,15 @@ def test_ithor_bf16_gradient_drift_is_traced_to_routing_flips(var_amd):
         n = 2 * B
         acts[prec] = {"s1": ctx.debug_buffer("ithor_s1")[:n * 64 * 300 * 20].clone(),
                       "s2": ctx.debug_buffer("ithor_s2")[:n * 64 * 150 * 13].clone()}
+        terms[prec] = {}
+        for l in range(1, 6):
+            cnt = B * ich[l] * side[l] ** 2
+            acts[prec][f"a{l}"] = ctx.debug_buffer(f"ithor_a{l}")[:cnt].clone()
+            terms[prec][l] = ctx.debug_buffer(f"ithor_ga{l}")[:cnt].clone().view(B, ich[l], -1)      # d loss / d pre-activation
         grads[prec] = tr.grads.clone()
         spans = _param_spans(m)
     nflip = 0
-    for k in ("s1", "s2"):
+    for k in acts["fp32"]:
         a32, a16 = acts["fp32"][k], acts["bf16"][k]
         scale = float(a32.abs().max())
         flip = (a32 > 0) != (a16 > 0)
@@ -249,14 +263,25 @@ def test_ithor_bf16_gradient_drift_is_traced_to_routing_flips(var_amd):
             assert float(survivor.max()) < 2e-2 * scale, (k, float(survivor.max()), scale)
         # away from the gates the two activations agree to bf16 operand rounding
         assert float((a32 - a16).abs().max()) < 3e-2 * scale, k
+    img_bias = {f"imgBranch.{i}.bias": l for l, i in zip(range(1, 6), (0, 2, 5, 8, 11))}
     worst = {}
     for k, (lo, hi) in spans.items():
-        d = float((grads["bf16"][lo:hi] - grads["fp32"][lo:hi]).norm() / (grads["fp32"][lo:hi].norm() + 1e-30))
+        g32, g16 = grads["fp32"][lo:hi], grads["bf16"][lo:hi]
+        d = float((g16 - g32).norm() / (g32.norm() + 1e-30))
         worst[k] = d
-        # (weights: 30 %; the small bias vectors -- 32 to 128 sums over every pixel of a max-pooled map, where a single
-        #  pool winner changing hands moves the whole sum -- 50 %)
-        assert d < (0.3 if hi - lo >= 1024 else 0.5), (k, d)
-    drifted = {k: v for k, v in worst.items() if v > 0.03}
+        if k in img_bias:
+            t32, t16 = terms["fp32"][img_bias[k]], terms["bf16"][img_bias[k]]
+            assert float((t32.sum((0, 2)) - g32).norm()) <= 1e-5 * float(g32.norm()), k       # the buffers ARE the sums' terms
+            kappa = float(t32.abs().sum((0, 2)).norm() / g32.norm())
+            one_sided = (t32 != 0) != (t16 != 0)                  # units the gradient reaches in one run only
+            diff = t16 - t32
+            routed = float(torch.where(one_sided, diff, torch.zeros_like(diff)).sum((0, 2)).norm() / g32.norm())
+            assert float(one_sided.float().mean()) < 0.01 and routed < 0.2, (k, float(one_sided.float().mean()), routed)
+            assert d < 2.0 ** -7 * kappa, (k, d, kappa)
+            print(f"{k}: drift {d:.3f} = routing {routed:.3f} + rounding x cancellation {kappa:.0f}")
+        else:
+            assert d < (0.3 if hi - lo >= 1024 else 0.5), (k, d)
+    drifted = {k: v for k, v in worst.items() if v > 0.03 and k not in img_bias}
     if drifted:
         assert nflip > 0, f"gradient tensors drift by more than 3 % in L2 without a single differing gate: {drifted}"
     print("gates that differ:", nflip, "| worst per-tensor L2 drift:", max(worst.values()))

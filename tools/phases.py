@@ -25,7 +25,9 @@ for _ in range(n): step()
 torch.cuda.synchronize()
 fn(buf)
 v = [x / n for x in buf]
-tot = sum(v)
+tot = sum(v[:16])
 print(which, "B", B, "total cycles/launch %.0f (%.1f us at 2.4 GHz)" % (tot, tot / 2400))
-for i, x in enumerate(v):
+if v[16]:
+    print("  in-kernel clock: %.0f shader cycles in %.2f us of s_memrealtime = %.3f GHz" % (v[17], v[16] / 100.0, v[17] / v[16] * 0.1))
+for i, x in enumerate(v[:16]):
     if x: print("  phase %2d: %8.0f cycles  %5.1f %%" % (i, x, 100 * x / tot))

@@ -642,10 +642,10 @@ int chain_forward(var_ctx* c, hipStream_t s, arm_state* st, const float* P, cons
         return VAR_ERR_ARG;
     }
     const int lds_bytes = (int)lds_max * 4;
-    static bool attr = false;
-    if (!attr) {
+    static unsigned attr = 0;      // bit d: set on device d (function attributes are per device)
+    if (!(attr & var_dev_bit(c))) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)armnet_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        attr = true;
+        attr |= var_dev_bit(c);
     }
     const int grid = kChainG - (st->drop_one ? 1 : 0);          // (one short: its outputs never arrive, every consumer's wait expires)
     st->drop_one = false;

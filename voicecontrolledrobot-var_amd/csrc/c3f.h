@@ -301,10 +301,10 @@ __global__ void __launch_bounds__(256) c3f_kernel(const float* __restrict__ x, c
 
 template <class C>
 int launch(var_ctx* c, hipStream_t s, const float* x, const f32x4* wp, const float* bias, float* y, int B) {
-    static bool attr = false;
-    if (!attr) {
+    static unsigned attr = 0;      // bit d: set on device d (function attributes are per device)
+    if (!(attr & var_dev_bit(c))) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)c3f_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDSF * 4));
-        attr = true;
+        attr |= var_dev_bit(c);
     }
     hipLaunchKernelGGL(c3f_kernel<C>, dim3(B * C::BANDS * C::CBG), dim3(256), C::LDSF * 4, s, x, wp, bias, y, B);
     VAR_HIP_CHECK(c, hipGetLastError());
@@ -441,10 +441,10 @@ __global__ void __launch_bounds__(256) c3s_kernel(const float* __restrict__ x, c
 
 template <class C>
 int launch_small(var_ctx* c, hipStream_t s, const float* x, const void* wsrc, const float* bias, float* y, int B) {
-    static bool attr = false;
-    if (!attr) {
+    static unsigned attr = 0;      // bit d: set on device d (function attributes are per device)
+    if (!(attr & var_dev_bit(c))) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)c3s_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDSF * 4));
-        attr = true;
+        attr |= var_dev_bit(c);
     }
     hipLaunchKernelGGL(c3s_kernel<C>, dim3(B * (C::COUT / 16)), dim3(256), C::LDSF * 4, s, x, wsrc, bias, y, B);
     VAR_HIP_CHECK(c, hipGetLastError());

@@ -429,10 +429,10 @@ inline int launch(var_ctx* c, hipStream_t s, const DenseP<AK, BK, MODE>& p, int 
     const int mt = (p.M + TM - 1) / TM, nt = (p.N + TN - 1) / TN, zt = batches * p.nsplit;
     if constexpr (AK && BK && MODE != 2) {
         if (resident_a_eligible(p)) {                      // one workgroup per CU, each with its A panel and a share of the n tiles
-            static bool attr[2] = {false, false};
-            if (!attr[MODE]) {
+            static unsigned attr[2] = {0, 0};              // bit d: set on device d
+            if (!(attr[MODE] & var_dev_bit(c))) {
                 VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)resident_a_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, RES_LDS));
-                attr[MODE] = true;
+                attr[MODE] |= var_dev_bit(c);
             }
             int cus = 256;
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);

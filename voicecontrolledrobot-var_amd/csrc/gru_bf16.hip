@@ -607,11 +607,11 @@ int gru_bf16_pack(var_ctx* c, hipStream_t s, const float* w_hh, const float* w_i
     const int n = (int)((kWfBytes + kWbBytes) / 16) + 2 * (G3 * 448 / 8) + 2 * q.nrow16 + 2 * q.nrow32 + q.ncnt;
     hipLaunchKernelGGL(gru_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w_hh, dirP, wf, wb, q);
     VAR_HIP_CHECK(c, hipGetLastError());
-    static bool attr = false;
-    if (!attr) {
+    static unsigned attr = 0;      // bit d: set on device d (function attributes are per device)
+    if (!(attr & var_dev_bit(c))) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)gru_step_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds));
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)gru_seq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds + 16));
-        attr = true;
+        attr |= var_dev_bit(c);
     }
     return VAR_OK;
 }

@@ -406,11 +406,11 @@ static int run_heads_fwd(var_ctx* c, hipStream_t s, const float* x, int R, const
                          bool finish, float* out0 = nullptr, float* out1 = nullptr, int split = 0) {
     constexpr int A1 = 32 * (K + 1) * 4, A2 = 5 * 32 * 33 * 4;
     constexpr int LDS_BYTES = A1 > A2 ? A1 : A2;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned attr_set = 0;      // bit d: set on device d (function attributes are per device)
+    if (!(attr_set & var_dev_bit(c))) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)heads_fwd_split_kernel<K>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set = true;
+        attr_set |= var_dev_bit(c);
     }
     hipLaunchKernelGGL(heads_fwd_split_kernel<K>, dim3((R + 31) / 32, 4), dim3(256), LDS_BYTES, s, x, R, w0t, b0, w1, hid, part);
     if (finish) hipLaunchKernelGGL(heads_finish_kernel, dim3((R + 255) / 256), dim3(256), 0, s, part, b1, R, emb_raw, emb, out0, out1, split);

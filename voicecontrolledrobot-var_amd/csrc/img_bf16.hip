@@ -236,10 +236,10 @@ int c3_launch(var_ctx* c, hipStream_t s, const float* x, const float* w, const f
         hipLaunchKernelGGL(c3_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, (uint4*)wp, IC, OC, MODE);
         VAR_HIP_CHECK(c, hipGetLastError());
     }
-    static bool attr = false;
-    if (!attr) {
+    static unsigned attr = 0;      // bit d: set on device d (function attributes are per device)
+    if (!(attr & var_dev_bit(c))) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)c3_kernel<IC, OC, H, TR, NI, MODE, WGS>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDSB));
-        attr = true;
+        attr |= var_dev_bit(c);
     }
     const int ntiles = ((B + NI - 1) / NI) * G::TILES, cap = 256 * WGS, grid = ntiles < cap ? ntiles : cap;
     if (nparts) *nparts = grid;
@@ -397,10 +397,10 @@ __global__ void __launch_bounds__(256) c3w_fold_kernel(const float* __restrict__
 template <int CI, int CO, int H, int TR>
 int c3w_launch(var_ctx* c, hipStream_t s, const float* x, const float* gy, float* dw, float* slab, int B) {
     using G = C3W<CI, CO, H, TR>;
-    static bool attr = false;
-    if (!attr) {
+    static unsigned attr = 0;      // bit d: set on device d (function attributes are per device)
+    if (!(attr & var_dev_bit(c))) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)c3w_kernel<CI, CO, H, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDSB));
-        attr = true;
+        attr |= var_dev_bit(c);
     }
     const int ntiles = B * G::TILES, grid = ntiles < 512 ? ntiles : 512;
     hipLaunchKernelGGL((c3w_kernel<CI, CO, H, TR>), dim3(grid), dim3(256), G::LDSB, s, x, gy, slab, B);

@@ -328,11 +328,11 @@ using T96f = TailCfg<48, false, 8, 1>;
 template <class C>
 static int launch_tail(var_ctx* c, hipStream_t s, int B) {
     ProfScope prof(c, s, TAG_IMG_DGRAD0 + 1);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned attr_set = 0;      // bit d: set on device d (function attributes are per device)
+    if (!(attr_set & var_dev_bit(c))) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)img_bwd_tail_kernel<C>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-        attr_set = true;
+        attr_set |= var_dev_bit(c);
     }
     const int ntiles = (B * C::NB + C::NU - 1) / C::NU;
     const int G = ntiles < kTailG ? ntiles : kTailG;

@@ -217,11 +217,11 @@ img_chain_kernel(const float* __restrict__ g5, const float* __restrict__ wa5, co
 // data gradients of conv 5, 4, 3 at 84 x 84: consumes gact[5] and act[2..4], leaves gact[4], gact[3], gact[2]
 int launch_img_bwd_chain(var_ctx* c, hipStream_t s, int B) {
     ProfScope prof(c, s, TAG_IMG_DGRAD0 + 2);
-    static bool attr_set = false;
+    static unsigned attr_set = 0;      // bit d: set on device d (function attributes are per device)
     constexpr int LDS_BYTES = kChainLdsFloats * 4;
-    if (!attr_set) {
+    if (!(attr_set & var_dev_bit(c))) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)img_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set = true;
+        attr_set |= var_dev_bit(c);
     }
     const PackLayout& K = c->kl;
     hipLaunchKernelGGL(img_chain_kernel, dim3(B), dim3(kChainNT), LDS_BYTES, s, c->gact[5], c->wpack + K.img_a[4],

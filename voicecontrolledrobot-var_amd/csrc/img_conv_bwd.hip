@@ -421,11 +421,11 @@ static int launch_wgrad345(var_ctx* c, hipStream_t s, int B) {
     ProfScope prof(c, s, TAG_IMG_WGRAD0 + 2);
     constexpr int LDS_BYTES = W2::LDS_BYTES > W3::LDS_BYTES ? (W2::LDS_BYTES > W4::LDS_BYTES ? W2::LDS_BYTES : W4::LDS_BYTES)
                                                            : (W3::LDS_BYTES > W4::LDS_BYTES ? W3::LDS_BYTES : W4::LDS_BYTES);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned attr_set = 0;      // bit d: set on device d (function attributes are per device)
+    if (!(attr_set & var_dev_bit(c))) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)img_wgrad345_kernel<W2, W3, W4>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set = true;
+        attr_set |= var_dev_bit(c);
     }
     auto groups = [&](int layer, int nb, int nu) {
         const int need = (B * nb + nu - 1) / nu, gmax = img_wgrad_groups(layer);
@@ -446,11 +446,11 @@ static int launch_pair(var_ctx* c, hipStream_t s, int layer, const void* wx, lon
                        const float* wd, const float* x, float* gx, int B) {
     ProfScope prof(c, s, TAG_IMG_WGRAD0 + layer);
     constexpr int LDS_BYTES = WC::LDS_BYTES > DC::LDS_BYTES ? WC::LDS_BYTES : DC::LDS_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned attr_set = 0;      // bit d: set on device d (function attributes are per device)
+    if (!(attr_set & var_dev_bit(c))) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)img_bwd_pair_kernel<WC, DC, D16>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set = true;
+        attr_set |= var_dev_bit(c);
     }
     const int need = (B * WC::NB + WC::NU - 1) / WC::NU;
     const int gmax = img_wgrad_groups(layer);

@@ -283,11 +283,11 @@ template <class C>
 static int launch_head(var_ctx* c, hipStream_t s, const void* image, long bstride, const int* bidx,
                        const float* params, int B) {
     ProfScope prof(c, s, TAG_IMG_FWD0 + 1);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned attr_set = 0;      // bit d: set on device d (function attributes are per device)
+    if (!(attr_set & var_dev_bit(c))) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)img_fwd_head_kernel<C>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-        attr_set = true;
+        attr_set |= var_dev_bit(c);
     }
     const int ntiles = (B * C::NB + C::NU - 1) / C::NU;
     const int G = ntiles < 256 ? ntiles : 256;

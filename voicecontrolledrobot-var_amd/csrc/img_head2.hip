@@ -344,11 +344,11 @@ using H2_84f = Head2Cfg<42, false, 3>;
 template <class C>
 int launch_head2(var_ctx* c, hipStream_t s, const void* image, long bstride, const int* bidx, const float* params, int B) {
     ProfScope prof(c, s, TAG_IMG_FWD0 + 1);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned attr_set = 0;      // bit d: set on device d (function attributes are per device)
+    if (!(attr_set & var_dev_bit(c))) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)img_head2_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                              C::LDS_BYTES));
-        attr_set = true;
+        attr_set |= var_dev_bit(c);
     }
     const int G = B < kHead2G ? B : kHead2G;
     const ParamLayout& L = c->pl;

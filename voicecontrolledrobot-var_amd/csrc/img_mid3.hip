@@ -28,8 +28,14 @@
 
 namespace {
 PH_DECL();
+#ifdef VAR_PHASES
+__device__ unsigned long long g_span[1024][2];          // per workgroup: s_memrealtime (100 MHz, chip-wide) at its first and last instruction
+#endif
 }
 #ifdef VAR_PHASES
+extern "C" int var_debug_spans_mid3(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(unsigned long long) * 2 * n) == hipSuccess ? 0 : -1;
+}
 extern "C" int var_debug_phases_mid3(unsigned long long* out) {
     unsigned long long z[32] = {0};
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(z)) != hipSuccess) return -1;
@@ -98,6 +104,9 @@ img_mid3_kernel(const float* __restrict__ x2, const float* __restrict__ wa3, con
     const size_t b = blockIdx.x;
     const int nt = wave & 3, kq = wave >> 2;                     // 16-channel tile; K quarter (conv 4, 5) / pixel group (conv 3)
     PHR_INIT(5, VAR_PH_THREAD);
+#ifdef VAR_PHASES
+    if (tid == 0) g_span[blockIdx.x][0] = wall_clock64();
+#endif
 
     // ---- constants (biases, the head's second layer) by LDS-DMA as well: a value parked in a register until the first barrier
     //      gave hipcc a pending load to wait for at an unrelated instruction (vmcnt(0): the whole prologue).  The block is four
@@ -511,6 +520,9 @@ img_mid3_kernel(const float* __restrict__ x2, const float* __restrict__ wa3, con
     }
     PHR(14);
     PHR_FLUSH();
+#ifdef VAR_PHASES
+    if (tid == 0) g_span[blockIdx.x][1] = wall_clock64();
+#endif
 }
 }  // namespace
 
@@ -519,7 +531,11 @@ img_mid3_kernel(const float* __restrict__ x2, const float* __restrict__ wa3, con
 template <int H2>
 static int launch_mid3(var_ctx* c, hipStream_t s, const float* params, int B, bool with_head) {
     using C = M3Cfg<H2>;
-    VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)img_mid3_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    static unsigned attr = 0;      // bit d: set on device d (function attributes are per device)
+    if (!(attr & var_dev_bit(c))) {
+        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)img_mid3_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        attr |= var_dev_bit(c);
+    }
     const ParamLayout& L = c->pl;
     const PackLayout& K = c->kl;
     hipLaunchKernelGGL((img_mid3_kernel<C>), dim3(B), dim3(M3_NT), C::LDS_BYTES, s, c->act[2], c->wpack + K.img_f[2],

@@ -449,11 +449,11 @@ img_tail2_kernel(const float* __restrict__ gy, const float* __restrict__ wd, con
 template <class C>
 int launch_tail2(var_ctx* c, hipStream_t s, int B) {
     ProfScope prof(c, s, TAG_IMG_DGRAD0 + 1);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned attr_set = 0;      // bit d: set on device d (function attributes are per device)
+    if (!(attr_set & var_dev_bit(c))) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)img_tail2_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                              C::LDS_BYTES));
-        attr_set = true;
+        attr_set |= var_dev_bit(c);
     }
     const int G = B < kTail2G ? B : kTail2G;
     c->wg_groups[0] = G;

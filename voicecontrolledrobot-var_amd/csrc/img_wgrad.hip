@@ -334,11 +334,11 @@ static int launch_wgrad(var_ctx* c, hipStream_t s, const void* x, long bstride, 
     static_assert(C::NCOMBO * C::SLAB <= 4 * 9248, "slab sizing");
     const int* bidx = layer == 0 ? c->saved_index : nullptr;
     ProfScope prof(c, s, TAG_IMG_WGRAD0 + layer);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned attr_set = 0;      // bit d: set on device d (function attributes are per device)
+    if (!(attr_set & var_dev_bit(c))) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)img_wgrad_kernel<C>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-        attr_set = true;
+        attr_set |= var_dev_bit(c);
     }
     const int need = (B * C::NB + C::NU - 1) / C::NU;
     const int gmax = kWgG[layer];

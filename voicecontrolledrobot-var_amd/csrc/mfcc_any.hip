@@ -158,11 +158,11 @@ int launch_mfcc_any(var_ctx* c, hipStream_t s, const int16_t* pcm, const int* le
     }
     const long total = (long)nclips * out_frames;
     const int lds_bytes = (WAVES * n_fft * 2 + WAVES * 64) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned attr_set = 0;      // bit d: set on device d (function attributes are per device)
+    if (!(attr_set & var_dev_bit(c))) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)mfcc_any_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (WAVES * MAXFFT * 2 + WAVES * 64) * 4));
-        attr_set = true;
+        attr_set |= var_dev_bit(c);
     }
     long blocks = (total + WAVES - 1) / WAVES;
     if (blocks > 4096) blocks = 4096;

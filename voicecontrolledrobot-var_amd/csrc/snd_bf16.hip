@@ -996,11 +996,11 @@ int snd1_bf16_fwd(var_ctx* c, hipStream_t s, const float* x0, int n0, const floa
     const BfWs o = bf_ws(maxclips);
     hipLaunchKernelGGL(pack_w1_kernel, dim3((11 * 2 * 64 + 255) / 256), dim3(256), 0, s, w, at<uint4>(ws, o.wp1));
     VAR_HIP_CHECK(c, hipGetLastError());
-    static bool attr = false;
-    if (!attr) {
+    static unsigned attr = 0;      // bit d: set on device d (function attributes are per device)
+    if (!(attr & var_dev_bit(c))) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd1_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDSB + 256));
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd1_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDSB + 256));
-        attr = true;
+        attr |= var_dev_bit(c);
     }
     const int n = n0 + n1;
     if (y) hipLaunchKernelGGL(snd1_fwd_kernel<true>, dim3(n < 512 ? n : 512), dim3(256), C1_LDSB + 256, s, x0, x1, n0, at<uint4>(ws, o.wp1), bias,
@@ -1025,11 +1025,11 @@ int snd2_bf16_fwd(var_ctx* c, hipStream_t s, const float* x, const float* w, con
     }
     hipLaunchKernelGGL(pack_w_kernel<false>, dim3((NQ * L::NTAP * 128 + 255) / 256), dim3(256), 0, s, w, at<uint4>(ws, o.wp2), L::NTAP);
     VAR_HIP_CHECK(c, hipGetLastError());
-    static bool attr = false;
-    if (!attr) {
+    static unsigned attr = 0;      // bit d: set on device d (function attributes are per device)
+    if (!(attr & var_dev_bit(c))) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd_fwd_kernel<Geo2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDSB));
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd_fwd_kernel<Geo2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDSB));
-        attr = true;
+        attr |= var_dev_bit(c);
     }
     const int ntiles = nclips * Geo2::TILES;
     ProfScope prof(c, s, TAG_ITHOR_S2_FWD);
@@ -1047,10 +1047,10 @@ int snd3_bf16_fwd(var_ctx* c, hipStream_t s, const float* w, const float* bias, 
     using L = FwdLayout<Geo3>;
     hipLaunchKernelGGL(pack_w_kernel<false>, dim3((NQ * L::NTAP * 128 + 255) / 256), dim3(256), 0, s, w, at<uint4>(ws, o.wp3), L::NTAP);
     VAR_HIP_CHECK(c, hipGetLastError());
-    static bool attr = false;
-    if (!attr) {
+    static unsigned attr = 0;      // bit d: set on device d (function attributes are per device)
+    if (!(attr & var_dev_bit(c))) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd_fwd_kernel<Geo3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDSB));
-        attr = true;
+        attr |= var_dev_bit(c);
     }
     hipLaunchKernelGGL((snd_fwd_kernel<Geo3, true>), dim3(nclips < 256 ? nclips : 256), dim3(256), L::LDSB, s, at<uint4>(ws, o.y8),
                        at<uint4>(ws, o.wp3), bias, y, (uint2*)nullptr, (unsigned*)nullptr, nclips);
@@ -1064,11 +1064,11 @@ static int dgrad_launch(var_ctx* c, hipStream_t s, const float* w, const uint4* 
     using L = DgLayout<G>;
     hipLaunchKernelGGL(pack_w_kernel<true>, dim3((NQ * L::NTAP * 128 + 255) / 256), dim3(256), 0, s, w, wpt, L::NTAP);
     VAR_HIP_CHECK(c, hipGetLastError());
-    static bool attr = false;
-    if (!attr) {
+    static unsigned attr = 0;      // bit d: set on device d (function attributes are per device)
+    if (!(attr & var_dev_bit(c))) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd_dgrad_kernel<G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDSB));
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd_dgrad_kernel<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDSB));
-        attr = true;
+        attr |= var_dev_bit(c);
     }
     if ((dx8 != nullptr) != G::OUT8 || (dx16 != nullptr) != G::OUT16) { VAR_SET_ERR(c, "sound data gradient: output set does not match the layer"); return VAR_ERR_ARG; }
     const int ntiles = nclips * G::TILES;
@@ -1116,10 +1116,10 @@ template <class G>
 static int wgrad_launch(var_ctx* c, hipStream_t s, const uint4* x8, const uint4* gy8, float* dw, float* slab, int nclips, int max_groups,
                         int tag) {
     using L = WgLayout<G>;
-    static bool attr = false;
-    if (!attr) {
+    static unsigned attr = 0;      // bit d: set on device d (function attributes are per device)
+    if (!(attr & var_dev_bit(c))) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd_wgrad_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDSB));
-        attr = true;
+        attr |= var_dev_bit(c);
     }
     int groups = nclips < max_groups ? nclips : max_groups;
     const int per = (nclips + groups - 1) / groups;
@@ -1148,10 +1148,10 @@ int snd3_bf16_wgrad(var_ctx* c, hipStream_t s, float* dw, float* slab, int nclip
 int snd1_bf16_wgrad(var_ctx* c, hipStream_t s, const float* x0, int n0, const float* x1, int n1, float* dw, float* slab, int maxclips,
                     void* ws) {
     const BfWs o = bf_ws(maxclips);
-    static bool attr = false;
-    if (!attr) {
+    static unsigned attr = 0;      // bit d: set on device d (function attributes are per device)
+    if (!(attr & var_dev_bit(c))) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd1_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDSB + 256));
-        attr = true;
+        attr |= var_dev_bit(c);
     }
     const int n = n0 + n1, grid = n < 512 ? n : 512;          // (two co-resident workgroups per CU beat one with two clips: 183 vs 302 us)
     hipLaunchKernelGGL(snd1_wgrad_kernel, dim3(grid), dim3(256), C1_LDSB + 256, s, x0, x1, n0, at<unsigned short>(ws, o.g116), slab, n);

@@ -448,11 +448,11 @@ int launch_snd_fwd(var_ctx* c, hipStream_t s, const float* params, const float* 
     const PackLayout& K = c->kl;
     const int lo = pos ? 0 : B, hi = neg ? 2 * B : B;
     if (hi <= lo) return VAR_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned attr_set = 0;      // bit d: set on device d (function attributes are per device)
+    if (!(attr_set & var_dev_bit(c))) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)snd_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                              F_END * 4));
-        attr_set = true;
+        attr_set |= var_dev_bit(c);
     }
     ProfScope prof(c, s, TAG_SND_FWD);
     hipLaunchKernelGGL(snd_fwd_kernel, dim3((hi - lo + FNC - 1) / FNC), dim3(FNT), F_END * 4, s, pos, neg, B, lo, hi,

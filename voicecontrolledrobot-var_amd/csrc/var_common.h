@@ -178,6 +178,9 @@ struct var_ctx {
                                               // (var_ithor_guard_loss; a rank's time-out reaches every rank through the NaN it sums in)
 };
 
+// MaxDynamicSharedMemorySize and friends are attributes of a function ON A DEVICE: the launchers' set-once flags are masks
+static inline unsigned var_dev_bit(const var_ctx* c) { return 1u << (c->device & 31); }
+
 #define VAR_SET_ERR(ctx, ...) do { if (ctx) snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__); } while (0)
 
 #define VAR_HIP_CHECK(ctx, expr)                                                              \
@@ -213,9 +216,11 @@ struct ProfScope {
 #define PH(i) do { if (ph_on) { const unsigned long long t_ = clock64(); g_phase[i] += t_ - ph_t; ph_t = t_; } } while (0)
 // register-accumulated form (PHR_INIT / PHR / PHR_FLUSH): a mark touches no memory, so it does not wait for the kernel's own
 // outstanding loads and stores the way PH()'s read-modify-write of g_phase does; 16 phases, written out once at the end
-#define PHR_INIT(blk, thr) unsigned long long ph_t = clock64(), ph_a[16] = {0}; const bool ph_on = (int)blockIdx.x == (blk) && (int)threadIdx.x == (thr)
+// g_phase[16] / [17]: the marked wave's whole span in s_memrealtime ticks (100 MHz) and in shader cycles (s_memtime): their ratio is
+// the clock the kernel ran at (MI355X_MICROARCH.md, DVFS give-back item 6; tools/phases.py prints it)
+#define PHR_INIT(blk, thr) unsigned long long ph_t = clock64(), ph_a[16] = {0}; const unsigned long long ph_c0 = ph_t, ph_r0 = wall_clock64(); const bool ph_on = (int)blockIdx.x == (blk) && (int)threadIdx.x == (thr)
 #define PHR(i) do { const unsigned long long t_ = clock64(); ph_a[i] += t_ - ph_t; ph_t = t_; } while (0)
-#define PHR_FLUSH() do { if (ph_on) { for (int i_ = 0; i_ < 16; ++i_) g_phase[i_] += ph_a[i_]; } } while (0)
+#define PHR_FLUSH() do { if (ph_on) { for (int i_ = 0; i_ < 16; ++i_) g_phase[i_] += ph_a[i_]; g_phase[16] += wall_clock64() - ph_r0; g_phase[17] += clock64() - ph_c0; } } while (0)
 #else
 #define PH_DECL()
 #define PH_INIT(blk)
