@@ -242,6 +242,65 @@ struct ColStager {
 };
 
 // ------------------------------------------------------------------------------------------
+// FlatStager: ColStager's job for the case "the band is the WHOLE map of NCH consecutive planes of one image" with an odd
+// row width (21 x 21, 11 x 11 maps at 84 x 84): there ColStager can only move 4 bytes per lane and load (rows are not
+// 8- or 16-byte aligned) -- 23 + 11 load instructions per lane and unit in the conv-3 weight gradient, and a CU accepts a
+// vector-memory instruction only every ~35 cycles: the kernel was bound by load ISSUE (408 wave-loads per unit against
+// 3.3 K cycles of matrix work).  The NCH planes are one contiguous, 16-byte aligned run in HBM: this stager reads it as
+// float4 (84 wave-loads per unit for the same bytes) and scatters the four floats to their padded LDS cells, whose offsets
+// are computed once per kernel.
+//   lds[ch*PLANE + (row + ROW0)*PW + COL0 + col] = plane[ch][row][col]
+// ------------------------------------------------------------------------------------------
+template <int NCH, int H, int W, int PW, int PLANE, int ROW0, int COL0, int NT, int NUNITS = 1>
+struct FlatStager {
+    static constexpr int NF = NCH * H * W, NV = NF / 4;      // floats / float4 of one unit's run
+    static constexpr int PP = (NUNITS * NV + NT - 1) / NT;
+    static constexpr int UNIT = NCH * PLANE;
+    static_assert(NF % 4 == 0, "the run must be whole float4");
+    int off[PP][4];        // LDS offsets of the lane's floats
+    float4 data[PP];
+    int voff[PP];          // float4 index inside its unit's run (clamped for lanes past the end)
+    int ucol[PP];          // unit (-1: no vector)
+
+    __device__ __forceinline__ void init(int tid) {
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {
+            const int v = tid + p * NT;
+            const bool live = v < NUNITS * NV;
+            const int u = live ? v / NV : 0;
+            ucol[p] = live ? u : -1;
+            voff[p] = live ? v - u * NV : 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = 4 * voff[p] + j;
+                const int ch = e / (H * W), rem = e - ch * (H * W);
+                const int r = rem / W, x = rem - r * W;
+                off[p][j] = u * UNIT + ch * PLANE + (r + ROW0) * PW + COL0 + x;
+            }
+        }
+    }
+    // base: the first unit's run; further units are the following images, `ustride` elements apart; units >= nvalid load
+    // unit 0's bytes and are written as zeros
+    template <class PT>
+    __device__ __forceinline__ void issue(const PT* base, long ustride, int, int nvalid) {
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {
+            const int u = ucol[p] > 0 && ucol[p] < nvalid ? ucol[p] : 0;
+            data[p] = ((const float4*)(base + (size_t)u * ustride))[voff[p]];
+        }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ lds, int, int nvalid) const {
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {
+            if (ucol[p] < 0) continue;
+            const bool ok = ucol[p] < nvalid;
+            lds[off[p][0]] = ok ? data[p].x : 0.f; lds[off[p][1]] = ok ? data[p].y : 0.f;
+            lds[off[p][2]] = ok ? data[p].z : 0.f; lds[off[p][3]] = ok ? data[p].w : 0.f;
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------
 // Two-phase copy of NU bands (ROWS rows x W cols of NCH planes each) from global memory to LDS: issue() puts
 // every load of the bands in flight into registers, store() writes them to LDS later -- the matrix work of the
 // current tile runs in between.  NT / (NU*NCH) consecutive lanes walk one plane's band (contiguous in memory),

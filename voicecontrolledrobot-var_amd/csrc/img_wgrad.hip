@@ -44,7 +44,9 @@ struct WgCfg {
     static constexpr int XS = (NU * UNIT_X + 3) & ~3, YS = NU * UNIT_Y;
     static constexpr int ZPAD = (XS + YS + 3) & ~3;  // a few always-zero floats: A operand of idle k-steps
     static constexpr int STAGE = ZPAD + 4;
-    static constexpr int LDS_FLOATS = ((DB ? 2 : 1) * STAGE > NW * 1024 ? (DB ? 2 : 1) * STAGE : NW * 1024);
+    static constexpr int FOLD = SMALLC ? NW * 1024 : NW * 3 * 1024;     // every wave parks its tiles at once (one round, one barrier pair)
+    static constexpr int LDS_FLOATS = ((DB ? 2 : 1) * STAGE > FOLD ? (DB ? 2 : 1) * STAGE : FOLD);
+    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS");
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
     static constexpr int SLAB = SMALLC ? (32 * 32 + 32) : (32 * 9 * 32 + 32);
     static constexpr int HSTEPS = (WO + 1) / 2;
@@ -54,6 +56,20 @@ struct WgCfg {
 
 // (a __device__ body so that it can also run as one half of a fused launch, img_conv_bwd.hip: bx / by / G stand for
 // blockIdx.x / blockIdx.y / gridDim.x of a stand-alone launch)
+#ifndef VAR_WG_PH
+#define VAR_WG_PH
+namespace { PH_DECL(); }
+#ifdef VAR_PHASES
+extern "C" int var_debug_phases_wgrad(unsigned long long* out) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
+#endif
+#ifndef VAR_WG_PH_BLOCK
+#define VAR_WG_PH_BLOCK 0
+#endif
 template <class C>
 __device__ __forceinline__ void img_wgrad_body(const void* __restrict__ xin, long bstride, const int* __restrict__ bidx,
                                                const float* __restrict__ gy, float* __restrict__ slabs, int B,
@@ -70,8 +86,13 @@ __device__ __forceinline__ void img_wgrad_body(const void* __restrict__ xin, lon
     const int nb = combo / C::CBLK, cb = combo - nb * C::CBLK;
     const int ky = C::SMALLC ? 0 : wave % 3, ks = C::SMALLC ? wave : wave / 3;
 
-    ColStager<C::XC, C::H, C::W, C::IR, C::PW, C::PLANE_X, 1, C::U8, NT, C::NU> sx;
-    ColStager<32, C::HO, C::WO, C::R, C::POW, C::PLANE_Y, 0, false, NT, C::NU> sy;
+    // whole odd-width maps (84 x 84: the 21 x 21 and 11 x 11 layers) are read as float4 runs (FlatStager, img_stage.h)
+    constexpr bool FLATX = !C::U8 && !C::SMALLC && C::NB == 1 && (C::W & 1) && C::R == C::HO;
+    constexpr bool FLATY = !C::SMALLC && C::NB == 1 && (C::WO & 1) && C::R == C::HO;
+    typename std::conditional<FLATX, FlatStager<C::XC, C::H, C::W, C::PW, C::PLANE_X, 1, 1, NT, C::NU>,
+                              ColStager<C::XC, C::H, C::W, C::IR, C::PW, C::PLANE_X, 1, C::U8, NT, C::NU>>::type sx;
+    typename std::conditional<FLATY, FlatStager<32, C::HO, C::WO, C::POW, C::PLANE_Y, 0, 0, NT, C::NU>,
+                              ColStager<32, C::HO, C::WO, C::R, C::POW, C::PLANE_Y, 0, false, NT, C::NU>>::type sy;
     sx.init(tid);
     sy.init(tid);
 
@@ -123,6 +144,7 @@ __device__ __forceinline__ void img_wgrad_body(const void* __restrict__ xin, lon
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float bsum = 0.f;
 
+    PHR_INIT(VAR_WG_PH_BLOCK, VAR_PH_THREAD);
     // zero the pads once (data cells are rewritten for every unit)
     lds_zero<NT>(lds, C::LDS_FLOATS, tid);
     const int first = bx * C::NU;
@@ -177,54 +199,67 @@ __device__ __forceinline__ void img_wgrad_body(const void* __restrict__ xin, lon
             __syncthreads();
         }
     } else {
+        PHR(0);
 #pragma unroll 1
         for (int unit0 = first; unit0 < total_units; unit0 += G * C::NU) {
             __syncthreads();                              // previous stage's MFMAs are done reading LDS
+            PHR(1);
             {
                 const Stage st = make_stage(unit0);       // same (cheap, uniform) bookkeeping the loads were issued with
                 sx.store(xs, st.row0x, st.nvalid);
                 sy.store(ys, st.row0y, st.nvalid);
             }
+            PHR(2);
             __syncthreads();
+            PHR(3);
             if (unit0 + G * C::NU < total_units) {        // in flight during the MFMAs below
                 const Stage st = make_stage(unit0 + G * C::NU);
                 sx.issue(st.bx, bstride, st.row0x, st.nvalid);
                 sy.issue(st.by, YSTRIDE, st.row0y, st.nvalid);
             }
+            PHR(4);
             __builtin_amdgcn_sched_barrier(0);
             multiply(lds);
             __builtin_amdgcn_sched_barrier(0);
+            PHR(5);
         }
     }
 
     // ---- fold the K slices through LDS (fixed order) and write this workgroup's partial slab ----
     float* slab = slabs + ((size_t)bx * C::NCOMBO + combo) * C::SLAB;
     bsum += __shfl_down(bsum, 32, 64);
-    constexpr int NTILE = C::SMALLC ? 1 : 3;
-#pragma unroll
-    for (int kx = 0; kx < NTILE; ++kx) {
+    if constexpr (C::SMALLC) {
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int n = (r & 3) + 8 * (r >> 2) + 4 * half;
-            lds[wave * 1024 + n * 32 + l31] = acc[kx][r];
+            lds[wave * 1024 + n * 32 + l31] = acc[0][r];
         }
         __syncthreads();
-        if constexpr (C::SMALLC) {
-            for (int e = tid; e < 1024; e += NT) {
-                float sum = 0.f;
+        for (int e = tid; e < 1024; e += NT) {
+            float sum = 0.f;
 #pragma unroll
-                for (int q = 0; q < C::KS; ++q) sum += lds[q * 1024 + e];
-                slab[e] = sum;
-            }
-        } else {
-            for (int e = tid; e < 3 * 1024; e += NT) {
-                const int kyy = e >> 10, i = e & 1023;
-                float sum = 0.f;
+            for (int q = 0; q < C::KS; ++q) sum += lds[q * 1024 + e];
+            slab[e] = sum;
+        }
+    } else {
+        // all three kx tiles of every wave in ONE round (was three, two barriers each); four consecutive c per thread and one
+        // 16-byte store
+        __syncthreads();
 #pragma unroll
-                for (int q = 0; q < C::KS; ++q) sum += lds[(q * 3 + kyy) * 1024 + i];
-                slab[((i >> 5) * 9 + kyy * 3 + kx) * 32 + (i & 31)] = sum;
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = (r & 3) + 8 * (r >> 2) + 4 * half;
+                lds[(wave * 3 + kx) * 1024 + n * 32 + l31] = acc[kx][r];
             }
+        __syncthreads();
+        for (int e = tid; e < 9 * 256; e += NT) {
+            const int tap = e >> 8, kyy = tap / 3, kx = tap - 3 * kyy, i = (e & 255) * 4;
+            f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < C::KS; ++q) sum += *(const f32x4*)(lds + ((q * 3 + kyy) * 3 + kx) * 1024 + i);
+            *(f32x4*)(slab + ((i >> 5) * 9 + tap) * 32 + (i & 31)) = sum;
         }
     }
     __syncthreads();
@@ -236,6 +271,8 @@ __device__ __forceinline__ void img_wgrad_body(const void* __restrict__ xin, lon
         for (int q = 0; q < C::KS; ++q) sum += lds[q * 32 + tid];
         slab[(C::SMALLC ? 1024 : 9216) + tid] = sum;
     }
+    PHR(6);
+    PHR_FLUSH();
 }
 
 template <class C>
@@ -249,7 +286,7 @@ img_wgrad_kernel(const void* __restrict__ xin, long bstride, const int* __restri
 using W84_0u = WgCfg<3, 32, 84, true, 6, 1, 4>;
 using W84_0f = WgCfg<3, 32, 84, false, 6, 1, 4>;
 using W84_2 = WgCfg<32, 64, 21, false, 11, 1, 4>;
-using W84_3 = WgCfg<64, 64, 11, false, 6, 1, 4>;
+using W84_3 = WgCfg<64, 64, 11, false, 6, 4, 4>;       // four images per stage: a unit of this layer is too short to cover a load round trip
 using W84_4 = WgCfg<64, 64, 6, false, 3, 4, 4>;
 using W96_0u = WgCfg<3, 32, 96, true, 6, 1, 4>;
 using W96_0f = WgCfg<3, 32, 96, false, 6, 1, 4>;
