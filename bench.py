@@ -415,6 +415,39 @@ def launch_ranks(n):
     raise SystemExit(rc)
 
 
+def dry_run_cpu(args, rank, world):
+    """The measurement's host-side skeleton with nothing on a GPU: rendezvous, barrier, K timed "steps", barrier, MAX of the
+    ranks' wall times, one JSON line from rank 0.  What can break an 8-GPU run before its first kernel breaks here too."""
+    if world > 1 or "RANK" in os.environ:
+        torch.distributed.init_process_group("gloo")
+    seen = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        time.sleep(1e-3)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(1e-3)
+    barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t.item())
+    if rank == 0:
+        emit(json.dumps({"metric": f"pretext triplets/sec ({args.hw}x{args.hw} RGB + 16 kHz/1 s audio)",
+                         "value": round(args.steps * args.batch * world / dt, 1), "unit": "triplets/s", "n_gpus": world,
+                         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+                         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                         "n_ranks_seen": seen, "dry_run": "CPU launch-logic rehearsal (a step is a 1 ms sleep): NOT a measurement",
+                         "config": {"per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}"}}))
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -442,6 +475,10 @@ def main():
                     help="multi-rank REHEARSAL on a box with one GPU: every rank uses cuda:0 and the ranks exchange through "
                          "gloo (RCCL refuses two ranks on one device).  Exercises the N > 1 code path end to end; the "
                          "number it prints is not a scaling measurement and is labelled as such.")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="launch-logic rehearsal WITHOUT a GPU: the ranks come up exactly as for a measurement (launcher, environment, "
+                         "process group -- gloo --, barriers, MAX over ranks, ONE JSON line from rank 0) but a step is a 1 ms sleep; the "
+                         "line is labelled and is not a measurement (tests/test_trainer_host.py runs it with 8 ranks on the CPU)")
     ap.add_argument("--pool", type=int, default=4096,
                     help="kuka workload: triplets in the HBM-resident synthetic pool (16384 = 1.4 GB > the 256 MB Infinity Cache)")
     args = ap.parse_args()
@@ -458,6 +495,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run_cpu:
+        return dry_run_cpu(args, rank, world)
     n_dev = torch.cuda.device_count()                          # counting devices does not initialise HIP
     if args.rehearse_one_device:
         local_rank = 0

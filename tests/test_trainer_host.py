@@ -195,3 +195,39 @@ def test_pool_training_loop_equals_the_reference_loop(tmp_path):
     assert rows[0] == ['avg_loss'] and len(rows) == 1 + epochs
     loaded = torch.load(tmp_path / '2.pt', weights_only=True)
     assert list(loaded.keys()) == [k for k, _ in var_amd.PARAM_SPECS]
+
+
+def _bench_dry_run(argv):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable] + argv, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                           # ONE JSON line, from rank 0, whatever the other ranks print
+    return json.loads(lines[0])
+
+
+def test_bench_launch_logic_with_eight_ranks_on_the_cpu():
+    """No 8-GPU node was available to the driver in rounds 1-3, so the N > 1 launch path of bench.py never ran at its real
+    width.  --dry-run-cpu runs everything of it that is not a kernel: the driver's launch line (torch.distributed.run,
+    --nproc-per-node 8, 127.0.0.1 rendezvous), RANK / WORLD_SIZE handling, the process group, the barriers around the timed
+    region, MAX over ranks, one JSON line from rank 0 with whole-job values -- and the self-launching form
+    `python bench.py --gpus N` (a child torch.distributed.run, started before anything touches a GPU)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = _bench_dry_run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), "bench.py", "--gpus", "8", "--steps", "4", "--warmup", "1", "--dry-run-cpu"])
+    assert out["n_gpus"] == 8 and out["n_ranks_seen"] == 8 and out["steps"] == 4 and out["warmup"] == 1
+    assert out["config"]["global_batch"] == 8 * out["config"]["per_gpu_batch"] and out["scaling"] == "weak"
+    assert abs(out["value"] - 4 * out["config"]["global_batch"] / (4 * out["ms_per_step"] * 1e-3)) < 1e-3 * out["value"]
+    assert "dry_run" in out
+    out = _bench_dry_run(["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run-cpu"])
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2
