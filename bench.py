@@ -629,21 +629,27 @@ def main():
         ctx.profile_select(-1)
 
     # north_star's own number: MFMA fraction of the image CNN forward + backward = its algorithmic FLOPs / the summed durations of
-    # its kernels INSIDE a step (HIP events around each family in turn, over eager steps under the step's own stream plan: the
-    # sound branch runs beside them as it does in the replayed graph).  The rocprofv3 timeline of the replayed step under
-    # profiles/ is the reference for these durations; the event brackets read a few percent longer.
-    img_us = {}
+    # its kernels.  Two legs, both with HIP events around each kernel family in turn over eager steps: `alone` -- every launch of
+    # the step on one stream, i.e. each kernel's own duration (what the rocprofv3 kernel stats of the serial run read too) -- and
+    # `beside_sound` -- under the step's own stream plan, the sound branch running beside them.  Inside the REPLAYED graph the
+    # kernels take less than the second leg reads (eager launches and the event brackets stretch whatever runs beside the MFCC):
+    # the rocprofv3 timeline of the replayed step under profiles/ is the reference for the in-step figure.
+    img_us, img_us_side = {}, {}
     if not args.no_roofline and HW in (84, 96):
         tags = (1, 2, 12, 7, 11, 15) if HW == 84 else (1, 2, 6, 7, 8, 9, 11, 15)
-        for tag in tags:
-            ctx.profile_select(tag)
-            for _ in range(20):
-                eager_step()
-                torch.cuda.synchronize()
-            ms, n = ctx.profile_read()
-            if n:
-                img_us[tag_kernel(tag, HW).rstrip("<,")] = round(1e3 * ms / 20, 2)      # per step (a family may launch twice)
-        ctx.profile_select(-1)
+        for serial, dst in ((True, img_us), (False, img_us_side)):
+            old_mask = ctx.set_streams(0) if serial else None
+            for tag in tags:
+                ctx.profile_select(tag)
+                for _ in range(20):
+                    eager_step()
+                    torch.cuda.synchronize()
+                ms, n = ctx.profile_read()
+                if n:
+                    dst[tag_kernel(tag, HW).rstrip("<,")] = round(1e3 * ms / 20, 2)      # per step (a family may launch twice)
+            ctx.profile_select(-1)
+            if serial:
+                ctx.set_streams(old_mask)
 
     if use_graph:
         tr.sync_device_scalars()                     # (the eager legs above advanced the optimiser's step count)
@@ -708,10 +714,14 @@ def main():
         if img_us:
             img_flops = sum(LAYER_FLOPS) * 3 * B          # forward + data gradient + weight gradient of the five convolutions
             img_flops -= LAYER_FLOPS[0] * B               # (conv 1 has no data gradient)
-            tot = sum(img_us.values())
+            tot, tot_side = sum(img_us.values()), sum(img_us_side.values())
             out["image_cnn_mfma_frac"] = round(img_flops / (tot * 1e-6) / 1e12 / F32_MFMA_PEAK, 4)
-            out["image_cnn"] = {"flops_per_step": img_flops, "kernels_us_in_step": img_us, "sum_us": round(tot, 1),
-                                "how": "HIP events around each kernel family over eager steps with the sound branch on its side stream"}
+            out["image_cnn"] = {"flops_per_step": img_flops, "kernels_us_alone": img_us, "sum_us_alone": round(tot, 1),
+                                "kernels_us_beside_sound": img_us_side, "sum_us_beside_sound": round(tot_side, 1),
+                                "mfma_frac_beside_sound": round(img_flops / (tot_side * 1e-6) / 1e12 / F32_MFMA_PEAK, 4),
+                                "how": "HIP events around each kernel family over eager steps: alone = every launch on one stream; "
+                                       "beside_sound = the step's stream plan (eager: an upper bound of the in-graph durations, see the "
+                                       "rocprofv3 timeline under profiles/)"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
             out["parity_vs_cpu"] = parity_vs_cpu(var_amd, model, pool)

@@ -59,7 +59,7 @@ struct WgCfg {
 #ifndef VAR_WG_PH
 #define VAR_WG_PH
 namespace { PH_DECL(); }
-#ifdef VAR_PHASES
+#if defined(VAR_PHASES) && defined(VAR_WGRAD_DEVICE_ONLY)      // (the entry lives in img_conv_bwd.o, whose grids run these bodies at 84 x 84)
 extern "C" int var_debug_phases_wgrad(unsigned long long* out) {
     unsigned long long z[32] = {0};
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(z)) != hipSuccess) return -1;
