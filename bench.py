@@ -459,7 +459,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
     ap.add_argument("--streams", type=int, default=None,
                     help="kuka workload: stream plan mask of var_set_streams (bit 0 sound forward, bit 1 sound backward on the "
-                         "side stream, bit 4 MFCC stays on the caller's stream; default 3)")
+                         "side stream, bit 4 MFCC stays on the caller's stream, bit 5 (32) the two-launch image forward; default 3)")
     ap.add_argument("--serial", action="store_true",
                     help="kuka workload: every kernel on ONE stream (var_set_streams(0)) -- per-kernel profiling runs")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",

@@ -324,7 +324,8 @@ int var_mfcc_psf(var_ctx* ctx, void* stream, const int16_t* pcm, const int* lens
  * kernel family (tag in [0, var_profile_tag_count()), -1 = off); var_profile_read returns the
  * summed durations and the launch count since the select (it synchronises on the events).
  * var_set_streams: which parts of a step leave the caller's stream (bit 0: sound CNN forward, bit 1: sound
- * CNN backward, bit 4: with bit 0, MFCC stays on the caller's stream); -1 restores the default (3).  0 puts every
+ * CNN backward, bit 4: with bit 0, MFCC stays on the caller's stream, bit 5: the one-launch image forward of image-only
+ * calls also beside a sound branch -- slower there, kept for timing); -1 restores the default (3).  0 puts every
  * kernel on the caller's stream (per-kernel timing).  Returns the old mask.
  * var_debug_buffer: address/length of a named workspace buffer ("act1".."act5", "gact1"..,
  * "sact1".."sact4", "gsact1".., "emb", "gemb", "wpack"; "ithor_s1".."ithor_s3", "ithor_gs1".."ithor_gs3") for

@@ -434,3 +434,21 @@ def test_ithor_replays_survive_synchronises_between_them(var_amd):
         for _ in range(2):
             assert float(replay().item()) == l0
             assert torch.equal(tr.grads, g0)
+
+
+def test_one_launch_image_forward_equals_the_two_launch_forward(var_amd, golden_dir):
+    """Round 4: an image-only forward at 84 x 84 (the frozen encoder at a full batch, the projection of a dataset) runs conv 1-5
+    and the image head as ONE launch (img_fwd_all_kernel: img_head2's body, then img_mid3's in the same workgroup); a forward
+    with a sound branch keeps the two launches (the step is CU-time bound: csrc/api.hip).  Same arithmetic in both: the
+    embeddings and the raw features must be bit-identical, at 3 images and at a full batch."""
+    sd = load(golden_dir, "kuka_weights.npz")
+    m = make_model(var_amd, sd, 84)
+    rng = np.random.default_rng(11)
+    for B in (3, 256):
+        img = torch.from_numpy(rng.integers(0, 256, size=(B, 3, 84, 84), dtype=np.uint8)).cuda()
+        snd = torch.from_numpy(rng.standard_normal((B, 1, 100, 40)).astype(np.float32)).cuda()
+        with torch.no_grad():
+            only = m(img, None, None)                              # image-only: the fused launch
+            both = m(img, snd, snd)                                # with a sound branch: two launches
+        for k in ("image_feat", "image_feat_raw"):
+            assert torch.equal(only[k], both[k]), (B, k)

@@ -320,6 +320,12 @@ static int encoder_fwd(var_ctx* c, hipStream_t s, const float* params, const voi
                               VAR_MFCC_FRAMES, c->mfcc_buf)) != VAR_OK) return rc;
     }
     if (snd && fork_ok && !forked && (rc = fork_side(c, s, 0)) != VAR_OK) return rc;     // the side stream starts after the caller's prior work
+    // The one-launch image forward (conv 1-5 + head, img_fwd_all_kernel) takes 71 us against 41.6 + 36.3 for the two launches --
+    // alone.  Beside the sound branch it LOSES (0.3045 vs 0.3017 ms per step, alternating runs): the step is bound by CU time, not
+    // by the image chain's latency, and the sound kernels get onto the CUs at the image kernels' boundaries -- one boundary fewer
+    // pushes the sound forward behind the whole image forward.  So: image-only forwards (the frozen encoder at full batch, the
+    // projection of a dataset) take the fused launch, a forward with a sound branch the two launches.
+    c->fuse_fwd = c->fuse_fwd_always || !snd;
     if (image && (rc = launch_img_fwd(c, s, params, image, is_u8, bstride, image_index, B)) != VAR_OK) return rc;
     if (image && (rc = launch_heads_fwd(c, s, s, params, B, true, false, false, finish)) != VAR_OK) return rc;
     if (snd) {
@@ -590,6 +596,7 @@ int var_set_streams(var_ctx* c, int mask) {
     const int old = c->streams;
     c->streams = mask < 0 ? default_streams() : (mask & 19);
     c->serial = c->streams == 0;
+    c->fuse_fwd_always = mask >= 0 && (mask & 32);   // bit 5: the one-launch image forward even beside a sound branch (A/B timing, tests)
     return old;
 }
 

@@ -29,6 +29,10 @@ int launch_img_fwd(var_ctx* c, hipStream_t s, const float* params, const void* i
     //  round-2 head, which spreads an image's tiles over workgroups; its NCHW act1 is never read by a backward)
     const bool head2 = c->H == 84 && !(c->fwd_only && B <= 64);
     c->act1_tiled = head2;
+    if (head2 && B <= kHead2G && c->fuse_fwd) {         // one image per workgroup in both halves: the whole image forward as ONE launch
+        c->head_in_mid = true;
+        return launch_img_fwd_all(c, s, params, image, is_u8, bstride, image_index, B);
+    }
     int rc = head2 ? launch_img_fwd_head2(c, s, params, image, is_u8, bstride, image_index, B)
                    : launch_img_fwd_head(c, s, params, image, is_u8, bstride, image_index, B);
     if (rc != VAR_OK) return rc;

@@ -66,9 +66,11 @@ struct Head2Cfg {
     static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 };
 
+#ifndef VAR_HEAD2_DEVICE_ONLY
 PH_DECL();
+#endif
 }  // namespace
-#ifdef VAR_PHASES
+#if defined(VAR_PHASES) && !defined(VAR_HEAD2_DEVICE_ONLY)
 extern "C" int var_debug_phases_head2(unsigned long long* out) {
     unsigned long long z[32] = {0};
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(z)) != hipSuccess) return -1;
@@ -77,21 +79,23 @@ extern "C" int var_debug_phases_head2(unsigned long long* out) {
 #endif
 namespace {
 
-template <class C>
-__global__ void __launch_bounds__(C::NT)
-img_head2_kernel(const void* __restrict__ image, long bstride, const int* __restrict__ bidx,
-                 const float* __restrict__ wp1, const float* __restrict__ bias1,
-                 const float* __restrict__ wp2, const float* __restrict__ bias2,
-                 float* __restrict__ y1, uint16_t* __restrict__ relu_bits, float* __restrict__ y2, int B) {
+// (a __device__ body: bx / G stand for blockIdx.x / gridDim.x of a stand-alone launch; `early` is run once by the waves of role B
+//  before their first barrier -- img_fwd_all_kernel (img_mid3.hip) requests the next layers' filters there)
+template <class C, class EARLY>
+__device__ __forceinline__ void img_head2_body(const void* __restrict__ image, long bstride, const int* __restrict__ bidx,
+                                               const float* __restrict__ wp1, const float* __restrict__ bias1,
+                                               const float* __restrict__ wp2, const float* __restrict__ bias2,
+                                               float* __restrict__ y1, float* __restrict__ y2, int B, const int bx, const int G,
+                                               EARLY early) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using XT = typename std::conditional<C::U8, uint8_t, float>::type;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, l15 = lane & 15;
     const float* lut = lds + C::LUT;
     // this workgroup's tiles: the NB bands of images blockIdx.x, blockIdx.x + gridDim.x, ...; tile j = (image, band)
-    const int nimg = ((int)blockIdx.x < B) ? (B - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int nimg = (bx < B) ? (B - 1 - bx) / G + 1 : 0;
     const int ntl = nimg * C::NB;
-    auto tile_img = [&](int j) { return (int)blockIdx.x + (j / C::NB) * (int)gridDim.x; };
+    auto tile_img = [&](int j) { return bx + (j / C::NB) * G; };
 
     PHR_INIT(3, VAR_PH_THREAD);
     if (tid < 256) lds[C::LUT + tid] = (float)tid / 255.f;
@@ -286,6 +290,7 @@ img_head2_kernel(const void* __restrict__ image, long bstride, const int* __rest
         const int oy2 = p2 / C::WO2, ox2 = p2 - oy2 * C::WO2;
         const int b2lane = q * C::PLANE_1 + C::A1ROW0 + 2 * oy2 * C::W1 + 2 * ox2 - 1;
         const bool edge = ox2 == 0;                              // taps kx = 0 of these lanes read the zero padding x = -1
+        early(wave - C::NA);
         __syncthreads();                                       // (pairs with role A's first barrier)
         PHR(1);
         for (int j = 0; j < ntl; ++j) {
@@ -337,10 +342,20 @@ img_head2_kernel(const void* __restrict__ image, long bstride, const int* __rest
     }
 }
 
+template <class C>
+__global__ void __launch_bounds__(C::NT)
+img_head2_kernel(const void* __restrict__ image, long bstride, const int* __restrict__ bidx,
+                 const float* __restrict__ wp1, const float* __restrict__ bias1,
+                 const float* __restrict__ wp2, const float* __restrict__ bias2,
+                 float* __restrict__ y1, uint16_t* __restrict__ relu_bits, float* __restrict__ y2, int B) {
+    img_head2_body<C>(image, bstride, bidx, wp1, bias1, wp2, bias2, y1, y2, B, (int)blockIdx.x, (int)gridDim.x, [](int) {});
+}
+
 //                      H1   U8   R2
 using H2_84u = Head2Cfg<42, true, 3>;
 using H2_84f = Head2Cfg<42, false, 3>;
 
+#ifndef VAR_HEAD2_DEVICE_ONLY      // img_mid3.hip includes this file for the device code above only
 template <class C>
 int launch_head2(var_ctx* c, hipStream_t s, const void* image, long bstride, const int* bidx, const float* params, int B) {
     ProfScope prof(c, s, TAG_IMG_FWD0 + 1);
@@ -359,8 +374,10 @@ int launch_head2(var_ctx* c, hipStream_t s, const void* image, long bstride, con
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }
+#endif  // VAR_HEAD2_DEVICE_ONLY
 }  // namespace
 
+#ifndef VAR_HEAD2_DEVICE_ONLY
 // var_debug_buffer("act1") at 84 x 84: the band-tiled act1 back to NCHW (rows 1.. of every band), into gact[1]
 __global__ void __launch_bounds__(256) act1_untile_kernel(const float* __restrict__ t, float* __restrict__ y, long n) {
     using C = H2_84u;
@@ -385,3 +402,4 @@ int launch_img_fwd_head2(var_ctx* c, hipStream_t s, const float* params, const v
     return is_u8 ? launch_head2<H2_84u>(c, s, image, bstride, image_index, params, B)
                  : launch_head2<H2_84f>(c, s, image, bstride, image_index, params, B);
 }
+#endif  // VAR_HEAD2_DEVICE_ONLY

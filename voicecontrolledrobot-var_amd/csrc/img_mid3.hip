@@ -28,6 +28,11 @@
 
 namespace {
 PH_DECL();
+}
+#define VAR_HEAD2_DEVICE_ONLY
+#include "img_head2.hip"             // Head2Cfg, img_head2_body: conv 1 + conv 2, for the fused forward at the end of this file
+#undef VAR_HEAD2_DEVICE_ONLY
+namespace {
 #ifdef VAR_PHASES
 __device__ unsigned long long g_span[1024][2];          // per workgroup: s_memrealtime (100 MHz, chip-wide) at its first and last instruction
 #endif
@@ -63,7 +68,9 @@ struct M3Cfg {
     static constexpr int D = 6, RING = 12288, RING_W = D * 256;
     static constexpr int CONSTS = 39936, LDS_FLOATS = 40960, LDS_BYTES = LDS_FLOATS * 4;
     static constexpr int C_B3 = CONSTS, C_B4 = C_B3 + 64, C_B5 = C_B4 + 64, C_HB0 = C_B5 + 64, C_HW1 = C_HB0 + 128;
-    static constexpr int X2O = 128, W3O = X2O + NX * 256;
+    // conv 3's filter in two halves: pieces 0..35 (channels 0..15) high up -- above everything img_head2_kernel uses, so that the
+    // fused forward (img_fwd_all_kernel) can request them while conv 1 / conv 2 still run -- pieces 36..71 behind act2
+    static constexpr int X2O = 128, W3B = X2O + NX * 256, W3A = 27904;
     static constexpr int NE = NX + 72, PPW = NE / 16;              // prologue pieces, per wave
     static constexpr int NE1 = XH + 36;                            // entries the first half of conv 3 needs
     static constexpr int F1 = (NE1 + 15) / 16;                     // ... per wave, at most
@@ -72,7 +79,7 @@ struct M3Cfg {
     static_assert(H4 == 6 && H5 == 3 && P5 == 9, "the maps this kernel is laid out for");
     static_assert(NE % 16 == 0 && NPT3 % T3 == 0, "whole prologue rounds, whole tiles per wave");
     static_assert(64 * P3 <= 9216 && A_END <= RING && RING + 16 * RING_W <= CONSTS, "LDS plan");
-    static_assert(W3O + 18432 <= CONSTS && C_HW1 + 384 <= LDS_FLOATS, "conv 3 phase fits in front of the constants");
+    static_assert(W3B + 9216 <= W3A && W3A + 9216 <= CONSTS && C_HW1 + 384 <= LDS_FLOATS, "conv 3 phase fits in front of the constants");
     static_assert(16 * 9 * 64 <= 9216 && X2O >= H2 + 2, "fold scratch; guard in front of act2 for the row -1 reads");
 };
 
@@ -92,26 +99,46 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 // other in this kernel goes through LDS (lgkmcnt); what arrives by DMA is waited for explicitly (wait_vm) by the wave that asked.
 __device__ __forceinline__ void bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// The constants block (biases, the head's second layer: four pieces) and the first half of conv 3's filter (36 pieces), requested
+// by EIGHT waves (wb = 0..7, five pieces each): the fused forward runs this from the conv-2 waves of img_head2_body before their
+// first barrier -- both land above everything that body keeps in LDS.
 template <class C>
-__global__ void __launch_bounds__(M3_NT)
-img_mid3_kernel(const float* __restrict__ x2, const float* __restrict__ wa3, const float* __restrict__ wa4,
-                const float* __restrict__ wa5, const float* __restrict__ params, int o_b3, int o_b4, int o_b5, int o_hb0, int o_hw1,
-                float* __restrict__ y3, float* __restrict__ y4, float* __restrict__ y5,
-                const float* __restrict__ hw0t, float* __restrict__ hid, float* __restrict__ part) {
+__device__ __forceinline__ void mid3_early(const float* __restrict__ wa3, const float* __restrict__ params, int o_b3, int o_b4, int o_b5,
+                                           int o_hb0, int o_hw1, int wb, int lane) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const int e = wb + 8 * r;                                  // e < 4: constants piece e; else filter piece e - 4
+        const bool isc = e < 4;
+        const int fo = 4 * ((e & 3) * 64 + lane);
+        // (the five arrays live in ONE parameter arena: an integer select, no pointer select)
+        const int offc = fo < 64 ? o_b3 + fo : fo < 128 ? o_b4 + (fo - 64) : fo < 192 ? o_b5 + (fo - 128)
+                       : fo < 320 ? o_hb0 + (fo - 192) : fo < 704 ? o_hw1 + (fo - 320) : o_hw1;
+        const long off = isc ? (long)offc : (long)(e - 4) * 256 + 4 * lane;
+        dma16((isc ? params : wa3) + off, lds + (isc ? C::CONSTS + e * 256 : C::W3A + (e - 4) * 256));
+    }
+}
+
+// PRE: mid3_early has run and landed (fused forward); b: the image of this workgroup
+template <class C, bool PRE>
+__device__ __forceinline__ void img_mid3_body(const float* __restrict__ x2, const float* __restrict__ wa3, const float* __restrict__ wa4,
+                                              const float* __restrict__ wa5, const float* __restrict__ params, int o_b3, int o_b4, int o_b5,
+                                              int o_hb0, int o_hw1, float* __restrict__ y3, float* __restrict__ y4, float* __restrict__ y5,
+                                              const float* __restrict__ hw0t, float* __restrict__ hid, float* __restrict__ part, const size_t b) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, i15 = lane & 15;
-    const size_t b = blockIdx.x;
     const int nt = wave & 3, kq = wave >> 2;                     // 16-channel tile; K quarter (conv 4, 5) / pixel group (conv 3)
     PHR_INIT(5, VAR_PH_THREAD);
 #ifdef VAR_PHASES
     if (tid == 0) g_span[blockIdx.x][0] = wall_clock64();
 #endif
-
-    // ---- constants (biases, the head's second layer) by LDS-DMA as well: a value parked in a register until the first barrier
-    //      gave hipcc a pending load to wait for at an unrelated instruction (vmcnt(0): the whole prologue).  The block is four
-    //      pieces; every wave requests piece wave & 3 (identical bytes from four waves), first, so that it is the oldest in its queue
-    {
+    // prologue pieces per wave, and how many of them the first half of conv 3 waits for
+    constexpr int PPW = PRE ? (C::NX + 36 + 15) / 16 : C::PPW, F1 = PRE ? (C::XH + 15) / 16 : C::F1;
+    if constexpr (!PRE) {
+        // ---- constants (biases, the head's second layer) by LDS-DMA as well: a value parked in a register until the first barrier
+        //      gave hipcc a pending load to wait for at an unrelated instruction (vmcnt(0): the whole prologue).  The block is four
+        //      pieces; every wave requests piece wave & 3 (identical bytes from four waves), first, so that it is the oldest in its queue
         const int fo = 4 * ((wave & 3) * 64 + lane);
         // (the five arrays live in ONE parameter arena: an integer select, no pointer select -- as pointers hipcc built a tree of
         //  divergent branches with a kernel-argument load and a wait in every leaf)
@@ -125,19 +152,21 @@ img_mid3_kernel(const float* __restrict__ x2, const float* __restrict__ wa3, con
         //  workspace block that follows act[2] -- valid memory either way, and it lands in front of the filter, unused)
         const float* xi = x2 + b * C::X2F;
         const unsigned l4 = 4u * (unsigned)lane;
-        // entry e = wave + 16 r of the list [act2 pieces of channels 0..15 | filter pieces 0..35 | rest of act2 | filter pieces 36..71]:
+        // entry e = wave + 16 r of the list [act2 pieces of channels 0..15 | filter pieces 0..35 | rest of act2 | filter pieces 36..71]
+        // (PRE: [act2 0..15 | rest of act2 | filter pieces 36..71 | the last pieces once more to fill the round]):
         // a round lies inside one segment (everything but `wave` is a compile-time constant) or across one boundary (one scalar select)
-        auto seg_of = [](int e) { return e < C::XH ? 0 : e < C::NE1 ? 1 : e < C::NX + 36 ? 2 : 3; };
-        auto piece_of = [](int sg, int e) { return sg == 0 ? e : sg == 1 ? e - C::XH : sg == 2 ? e - 36 : e - C::NX; };
+        auto seg_of = [](int e) { return PRE ? (e < C::NX ? 0 : 3) : e < C::XH ? 0 : e < C::NE1 ? 1 : e < C::NX + 36 ? 2 : 3; };
+        auto piece_of = [](int sg, int e) { return PRE ? (sg == 0 ? e : e - C::NX + 36) : sg == 0 ? e : sg == 1 ? e - C::XH : sg == 2 ? e - 36 : e - C::NX; };
 #pragma unroll
-        for (int r = 0; r < C::PPW; ++r) {
+        for (int r = 0; r < PPW; ++r) {
             const int lo = 16 * r, sa = seg_of(lo), sb = seg_of(lo + 15);
-            const int bnd = sa == 0 ? C::XH : sa == 1 ? C::NE1 : C::NX + 36;          // first entry of the next segment
+            const int bnd = PRE ? C::NX : sa == 0 ? C::XH : sa == 1 ? C::NE1 : C::NX + 36;   // first entry of the next segment
             const bool first = sa == sb || wave < bnd - lo;
             const int sg = first ? sa : sb;
-            const int pc = piece_of(sg, lo) + wave;                                 // (piece_of is linear in e)
+            int pc = piece_of(sg, lo) + wave;                                       // (piece_of is linear in e)
             const bool isx = (sg & 1) == 0;
-            dma16((isx ? xi : wa3) + pc * 256 + l4, lds + (isx ? C::X2O : C::W3O) + pc * 256);
+            if (!isx && pc > 71) pc = 71;                                           // (PRE: the round's filler entries)
+            dma16((isx ? xi : wa3) + pc * 256 + l4, lds + (isx ? C::X2O + pc * 256 : pc < 36 ? C::W3A + pc * 256 : C::W3B + (pc - 36) * 256));
         }
     }
 
@@ -166,7 +195,7 @@ img_mid3_kernel(const float* __restrict__ x2, const float* __restrict__ wa3, con
         float bb[2][4][T3];
         auto fetch = [&](int buf, int G) {
             const int cg = G / 9, tap = G % 9, toff = (tap / 3) * C::H2 + tap % 3;
-            a[buf] = *(const f32x4q*)(lds + C::W3O + (G * 4 + nt) * 256 + 4 * lane);
+            a[buf] = *(const f32x4q*)(lds + (G < 9 ? C::W3A + (G * 4 + nt) * 256 : C::W3B + ((G - 9) * 4 + nt) * 256) + 4 * lane);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -231,7 +260,7 @@ img_mid3_kernel(const float* __restrict__ x2, const float* __restrict__ wa3, con
         asm volatile("" ::"s"(y3), "s"(y4), "s"(y5), "s"(hid), "s"(part), "s"(wa4), "s"(wa5), "s"(hw0t));
     }
     PHR(0);
-    wait_vm<C::PPW - C::F1>();                                   // this wave's pieces of the first half have landed
+    wait_vm<PPW - F1>();                                         // this wave's pieces of the first half have landed
     bar();
     PHR(1);
     if (act3w) conv3_groups(std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{});
@@ -524,7 +553,67 @@ img_mid3_kernel(const float* __restrict__ x2, const float* __restrict__ wa3, con
     if (tid == 0) g_span[blockIdx.x][1] = wall_clock64();
 #endif
 }
+template <class C>
+__global__ void __launch_bounds__(M3_NT)
+img_mid3_kernel(const float* __restrict__ x2, const float* __restrict__ wa3, const float* __restrict__ wa4,
+                const float* __restrict__ wa5, const float* __restrict__ params, int o_b3, int o_b4, int o_b5, int o_hb0, int o_hw1,
+                float* __restrict__ y3, float* __restrict__ y4, float* __restrict__ y5,
+                const float* __restrict__ hw0t, float* __restrict__ hid, float* __restrict__ part) {
+    img_mid3_body<C, false>(x2, wa3, wa4, wa5, params, o_b3, o_b4, o_b5, o_hb0, o_hw1, y3, y4, y5, hw0t, hid, part, blockIdx.x);
+}
+
+// The WHOLE image forward of one image in one workgroup: conv 1 + conv 2 (img_head2_body: role-split waves over the image's seven
+// bands), then conv 3-5 + image head (the body above) -- at a full batch both kernels were one-image-per-workgroup grids anyway.
+// What the fusion removes: one kernel boundary (4.5-5 us of dispatch and end-of-kernel work outside every workgroup,
+// profiles/r04_inkernel_clock.txt) and most of the second kernel's cold start -- the constants and the first half of conv 3's
+// filter are requested by the conv-2 waves before their first band and wait in LDS above everything conv 1 / 2 use; act2 still
+// travels through memory (this CU wrote it and drained its stores: the DMA reads it back from L2), it does not fit next to
+// img_head2's 110 KB of tiles.
+template <class CH, class CM>
+__global__ void __launch_bounds__(M3_NT)
+img_fwd_all_kernel(const void* __restrict__ image, long bstride, const int* __restrict__ bidx, const float* __restrict__ wp1,
+                   const float* __restrict__ wp2, float* __restrict__ y1, float* __restrict__ y2,
+                   const float* __restrict__ wa3, const float* __restrict__ wa4, const float* __restrict__ wa5,
+                   const float* __restrict__ params, int o_b1, int o_b2, int o_b3, int o_b4, int o_b5, int o_hb0, int o_hw1,
+                   float* __restrict__ y3, float* __restrict__ y4, float* __restrict__ y5, const float* __restrict__ hw0t,
+                   float* __restrict__ hid, float* __restrict__ part, int B) {
+    static_assert(CH::NT == M3_NT && CH::LDS_FLOATS <= CM::W3A, "16 waves; conv 3's early filter half lies above the head's tiles");
+    const int lane = threadIdx.x & 63;
+    img_head2_body<CH>(image, bstride, bidx, wp1, params + o_b1, wp2, params + o_b2, y1, y2, B, (int)blockIdx.x, (int)gridDim.x,
+                       [&](int wb) { mid3_early<CM>(wa3, params, o_b3, o_b4, o_b5, o_hb0, o_hw1, wb, lane); });
+    // this workgroup's act2 stores have left the CU (every wave drains its own queue -- the early pieces with it), every wave is
+    // done with the head's LDS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    img_mid3_body<CM, true>(y2, wa3, wa4, wa5, params, o_b3, o_b4, o_b5, o_hb0, o_hw1, y3, y4, y5, hw0t, hid, part, blockIdx.x);
+}
 }  // namespace
+
+// conv 1 .. conv 5 + image head at 84 x 84 as ONE launch (one image per workgroup: B <= 256); leaves act[1] (band-tiled), act[2..5],
+// hid_i and the head partials like launch_img_fwd_head2 + launch_img_fwd_mid
+int launch_img_fwd_all(var_ctx* c, hipStream_t s, const float* params, const void* image, int is_u8, long bstride,
+                       const int* image_index, int B) {
+    using CM = M3Cfg<21>;
+    ProfScope prof(c, s, TAG_IMG_FWD0 + 1);
+    const ParamLayout& L = c->pl;
+    const PackLayout& K = c->kl;
+    auto go = [&](auto ch) -> int {
+        using CH = decltype(ch);
+        auto kern = img_fwd_all_kernel<CH, CM>;
+        static unsigned attr = 0;      // bit d: set on device d (function attributes are per device)
+        if (!(attr & var_dev_bit(c))) {
+            VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CM::LDS_BYTES));
+            attr |= var_dev_bit(c);
+        }
+        hipLaunchKernelGGL(kern, dim3(B), dim3(M3_NT), CM::LDS_BYTES, s, image, bstride, image_index, c->wpack + K.img_f[0],
+                           c->wpack + K.img_f[1], c->act[1], c->act[2], c->wpack + K.img_f[2], c->wpack + K.img_f[3], c->wpack + K.img_f[4],
+                           params, L.img_b[0], L.img_b[1], L.img_b[2], L.img_b[3], L.img_b[4], L.ih_b0, L.ih_w1, c->act[3], c->act[4],
+                           c->act[5], c->wpack + K.ih_w0t, c->hid_i, c->head_part, B);
+        VAR_HIP_CHECK(c, hipGetLastError());
+        return VAR_OK;
+    };
+    return is_u8 ? go(H2_84u{}) : go(H2_84f{});
+}
 
 // conv 3 + conv 4 + conv 5 of the image CNN (act2 21 x 21 for 84 x 84 inputs, 24 x 24 for 96 x 96); leaves act[3], act[4],
 // act[5] and, with_head, the image head's hidden layer (hid_i) and 128 -> 3 partials (head_part rows [0, B))

@@ -153,6 +153,9 @@ struct var_ctx {
     // var_arm_encoder_fwd's embedding outputs: the finish kernels of the heads write them directly (no copy launch afterwards)
     float *out_img = nullptr, *out_pos = nullptr, *out_neg = nullptr;
     bool head_in_mid = false;             // the last image forward also ran the image head (img_mid3.hip)
+    bool fuse_fwd_always = false;         // var_set_streams bit 5
+    bool fuse_fwd = false;                // 84 x 84, B <= 256: conv 1-5 + image head as ONE launch (img_fwd_all_kernel).  Set per call by
+                                          // encoder_fwd (api.hip): image-only forwards, or always with var_set_streams bit 5 -- see there
     int saved_B = 0;
     const void* saved_image = nullptr;
     int saved_u8 = 0;
@@ -271,6 +274,8 @@ int launch_img_fwd_head2(var_ctx* c, hipStream_t s, const float* params, const v
 #endif
 static constexpr int kHead2G = VAR_HEAD2_G;   // persistent workgroups of img_head2_kernel (one image = NB tiles each)
 int launch_img_fwd_mid(var_ctx* c, hipStream_t s, const float* params, int B, bool with_head);
+int launch_img_fwd_all(var_ctx* c, hipStream_t s, const float* params, const void* image, int is_u8, long bstride,
+                       const int* image_index, int B);      // img_mid3.hip: conv 1-5 + image head in one launch (84 x 84, B <= 256)
 // (launch_img_fwd also leaves c->relu1)
 // default: the whole sound branch -- MFCC front-end, sound CNN and sound head, forward and backward -- beside the image
 // CNN on one side stream.  (Round 1 kept the 61-us MFCC on the caller's stream, mask 19; with round 2's 43-us kernel the
