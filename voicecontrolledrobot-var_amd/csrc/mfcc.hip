@@ -110,13 +110,24 @@ __device__ __forceinline__ void fft16(cplx (&v)[16]) {
 
 constexpr int FT = 16;                    // frames per tile
 constexpr int NTHR = 256;                 // 4 waves
-constexpr int TPITCH = 17 * 16;           // complex elements per frame of the transpose tile (row pitch 17)
-constexpr int PPITCH = 258;               // floats per frame of the power tile (== 2 mod 32)
+// Round 4: THREE workgroups per CU instead of two (the kernel is bound by dependent-instruction latency, not by any pipe: a
+// third resident workgroup is worth what it adds in waves).  Two budgets had to come down for that:
+//   LDS 67 -> 44 KB: the power tile and the mel partial sums live INSIDE the transpose buffer -- a frame's region there holds
+//     272 complex numbers during the FFT and is dead from the even/odd split to the next tile's FFT: its first 258 floats become
+//     the frame's power row (written from registers behind a wave barrier, once the split has read its last partner bin), the
+//     288 floats behind them a sixteenth of the partial-sum block;
+//   VGPRs 244 -> <= 168: the two twiddle tables (64 registers of per-lane constants) are LDS operands now (one ds_read_b64 per
+//     use, the four frames of a wave read the same addresses), and the next tile's samples are requested behind the split, when
+//     the FFT's 32 data registers are dead, instead of before it.
+constexpr int TPITCH = 273;               // complex elements per frame region (272 used by the 17 x 16 transpose tile): 546 floats == 2 mod 32
+constexpr int PPITCH = 2 * TPITCH;        // floats between two frames' power rows: conflict-free for the 16 x 4 operand read
+constexpr int PARTOFF = 272, PARTLEN = 192;   // a frame region's share of the partial-sum block: floats [272, 464)
 constexpr int LPITCH = 42;                // floats per frame of the log-mel tile (10 i mod 32 distinct for i < 16)
 
-// LDS carve-up (floats): 56 KB per workgroup; the register budget (244 VGPRs) sets two workgroups per CU
-constexpr int L_WIN = 0, L_TBUF = 512, L_TOTAL = L_TBUF + 2 * FT * TPITCH;
-constexpr int MFCC_LDS_BYTES = L_TOTAL * 4;     // dynamic part (36 KB); 31 KB more are static arrays of the kernel
+// LDS carve-up (floats): 44 KB per workgroup incl. the static arrays
+constexpr int L_WIN = 0, L_TW = 512, L_TW5 = 1024, L_TBUF = 1536, L_TOTAL = L_TBUF + 2 * FT * TPITCH;
+constexpr int MFCC_LDS_BYTES = L_TOTAL * 4;     // dynamic part (40 KB)
+static_assert(258 <= PARTOFF && PARTOFF + PARTLEN <= PPITCH && 16 * PARTLEN == 4 * 3 * 4 * 64, "power row and partial sums fit a frame's region");
 
 typedef float f32x4m __attribute__((ext_vector_type(4)));
 
@@ -155,40 +166,24 @@ __device__ __forceinline__ float row_sum16(float e) {          // every lane of 
 }
 
 template <bool PSF>
-__global__ void __launch_bounds__(NTHR, 2)
+__global__ void __launch_bounds__(NTHR, 3)
 mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const int* __restrict__ clip_index,
             int pcm_stride, int out_frames, int total_frames, const float* __restrict__ tab, float* __restrict__ out) {
     // separate LDS objects, so that the compiler may move a wave's reads of one past its writes of another (with one
     // array the 16 partner-bin reads of the split were each held behind the previous bin's power store)
-    extern __shared__ __attribute__((aligned(16))) float lds[];         // window table + transpose tile (dynamic part)
-    __shared__ __attribute__((aligned(16))) float pw[FT * PPITCH + 8];  // power spectrum tile x 4 (A operand of the mel products)
-    __shared__ __attribute__((aligned(16))) float part[4 * 3 * 4 * 64]; // mel partial sums of the four waves
+    extern __shared__ __attribute__((aligned(16))) float lds[];         // window + twiddle tables, transpose tile (dynamic part)
     __shared__ __attribute__((aligned(16))) float lmel[FT * LPITCH];    // log-mel tile (A operand of the DCT products)
     __shared__ int live_s[2 * FT];                                      // [parity][frame]
     __shared__ float en_s[2 * FT];                                      // PSF: frame energy
     const float* win = lds + L_WIN;                 // window / 32768, zero outside its 400 taps
-    cplx* tbuf = (cplx*)(lds + L_TBUF);             // transpose tile; then the spectrum Z[k] (256 per frame)
+    cplx* tbuf = (cplx*)(lds + L_TBUF);             // transpose tile; then the spectrum Z[k] (256 per frame); then power rows + partial sums
+    float* pw = lds + L_TBUF;                       // power row of frame f: pw[f * PPITCH + k], k = 0..257 (4 |X|^2; column 257 = 0)
+    const cplx* twl = (const cplx*)(lds + L_TW);    // W256^(j k1) at [k1][j]
+    const cplx* tw5l = (const cplx*)(lds + L_TW5);  // W512^(j + 16 m) at [m][j]
+    auto part_at = [&](int e) { return lds + L_TBUF + (e / PARTLEN) * PPITCH + PARTOFF + (e % PARTLEN); };   // partial-sum block, element e
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
     const int fi = 4 * wave + g;                                           // this lane group's frame within the tile
-
-    for (int e = tid; e < FT * PPITCH + 8; e += NTHR) pw[e] = 0.f;          // pad column 257 and the slack stay zero
-    for (int e = tid; e < 512; e += NTHR) lds[L_WIN + e] = tab[TB_WIN512 + e];
-    if (tid < 2 * FT) live_s[tid] = 0;
-    // lane constants in registers: W256^(j k1), W512^(j + 16 m), mel / DCT B operands (the window taps stay in LDS:
-    // with them the kernel spills).  Measured: squeezing the kernel under 168 VGPRs for three workgroups per CU --
-    // constants re-read from the table per tile -- spills as well and runs at 65 us instead of 46.
-    cplx tw[16], tw5[16];
-#pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) tw[k1] = ((const cplx*)(tab + TB_TW256))[(j * k1) & 255];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) tw5[m] = ((const cplx*)(tab + TB_TW512))[j + 16 * m];
-    float melb[kMelSlots], dctb[10];
-#pragma unroll
-    for (int s = 0; s < kMelSlots; ++s) melb[s] = tab[TB_MELB + (wave * kMelSlots + s) * 64 + lane];
-#pragma unroll
-    for (int s = 0; s < 10; ++s) dctb[s] = tab[TB_DCTB + ((wave < 3 ? wave : 0) * 10 + s) * 64 + lane];
-    __syncthreads();
 
     const int ntiles = (total_frames + FT - 1) / FT;
     cplx* tb = tbuf + fi * TPITCH;
@@ -264,9 +259,31 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
     fetch(fr, two);
     uint32_t pm1 = fetch_prev(fr);
     FrameMeta mnext = meta_of(tile + gridDim.x);
+    __builtin_amdgcn_sched_barrier(0);
+    // Tables AFTER the first tile's requests: a workgroup lives for only ~4 tiles (768 workgroups), and its start used to be
+    // three dependent round trips in a row -- tables, then the clip lookups, then the samples (~12 K cycles, a sixth of its life).
+    // Now the lookups and the samples are in flight while the tables are read and written to LDS.
+    for (int e = tid; e < 512; e += NTHR) lds[L_WIN + e] = tab[TB_WIN512 + e];
+    {   // twiddle tables: entry (k1 | m, j2) = tid
+        const int a = tid >> 4, j2 = tid & 15;
+        ((cplx*)(lds + L_TW))[tid] = ((const cplx*)(tab + TB_TW256))[(j2 * a) & 255];
+        ((cplx*)(lds + L_TW5))[tid] = ((const cplx*)(tab + TB_TW512))[j2 + 16 * a];
+    }
+    if (tid < 2 * FT) live_s[tid] = 0;
+    // mel / DCT B operands stay in registers (28); the twiddles are LDS operands (see the head of this file)
+    float melb[kMelSlots], dctb[10];
+#pragma unroll
+    for (int s = 0; s < kMelSlots; ++s) melb[s] = tab[TB_MELB + (wave * kMelSlots + s) * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < 10; ++s) dctb[s] = tab[TB_DCTB + ((wave < 3 ? wave : 0) * 10 + s) * 64 + lane];
+    __syncthreads();
     int par = 0;
     // (measured: handing the tiles out through a device-wide atomic counter -- to balance the runs of dead tiles of
     //  "empty" clips -- costs more than it balances: 3200 draws on one address take the kernel from 40 to 55 us)
+    // (measured, round 4: dealing the tiles by LIVE rank -- every workgroup scans the clips' lengths, a prefix table in LDS, equal
+    //  shares of live tiles, tiles cut at clip ends -- 44.4 us instead of 40.6: the launch is not waiting for unlucky workgroups,
+    //  a CU with three resident workgroups simply turns out ~50 tiles per us however they are dealt; the 12 % of extra
+    //  (quarter-filled) tiles and the scan cost what the balance gave.  Same finding as round 3's live-tiles-first pre-pass.)
 #pragma unroll 1
     for (; tile < ntiles; tile += gridDim.x, par ^= FT) {
         PH(0);
@@ -314,17 +331,11 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
             for (int n1 = 0; n1 < 16; ++n1)
                 v[n1] = f2{(float)(int16_t)(two[n1] & 0xffff), (float)((int32_t)two[n1] >> 16)} * *(const f2*)(win + 32 * n1 + 2 * j);
         }
-        // the next tile's samples fly during the rest of this one (its clip row / length were fetched a tile earlier)
-        fr = frame_of(mnext);
-        fetch(fr, two);
-        pm1 = fetch_prev(fr);
-        mnext = meta_of(tile + 2 * gridDim.x);
-        __builtin_amdgcn_sched_barrier(0);          // keep the loads HERE (hipcc otherwise sinks them towards their first use)
         PH(2);
         // 2. 16-point FFT over n1 (this lane is n2 = j), twiddle W256^(n2 k1), transpose through LDS, FFT over n2
         fft16(v);
 #pragma unroll
-        for (int k1 = 1; k1 < 16; ++k1) v[k1] = cmul(v[k1], tw[k1]);
+        for (int k1 = 1; k1 < 16; ++k1) v[k1] = cmul(v[k1], twl[k1 * 16 + j]);
         PH(3);
 #pragma unroll
         for (int k1 = 0; k1 < 16; ++k1) tb[k1 * 17 + j] = v[k1];
@@ -341,10 +352,11 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
         WAVE_SYNC();
         // 4. even/odd split of the real transform, power x 4 (the 1/4 is folded into the mel weights): bins k = j + 16 m
         //    2 X[k] = (Zk + conj Zm) + W512^k * (-i) (Zk - conj Zm),  m = 256 - k
+        float pwr[16];
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
             const int k = j + 16 * m;
-            const cplx zk = v[m], zm = tb[(256 - k) & 255], w5 = tw5[m];
+            const cplx zk = v[m], zm = tb[(256 - k) & 255], w5 = tw5l[m * 16 + j];
             f2 sm, df, u, X;
             asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(sm) : "v"(zk), "v"(zm));             // Zk + conj Zm
             asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(df) : "v"(zk), "v"(zm));             // Zk - conj Zm
@@ -352,12 +364,24 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
             asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(u) : "v"(df), "v"(w5), "v"(sm));
             asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(X) : "v"(df), "v"(w5), "v"(u));
             const f2 q = X * X;
-            pf[k] = q.x + q.y;
+            pwr[m] = q.x + q.y;
         }
+        const float r256 = v[0].x - v[0].y, p256 = 4.f * r256 * r256;              // bin 256 = (Re Z0 - Im Z0)^2
+        // the next tile's samples: requested here, where the FFT's registers are dead; they fly during the mel / log / DCT phases
+        // (their clip row / length were fetched a tile earlier)
+        const float en_keep = en;
+        fr = frame_of(mnext);
+        fetch(fr, two);
+        pm1 = fetch_prev(fr);
+        mnext = meta_of(tile + 2 * gridDim.x);
+        __builtin_amdgcn_sched_barrier(0);          // keep the loads HERE (hipcc otherwise sinks them towards their first use)
+        WAVE_SYNC();                                // every partner-bin read of this wave's frames is done: the rows may be overwritten
+#pragma unroll
+        for (int m = 0; m < 16; ++m) pf[j + 16 * m] = pwr[m];
         if (j == 0) {
-            const float r = v[0].x - v[0].y, p256 = 4.f * r * r;                     // bin 256 = (Re Z0 - Im Z0)^2
             pf[256] = p256;
-            if (PSF) en_s[par + fi] = 0.5f * en + (pf[0] + p256) * (1.f / 4096.f);   // sum of the 257 bins of |X|^2 / 512
+            pf[257] = 0.f; pf[258] = 0.f; pf[259] = 0.f;      // (the last k-steps of the third filter tile read bins up to 259: zero weights, finite operands)
+            if (PSF) en_s[par + fi] = 0.5f * en_keep + (pwr[0] + p256) * (1.f / 4096.f);   // sum of the 257 bins of |X|^2 / 512
         }
         PH(6);
         __syncthreads();                                            // (1) power tile complete
@@ -378,7 +402,7 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
 #pragma unroll
         for (int tl = 0; tl < 3; ++tl)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) part[((wave * 3 + tl) * 4 + r) * 64 + lane] = acc[tl][r];
+            for (int r = 0; r < 4; ++r) *part_at(((wave * 3 + tl) * 4 + r) * 64 + lane) = acc[tl][r];
         PH(8);
         __syncthreads();                                            // (2) partial sums in place
         PH(9);
@@ -386,10 +410,10 @@ mfcc_kernel(const int16_t* __restrict__ pcm, const int* __restrict__ lens, const
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int r = tid >> 6, l2 = tid & 63;                  // (r, lane') of filter tile q
-            float s = part[((0 * 3 + q) * 4 + r) * 64 + l2];
-            s += part[((1 * 3 + q) * 4 + r) * 64 + l2];
-            s += part[((2 * 3 + q) * 4 + r) * 64 + l2];
-            s += part[((3 * 3 + q) * 4 + r) * 64 + l2];
+            float s = *part_at(((0 * 3 + q) * 4 + r) * 64 + l2);
+            s += *part_at(((1 * 3 + q) * 4 + r) * 64 + l2);
+            s += *part_at(((2 * 3 + q) * 4 + r) * 64 + l2);
+            s += *part_at(((3 * 3 + q) * 4 + r) * 64 + l2);
             const int frame = 4 * (l2 >> 4) + r, mel = 16 * q + (l2 & 15);
             if (mel < NMEL) lmel[frame * LPITCH + mel] = PSF ? __logf(s == 0.f ? kPsfEps : s) : __logf(s + 1e-6f);   // v_log_f32: 1 ulp
         }
@@ -504,7 +528,7 @@ static int launch_flavour(var_ctx* c, hipStream_t s, const int16_t* pcm, const i
     const long total = (long)nclips * out_frames;
     if (total > (1L << 23)) { VAR_SET_ERR(c, "%s: %d clips x %d frames is too many", who, nclips, out_frames); return VAR_ERR_ARG; }
     const int ntiles = (int)((total + FT - 1) / FT);
-    const int grid = ntiles < 512 ? ntiles : 512;              // persistent: two 70 KB workgroups per CU
+    const int grid = ntiles < 768 ? ntiles : 768;              // persistent: three 44 KB workgroups per CU
     hipLaunchKernelGGL(mfcc_kernel<PSF>, dim3(grid), dim3(NTHR), MFCC_LDS_BYTES, s, pcm, lens, clip_index, pcm_stride, out_frames,
                        (int)total, tab, out);
     VAR_HIP_CHECK(c, hipGetLastError());
