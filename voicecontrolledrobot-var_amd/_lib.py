@@ -65,6 +65,7 @@ _SIGNATURES = {
     "var_armnet_plan": (_i, [_vp, _i]),
     "var_armnet_forward": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "var_armnet_status": (_i, [_vp, _vp]),
+    "var_join_status": (_i, [_vp, _vp]),
     "var_armnet_clear_status": (_i, [_vp]),
     "var_debug_armnet_drop_workgroup": (_i, [_vp]),
     "var_mfcc_psf": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -184,6 +185,12 @@ class Context:
     def set_streams(self, mask):
         """Stream plan of a step (include/var_hip.h); -1 = default.  Returns the previous mask."""
         return self.lib.var_set_streams(self.handle, int(mask))
+
+    def join_timeouts(self):
+        """Device-side stream hand-overs of training steps that gave up since var_init (include/var_hip.h: var_join_status)."""
+        n = ctypes.c_uint(0)
+        self.check(self.lib.var_join_status(self.handle, ctypes.byref(n)), "var_join_status")
+        return n.value
 
     def profile_read(self):
         ms, n = _f(), _i()

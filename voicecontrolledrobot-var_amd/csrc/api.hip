@@ -51,6 +51,7 @@ int var_init(int device_id, var_ctx** out) {
     if (e == hipSuccess) e = hipMalloc((void**)&c->loss_buf, sizeof(float) * 64);
     if (e == hipSuccess) e = hipMemset(c->loss_buf, 0, sizeof(float) * 64);
     c->done_ctr = (unsigned*)(c->loss_buf + 32);
+    c->jsig = (unsigned*)(c->loss_buf + 40);
     if (e != hipSuccess) {
         snprintf(g_init_err, sizeof(g_init_err), "var_init: %s", hipGetErrorString(e));
         delete c;
@@ -296,9 +297,11 @@ __global__ void __launch_bounds__(256) gemb_in_kernel(const float* __restrict__ 
     gemb[2 * n + e] = g2 ? g2[e] : 0.f;
 }
 
+// dev_join: the caller (the fused training step) goes straight on into encoder_bwd, whose first kernel on `s` is the only
+// consumer of the side stream's results: no join here -- that kernel waits for the sound heads on the device (heads.hip)
 static int encoder_fwd(var_ctx* c, hipStream_t s, const float* params, const void* image, int is_u8,
                        long bstride, const int* image_index, const float* pos, const float* neg,
-                       const AudioIn* audio, int B, bool finish = true) {
+                       const AudioIn* audio, int B, bool finish = true, bool dev_join = false) {
     int rc;
     if (audio && audio->pcm) {
         pos = c->mfcc_buf;
@@ -330,8 +333,9 @@ static int encoder_fwd(var_ctx* c, hipStream_t s, const float* params, const voi
     if (image && (rc = launch_heads_fwd(c, s, s, params, B, true, false, false, finish)) != VAR_OK) return rc;
     if (snd) {
         if ((rc = launch_snd_fwd(c, ss, params, pos, neg, B)) != VAR_OK) return rc;
+        c->dev_join = dev_join && fork_ok && (c->streams & 2) && !(c->streams & 64) && image && pos && neg;
         if ((rc = launch_heads_fwd(c, ss, ss, params, B, false, pos != nullptr, neg != nullptr, finish)) != VAR_OK) return rc;
-        if (fork_ok && (rc = join_side(c, s, 0)) != VAR_OK) return rc;
+        if (fork_ok && !c->dev_join && (rc = join_side(c, s, 0)) != VAR_OK) return rc;
     }
     c->saved_B = B;
     c->saved_gen = ++c->fwd_gen;
@@ -457,8 +461,12 @@ static int loss_grad_impl(var_ctx* c, hipStream_t s, const float* params, const 
     // tests/test_gpu_round2.py::test_config2_batch256_full_batch_parity covers both.)
     const bool fused = !feats_out && image && (mfcc_pos || (audio && audio->pcm)) && (mfcc_neg || (audio && audio->pcm));
     if ((rc = encoder_fwd(c, s, params, image, image_is_u8, image_bstride, image_index, mfcc_pos, mfcc_neg, audio, B,
-                          !fused)) != VAR_OK) return rc;
-    if (fused) return encoder_bwd(c, s, params, grads, true, margin, inv_count, loss_out);
+                          !fused, fused)) != VAR_OK) return rc;
+    if (fused) {
+        rc = encoder_bwd(c, s, params, grads, true, margin, inv_count, loss_out);
+        c->dev_join = false;
+        return rc;
+    }
     if ((rc = launch_triplet(c, s, c->emb, c->emb + 3 * B, c->emb + 6 * B, B, margin, inv_count, loss_out,
                              c->gemb, c->gemb + 3 * B, c->gemb + 6 * B)) != VAR_OK) return rc;
     if (feats_out)
@@ -594,10 +602,18 @@ static int default_streams() { return kDefaultStreams; }
 int var_set_streams(var_ctx* c, int mask) {
     if (!c) return -1;
     const int old = c->streams;
-    c->streams = mask < 0 ? default_streams() : (mask & 19);
+    c->streams = mask < 0 ? default_streams() : (mask & (19 | 64));   // bit 6: keep the graph edge between the forward's two streams
     c->serial = c->streams == 0;
     c->fuse_fwd_always = mask >= 0 && (mask & 32);   // bit 5: the one-launch image forward even beside a sound branch (A/B timing, tests)
     return old;
+}
+
+int var_join_status(var_ctx* c, unsigned* timeouts) {
+    CHECK_CTX(c);
+    if (!timeouts) { VAR_SET_ERR(c, "var_join_status: null argument"); return VAR_ERR_ARG; }
+    SET_DEVICE(c);
+    VAR_HIP_CHECK(c, hipMemcpy(timeouts, c->jsig + 3, sizeof(unsigned), hipMemcpyDeviceToHost));
+    return VAR_OK;
 }
 
 int var_profile_select(var_ctx* c, int tag) {

@@ -138,6 +138,11 @@ struct var_ctx {
     float* ghid = nullptr;        // (3B,128)
     void* pack_segs_dev = nullptr; int pack_nseg = 0;   // pack segment table in device memory (pack_adam.hip)
     unsigned* done_ctr = nullptr; // self-resetting block counter of the graph-replayed Adam kernel
+    // Device-side hand-over between the two streams of a training step (heads.hip: JoinSig): [0] arrivals of the sound heads'
+    // forward workgroups, [1] "the sound embeddings' partials are complete", [2] arrivals of the image rows' workgroups,
+    // [3] waits that timed out (sticky; var_join_status)
+    unsigned* jsig = nullptr;
+    bool dev_join = false;        // this step's forward left the side stream un-joined: the image rows wait on jsig[1]
     uint16_t* relu1 = nullptr;    // ReLU bits of the first image activation: [b][half][y][x], bit r <-> channel (r&3)+8(r>>2)+4*half
     float* slabs = nullptr;       // split-K partial weight gradients
     size_t slab_floats = 0;
