@@ -325,14 +325,15 @@ int var_mfcc_psf(var_ctx* ctx, void* stream, const int16_t* pcm, const int* lens
  * summed durations and the launch count since the select (it synchronises on the events).
  * var_set_streams: which parts of a step leave the caller's stream (bit 0: sound CNN forward, bit 1: sound
  * CNN backward, bit 4: with bit 0, MFCC stays on the caller's stream, bit 5: the one-launch image forward of image-only
- * calls also beside a sound branch -- slower there, kept for timing, bit 6: the training step's forward joins its two
- * streams with a graph edge again instead of the device-side flag, see var_join_status); -1 restores the default (3).
+ * calls also beside a sound branch -- slower there, kept for timing, bit 6: the training step's forward and backward
+ * hand over between their two streams with graph edges again instead of device-side flags, see var_join_status); -1 restores the default (3).
  * 0 puts every kernel on the caller's stream (per-kernel timing).  Returns the old mask.
- * var_join_status: in a training step (var_arm_loss_grad* with all three branches, two streams) the first backward kernel
- * on the caller's stream does not wait for the sound branch through the stream (a barrier packet in a replayed graph costs
- * ~10 us there) but polls a flag the sound heads' last workgroup raises; a poll gives up after 50 ms -- the sound branch
- * never ran: a fault, the step's numbers are undefined -- and counts itself.  *timeouts = that count since var_init
- * (synchronous copy; the reference's loss.backward(), VAR/pretext_VAR.py:68, has no such failure mode, so it is reported).
+ * var_join_status: in a training step (var_arm_loss_grad* with all three branches, two streams) the backward's first kernels
+ * do not wait for the other stream's forward through the streams (a barrier packet in a replayed graph costs ~10 us there):
+ * the last workgroup of each branch's last forward kernel counts a flag up and polls the other branch's before it ends; a
+ * poll gives up after 50 ms -- the other branch never ran: a fault, the step's numbers are undefined -- and counts itself.
+ * *timeouts = that count since var_init (synchronous copy; the reference's loss.backward(), VAR/pretext_VAR.py:68, has no
+ * such failure mode, so it is reported).
  * var_debug_buffer: address/length of a named workspace buffer ("act1".."act5", "gact1"..,
  * "sact1".."sact4", "gsact1".., "emb", "gemb", "wpack"; "ithor_s1".."ithor_s3", "ithor_gs1".."ithor_gs3") for
  * layer-wise parity tests.

@@ -33,12 +33,13 @@ def make_model(var_amd, sd, h=84):
 
 @pytest.mark.parametrize("B", [48, 256])
 def test_device_side_stream_join_equals_the_graph_edge(var_amd, golden_dir, B):
-    """Round 4: in a training step the first backward kernel on the caller's stream (the image rows of the heads' backward) no
-    longer waits for the sound branch through a graph edge -- a barrier packet there cost ~10 us of every replayed step -- but
-    polls a flag the last workgroup of the sound heads' forward raises behind a release fence (csrc/heads.hip: join_signal /
-    join_wait / join_release).  Same arithmetic either way: replayed steps with the flag (default) and with the edge
-    (var_set_streams bit 6) from the same start must leave bit-identical losses and parameters, eager steps likewise, and no
-    wait may have timed out (var_join_status)."""
+    """Round 4: inside a training step no graph edge crosses the two streams between the fork and the final join -- a barrier
+    packet in front of the first backward kernel cost ~10 us of every replayed step.  The image rows of the heads' backward need
+    the sound embeddings' partials, the sound rows the image's: the last workgroup of each producer (sound heads' forward / the
+    conv 3-5 kernel) counts a flag up and does not end before the other stream's flag has been counted up too, and the rows read
+    the other stream's partials with agent-scope loads (csrc/var_common.h: join_signal; csrc/heads.hip).  Same arithmetic either
+    way: replayed steps with the flags (default) and with the edges (var_set_streams bit 6) from the same start must leave
+    bit-identical losses and parameters, eager steps likewise, and no wait may have timed out (var_join_status)."""
     from var_amd._lib import Context
     sd = load(golden_dir, "kuka_weights.npz")
     ctx = Context.get(0)

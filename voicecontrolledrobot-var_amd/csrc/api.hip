@@ -312,6 +312,8 @@ static int encoder_fwd(var_ctx* c, hipStream_t s, const float* params, const voi
     // fork / join pair costs more than the overlap gives
     const bool fork_ok = (c->streams & 1) && B > 32;
     hipStream_t ss = fork_ok ? c->side : s;
+    // (decided before the first launch: the image forward's last kernel raises the flag the sound rows wait for)
+    c->dev_join = dev_join && fork_ok && (c->streams & 2) && !(c->streams & 64) && image && pos && neg;
     // Launch ORDER matters under graph replay: the chain that is enqueued first after a fork keeps the hardware
     // queue of its predecessor, the other branch pays a cross-queue hand-over (5-10 us).  So the caller's stream
     // (MFCC -> image CNN -> image head) is enqueued first and the sound branch, which has slack, afterwards.
@@ -333,7 +335,6 @@ static int encoder_fwd(var_ctx* c, hipStream_t s, const float* params, const voi
     if (image && (rc = launch_heads_fwd(c, s, s, params, B, true, false, false, finish)) != VAR_OK) return rc;
     if (snd) {
         if ((rc = launch_snd_fwd(c, ss, params, pos, neg, B)) != VAR_OK) return rc;
-        c->dev_join = dev_join && fork_ok && (c->streams & 2) && !(c->streams & 64) && image && pos && neg;
         if ((rc = launch_heads_fwd(c, ss, ss, params, B, false, pos != nullptr, neg != nullptr, finish)) != VAR_OK) return rc;
         if (fork_ok && !c->dev_join && (rc = join_side(c, s, 0)) != VAR_OK) return rc;
     }
@@ -412,7 +413,9 @@ static int encoder_bwd(var_ctx* c, hipStream_t s, const float* params, float* gr
     // streams: s = image head + the image backward chain, side = sound head + sound CNN backward + loss value
     hipStream_t ss = (c->streams & 2) ? c->side : s;
     // (same ordering rule as in the forward: the caller's chain first, then the side branch)
-    if ((rc = fork_side(c, s, 1)) != VAR_OK) return rc;
+    // (dev_join: the side stream has not been joined since the forward's fork and needs no edge from `s` either: its rows kernel
+    // waits for the image partials on the device)
+    if (!c->dev_join && (rc = fork_side(c, s, 1)) != VAR_OK) return rc;
     if (c->saved_image) {
         if ((rc = launch_heads_bwd(c, s, s, params, grads, B, true, 0, 0, fused, margin, inv_count)) != VAR_OK) return rc;
         if ((rc = launch_img_bwd(c, s, params, grads, B)) != VAR_OK) return rc;
@@ -612,7 +615,9 @@ int var_join_status(var_ctx* c, unsigned* timeouts) {
     CHECK_CTX(c);
     if (!timeouts) { VAR_SET_ERR(c, "var_join_status: null argument"); return VAR_ERR_ARG; }
     SET_DEVICE(c);
-    VAR_HIP_CHECK(c, hipMemcpy(timeouts, c->jsig + 3, sizeof(unsigned), hipMemcpyDeviceToHost));
+    unsigned w[8];
+    VAR_HIP_CHECK(c, hipMemcpy(w, c->jsig, sizeof(w), hipMemcpyDeviceToHost));
+    *timeouts = w[3] + w[7];
     return VAR_OK;
 }
 

@@ -122,70 +122,48 @@ __device__ __forceinline__ float triplet_row(const Emb3& a, const Emb3& p, const
 }
 
 // ------------------------------------------------------------------------------------------
-// Device-side hand-over from the side stream to the caller's (JoinSig = var_ctx::jsig).  In a replayed step the first
-// backward kernel on the caller's stream -- the image rows below -- needs the sound embeddings' partials from the side stream.
-// As a graph edge that dependency is a barrier packet in front of the kernel, and the queue takes ~10 us over it even when the
-// other side finished long before (the timeline: conv 3-5 ends at 114.6 us, sound heads at 110.0, rows start at 125.3).  So the
-// training step leaves the edge out: the last workgroup of the sound heads' forward raises sig[1], the image rows poll it (it is
-// up before they start unless the sound branch is late) and then read; their last workgroup lowers it again for the next step,
-// whose sound branch cannot start before this step's Adam.  A wait gives up after 50 ms and counts
-// itself in sig[3] (var_join_status): the step's numbers are then undefined, nothing hangs.
+// Device-side hand-over between the caller's stream and the side stream (var_ctx::jsig; join_* in var_common.h).  In a replayed
+// step the first backward kernel on the caller's stream -- the image rows below -- needs the sound embeddings' partials from the
+// side stream, and the sound rows on the side stream need the image's from the caller's (img_mid3.hip leaves them).
+// As a graph edge such a dependency is a barrier packet in front of the kernel, and the queue takes ~10 us over it even when the
+// other side finished long before (the timeline: conv 3-5 ends at 114.6 us, sound heads at 110.0, rows start at 125.3); a kernel
+// with a successor on the other queue costs its same-queue successor ~6 us as well.  So the training step leaves both edges
+// out -- between its fork and its final join no graph edge crosses the streams: the last workgroup of the sound heads' forward
+// counts sig[1] up; the conv 3-5 kernel's last workgroup, on the caller's stream, does not end before it has seen that (it has
+// happened by then unless the sound branch is late); the image rows read the partials with agent-scope loads.  The other
+// direction is the same with sig[4..7]: counted up by the last workgroup of the conv 3-5 kernel, awaited by the sound heads'
+// last workgroup.  A wait gives up after 50 ms and counts itself in sig[3] / sig[7] (var_join_status): the step's numbers are
+// then undefined, nothing hangs.
 // ------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(1))) unsigned gu32h;
-// No fences (a release fence at agent scope writes the XCD's whole L2 back, an acquire drops it -- beside the conv kernels that
-// cost what the edge did): the handed-over floats themselves travel as agent-scope atomic stores and loads, which go past the
-// non-coherent cache levels; the producer's barrier waits for its stores' acknowledgements (vmcnt) before one thread counts the
-// workgroup in, and the consumer issues its loads only after it has seen the flag.
-__device__ __forceinline__ void join_store(float* p, float v) {
-    __hip_atomic_store((gu32h*)p, __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float join_load(const float* p) {
-    return __builtin_bit_cast(float, __hip_atomic_load((gu32h*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void join_signal(unsigned* sig, unsigned n_wg) {      // every thread's join_store()s are issued
-    __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(sig, 1u) == n_wg - 1) {
-        atomicExch(sig, 0u);
-        atomicExch(sig + 1, 1u);
-    }
-}
-__device__ __forceinline__ void join_wait(unsigned* sig) {
-    if (threadIdx.x == 0) {
-        const unsigned long long t0 = wall_clock64();
-        while (__hip_atomic_load((gu32h*)(sig + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-            if (wall_clock64() - t0 > 5000000ull) { atomicAdd(sig + 3, 1u); break; }      // 50 ms of the 100 MHz counter
-            __builtin_amdgcn_s_sleep(8);
-        }
-    }
-    __syncthreads();
-}
-__device__ __forceinline__ void join_release(unsigned* sig, unsigned n_wg) {     // the last consumer lowers the flag
-    __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(sig + 2, 1u) == n_wg - 1) {
-        atomicExch(sig + 2, 0u);
-        atomicExch(sig + 1, 0u);
-    }
-}
+// Who polls: the LAST workgroup of the kernel in front of the consumer on its own stream (var_common.h: join_signal) -- the conv
+// 3-5 kernel waits for the sound heads' flag before it ends, the sound heads for the conv 3-5 kernel's; the rows kernels behind
+// them start with everything in place.  (Polling in the rows kernels themselves -- one workgroup per row -- hung a step whose
+// sound branch had run ahead until the time-out: 512 resident workgroups, a few VGPRs and 512 B of LDS each, sat on every CU,
+// while the conv 3-5 kernel they were waiting for needs a CU's WHOLE LDS and register file per workgroup and could not be placed
+// anywhere.  A one-wave gate kernel in front of the rows is safe but costs what the edge did, ~8 us per kernel boundary at that
+// point of the step; sixteen persistent polling workgroups walking the rows are safe and take 16 us instead of 6.)
 
 // rows [g0, g0 + gridDim.x) of the (3B) stack [image | positive | negative]; part = (3B,4,4) forward partials
-// sig: wait for the other stream's partials on the device first (see above); nullptr: they are complete by stream order
+// sig: the partials of the rows in sig_rows (bit r: image / positive / negative) come from the other stream (complete: see
+// above) and are read with agent-scope loads; nullptr: one stream
 __global__ void __launch_bounds__(128)
 heads_bwd_rows_fused_kernel(int R, int B, int g0, const float* __restrict__ w1, const float* __restrict__ hid,
                             const float* part, const float* __restrict__ b1_img,
                             const float* __restrict__ b1_snd, float margin, float inv_count,
                             float* __restrict__ emb_raw, float* __restrict__ emb, float* __restrict__ graw_out,
-                            float* __restrict__ ghid, float* __restrict__ ghidT, unsigned* sig) {
+                            float* __restrict__ ghid, float* __restrict__ ghidT, unsigned* sig, int sig_rows) {
     const int row = blockIdx.x, n = threadIdx.x;
     const int g = g0 + row, role = g / B, i = g - role * B;
-    __shared__ __attribute__((aligned(16))) float sp[32];      // the sample's positive / negative partials, handed over on the device
-    if (sig) {
-        join_wait(sig);
-        if (n < 32) sp[n] = join_load(part + (size_t)((1 + (n >> 4)) * B + i) * 16 + (n & 15));
-        __syncthreads();
+    __shared__ __attribute__((aligned(16))) float sp[48];      // the sample's three partial rows
+    if (n < 48) {
+        const int r = n >> 4;
+        const float* src = part + (size_t)(r * B + i) * 16 + (n & 15);
+        sp[n] = (sig && ((sig_rows >> r) & 1)) ? join_load(src) : *src;
     }
-    const Emb3 ea = finish_emb(part + (size_t)i * 16, b1_img);
-    const Emb3 ep = finish_emb(sig ? sp : part + (size_t)(B + i) * 16, b1_snd);
-    const Emb3 en = finish_emb(sig ? sp + 16 : part + (size_t)(2 * B + i) * 16, b1_snd);
+    __syncthreads();
+    const Emb3 ea = finish_emb(sp, b1_img);
+    const Emb3 ep = finish_emb(sp + 16, b1_snd);
+    const Emb3 en = finish_emb(sp + 32, b1_snd);
     float ga[3], gp[3], gn[3];
     (void)triplet_row(ea, ep, en, margin, inv_count, ga, gp, gn);
     const Emb3& me = role == 0 ? ea : (role == 1 ? ep : en);
@@ -200,7 +178,6 @@ heads_bwd_rows_fused_kernel(int R, int B, int g0, const float* __restrict__ w1, 
     if (!(hid[(size_t)row * kHid + n] > 0.f)) v = 0.f;
     ghid[(size_t)row * kHid + n] = v;
     ghidT[(size_t)n * R + row] = v;
-    if (sig) join_release(sig, gridDim.x);
 }
 
 // loss_out[0] = inv_count * sum_i max(||a-p+eps|| - ||a-n+eps|| + margin, 0) from the forward partials (fixed order)
@@ -353,7 +330,7 @@ heads_bwd_gemm_kernel(int R /*rows in this call*/, int RT /*row stride of ghidT*
 template <int K>
 __global__ void __launch_bounds__(256)
 heads_fwd_split_kernel(const float* __restrict__ x, int R, const float* __restrict__ w0t, const float* __restrict__ b0,
-                       const float* __restrict__ w1, float* __restrict__ hid, float* __restrict__ part, unsigned* sig) {
+                       const float* __restrict__ w1, float* __restrict__ hid, float* __restrict__ part, unsigned* sig, unsigned* sig_other) {
     constexpr int LDX = K + 1, NT = 256, KSL = 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;                    // [32][K+1]
@@ -435,7 +412,7 @@ heads_fwd_split_kernel(const float* __restrict__ x, int R, const float* __restri
             else part[((size_t)(r0 + r) * 4 + nblk) * 4 + d] = s;
         }
     }
-    if (sig) join_signal(sig, gridDim.x * gridDim.y);          // (the consumer on the other stream waits on the device)
+    if (sig) join_signal(sig, gridDim.x * gridDim.y, sig_other);   // (training step: hand-over between the streams on the device)
 }
 
 // emb_raw = b1 + ((part0 + part1) + (part2 + part3)); emb = emb_raw / max(||emb_raw||, 1e-12)
@@ -461,7 +438,8 @@ heads_finish_kernel(const float* __restrict__ part, const float* __restrict__ b1
 template <int K>
 static int run_heads_fwd(var_ctx* c, hipStream_t s, const float* x, int R, const float* w0t, const float* b0,
                          const float* w1, const float* b1, float* hid, float* emb_raw, float* emb, float* part,
-                         bool finish, float* out0 = nullptr, float* out1 = nullptr, int split = 0, unsigned* sig = nullptr) {
+                         bool finish, float* out0 = nullptr, float* out1 = nullptr, int split = 0, unsigned* sig = nullptr,
+                         unsigned* sig_other = nullptr) {
     constexpr int A1 = 32 * (K + 1) * 4, A2 = 5 * 32 * 33 * 4;
     constexpr int LDS_BYTES = A1 > A2 ? A1 : A2;
     static unsigned attr_set = 0;      // bit d: set on device d (function attributes are per device)
@@ -470,7 +448,7 @@ static int run_heads_fwd(var_ctx* c, hipStream_t s, const float* x, int R, const
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set |= var_dev_bit(c);
     }
-    hipLaunchKernelGGL(heads_fwd_split_kernel<K>, dim3((R + 31) / 32, 4), dim3(256), LDS_BYTES, s, x, R, w0t, b0, w1, hid, part, sig);
+    hipLaunchKernelGGL(heads_fwd_split_kernel<K>, dim3((R + 31) / 32, 4), dim3(256), LDS_BYTES, s, x, R, w0t, b0, w1, hid, part, sig, sig_other);
     if (finish) hipLaunchKernelGGL(heads_finish_kernel, dim3((R + 255) / 256), dim3(256), 0, s, part, b1, R, emb_raw, emb, out0, out1, split);
     return VAR_OK;
 }
@@ -487,7 +465,8 @@ int launch_heads_fwd(var_ctx* c, hipStream_t s, hipStream_t ss, const float* par
     } else if (has_img) {
         ProfScope prof(c, s, TAG_HEADS_FWD);
         if ((rc = run_heads_fwd<kImgFeat>(c, s, c->act[5], B, c->wpack + K.ih_w0t, params + L.ih_b0, params + L.ih_w1,
-                                          params + L.ih_b1, c->hid_i, c->emb_raw, c->emb, c->head_part, finish, c->out_img, nullptr, B)) != VAR_OK) return rc;
+                                          params + L.ih_b1, c->hid_i, c->emb_raw, c->emb, c->head_part, finish, c->out_img, nullptr, B,
+                                          c->dev_join ? c->jsig + 4 : nullptr, c->jsig)) != VAR_OK) return rc;
     }
     if (has_pos || has_neg) {
         const int lo = has_pos ? 0 : B, hi = has_neg ? 2 * B : B;
@@ -496,7 +475,7 @@ int launch_heads_fwd(var_ctx* c, hipStream_t s, hipStream_t ss, const float* par
                                           c->hid_s + (size_t)lo * kHid, c->emb_raw + 3 * (B + lo),
                                           c->emb + 3 * (B + lo), c->head_part + 16 * (size_t)(B + lo), finish,
                                           lo == 0 ? c->out_pos : nullptr, c->out_neg, lo == 0 ? B : 0,
-                                          c->dev_join ? c->jsig : nullptr)) != VAR_OK) return rc;
+                                          c->dev_join ? c->jsig : nullptr, c->jsig + 4)) != VAR_OK) return rc;
     }
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
@@ -536,7 +515,7 @@ int launch_heads_bwd(var_ctx* c, hipStream_t s, hipStream_t ss, const float* par
             if (fused)
                 hipLaunchKernelGGL(heads_bwd_rows_fused_kernel, dim3(B), dim3(128), 0, s, B, B, 0, params + L.ih_w1,
                                    c->hid_i, c->head_part, params + L.ih_b1, params + L.sh_b1, margin, inv_count,
-                                   c->emb_raw, c->emb, graw, c->ghid, ghidT, c->dev_join ? c->jsig : nullptr);
+                                   c->emb_raw, c->emb, graw, c->ghid, ghidT, c->dev_join ? c->jsig : nullptr, 6);
             else
                 hipLaunchKernelGGL(heads_bwd_rows_kernel, dim3(B), dim3(128), 0, s, B, params + L.ih_w1, c->hid_i,
                                    c->emb_raw, c->emb, c->gemb, graw, c->ghid, ghidT);
@@ -547,7 +526,7 @@ int launch_heads_bwd(var_ctx* c, hipStream_t s, hipStream_t ss, const float* par
                 hipLaunchKernelGGL(heads_bwd_rows_fused_kernel, dim3(R), dim3(128), 0, ss, R, B, B + snd_lo,
                                    params + L.sh_w1, c->hid_s + (size_t)snd_lo * kHid, c->head_part, params + L.ih_b1,
                                    params + L.sh_b1, margin, inv_count, c->emb_raw, c->emb, graw + 4 * (B + snd_lo),
-                                   c->ghid + (size_t)(B + snd_lo) * kHid, ghidT + (size_t)B * kHid, (unsigned*)nullptr);
+                                   c->ghid + (size_t)(B + snd_lo) * kHid, ghidT + (size_t)B * kHid, c->dev_join ? c->jsig + 4 : nullptr, 1);
             else
                 hipLaunchKernelGGL(heads_bwd_rows_kernel, dim3(R), dim3(128), 0, ss, R, params + L.sh_w1,
                                    c->hid_s + (size_t)snd_lo * kHid, c->emb_raw + 3 * (B + snd_lo),

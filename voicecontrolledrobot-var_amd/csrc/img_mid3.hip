@@ -124,7 +124,7 @@ template <class C, bool PRE>
 __device__ __forceinline__ void img_mid3_body(const float* __restrict__ x2, const float* __restrict__ wa3, const float* __restrict__ wa4,
                                               const float* __restrict__ wa5, const float* __restrict__ params, int o_b3, int o_b4, int o_b5,
                                               int o_hb0, int o_hw1, float* __restrict__ y3, float* __restrict__ y4, float* __restrict__ y5,
-                                              const float* __restrict__ hw0t, float* __restrict__ hid, float* __restrict__ part, const size_t b) {
+                                              const float* __restrict__ hw0t, float* __restrict__ hid, float* __restrict__ part, const size_t b, unsigned* sig = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, i15 = lane & 15;
@@ -540,10 +540,19 @@ __device__ __forceinline__ void img_mid3_body(const float* __restrict__ x2, cons
             float sum = hh[l] * lds[C::C_HW1 + d * kHid + l] + hh[64 + l] * lds[C::C_HW1 + d * kHid + 64 + l];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
-            if (l == 0) part[b * 16 + d] = sum;
+            if (l == 0) {
+                if (sig) join_store(part + b * 16 + d, sum);
+                else part[b * 16 + d] = sum;
+            }
         }
-        if (tid >= 192 && tid < 192 + 13) part[b * 16 + (tid - 192 + 3)] = 0.f;
+        if (tid >= 192 && tid < 192 + 13) {
+            if (sig) join_store(part + b * 16 + (tid - 192 + 3), 0.f);
+            else part[b * 16 + (tid - 192 + 3)] = 0.f;
+        }
         if (tid < kHid) hid[b * kHid + tid] = ohid;
+        // training step: the sound rows of the heads' backward, on the other stream, need these partials, and the image rows behind
+        // this kernel the sound branch's: handed over on the device (var_common.h: join_*; heads.hip)
+        if (sig) join_signal(sig, gridDim.x, sig - 4);           // (sig = jsig + 4: the sound side's words lie in front)
     } else {
         wait_vm<0>();                                            // (nothing of the stream may still be landing when the workgroup ends)
     }
@@ -558,8 +567,8 @@ __global__ void __launch_bounds__(M3_NT)
 img_mid3_kernel(const float* __restrict__ x2, const float* __restrict__ wa3, const float* __restrict__ wa4,
                 const float* __restrict__ wa5, const float* __restrict__ params, int o_b3, int o_b4, int o_b5, int o_hb0, int o_hw1,
                 float* __restrict__ y3, float* __restrict__ y4, float* __restrict__ y5,
-                const float* __restrict__ hw0t, float* __restrict__ hid, float* __restrict__ part) {
-    img_mid3_body<C, false>(x2, wa3, wa4, wa5, params, o_b3, o_b4, o_b5, o_hb0, o_hw1, y3, y4, y5, hw0t, hid, part, blockIdx.x);
+                const float* __restrict__ hw0t, float* __restrict__ hid, float* __restrict__ part, unsigned* sig) {
+    img_mid3_body<C, false>(x2, wa3, wa4, wa5, params, o_b3, o_b4, o_b5, o_hb0, o_hw1, y3, y4, y5, hw0t, hid, part, blockIdx.x, sig);
 }
 
 // The WHOLE image forward of one image in one workgroup: conv 1 + conv 2 (img_head2_body: role-split waves over the image's seven
@@ -629,7 +638,8 @@ static int launch_mid3(var_ctx* c, hipStream_t s, const float* params, int B, bo
     const PackLayout& K = c->kl;
     hipLaunchKernelGGL((img_mid3_kernel<C>), dim3(B), dim3(M3_NT), C::LDS_BYTES, s, c->act[2], c->wpack + K.img_f[2],
                        c->wpack + K.img_f[3], c->wpack + K.img_f[4], params, L.img_b[2], L.img_b[3], L.img_b[4], L.ih_b0, L.ih_w1,
-                       c->act[3], c->act[4], c->act[5], with_head ? c->wpack + K.ih_w0t : nullptr, c->hid_i, c->head_part);
+                       c->act[3], c->act[4], c->act[5], with_head ? c->wpack + K.ih_w0t : nullptr, c->hid_i, c->head_part,
+                       (with_head && c->dev_join) ? c->jsig + 4 : nullptr);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }

@@ -138,9 +138,9 @@ struct var_ctx {
     float* ghid = nullptr;        // (3B,128)
     void* pack_segs_dev = nullptr; int pack_nseg = 0;   // pack segment table in device memory (pack_adam.hip)
     unsigned* done_ctr = nullptr; // self-resetting block counter of the graph-replayed Adam kernel
-    // Device-side hand-over between the two streams of a training step (heads.hip: JoinSig): [0] arrivals of the sound heads'
-    // forward workgroups, [1] "the sound embeddings' partials are complete", [2] arrivals of the image rows' workgroups,
-    // [3] waits that timed out (sticky; var_join_status)
+    // Device-side hand-over between the two streams of a training step (heads.hip, join_signal below): [0] arrivals of the sound
+    // heads' forward workgroups, [1] completed launches of that kernel, [2] how many of them the caller's stream has waited for,
+    // [3] waits for it that timed out (sticky; var_join_status); [4..7] the same for the conv 3-5 kernel and the side stream
     unsigned* jsig = nullptr;
     bool dev_join = false;        // this step's forward left the side stream un-joined: the image rows wait on jsig[1]
     uint16_t* relu1 = nullptr;    // ReLU bits of the first image activation: [b][half][y][x], bit r <-> channel (r&3)+8(r>>2)+4*half
@@ -238,6 +238,44 @@ struct ProfScope {
 #define PHR(i)
 #define PHR_FLUSH()
 #endif
+
+
+// ------------------------------------------------------------------------------------------
+// Device-side hand-over between the two streams of a training step (heads.hip explains when and why; sig = var_ctx::jsig or
+// jsig + 4: [0] arrivals of the producer's workgroups, [1] the flag: completed producer launches, [2] how many of them the other
+// stream has waited for, [3] its timed-out waits).
+typedef __attribute__((address_space(1))) unsigned gu32h;
+// No fences (a release fence at agent scope writes the XCD's whole L2 back, an acquire drops it -- beside the conv kernels that
+// cost what the edge did): the handed-over floats themselves travel as agent-scope atomic stores and loads, which go past the
+// non-coherent cache levels; the producer's barrier waits for its stores' acknowledgements (vmcnt) before one thread counts the
+// workgroup in, and the consumer issues its loads only after it has seen the flag.
+__device__ __forceinline__ void join_store(float* p, float v) {
+    __hip_atomic_store((gu32h*)p, __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float join_load(const float* p) {
+    return __builtin_bit_cast(float, __hip_atomic_load((gu32h*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// The producer's side: every thread's join_store()s are issued.  The LAST workgroup to arrive counts this stream's flag up and
+// then waits (one thread; 50 ms at most, counted in other[3]) until the OTHER stream's flag has been counted up once more than
+// this side has consumed it (other[2]): the kernel behind this one needs that stream's results, and the wait belongs here, not
+// there -- a kernel that starts by polling may be resident on every CU while what it waits for cannot be placed (heads.hip).
+// Each side counts its own flag up before it waits for the other's: no cycle.  Flags only count up: nothing to lower, no
+// arrival counting in the consumers (768 same-address atomics took longer than the kernels they were in).
+__device__ __forceinline__ void join_signal(unsigned* sig, unsigned n_wg, unsigned* other) {
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(sig, 1u) == n_wg - 1) {
+        atomicExch(sig, 0u);
+        atomicAdd(sig + 1, 1u);
+        const unsigned want = __hip_atomic_load((gu32h*)(other + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        const unsigned long long t0 = wall_clock64();
+        while ((int)(__hip_atomic_load((gu32h*)(other + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+            if (wall_clock64() - t0 > 5000000ull) { atomicAdd(other + 3, 1u); break; }    // 50 ms of the 100 MHz counter
+            __builtin_amdgcn_s_sleep(8);
+        }
+        __hip_atomic_store((gu32h*)(other + 2), want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// ------------------------------------------------------------------------------------------
 
 static inline int conv_out(int h) { return (h - 1) / 2 + 1; }   // 3x3 s2 p1
 
