@@ -417,11 +417,11 @@ static int encoder_bwd(var_ctx* c, hipStream_t s, const float* params, float* gr
     // waits for the image partials on the device)
     if (!c->dev_join && (rc = fork_side(c, s, 1)) != VAR_OK) return rc;
     if (c->saved_image) {
-        if ((rc = launch_heads_bwd(c, s, s, params, grads, B, true, 0, 0, fused, margin, inv_count)) != VAR_OK) return rc;
+        if ((rc = launch_heads_bwd(c, s, s, params, grads, B, true, 0, 0, fused, margin, inv_count, fused ? loss_out : nullptr)) != VAR_OK) return rc;
         if ((rc = launch_img_bwd(c, s, params, grads, B)) != VAR_OK) return rc;
     }
     if ((rc = launch_heads_bwd(c, ss, ss, params, grads, B, false, snd_lo, snd_hi, fused, margin, inv_count)) != VAR_OK) return rc;
-    if (fused && (rc = launch_triplet_loss(c, ss, params, B, margin, inv_count, loss_out)) != VAR_OK) return rc;
+    // (fused: the loss value is summed by the image head's backward from the terms its rows kernel leaves -- heads.hip)
     if ((rc = launch_snd_bwd(c, ss, params, grads, B)) != VAR_OK) return rc;
     return join_side(c, s, 1);
 }

@@ -145,13 +145,14 @@ __device__ __forceinline__ float triplet_row(const Emb3& a, const Emb3& p, const
 
 // rows [g0, g0 + gridDim.x) of the (3B) stack [image | positive | negative]; part = (3B,4,4) forward partials
 // sig: the partials of the rows in sig_rows (bit r: image / positive / negative) come from the other stream (complete: see
-// above) and are read with agent-scope loads; nullptr: one stream
+// above) and are read with agent-scope loads; nullptr: one stream.  loss_terms: sample i's loss term goes to loss_terms[i]
 __global__ void __launch_bounds__(128)
 heads_bwd_rows_fused_kernel(int R, int B, int g0, const float* __restrict__ w1, const float* __restrict__ hid,
                             const float* part, const float* __restrict__ b1_img,
                             const float* __restrict__ b1_snd, float margin, float inv_count,
                             float* __restrict__ emb_raw, float* __restrict__ emb, float* __restrict__ graw_out,
-                            float* __restrict__ ghid, float* __restrict__ ghidT, unsigned* sig, int sig_rows) {
+                            float* __restrict__ ghid, float* __restrict__ ghidT, unsigned* sig, int sig_rows,
+                            float* __restrict__ loss_terms) {
     const int row = blockIdx.x, n = threadIdx.x;
     const int g = g0 + row, role = g / B, i = g - role * B;
     __shared__ __attribute__((aligned(16))) float sp[48];      // the sample's three partial rows
@@ -165,7 +166,8 @@ heads_bwd_rows_fused_kernel(int R, int B, int g0, const float* __restrict__ w1, 
     const Emb3 ep = finish_emb(sp + 16, b1_snd);
     const Emb3 en = finish_emb(sp + 32, b1_snd);
     float ga[3], gp[3], gn[3];
-    (void)triplet_row(ea, ep, en, margin, inv_count, ga, gp, gn);
+    const float lterm = triplet_row(ea, ep, en, margin, inv_count, ga, gp, gn);
+    if (loss_terms && n == 0) loss_terms[i] = lterm;           // (the image rows: summed by heads_bwd_gemm_kernel's last block)
     const Emb3& me = role == 0 ? ea : (role == 1 ? ep : en);
     const float e0 = role == 0 ? ga[0] : (role == 1 ? gp[0] : gn[0]);
     const float e1 = role == 0 ? ga[1] : (role == 1 ? gp[1] : gn[1]);
@@ -263,7 +265,8 @@ heads_bwd_gemm_kernel(int R /*rows in this call*/, int RT /*row stride of ghidT*
                       const float* __restrict__ w0, const float* __restrict__ hid,
                       const float* __restrict__ graw, const float* __restrict__ ghid,
                       const float* __restrict__ ghidT, float* __restrict__ dw0, float* __restrict__ db0,
-                      float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ gx) {
+                      float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ gx,
+                      const float* __restrict__ loss_terms, float inv_count, float* __restrict__ loss_out) {
     constexpr int KB = K / 32;
     __shared__ float red[4][1024];
     __shared__ float reda[4][32];
@@ -271,6 +274,19 @@ heads_bwd_gemm_kernel(int R /*rows in this call*/, int RT /*row stride of ghidT*
     const int tile = blockIdx.x;                         // one tile per workgroup, 4 waves split its reduction
     const int RB = (R + 31) / 32;
     const int n_dw0 = 4 * KB, n_dw1 = 4;
+    if (loss_terms && tile == (int)gridDim.x - 1) {
+        // one more workgroup: the loss VALUE, loss_out[0] = inv_count * sum_i term_i in triplet_loss_kernel's fixed order (the
+        // terms come from the rows kernel in front of this one; as a kernel of its own on the side stream the sum stood between
+        // the sound heads and the sound CNN's backward, 10-25 us of that stream's critical path)
+        float local = 0.f;
+        for (int i = tid; i < R; i += 256) local += loss_terms[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+        if (lane == 0) reda[0][wave] = local;
+        __syncthreads();
+        if (tid == 0) loss_out[0] = ((reda[0][0] + reda[0][1]) + (reda[0][2] + reda[0][3])) * inv_count;
+        return;
+    }
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -502,10 +518,11 @@ int launch_triplet_loss(var_ctx* c, hipStream_t s, const float* params, int B, f
 // gemb (3B,3) must hold the gradients wrt the normalised embeddings [img | pos | neg].
 // Produces gact[5] (B,576), gsact[4] (2B,160) and the 8 head gradient tensors.
 int launch_heads_bwd(var_ctx* c, hipStream_t s, hipStream_t ss, const float* params, float* grads, int B, bool has_img,
-                     int snd_lo, int snd_hi, bool fused, float margin, float inv_count) {
+                     int snd_lo, int snd_hi, bool fused, float margin, float inv_count, float* loss_out) {
     const ParamLayout& L = c->pl;
     const size_t mB = (size_t)c->maxB;
     float* graw = c->gemb + 9 * mB;                       // (3B,4)
+    float* lterms = (fused && has_img && loss_out) ? c->gemb + 21 * mB : nullptr;     // (B): per-sample loss terms (fused step)
     float* ghidT = c->ghid + 3 * mB * kHid;               // second half of the ghid buffer: [128][rows]
     {
         // fused: the rows finish their sample's embeddings and form the triplet gradient themselves (forward
@@ -515,7 +532,7 @@ int launch_heads_bwd(var_ctx* c, hipStream_t s, hipStream_t ss, const float* par
             if (fused)
                 hipLaunchKernelGGL(heads_bwd_rows_fused_kernel, dim3(B), dim3(128), 0, s, B, B, 0, params + L.ih_w1,
                                    c->hid_i, c->head_part, params + L.ih_b1, params + L.sh_b1, margin, inv_count,
-                                   c->emb_raw, c->emb, graw, c->ghid, ghidT, c->dev_join ? c->jsig : nullptr, 6);
+                                   c->emb_raw, c->emb, graw, c->ghid, ghidT, c->dev_join ? c->jsig : nullptr, 6, lterms);
             else
                 hipLaunchKernelGGL(heads_bwd_rows_kernel, dim3(B), dim3(128), 0, s, B, params + L.ih_w1, c->hid_i,
                                    c->emb_raw, c->emb, c->gemb, graw, c->ghid, ghidT);
@@ -526,7 +543,8 @@ int launch_heads_bwd(var_ctx* c, hipStream_t s, hipStream_t ss, const float* par
                 hipLaunchKernelGGL(heads_bwd_rows_fused_kernel, dim3(R), dim3(128), 0, ss, R, B, B + snd_lo,
                                    params + L.sh_w1, c->hid_s + (size_t)snd_lo * kHid, c->head_part, params + L.ih_b1,
                                    params + L.sh_b1, margin, inv_count, c->emb_raw, c->emb, graw + 4 * (B + snd_lo),
-                                   c->ghid + (size_t)(B + snd_lo) * kHid, ghidT + (size_t)B * kHid, c->dev_join ? c->jsig + 4 : nullptr, 1);
+                                   c->ghid + (size_t)(B + snd_lo) * kHid, ghidT + (size_t)B * kHid, c->dev_join ? c->jsig + 4 : nullptr, 1,
+                                   (float*)nullptr);
             else
                 hipLaunchKernelGGL(heads_bwd_rows_kernel, dim3(R), dim3(128), 0, ss, R, params + L.sh_w1,
                                    c->hid_s + (size_t)snd_lo * kHid, c->emb_raw + 3 * (B + snd_lo),
@@ -538,9 +556,10 @@ int launch_heads_bwd(var_ctx* c, hipStream_t s, hipStream_t ss, const float* par
         ProfScope prof(c, s, TAG_HEADS_BWD_W);
         if (has_img) {
             const int tiles = 4 * (kImgFeat / 32) + 4 + ((B + 31) / 32) * (kImgFeat / 32);
-            hipLaunchKernelGGL(heads_bwd_gemm_kernel<kImgFeat>, dim3(tiles), dim3(256), 0, s, B, B,
+            hipLaunchKernelGGL(heads_bwd_gemm_kernel<kImgFeat>, dim3(tiles + (lterms ? 1 : 0)), dim3(256), 0, s, B, B,
                                c->act[5], params + L.ih_w0, c->hid_i, graw, c->ghid, ghidT,
-                               grads + L.ih_w0, grads + L.ih_b0, grads + L.ih_w1, grads + L.ih_b1, c->gact[5]);
+                               grads + L.ih_w0, grads + L.ih_b0, grads + L.ih_w1, grads + L.ih_b1, c->gact[5],
+                               (const float*)lterms, inv_count, loss_out);
         }
         if (snd_hi > snd_lo) {
             const int R = snd_hi - snd_lo;
@@ -550,7 +569,7 @@ int launch_heads_bwd(var_ctx* c, hipStream_t s, hipStream_t ss, const float* par
                                c->hid_s + (size_t)snd_lo * kHid, graw + 4 * (B + snd_lo),
                                c->ghid + (size_t)(B + snd_lo) * kHid, ghidT + (size_t)B * kHid,
                                grads + L.sh_w0, grads + L.sh_b0, grads + L.sh_w1, grads + L.sh_b1,
-                               c->gsact[4] + (size_t)snd_lo * kSndFeat);
+                               c->gsact[4] + (size_t)snd_lo * kSndFeat, (const float*)nullptr, 0.f, (float*)nullptr);
         }
     }
     VAR_HIP_CHECK(c, hipGetLastError());

@@ -339,7 +339,7 @@ int launch_snd_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads,
 int launch_heads_fwd(var_ctx* c, hipStream_t s, hipStream_t ss, const float* params, int B, bool has_img, bool has_pos,
                      bool has_neg, bool finish = true);
 int launch_heads_bwd(var_ctx* c, hipStream_t s, hipStream_t ss, const float* params, float* grads, int B, bool has_img,
-                     int snd_lo, int snd_hi, bool fused = false, float margin = 0.f, float inv_count = 0.f);
+                     int snd_lo, int snd_hi, bool fused = false, float margin = 0.f, float inv_count = 0.f, float* loss_out = nullptr);
 int launch_triplet_loss(var_ctx* c, hipStream_t s, const float* params, int B, float margin, float inv_count,
                         float* loss_out);
 int launch_triplet(var_ctx* c, hipStream_t s, const float* a, const float* p, const float* n, int B,
