@@ -331,7 +331,7 @@ int var_mfcc_psf(var_ctx* ctx, void* stream, const int16_t* pcm, const int* lens
  * var_join_status: in a training step (var_arm_loss_grad* with all three branches, two streams) the backward's first kernels
  * do not wait for the other stream's forward through the streams (a barrier packet in a replayed graph costs ~10 us there):
  * the last workgroup of each branch's last forward kernel counts a flag up and polls the other branch's before it ends; a
- * poll gives up after 50 ms -- the other branch never ran: a fault, the step's numbers are undefined -- and counts itself.
+ * poll gives up after 5 ms -- the other branch never ran: a fault, the step's numbers are undefined -- and counts itself.
  * *timeouts = that count since var_init (synchronous copy; the reference's loss.backward(), VAR/pretext_VAR.py:68, has no
  * such failure mode, so it is reported).
  * var_debug_buffer: address/length of a named workspace buffer ("act1".."act5", "gact1"..,

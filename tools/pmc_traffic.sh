@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmc_$C
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc_$C -- python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --no-graph $EXTRA > $R/gpurun_out/pmc_$C.log 2>&1 || exit 1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc_$C -- python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --no-graph --streams 67 $EXTRA > $R/gpurun_out/pmc_$C.log 2>&1 || exit 1
 done
 python3 - "$R" "$TAG" <<'PY'
 import csv, glob, json, sys, collections

@@ -132,7 +132,7 @@ __device__ __forceinline__ float triplet_row(const Emb3& a, const Emb3& p, const
 // counts sig[1] up; the conv 3-5 kernel's last workgroup, on the caller's stream, does not end before it has seen that (it has
 // happened by then unless the sound branch is late); the image rows read the partials with agent-scope loads.  The other
 // direction is the same with sig[4..7]: counted up by the last workgroup of the conv 3-5 kernel, awaited by the sound heads'
-// last workgroup.  A wait gives up after 50 ms and counts itself in sig[3] / sig[7] (var_join_status): the step's numbers are
+// last workgroup.  A wait gives up after 5 ms and counts itself in sig[3] / sig[7] (var_join_status): the step's numbers are
 // then undefined, nothing hangs.
 // ------------------------------------------------------------------------------------------
 // Who polls: the LAST workgroup of the kernel in front of the consumer on its own stream (var_common.h: join_signal) -- the conv

@@ -256,7 +256,7 @@ __device__ __forceinline__ float join_load(const float* p) {
     return __builtin_bit_cast(float, __hip_atomic_load((gu32h*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 // The producer's side: every thread's join_store()s are issued.  The LAST workgroup to arrive counts this stream's flag up and
-// then waits (one thread; 50 ms at most, counted in other[3]) until the OTHER stream's flag has been counted up once more than
+// then waits (one thread; 5 ms at most, counted in other[3]) until the OTHER stream's flag has been counted up once more than
 // this side has consumed it (other[2]): the kernel behind this one needs that stream's results, and the wait belongs here, not
 // there -- a kernel that starts by polling may be resident on every CU while what it waits for cannot be placed (heads.hip).
 // Each side counts its own flag up before it waits for the other's: no cycle.  Flags only count up: nothing to lower, no
@@ -269,7 +269,7 @@ __device__ __forceinline__ void join_signal(unsigned* sig, unsigned n_wg, unsign
         const unsigned want = __hip_atomic_load((gu32h*)(other + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
         const unsigned long long t0 = wall_clock64();
         while ((int)(__hip_atomic_load((gu32h*)(other + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
-            if (wall_clock64() - t0 > 5000000ull) { atomicAdd(other + 3, 1u); break; }    // 50 ms of the 100 MHz counter
+            if (wall_clock64() - t0 > 500000ull) { atomicAdd(other + 3, 1u); break; }     // 5 ms of the 100 MHz counter
             __builtin_amdgcn_s_sleep(8);
         }
         __hip_atomic_store((gu32h*)(other + 2), want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
