@@ -26,7 +26,7 @@
 //     the second filter half leave behind the MFMA groups of conv 3, one or two instructions at a time.
 // Register loads are consumed (turned into mask bits) at points where the wave's DMA queue is empty: hipcc's own wait for a
 // parked load is vmcnt(0) more often than not, and would drain a stage's filter pieces there.
-// 84 x 84 (act2 21 x 21) only so far; the geometry is a template parameter, the LDS plan of conv 3 is laid out for 21.
+// 84 x 84 (act2 21 x 21) and 96 x 96 (24 x 24): the geometry is a template parameter; conv 3's passes are dealt per size.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -69,7 +69,10 @@ struct ChCfg {
     static constexpr int NPAD3 = 64 * (2 * W3 - 1);                // pad cells of the gact3 tile
     static_assert(H4 == 6 && H5 == 3, "the maps this kernel is laid out for");
     static_assert(N4Q <= kChainNT, "gact4: one float4 per lane");
-    static_assert(END54 <= LDS_FLOATS && END3 <= SL + NSL * 256 && G3F % 4 == 0, "LDS plan; 16-byte alignment");
+    // (96 x 96: the result tile runs on into the gact5 / gact4 area behind the slots -- dead by then)
+    static constexpr int MING = H2 == 21 ? 4 : 8;                  // MFMA groups of the shortest first item of a conv-3 pass (below)
+    static_assert(END54 <= LDS_FLOATS && END3 <= LDS_FLOATS && G3 + G3F <= SL + NSL * 256 && G3F % 4 == 0, "LDS plan; 16-byte alignment");
+    static_assert(H2 == 21 || H2 == 24, "the conv-3 passes are dealt for these two maps");
     static_assert((64 * P4) % 4 == 0 && (64 * P3) % 4 == 0 && (16 * PL2) % 4 == 0, "whole float4");
 };
 
@@ -457,13 +460,30 @@ img_chain_kernel(const float* __restrict__ g5, const float* __restrict__ wpack, 
     auto conv3_pass = [&](auto pass_c, auto&& mid) {
         constexpr int PS = decltype(pass_c)::value;
         auto none = [](int) {};
-        if (wave < 2) c3_item<C, 4, 0, PS>(lds, 4 * wave, lane, mid);
-        else if (wave < 5) c3_item<C, 2, 1, PS>(lds, 2 * (wave - 2), lane, mid);
-        else if (wave < 8) c3_item<C, 2, 2, PS>(lds, 2 * (wave - 5), lane, mid);
-        else if (wave == 8) {
-            c3_item<C, 1, 1, PS>(lds, 6, lane, mid);
-            c3_item<C, 1, 2, PS>(lds, 6, lane, none);
-        } else c3_item<C, 1, 3, PS>(lds, wave - 9, lane, mid);
+        if constexpr (C::H2 == 21) {
+            if (wave < 2) c3_item<C, 4, 0, PS>(lds, 4 * wave, lane, mid);
+            else if (wave < 5) c3_item<C, 2, 1, PS>(lds, 2 * (wave - 2), lane, mid);
+            else if (wave < 8) c3_item<C, 2, 2, PS>(lds, 2 * (wave - 5), lane, mid);
+            else if (wave == 8) {
+                c3_item<C, 1, 1, PS>(lds, 6, lane, mid);
+                c3_item<C, 1, 2, PS>(lds, 6, lane, none);
+            } else c3_item<C, 1, 3, PS>(lds, wave - 9, lane, mid);
+        } else {
+            // 24 x 24: four classes of 144 pixels = 9 tiles each, 81 (tile, tap) units per pass.  Nine waves take an odd-odd tile and
+            // an even-even one (4 + 1 units), six waves three tiles of an even-odd / odd-even class (6 units), one wave only carries
+            // its share of the loads and stores; per SIMD (wave & 3) 21 / 21 / 22 / 17 units.
+            const int simd = wave & 3, slot = wave >> 2;
+            const int t = simd < 2 ? (slot < 3 ? 3 * simd + slot : -1) : simd == 2 ? (slot < 2 ? 6 + slot : -1) : (slot == 0 ? 8 : -1);
+            if (t >= 0) {
+                c3_item<C, 1, 3, PS>(lds, t, lane, mid);
+                c3_item<C, 1, 0, PS>(lds, t, lane, none);
+            } else if (wave == 12 || wave == 13 || wave == 10) c3_item<C, 3, 1, PS>(lds, wave == 12 ? 0 : wave == 13 ? 3 : 6, lane, mid);
+            else if (wave == 14 || wave == 7 || wave == 11) c3_item<C, 3, 2, PS>(lds, wave == 14 ? 0 : wave == 7 ? 3 : 6, lane, mid);
+            else {
+#pragma unroll
+                for (int g = 0; g < C::MING; ++g) mid(g);
+            }
+        }
     };
     auto finish2 = [&](f32x4c (&m2)[C::R2], f32x4c (&o)[C::R2]) {
 #pragma unroll
@@ -494,7 +514,7 @@ img_chain_kernel(const float* __restrict__ g5, const float* __restrict__ wpack, 
             ((f32x4c*)(g3 + b * 64 * C::P3))[e] = o3v[r];
         } else if (g == C::R3R + 1) load_m2(m2b, 1);
     });
-    static_assert(C::R3R + 1 < 4 && C::R2 <= 4, "every conv-3 item has four groups to hang these on");
+    static_assert(C::R3R + 2 <= C::MING && C::R2 <= C::MING, "every wave's first conv-3 item has the groups to hang these on");
     PHR(6);
     wait_vm<0>();                                                // the masks; the filter's second half
     bar();
@@ -517,10 +537,10 @@ img_chain_kernel(const float* __restrict__ g5, const float* __restrict__ wpack, 
 }
 }  // namespace
 
-// data gradients of conv 5, 4, 3 at 84 x 84: consumes gact[5] and act[2..4], leaves gact[4], gact[3], gact[2]
-int launch_img_bwd_chain(var_ctx* c, hipStream_t s, int B) {
-    ProfScope prof(c, s, TAG_IMG_DGRAD0 + 2);
-    using C = ChCfg<21>;
+// data gradients of conv 5, 4, 3: consumes gact[5] and act[2..4], leaves gact[4], gact[3], gact[2]
+template <int H2>
+static int launch_chain(var_ctx* c, hipStream_t s, int B) {
+    using C = ChCfg<H2>;
     static unsigned attr_set = 0;      // bit d: set on device d (function attributes are per device)
     if (!(attr_set & var_dev_bit(c))) {
         VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)img_chain_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
@@ -531,4 +551,9 @@ int launch_img_bwd_chain(var_ctx* c, hipStream_t s, int B) {
                        K.img_a[2], c->act[4], c->act[3], c->act[2], c->gact[4], c->gact[3], c->gact[2]);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
+}
+
+int launch_img_bwd_chain(var_ctx* c, hipStream_t s, int B) {
+    ProfScope prof(c, s, TAG_IMG_DGRAD0 + 2);
+    return c->H == 84 ? launch_chain<21>(c, s, B) : launch_chain<24>(c, s, B);
 }

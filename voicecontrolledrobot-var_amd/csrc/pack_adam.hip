@@ -92,7 +92,7 @@ static PackTable make_pack_table(var_ctx* c) {
         // conv 1, 2: [k][n]; conv 3..5: A-fragment pieces for img_mid3.hip (conv 3 with its channel groups outermost)
         add(K.img_f[i], Kp * kImgCh[i + 1], L.img_w[i], kImgCh[i], kImgCh[i + 1], 9, i < 2 ? 0 : (i == 2 ? 5 : 4));
     }
-    for (int i = 1; i < 5; i++) add(K.img_d[i], 9 * kImgCh[i + 1] * kImgCh[i], L.img_w[i], kImgCh[i], kImgCh[i + 1], 9, 1);
+    add(K.img_d[1], 9 * kImgCh[2] * kImgCh[1], L.img_w[1], kImgCh[1], kImgCh[2], 9, 1);    // (layers 2..4: img_a, the chain's form)
     // (segments must stay sorted by dst for the gather kernel's search: img_a sits between the sound images and the heads in PackLayout)
     add(K.snd_f[0], 200 * 32, L.snd_w[0], 40, 32, 5, 2);
     for (int i = 1; i < 4; i++) add(K.snd_f[i], 96 * 32, L.snd_w[i], 32, 32, 3, 0);

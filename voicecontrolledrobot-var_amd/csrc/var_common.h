@@ -53,7 +53,7 @@ inline ParamLayout make_param_layout() {
 // sound conv l     : Ws[k][n], k = kt*CINw + c  (conv0: k = kt*40 + f), and WsT[kt][n][c] for dX
 struct PackLayout {
     int img_f[5];
-    int img_d[5];     // [0] unused
+    int img_d[5];     // [1] only: conv 2's transposed filter for the tail kernels ([2..4]: img_a below)
     int img_a[5];     // [0], [1] unused: Wd of layers 2..4 in MFMA A-fragment order (img_chain.hip), see below
     int snd_f[4];
     int snd_d[4];     // [0] unused
@@ -69,8 +69,8 @@ inline PackLayout make_pack_layout() {
         int K = kImgCh[i] * 9; if (K & 1) K++;
         P.img_f[i] = o; o += K * kImgCh[i + 1];
     }
-    P.img_d[0] = -1;
-    for (int i = 1; i < 5; i++) { P.img_d[i] = o; o += 9 * kImgCh[i + 1] * kImgCh[i]; }
+    P.img_d[0] = P.img_d[2] = P.img_d[3] = P.img_d[4] = -1;
+    P.img_d[1] = o; o += 9 * kImgCh[2] * kImgCh[1];
     const int snd_k[4] = {200, 96, 96, 96};
     for (int i = 0; i < 4; i++) { P.snd_f[i] = o; o += snd_k[i] * 32; }
     P.snd_d[0] = -1;
