@@ -291,26 +291,25 @@ def tag_kernel(tag, hw):
     if hw == 84:
         return {1: "img_head2_kernel<", 2: "img_mid3_kernel<", 7: "img_wgrad345_kernel<", 11: "img_tail2_kernel<",
                 12: "img_chain_kernel", 15: "img_wgrad_reduce_kernel"}.get(tag)
-    return {1: "img_fwd_head_kernel<", 2: "img_mid3_kernel<", 6: "img_wgrad_kernel<", 7: "img_bwd_pair_kernel<WgCfg<32, 64,",
-            8: "img_bwd_pair_kernel<WgCfg<64, 64, 12,", 9: "img_bwd_pair_kernel<WgCfg<64, 64, 6,", 11: "img_bwd_tail_kernel<",
-            15: "img_wgrad_reduce_kernel"}.get(tag)
+    return {1: "img_fwd_head_kernel<", 2: "img_mid3_kernel<", 6: "img_wgrad_kernel<", 7: "img_wgrad345_kernel<", 11: "img_bwd_tail_kernel<",
+            12: "img_chain_kernel", 15: "img_wgrad_reduce_kernel"}.get(tag)
 
 
 def tag_flops(tag):
     """Algorithmic FLOPs per triplet of a profiled conv launch (csrc/api.hip kTagNames).  84 x 84: tag 1 = conv 1 + conv 2
     forward, 2 = conv 3 + 4 + 5 forward (+ image head, not counted), 7 = the weight gradients of conv 3-5, 11 = data gradient
     of conv 2 + weight gradients of conv 2 and conv 1, 12 = the data gradients of conv 5, 4, 3.  96 x 96: 6 = weight gradient
-    of conv 2, 7-9 = weight + data gradient of one layer, 11 = data gradient of conv 2 + weight gradient of conv 1.
+    of conv 2, 7 and 12 as at 84 x 84, 11 = data gradient of conv 2 + weight gradient of conv 1.
     Halo recomputation inside the fused kernels is not counted."""
     L = LAYER_FLOPS
     if tag == 1:
         return L[0] + L[1]
     if tag == 2:
         return L[2] + L[3] + L[4]
+    if tag in (7, 12):
+        return L[2] + L[3] + L[4]
     if HW == 84:
-        return {7: L[2] + L[3] + L[4], 11: 2 * L[1] + L[0], 12: L[2] + L[3] + L[4]}.get(tag, 0)
-    if tag in (7, 8, 9):
-        return 2 * L[tag - 5]
+        return {11: 2 * L[1] + L[0]}.get(tag, 0)
     if tag == 11:
         return L[1] + L[0]
     return L[tag % 5]

@@ -587,10 +587,10 @@ int var_mfcc_ex(var_ctx* c, void* stream, const int16_t* pcm, const int* lens, c
 // what each profiled launch computes (both image sizes; bench.py maps (tag, image size) to the kernel's name)
 static const char* kTagNames[TAG_COUNT] = {
     "(unused)", "img conv1+conv2 forward", "img conv3+4+5 forward + image head", "(unused)",
-    "(unused)", "(unused)", "img conv2 weight gradient (96x96)", "img conv3+4+5 weight gradients (84x84) / conv3 weight+data gradient (96x96)",
-    "img conv4 weight+data gradient (96x96)", "img conv5 weight+data gradient (96x96)", "(unused)",
+    "(unused)", "(unused)", "img conv2 weight gradient (96x96)", "img conv3+4+5 weight gradients",
+    "(unused)", "(unused)", "(unused)",
     "img conv2 data gradient + conv2, conv1 weight gradients (84x84) / conv2 data + conv1 weight gradient (96x96)",
-    "img conv5-4-3 data gradient chain (84x84)", "(unused)", "(unused)", "img weight-gradient slab fold",
+    "img conv5-4-3 data gradient chain", "(unused)", "(unused)", "img weight-gradient slab fold",
     "snd_fwd_kernel", "snd_dgrad_kernel", "snd_wgrad_kernel", "snd_reduce_kernel", "heads_fwd_kernel",
     "heads_bwd_rows_kernel", "heads_bwd_gemm_kernel", "triplet_kernel", "adam_kernel", "pack_weights_kernel",
     "mfcc_kernel", "ithor conv 11x5 s2 forward", "ithor conv 11x5 s2 data gradient", "ithor conv 11x5 s2 weight gradient"};
