@@ -335,6 +335,187 @@ heads_bwd_gemm_kernel(int R /*rows in this call*/, int RT /*row stride of ghidT*
         if (kind == 1 && i0 == 0 && tid < 3) db1[tid] = v;
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// The training step's backward of one head in ONE launch: heads_bwd_rows_fused_kernel's row work inside heads_bwd_gemm_kernel's
+// workgroups.  Both kernels are at the floor of what a launch costs at this point of the step (6.6 + 8.1 us with the chip nearly
+// idle, the data-gradient chain waiting behind them), and the rows are cheap: every workgroup works out the three scalars
+// (the gradient wrt the raw embedding) of the rows ITS tile reduces over -- all R for a weight-gradient tile, one per thread; its
+// own 32 for a data-gradient tile -- and forms its A operand from them on the fly:
+//   ghid[row][n] = (q0 w1[0][n] + q1 w1[1][n] + q2 w1[2][n]) . (hid[row][n] > 0)         (the rows kernel's expression, same order)
+// so ghid / ghidT / graw never exist in memory.  The products, their order and the folds are heads_bwd_gemm_kernel's.
+// The workgroup of the (dW1, block 0) tile also leaves the rows' embeddings (emb_raw, emb); one more workgroup sums the loss.
+// ------------------------------------------------------------------------------------------
+constexpr int kFusedMaxRows = 1024;
+struct RowQ { float q0, q1, q2, lterm; };
+__device__ __forceinline__ RowQ row_scalars(int g, int B, const float* part, const float* __restrict__ b1_img, const float* __restrict__ b1_snd,
+                                            float margin, float inv_count, Emb3& me) {
+    const int role = g / B, i = g - role * B;
+    const Emb3 ea = finish_emb(part + (size_t)i * 16, b1_img);
+    const Emb3 ep = finish_emb(part + (size_t)(B + i) * 16, b1_snd);
+    const Emb3 en = finish_emb(part + (size_t)(2 * B + i) * 16, b1_snd);
+    float ga[3], gp[3], gn[3];
+    RowQ r;
+    r.lterm = triplet_row(ea, ep, en, margin, inv_count, ga, gp, gn);
+    me = role == 0 ? ea : (role == 1 ? ep : en);
+    const float e0 = role == 0 ? ga[0] : (role == 1 ? gp[0] : gn[0]);
+    const float e1 = role == 0 ? ga[1] : (role == 1 ? gp[1] : gn[1]);
+    const float e2 = role == 0 ? ga[2] : (role == 1 ? gp[2] : gn[2]);
+    const float dot = me.y[0] * e0 + me.y[1] * e1 + me.y[2] * e2;
+    r.q0 = (e0 - me.y[0] * dot) / me.den;
+    r.q1 = (e1 - me.y[1] * dot) / me.den;
+    r.q2 = (e2 - me.y[2] * dot) / me.den;
+    return r;
+}
+
+// tile_gemm with the A operand made by the caller: araw(q) is fetched a block of steps ahead (a global or LDS read), amake(raw, q)
+// turns it into the operand when it is used
+template <class AR, class AM>
+__device__ __forceinline__ void tile_gemm_fn(int Q, const float* __restrict__ Bm, int ldb, bool aok, int lane, int wave, f32x16& acc,
+                                             float& asum, AR&& araw, AM&& amake) {
+    constexpr int UB = 8;
+    const int half = lane >> 5, l31 = lane & 31;
+    const float* bp = Bm + l31;
+    const int steps = (Q + 1) / 2;
+    const int mine = (steps - wave + 3) / 4;
+    float ab[2][UB], bb[2][UB];
+    auto fetch = [&](int buf, int i0) {
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int q = 2 * (wave + 4 * (i0 + u)) + half;
+            const int qc = q < Q ? q : Q - 1;
+            ab[buf][u] = araw(qc);
+            bb[buf][u] = bp[(size_t)qc * ldb];
+        }
+    };
+    auto mul = [&](int buf, int i0) {
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int q = 2 * (wave + 4 * (i0 + u)) + half;
+            const int qc = q < Q ? q : Q - 1;
+            const float a = (aok && q < Q && i0 + u < mine) ? amake(ab[buf][u], qc) : 0.f;
+            asum += a;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb[buf][u], acc, 0, 0, 0);
+        }
+    };
+    fetch(0, 0);
+#pragma unroll 1
+    for (int i0 = 0; i0 < mine; i0 += 2 * UB) {
+        fetch(1, i0 + UB);
+        __builtin_amdgcn_sched_barrier(0);
+        mul(0, i0);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(0, i0 + 2 * UB);
+        __builtin_amdgcn_sched_barrier(0);
+        mul(1, i0 + UB);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// rows [0, R) of this call are rows [g0, g0 + R) of the (3B) stack [image | positive | negative]; hid, x, gx belong to this call's rows
+template <int K>
+__global__ void __launch_bounds__(256)
+heads_bwd_fused_kernel(int R, int B, int g0, const float* part, const float* __restrict__ b1_img, const float* __restrict__ b1_snd,
+                       float margin, float inv_count, const float* __restrict__ x, const float* __restrict__ w0,
+                       const float* __restrict__ w1, const float* __restrict__ hid, float* __restrict__ dw0, float* __restrict__ db0,
+                       float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ gx, float* __restrict__ emb_raw,
+                       float* __restrict__ emb, float* __restrict__ loss_out) {
+    constexpr int KB = K / 32;
+    __shared__ float red[4][1024];
+    __shared__ float reda[4][32];
+    __shared__ float4 qs[kFusedMaxRows];                       // (q0, q1, q2, -) of the rows this tile reduces over
+    __shared__ float ht[32][kHid + 1];                         // a data-gradient tile's 32 rows of hid
+    __shared__ float w1s[3][kHid];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int tile = blockIdx.x;
+    const int n_dw0 = 4 * KB, n_dw1 = 4;
+    const bool loss_blk = loss_out && tile == (int)gridDim.x - 1;
+    const int kind = loss_blk ? 3 : tile < n_dw0 ? 0 : tile < n_dw0 + n_dw1 ? 1 : 2;
+    int i0 = 0, i1 = 0;
+    if (kind == 0) { i0 = tile / KB; i1 = tile - i0 * KB; }                      // nb, kb
+    else if (kind == 1) i0 = tile - n_dw0;                                     // nb
+    else if (kind == 2) { const int g = tile - n_dw0 - n_dw1; i0 = g / KB; i1 = g - i0 * KB; }      // rb, kb
+    // ---- the rows' scalars ----
+    const int rfirst = kind == 2 ? i0 * 32 : 0, rlast = kind == 2 ? (i0 * 32 + 32 < R ? i0 * 32 + 32 : R) : R;
+    float local = 0.f;
+    for (int r = rfirst + tid; r < rlast; r += 256) {
+        Emb3 me;
+        const RowQ q = row_scalars(g0 + r, B, part, b1_img, b1_snd, margin, inv_count, me);
+        qs[r - rfirst] = make_float4(q.q0, q.q1, q.q2, 0.f);
+        local += q.lterm;                                      // (i = tid, tid + 256, ...: triplet_loss_kernel's order)
+        if (kind == 1 && i0 == 0) {
+            const int g = g0 + r;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { emb_raw[g * 3 + d] = me.raw[d]; emb[g * 3 + d] = me.y[d]; }
+        }
+    }
+    if (kind == 3) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+        if (lane == 0) reda[0][wave] = local;
+        __syncthreads();
+        if (tid == 0) loss_out[0] = ((reda[0][0] + reda[0][1]) + (reda[0][2] + reda[0][3])) * inv_count;
+        return;
+    }
+    if (kind == 2) {
+        for (int e = tid; e < 32 * kHid / 4; e += 256) {
+            const int r = e / (kHid / 4), c4 = e - r * (kHid / 4);
+            const int row = i0 * 32 + r;
+            const float4 v = row < R ? ((const float4*)(hid + (size_t)row * kHid))[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            ht[r][4 * c4] = v.x; ht[r][4 * c4 + 1] = v.y; ht[r][4 * c4 + 2] = v.z; ht[r][4 * c4 + 3] = v.w;
+        }
+        for (int e = tid; e < 3 * kHid; e += 256) w1s[e / kHid][e % kHid] = w1[e];
+    }
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float asum = 0.f;
+    if (kind == 0) {
+        const int n = i0 * 32 + l31;
+        const float wa = w1[n], wb = w1[kHid + n], wc = w1[2 * kHid + n];
+        const float* hp = hid + n;
+        tile_gemm_fn(R, x + i1 * 32, K, true, lane, wave, acc, asum,
+                     [&](int q) { return hp[(size_t)q * kHid]; },
+                     [&](float h, int q) { const float4 s = qs[q]; const float v = s.x * wa + s.y * wb + s.z * wc; return h > 0.f ? v : 0.f; });
+    } else if (kind == 1) {
+        tile_gemm_fn(R, hid + i0 * 32, kHid, l31 < 3, lane, wave, acc, asum,
+                     [&](int q) { return ((const float*)&qs[q])[l31 < 3 ? l31 : 0]; },
+                     [&](float v, int) { return v; });
+    } else {
+        const bool aok = l31 < R - i0 * 32;
+        const float4 s = qs[aok ? l31 : 0];
+        tile_gemm_fn(kHid, w0 + i1 * 32, K, aok, lane, wave, acc, asum,
+                     [&](int q) { return ht[l31][q]; },
+                     [&](float h, int q) { const float v = s.x * w1s[0][q] + s.y * w1s[1][q] + s.z * w1s[2][q]; return h > 0.f ? v : 0.f; });
+    }
+    // fold the four K slices (fixed order)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[r];
+    asum += __shfl_down(asum, 32, 64);
+    if (half == 0) reda[wave][l31] = asum;
+    __syncthreads();
+    for (int e = tid; e < 1024; e += 256) {
+        const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        const int i = e >> 5, j = e & 31;                // D[i][j]
+        if (kind == 0) {
+            dw0[(size_t)(i0 * 32 + i) * K + i1 * 32 + j] = v;
+        } else if (kind == 1) {
+            if (i < 3) dw1[i * kHid + i0 * 32 + j] = v;
+        } else {
+            const int row = i0 * 32 + i;
+            if (row < R) {
+                const size_t o = (size_t)row * K + i1 * 32 + j;
+                gx[o] = x[o] > 0.f ? v : 0.f;
+            }
+        }
+    }
+    if (tid < 32) {
+        const float v = (reda[0][tid] + reda[1][tid]) + (reda[2][tid] + reda[3][tid]);
+        if (kind == 0 && i1 == 0) db0[i0 * 32 + tid] = v;
+        if (kind == 1 && i0 == 0 && tid < 3) db1[tid] = v;
+    }
+}
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -524,6 +705,29 @@ int launch_heads_bwd(var_ctx* c, hipStream_t s, hipStream_t ss, const float* par
     float* graw = c->gemb + 9 * mB;                       // (3B,4)
     float* lterms = (fused && has_img && loss_out) ? c->gemb + 21 * mB : nullptr;     // (B): per-sample loss terms (fused step)
     float* ghidT = c->ghid + 3 * mB * kHid;               // second half of the ghid buffer: [128][rows]
+    // The training step (fused): rows and products of a head in ONE launch each (heads_bwd_fused_kernel)
+    if (fused && B <= kFusedMaxRows && snd_hi - snd_lo <= kFusedMaxRows) {
+        ProfScope prof(c, s, TAG_HEADS_BWD_W);
+        if (has_img) {
+            const int tiles = 4 * (kImgFeat / 32) + 4 + ((B + 31) / 32) * (kImgFeat / 32);
+            hipLaunchKernelGGL(heads_bwd_fused_kernel<kImgFeat>, dim3(tiles + (loss_out ? 1 : 0)), dim3(256), 0, s, B, B, 0,
+                               (const float*)c->head_part, params + L.ih_b1, params + L.sh_b1, margin, inv_count,
+                               (const float*)c->act[5], params + L.ih_w0, params + L.ih_w1, (const float*)c->hid_i,
+                               grads + L.ih_w0, grads + L.ih_b0, grads + L.ih_w1, grads + L.ih_b1, c->gact[5], c->emb_raw, c->emb,
+                               loss_out);
+        }
+        if (snd_hi > snd_lo) {
+            const int R = snd_hi - snd_lo;
+            const int tiles = 4 * (kSndFeat / 32) + 4 + ((R + 31) / 32) * (kSndFeat / 32);
+            hipLaunchKernelGGL(heads_bwd_fused_kernel<kSndFeat>, dim3(tiles), dim3(256), 0, ss, R, B, B + snd_lo,
+                               (const float*)c->head_part, params + L.ih_b1, params + L.sh_b1, margin, inv_count,
+                               (const float*)(c->sact[4] + (size_t)snd_lo * kSndFeat), params + L.sh_w0, params + L.sh_w1,
+                               (const float*)(c->hid_s + (size_t)snd_lo * kHid), grads + L.sh_w0, grads + L.sh_b0, grads + L.sh_w1,
+                               grads + L.sh_b1, c->gsact[4] + (size_t)snd_lo * kSndFeat, c->emb_raw, c->emb, (float*)nullptr);
+        }
+        VAR_HIP_CHECK(c, hipGetLastError());
+        return VAR_OK;
+    }
     {
         // fused: the rows finish their sample's embeddings and form the triplet gradient themselves (forward
         // partials in c->head_part); otherwise gemb holds the gradients wrt the normalised embeddings
