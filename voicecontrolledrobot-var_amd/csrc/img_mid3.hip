@@ -346,7 +346,6 @@ __device__ __forceinline__ void img_mid3_body(const float* __restrict__ x2, cons
         fetch4(0, 0);
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
-            constexpr int LAST = 26;
             const int ky = s / 3, kx = s % 3;
             // (1) this step's operands (edge selects; the LDS wait sits here), (2) piece s + 1 -- conv 5's first one after the last
             // tap -- and the next step's reads, (3) the MFMAs, the refill of the slot piece s has left behind the first of them
