@@ -328,7 +328,8 @@ int var_mfcc_psf(var_ctx* ctx, void* stream, const int16_t* pcm, const int* lens
  * calls also beside a sound branch -- slower there, kept for timing, bit 6: the training step's forward and backward
  * hand over between their two streams with graph edges again instead of device-side flags, see var_join_status); -1 restores the default (3).
  * 0 puts every kernel on the caller's stream (per-kernel timing).  Returns the old mask.
- * var_join_status: in a training step (var_arm_loss_grad* with all three branches, two streams) the backward's first kernels
+ * var_join_status: in a training step recorded under stream capture (var_arm_loss_grad* with all three branches, two
+ * streams; launched eagerly the step keeps its stream edges) the backward's first kernels
  * do not wait for the other stream's forward through the streams (a barrier packet in a replayed graph costs ~10 us there):
  * the last workgroup of each branch's last forward kernel counts a flag up and polls the other branch's before it ends; a
  * poll gives up after 5 ms -- the other branch never ran: a fault, the step's numbers are undefined -- and counts itself.

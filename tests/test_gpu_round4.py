@@ -39,7 +39,8 @@ def test_device_side_stream_join_equals_the_graph_edge(var_amd, golden_dir, B):
     conv 3-5 kernel) counts a flag up and does not end before the other stream's flag has been counted up too, and the rows read
     the other stream's partials with agent-scope loads (csrc/var_common.h: join_signal; csrc/heads.hip).  Same arithmetic either
     way: replayed steps with the flags (default) and with the edges (var_set_streams bit 6) from the same start must leave
-    bit-identical losses and parameters, eager steps likewise, and no wait may have timed out (var_join_status)."""
+    bit-identical losses and parameters, eager steps (which always keep the edges) likewise, and no wait may have timed out
+    (var_join_status)."""
     from var_amd._lib import Context
     sd = load(golden_dir, "kuka_weights.npz")
     ctx = Context.get(0)

@@ -313,7 +313,12 @@ static int encoder_fwd(var_ctx* c, hipStream_t s, const float* params, const voi
     const bool fork_ok = (c->streams & 1) && B > 32;
     hipStream_t ss = fork_ok ? c->side : s;
     // (decided before the first launch: the image forward's last kernel raises the flag the sound rows wait for)
-    c->dev_join = dev_join && fork_ok && (c->streams & 2) && !(c->streams & 64) && image && pos && neg;
+    // Only under stream capture: in a replayed graph both branches sit in the device's queues before either starts, so a wait can
+    // only be as long as the other branch's kernels; launched eagerly, a host thread that is descheduled between the two branches'
+    // launches would turn into a time-out and a step with stale numbers -- and eagerly the edges' cost drowns in launch overhead.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (dev_join && hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
+    c->dev_join = dev_join && cap == hipStreamCaptureStatusActive && fork_ok && (c->streams & 2) && !(c->streams & 64) && image && pos && neg;
     // Launch ORDER matters under graph replay: the chain that is enqueued first after a fork keeps the hardware
     // queue of its predecessor, the other branch pays a cross-queue hand-over (5-10 us).  So the caller's stream
     // (MFCC -> image CNN -> image head) is enqueued first and the sound branch, which has slack, afterwards.

@@ -681,6 +681,7 @@ def train_representation_from_pool(model, pool, epochs, batch, lr=1e-4, weight_d
     loss_list = []
     acc = torch.zeros(1, dtype=torch.float32, device=tr.dev)
     ran = torch.zeros(1, dtype=torch.float32, device=tr.dev)
+    join_timeouts0 = 0 if is_ithor else tr.ctx.join_timeouts()
     for ep in range(epochs):
         tr.set_lr(multistep_lr(lr, milestones, gamma, ep))
         table = pool.epoch_index_table(batch, drop_last)
@@ -697,6 +698,11 @@ def train_representation_from_pool(model, pool, epochs, batch, lr=1e-4, weight_d
             acc += torch.where(ok, l, torch.zeros_like(l)).reshape(-1)[:1]
             ran += ok.reshape(-1)[:1].float()
         n_ran = int(ran.item())
+        if not is_ithor and tr.ctx.join_timeouts() > join_timeouts0:
+            # a replayed step hands over between its two streams on the device (csrc/heads.hip); a wait that gave up means a
+            # branch of some step never ran -- a fault of the device or the runtime, and that step's numbers were garbage
+            raise VarHipError(f"a device-side stream hand-over timed out in epoch {start_ep + ep} (var_join_status: "
+                              f"{tr.ctx.join_timeouts() - join_timeouts0}); var_set_streams(ctx, 3 | 64) restores the stream edges")
         if is_ithor and n_ran < spe:
             # bf16 mode: a persistent GRU launch did not get its whole grid resident and timed out; the optimiser skipped those
             # steps (the Adam kernels' guards, csrc/pack_adam.hip), parameters and moments are intact.  The captured graphs keep
