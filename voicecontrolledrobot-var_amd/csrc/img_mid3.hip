@@ -584,7 +584,7 @@ img_fwd_all_kernel(const void* __restrict__ image, long bstride, const int* __re
                    const float* __restrict__ wa3, const float* __restrict__ wa4, const float* __restrict__ wa5,
                    const float* __restrict__ params, int o_b1, int o_b2, int o_b3, int o_b4, int o_b5, int o_hb0, int o_hw1,
                    float* __restrict__ y3, float* __restrict__ y4, float* __restrict__ y5, const float* __restrict__ hw0t,
-                   float* __restrict__ hid, float* __restrict__ part, int B) {
+                   float* __restrict__ hid, float* __restrict__ part, int B, unsigned* sig) {
     static_assert(CH::NT == M3_NT && CH::LDS_FLOATS <= CM::W3A, "16 waves; conv 3's early filter half lies above the head's tiles");
     const int lane = threadIdx.x & 63;
     img_head2_body<CH>(image, bstride, bidx, wp1, params + o_b1, wp2, params + o_b2, y1, y2, B, (int)blockIdx.x, (int)gridDim.x,
@@ -593,7 +593,7 @@ img_fwd_all_kernel(const void* __restrict__ image, long bstride, const int* __re
     // done with the head's LDS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    img_mid3_body<CM, true>(y2, wa3, wa4, wa5, params, o_b3, o_b4, o_b5, o_hb0, o_hw1, y3, y4, y5, hw0t, hid, part, blockIdx.x);
+    img_mid3_body<CM, true>(y2, wa3, wa4, wa5, params, o_b3, o_b4, o_b5, o_hb0, o_hw1, y3, y4, y5, hw0t, hid, part, blockIdx.x, sig);
 }
 }  // namespace
 
@@ -616,7 +616,7 @@ int launch_img_fwd_all(var_ctx* c, hipStream_t s, const float* params, const voi
         hipLaunchKernelGGL(kern, dim3(B), dim3(M3_NT), CM::LDS_BYTES, s, image, bstride, image_index, c->wpack + K.img_f[0],
                            c->wpack + K.img_f[1], c->act[1], c->act[2], c->wpack + K.img_f[2], c->wpack + K.img_f[3], c->wpack + K.img_f[4],
                            params, L.img_b[0], L.img_b[1], L.img_b[2], L.img_b[3], L.img_b[4], L.ih_b0, L.ih_w1, c->act[3], c->act[4],
-                           c->act[5], c->wpack + K.ih_w0t, c->hid_i, c->head_part, B);
+                           c->act[5], c->wpack + K.ih_w0t, c->hid_i, c->head_part, B, c->dev_join ? c->jsig + 4 : nullptr);
         VAR_HIP_CHECK(c, hipGetLastError());
         return VAR_OK;
     };
