@@ -68,9 +68,15 @@ struct Head2Cfg {
 
 #ifndef VAR_HEAD2_DEVICE_ONLY
 PH_DECL();
+#ifdef VAR_PHASES
+__device__ unsigned long long g_span_h2[1024][2];       // per workgroup: s_memrealtime (100 MHz, chip-wide) at its first and last instruction
+#endif
 #endif
 }  // namespace
 #if defined(VAR_PHASES) && !defined(VAR_HEAD2_DEVICE_ONLY)
+extern "C" int var_debug_spans_head2(unsigned long long* out, int n) {      // tools/probe/head2_spans.py
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span_h2), sizeof(unsigned long long) * 2 * n) == hipSuccess ? 0 : -1;
+}
 extern "C" int var_debug_phases_head2(unsigned long long* out) {
     unsigned long long z[32] = {0};
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(z)) != hipSuccess) return -1;
@@ -348,7 +354,13 @@ img_head2_kernel(const void* __restrict__ image, long bstride, const int* __rest
                  const float* __restrict__ wp1, const float* __restrict__ bias1,
                  const float* __restrict__ wp2, const float* __restrict__ bias2,
                  float* __restrict__ y1, uint16_t* __restrict__ relu_bits, float* __restrict__ y2, int B) {
+#if defined(VAR_PHASES) && !defined(VAR_HEAD2_DEVICE_ONLY)
+    if (threadIdx.x == 0) g_span_h2[blockIdx.x][0] = wall_clock64();
+#endif
     img_head2_body<C>(image, bstride, bidx, wp1, bias1, wp2, bias2, y1, y2, B, (int)blockIdx.x, (int)gridDim.x, [](int) {});
+#if defined(VAR_PHASES) && !defined(VAR_HEAD2_DEVICE_ONLY)
+    if (threadIdx.x == 0) g_span_h2[blockIdx.x][1] = wall_clock64();
+#endif
 }
 
 //                      H1   U8   R2
