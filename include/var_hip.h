@@ -105,6 +105,12 @@ int var_arm_encoder_fwd(var_ctx* ctx, void* stream, const float* params,
  * Envs/vec_env/vec_pretext_normalize.py:96-101 (`calcReward`: torch.sum(a * b, dim=1)) as ONE launch on `stream`; the sum
  * runs over k in index order in fp32. */
 int var_row_dot(var_ctx* ctx, void* stream, const float* a, const float* b, int rows, int dim, float* out);
+/* Arms the NEXT var_arm_encoder_fwd with an image and at most 32 rows (the RL stage's envs): its image-head launch also leaves
+ * reward_out[b] = <image_feat[b], goal_feat[b]> (3 floats per row, var_row_dot's sum) -- the intrinsic reward of
+ * VAR/pretext_base.py's calcReward without a launch of its own (each launch is ~5 us on that path).  goal_feat must be complete
+ * on the forward's stream (the cached goal embedding of the later steps of an episode).  Disarmed by that forward, or by
+ * (NULL, NULL); forwards of more rows ignore it. */
+int var_set_reward_dot(var_ctx* ctx, const float* goal_feat, float* reward_out);
 
 /* autograd backward of the encoder (loss.backward(), VAR/pretext_VAR.py:68) from the
  * gradients of the three embeddings; writes d(loss)/d(param) for all 213478

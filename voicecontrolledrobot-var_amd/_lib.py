@@ -66,6 +66,7 @@ _SIGNATURES = {
     "var_armnet_forward": (_i, [_vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "var_armnet_status": (_i, [_vp, _vp]),
     "var_join_status": (_i, [_vp, _vp]),
+    "var_set_reward_dot": (_i, [_vp, _vp, _vp]),
     "var_armnet_clear_status": (_i, [_vp]),
     "var_debug_armnet_drop_workgroup": (_i, [_vp]),
     "var_mfcc_psf": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -404,6 +404,14 @@ int var_row_dot(var_ctx* c, void* stream, const float* a, const float* b, int ro
     return VAR_OK;
 }
 
+int var_set_reward_dot(var_ctx* c, const float* goal_feat, float* reward_out) {
+    CHECK_CTX(c);
+    if ((goal_feat == nullptr) != (reward_out == nullptr)) { VAR_SET_ERR(c, "var_set_reward_dot: both pointers or neither"); return VAR_ERR_ARG; }
+    c->dot_with = goal_feat;
+    c->dot_out = reward_out;
+    return VAR_OK;
+}
+
 // fused: the head rows finish the embeddings and form the triplet gradient themselves (heads.hip); the loss value
 // is computed on the side branch
 static int encoder_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads, bool fused = false,

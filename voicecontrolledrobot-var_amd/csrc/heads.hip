@@ -524,10 +524,21 @@ heads_bwd_fused_kernel(int R, int B, int g0, const float* part, const float* __r
 // output layer; heads_finish_kernel adds the four partials in a fixed order, the bias, and normalises.
 // (One 16-wave workgroup per 32 rows would keep only 8 / 16 CUs busy for 8 us of matrix work each.)
 // ------------------------------------------------------------------------------------------
+// Small batches (one row block: the RL stage's 8 envs, where every launch is at the floor of what a launch costs): the LAST of the
+// four workgroups to arrive also runs heads_finish_kernel's arithmetic on the block's rows and, when asked, the reward's row dot
+// (var_set_reward_dot) -- two launches fewer on the frozen encoder's latency path.  The partials travel as agent-scope stores /
+// loads then (var_common.h: join_store / join_load), the arrival count rewinds itself.
+struct FinishArgs {
+    const float* b1; float* emb_raw; float* emb; float* out0; float* out1; int split;
+    unsigned* ctr;                 // nullptr: no finish in this launch
+    const float* dot_with; float* dot_out;
+};
+
 template <int K>
 __global__ void __launch_bounds__(256)
 heads_fwd_split_kernel(const float* __restrict__ x, int R, const float* __restrict__ w0t, const float* __restrict__ b0,
-                       const float* __restrict__ w1, float* __restrict__ hid, float* __restrict__ part, unsigned* sig, unsigned* sig_other) {
+                       const float* __restrict__ w1, float* __restrict__ hid, float* __restrict__ part, unsigned* sig, unsigned* sig_other,
+                       FinishArgs fin) {
     constexpr int LDX = K + 1, NT = 256, KSL = 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;                    // [32][K+1]
@@ -605,11 +616,44 @@ heads_fwd_split_kernel(const float* __restrict__ x, int R, const float* __restri
 #pragma unroll 8
         for (int j = 0; j < 32; ++j) s += hs[r * 33 + j] * w1[d * kHid + nblk * 32 + j];
         if (r0 + r < R) {
-            if (sig) join_store(part + ((size_t)(r0 + r) * 4 + nblk) * 4 + d, s);
+            if (sig || fin.ctr) join_store(part + ((size_t)(r0 + r) * 4 + nblk) * 4 + d, s);
             else part[((size_t)(r0 + r) * 4 + nblk) * 4 + d] = s;
         }
     }
     if (sig) join_signal(sig, gridDim.x * gridDim.y, sig_other);   // (training step: hand-over between the streams on the device)
+    if (fin.ctr) {
+        __shared__ int last_s;
+        __syncthreads();                                       // (every join_store of this workgroup is acknowledged)
+        if (tid == 0) {
+            last_s = atomicAdd(fin.ctr, 1u) == gridDim.y - 1;
+            if (last_s) atomicExch(fin.ctr, 0u);
+        }
+        __syncthreads();
+        const int row = r0 + tid;
+        if (last_s && tid < 32 && row < R) {
+            float p[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) p[k] = join_load(part + (size_t)row * 16 + k);
+            // (heads_finish_kernel's arithmetic)
+            const float a = ((p[0] + p[4]) + (p[8] + p[12])) + fin.b1[0];
+            const float b = ((p[1] + p[5]) + (p[9] + p[13])) + fin.b1[1];
+            const float c = ((p[2] + p[6]) + (p[10] + p[14])) + fin.b1[2];
+            const float nrm = sqrtf(a * a + b * b + c * c);
+            const float den = nrm > 1e-12f ? nrm : 1e-12f;
+            const float y0 = a / den, y1 = b / den, y2 = c / den;
+            fin.emb_raw[row * 3 + 0] = a; fin.emb_raw[row * 3 + 1] = b; fin.emb_raw[row * 3 + 2] = c;
+            fin.emb[row * 3 + 0] = y0; fin.emb[row * 3 + 1] = y1; fin.emb[row * 3 + 2] = y2;
+            float* o = row < fin.split ? (fin.out0 ? fin.out0 + 3 * row : nullptr) : (fin.out1 ? fin.out1 + 3 * (row - fin.split) : nullptr);
+            if (o) { o[0] = y0; o[1] = y1; o[2] = y2; }
+            if (fin.dot_out) {                                   // row_dot_kernel's sum, k = 0, 1, 2
+                float sdot = 0.f;
+                sdot += y0 * fin.dot_with[row * 3 + 0];
+                sdot += y1 * fin.dot_with[row * 3 + 1];
+                sdot += y2 * fin.dot_with[row * 3 + 2];
+                fin.dot_out[row] = sdot;
+            }
+        }
+    }
 }
 
 // emb_raw = b1 + ((part0 + part1) + (part2 + part3)); emb = emb_raw / max(||emb_raw||, 1e-12)
@@ -645,8 +689,14 @@ static int run_heads_fwd(var_ctx* c, hipStream_t s, const float* x, int R, const
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set |= var_dev_bit(c);
     }
-    hipLaunchKernelGGL(heads_fwd_split_kernel<K>, dim3((R + 31) / 32, 4), dim3(256), LDS_BYTES, s, x, R, w0t, b0, w1, hid, part, sig, sig_other);
-    if (finish) hipLaunchKernelGGL(heads_finish_kernel, dim3((R + 255) / 256), dim3(256), 0, s, part, b1, R, emb_raw, emb, out0, out1, split);
+    // one row block and a finish wanted: the last workgroup finishes (FinishArgs above); the reward's row dot rides along when
+    // var_set_reward_dot armed it for this (image) head
+    const bool fin_in = finish && R <= 32 && !sig;
+    FinishArgs fin{b1, emb_raw, emb, out0, out1, split, fin_in ? c->jsig + 12 : nullptr, nullptr, nullptr};
+    if (fin_in && K == kImgFeat && c->dot_out) { fin.dot_with = c->dot_with; fin.dot_out = c->dot_out; }
+    if (K == kImgFeat) { c->dot_with = nullptr; c->dot_out = nullptr; }          // (armed for one forward)
+    hipLaunchKernelGGL(heads_fwd_split_kernel<K>, dim3((R + 31) / 32, 4), dim3(256), LDS_BYTES, s, x, R, w0t, b0, w1, hid, part, sig, sig_other, fin);
+    if (finish && !fin_in) hipLaunchKernelGGL(heads_finish_kernel, dim3((R + 255) / 256), dim3(256), 0, s, part, b1, R, emb_raw, emb, out0, out1, split);
     return VAR_OK;
 }
 

@@ -142,6 +142,8 @@ struct var_ctx {
     // heads' forward workgroups, [1] completed launches of that kernel, [2] how many of them the caller's stream has waited for,
     // [3] waits for it that timed out (sticky; var_join_status); [4..7] the same for the conv 3-5 kernel and the side stream
     unsigned* jsig = nullptr;
+    const float* dot_with = nullptr;   // var_set_reward_dot: the next small-batch image-head forward also leaves <emb, dot_with> rows in dot_out
+    float* dot_out = nullptr;
     bool dev_join = false;        // this step's forward left the side stream un-joined: the image rows wait on jsig[1]
     uint16_t* relu1 = nullptr;    // ReLU bits of the first image activation: [b][half][y][x], bit r <-> channel (r&3)+8(r>>2)+4*half
     float* slabs = nullptr;       // split-K partial weight gradients

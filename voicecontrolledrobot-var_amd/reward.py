@@ -107,10 +107,15 @@ class IntrinsicReward:
 
         def body(with_goal):
             w.bind()
+            if not with_goal and B <= 32:
+                # the goal embedding is cached: <image_feat, goal_feat> rides in the image head's launch (var_set_reward_dot)
+                c.check(c.lib.var_set_reward_dot(c.handle, ptr(self._goal_feat), ptr(self._reward)), "var_set_reward_dot")
             c.check(c.lib.var_arm_encoder_fwd(c.handle, current_stream_handle(), ptr(flat), ptr(self._img), 1,
                                               self._img.stride(0), ptr(self._goal) if with_goal else None, None, B, hw,
                                               ptr(self._image_feat), ptr(self._goal_feat) if with_goal else None,
                                               None, None, None, 2), "var_arm_encoder_fwd")      # 2: inference, small-batch kernels
+            if not with_goal and B <= 32:
+                return
             # <image_feat, goal_feat> (calcReward's torch.sum(a * b, dim=1): one launch instead of a product and a reduction)
             c.check(c.lib.var_row_dot(c.handle, current_stream_handle(), ptr(self._image_feat), ptr(self._goal_feat), B,
                                       self._image_feat.shape[1], ptr(self._reward)), "var_row_dot")
