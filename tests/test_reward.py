@@ -64,6 +64,9 @@ def test_intrinsic_reward_on_hip_encoder(golden_dir):
     assert np.max(np.abs(dot1.cpu().numpy() - fx["d.reward"])) < 1e-4
     f2, g2, dot2 = r.step(torch.from_numpy(img).cuda(), None)
     assert np.array_equal(f2.cpu().numpy(), f1.cpu().numpy()) and np.array_equal(g2.cpu().numpy(), goal_feat)
+    # (round 4: in that graph the image head's launch finishes the embeddings and takes the row dot itself, var_set_reward_dot:
+    # same sums as heads_finish_kernel + row_dot_kernel)
+    assert np.array_equal(dot2.cpu().numpy(), dot1.cpu().numpy())
 
 
 @pytest.mark.gpu
