@@ -336,6 +336,7 @@ static int encoder_fwd(var_ctx* c, hipStream_t s, const float* params, const voi
     // pushes the sound forward behind the whole image forward.  So: image-only forwards (the frozen encoder at full batch, the
     // projection of a dataset) take the fused launch, a forward with a sound branch the two launches.
     c->fuse_fwd = c->fuse_fwd_always || !snd;
+    c->mid_finish = finish;
     if (image && (rc = launch_img_fwd(c, s, params, image, is_u8, bstride, image_index, B)) != VAR_OK) return rc;
     if (image && (rc = launch_heads_fwd(c, s, s, params, B, true, false, false, finish)) != VAR_OK) return rc;
     if (snd) {

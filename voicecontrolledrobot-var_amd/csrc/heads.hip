@@ -706,9 +706,10 @@ int launch_heads_fwd(var_ctx* c, hipStream_t s, hipStream_t ss, const float* par
     const PackLayout& K = c->kl;
     int rc;
     if (has_img && c->head_in_mid) {
-        // the fused conv 3-5 kernel already left hid_i and the 128 -> 3 partials of every image
-        if (finish) hipLaunchKernelGGL(heads_finish_kernel, dim3((B + 255) / 256), dim3(256), 0, s, c->head_part,
-                                       params + L.ih_b1, B, c->emb_raw, c->emb, c->out_img, (float*)nullptr, B);
+        // the fused conv 3-5 kernel already left hid_i and the 128 -> 3 partials of every image -- and, when a finish was wanted
+        // (var_ctx::mid_finish), the embeddings themselves
+        if (finish && !c->mid_finish) hipLaunchKernelGGL(heads_finish_kernel, dim3((B + 255) / 256), dim3(256), 0, s, c->head_part,
+                                                         params + L.ih_b1, B, c->emb_raw, c->emb, c->out_img, (float*)nullptr, B);
     } else if (has_img) {
         ProfScope prof(c, s, TAG_HEADS_FWD);
         if ((rc = run_heads_fwd<kImgFeat>(c, s, c->act[5], B, c->wpack + K.ih_w0t, params + L.ih_b0, params + L.ih_w1,

@@ -49,6 +49,8 @@ extern "C" int var_debug_phases_mid3(unsigned long long* out) {
 #endif
 namespace {
 typedef float f32x4q __attribute__((ext_vector_type(4)));
+// the embedding's finish inside the kernel (heads.hip: heads_finish_kernel's arithmetic on this image's row): b1 = nullptr -> none
+struct MidFinish { const float* b1; float* emb_raw; float* emb; float* out; };
 constexpr int M3_NT = 1024;                    // 16 waves
 
 template <int H2_>
@@ -124,7 +126,8 @@ template <class C, bool PRE>
 __device__ __forceinline__ void img_mid3_body(const float* __restrict__ x2, const float* __restrict__ wa3, const float* __restrict__ wa4,
                                               const float* __restrict__ wa5, const float* __restrict__ params, int o_b3, int o_b4, int o_b5,
                                               int o_hb0, int o_hw1, float* __restrict__ y3, float* __restrict__ y4, float* __restrict__ y5,
-                                              const float* __restrict__ hw0t, float* __restrict__ hid, float* __restrict__ part, const size_t b, unsigned* sig = nullptr) {
+                                              const float* __restrict__ hw0t, float* __restrict__ hid, float* __restrict__ part, const size_t b, unsigned* sig = nullptr,
+                                              MidFinish fin = MidFinish{nullptr, nullptr, nullptr, nullptr}) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, i15 = lane & 15;
@@ -542,6 +545,7 @@ __device__ __forceinline__ void img_mid3_body(const float* __restrict__ x2, cons
             if (l == 0) {
                 if (sig) join_store(part + b * 16 + d, sum);
                 else part[b * 16 + d] = sum;
+                if (fin.b1) hh[kHid + d] = sum;                  // (hh: 128 hidden values; three more floats behind them)
             }
         }
         if (tid >= 192 && tid < 192 + 13) {
@@ -549,6 +553,20 @@ __device__ __forceinline__ void img_mid3_body(const float* __restrict__ x2, cons
             else part[b * 16 + (tid - 192 + 3)] = 0.f;
         }
         if (tid < kHid) hid[b * kHid + tid] = ohid;
+        if (fin.b1) {
+            // An inference / operator-API forward wants the normalised embedding: this image's row of heads_finish_kernel, here
+            // (blocks 1..3 of the partial are zero: ((s + 0) + (0 + 0)) + b1 = s + b1 bit for bit) -- one launch fewer behind the kernel
+            bar();
+            if (tid == 0) {
+                const float z = 0.f + 0.f;
+                const float a = ((hh[kHid] + 0.f) + z) + fin.b1[0], bb = ((hh[kHid + 1] + 0.f) + z) + fin.b1[1], cc = ((hh[kHid + 2] + 0.f) + z) + fin.b1[2];
+                const float nrm = sqrtf(a * a + bb * bb + cc * cc);
+                const float den = nrm > 1e-12f ? nrm : 1e-12f;
+                fin.emb_raw[b * 3 + 0] = a; fin.emb_raw[b * 3 + 1] = bb; fin.emb_raw[b * 3 + 2] = cc;
+                fin.emb[b * 3 + 0] = a / den; fin.emb[b * 3 + 1] = bb / den; fin.emb[b * 3 + 2] = cc / den;
+                if (fin.out) { fin.out[b * 3 + 0] = a / den; fin.out[b * 3 + 1] = bb / den; fin.out[b * 3 + 2] = cc / den; }
+            }
+        }
         // training step: the sound rows of the heads' backward, on the other stream, need these partials, and the image rows behind
         // this kernel the sound branch's: handed over on the device (var_common.h: join_*; heads.hip)
         if (sig) join_signal(sig, gridDim.x, sig - 4);           // (sig = jsig + 4: the sound side's words lie in front)
@@ -566,8 +584,8 @@ __global__ void __launch_bounds__(M3_NT)
 img_mid3_kernel(const float* __restrict__ x2, const float* __restrict__ wa3, const float* __restrict__ wa4,
                 const float* __restrict__ wa5, const float* __restrict__ params, int o_b3, int o_b4, int o_b5, int o_hb0, int o_hw1,
                 float* __restrict__ y3, float* __restrict__ y4, float* __restrict__ y5,
-                const float* __restrict__ hw0t, float* __restrict__ hid, float* __restrict__ part, unsigned* sig) {
-    img_mid3_body<C, false>(x2, wa3, wa4, wa5, params, o_b3, o_b4, o_b5, o_hb0, o_hw1, y3, y4, y5, hw0t, hid, part, blockIdx.x, sig);
+                const float* __restrict__ hw0t, float* __restrict__ hid, float* __restrict__ part, unsigned* sig, MidFinish fin) {
+    img_mid3_body<C, false>(x2, wa3, wa4, wa5, params, o_b3, o_b4, o_b5, o_hb0, o_hw1, y3, y4, y5, hw0t, hid, part, blockIdx.x, sig, fin);
 }
 
 // The WHOLE image forward of one image in one workgroup: conv 1 + conv 2 (img_head2_body: role-split waves over the image's seven
@@ -584,7 +602,7 @@ img_fwd_all_kernel(const void* __restrict__ image, long bstride, const int* __re
                    const float* __restrict__ wa3, const float* __restrict__ wa4, const float* __restrict__ wa5,
                    const float* __restrict__ params, int o_b1, int o_b2, int o_b3, int o_b4, int o_b5, int o_hb0, int o_hw1,
                    float* __restrict__ y3, float* __restrict__ y4, float* __restrict__ y5, const float* __restrict__ hw0t,
-                   float* __restrict__ hid, float* __restrict__ part, int B, unsigned* sig) {
+                   float* __restrict__ hid, float* __restrict__ part, int B, unsigned* sig, MidFinish fin) {
     static_assert(CH::NT == M3_NT && CH::LDS_FLOATS <= CM::W3A, "16 waves; conv 3's early filter half lies above the head's tiles");
     const int lane = threadIdx.x & 63;
     img_head2_body<CH>(image, bstride, bidx, wp1, params + o_b1, wp2, params + o_b2, y1, y2, B, (int)blockIdx.x, (int)gridDim.x,
@@ -593,7 +611,7 @@ img_fwd_all_kernel(const void* __restrict__ image, long bstride, const int* __re
     // done with the head's LDS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    img_mid3_body<CM, true>(y2, wa3, wa4, wa5, params, o_b3, o_b4, o_b5, o_hb0, o_hw1, y3, y4, y5, hw0t, hid, part, blockIdx.x, sig);
+    img_mid3_body<CM, true>(y2, wa3, wa4, wa5, params, o_b3, o_b4, o_b5, o_hb0, o_hw1, y3, y4, y5, hw0t, hid, part, blockIdx.x, sig, fin);
 }
 }  // namespace
 
@@ -616,7 +634,8 @@ int launch_img_fwd_all(var_ctx* c, hipStream_t s, const float* params, const voi
         hipLaunchKernelGGL(kern, dim3(B), dim3(M3_NT), CM::LDS_BYTES, s, image, bstride, image_index, c->wpack + K.img_f[0],
                            c->wpack + K.img_f[1], c->act[1], c->act[2], c->wpack + K.img_f[2], c->wpack + K.img_f[3], c->wpack + K.img_f[4],
                            params, L.img_b[0], L.img_b[1], L.img_b[2], L.img_b[3], L.img_b[4], L.ih_b0, L.ih_w1, c->act[3], c->act[4],
-                           c->act[5], c->wpack + K.ih_w0t, c->hid_i, c->head_part, B, c->dev_join ? c->jsig + 4 : nullptr);
+                           c->act[5], c->wpack + K.ih_w0t, c->hid_i, c->head_part, B, c->dev_join ? c->jsig + 4 : nullptr,
+                           MidFinish{c->mid_finish ? params + L.ih_b1 : nullptr, c->emb_raw, c->emb, c->out_img});
         VAR_HIP_CHECK(c, hipGetLastError());
         return VAR_OK;
     };
@@ -638,7 +657,8 @@ static int launch_mid3(var_ctx* c, hipStream_t s, const float* params, int B, bo
     hipLaunchKernelGGL((img_mid3_kernel<C>), dim3(B), dim3(M3_NT), C::LDS_BYTES, s, c->act[2], c->wpack + K.img_f[2],
                        c->wpack + K.img_f[3], c->wpack + K.img_f[4], params, L.img_b[2], L.img_b[3], L.img_b[4], L.ih_b0, L.ih_w1,
                        c->act[3], c->act[4], c->act[5], with_head ? c->wpack + K.ih_w0t : nullptr, c->hid_i, c->head_part,
-                       (with_head && c->dev_join) ? c->jsig + 4 : nullptr);
+                       (with_head && c->dev_join) ? c->jsig + 4 : nullptr,
+                       MidFinish{(with_head && c->mid_finish) ? params + L.ih_b1 : nullptr, c->emb_raw, c->emb, c->out_img});
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }

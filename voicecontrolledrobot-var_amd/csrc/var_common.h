@@ -160,6 +160,7 @@ struct var_ctx {
     // var_arm_encoder_fwd's embedding outputs: the finish kernels of the heads write them directly (no copy launch afterwards)
     float *out_img = nullptr, *out_pos = nullptr, *out_neg = nullptr;
     bool head_in_mid = false;             // the last image forward also ran the image head (img_mid3.hip)
+    bool mid_finish = false;              // ... and is to finish the image embeddings too (encoder_fwd: finish wanted)
     bool fuse_fwd_always = false;         // var_set_streams bit 5
     bool fuse_fwd = false;                // 84 x 84, B <= 256: conv 1-5 + image head as ONE launch (img_fwd_all_kernel).  Set per call by
                                           // encoder_fwd (api.hip): image-only forwards, or always with var_set_streams bit 5 -- see there
