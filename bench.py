@@ -291,7 +291,7 @@ def tag_kernel(tag, hw):
     if hw == 84:
         return {1: "img_head2_kernel<", 2: "img_mid3_kernel<", 7: "img_wgrad345_kernel<", 11: "img_tail2_kernel<",
                 12: "img_chain_kernel", 15: "img_wgrad_reduce_kernel"}.get(tag)
-    return {1: "img_fwd_head_kernel<", 2: "img_mid3_kernel<", 6: "img_wgrad_kernel<", 7: "img_wgrad345_kernel<", 11: "img_bwd_tail_kernel<",
+    return {1: "img_head2_kernel<", 2: "img_mid3_kernel<", 6: "img_wgrad_kernel<", 7: "img_wgrad345_kernel<", 11: "img_bwd_tail_kernel<",
             12: "img_chain_kernel", 15: "img_wgrad_reduce_kernel"}.get(tag)
 
 

@@ -287,12 +287,13 @@ def test_graph_replayed_epoch_equals_eager_steps(var_amd, golden_dir):
 
 
 @pytest.mark.parametrize("h,B", [(84, 1), (84, 2), (84, 3), (84, 37), (96, 1), (96, 2), (96, 3), (96, 37),
-                                 (84, 257), (84, 300), (84, 512)])
+                                 (84, 257), (84, 300), (84, 512), (96, 257), (96, 300)])
 def test_odd_batches_vs_oracle(var_amd, h, B):
     """Batches that fill no tile of any kernel (1, 2, 3 images; 37 = odd band count for the two-band tiles of the
     fused head / tail kernels), both supported image sizes, and -- 84 x 84 -- batches beyond the 256 persistent workgroups
     of img_head2 / img_tail2 (257: one workgroup walks a second image, the band ring and the accumulators cross an image
-    boundary; 300: ragged; 512: every workgroup two images): loss and gradient arena vs torch and the C oracle."""
+    boundary; 300: ragged; 512: every workgroup two images; 96 x 96: img_head2's six-band form the same way): loss and gradient
+    arena vs torch and the C oracle."""
     torch.manual_seed(1)
     m = var_amd.VARPretextNet(cfg(h)).to("cuda")
     tr = var_amd.VARTrainer(m)

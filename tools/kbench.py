@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Per-kernel-family timings of one training step (B=256, 84x84) with every launch on ONE stream
+"""Per-kernel-family timings of one training step (B=256, 84x84 or --hw 96) with every launch on ONE stream
 (var_set_streams(0)), measured with the library's own HIP-event hooks (var_profile_select/read).
-Usage: python tools/kbench.py [--batch 256] [--steps 20] [--tags 0,1,2]"""
+Usage: python tools/kbench.py [--batch 256] [--steps 20] [--tags 0,1,2] [--hw 96]"""
 import argparse
 import os
 import sys
@@ -18,13 +18,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--tags", type=str, default="")
+ap.add_argument("--hw", type=int, default=84)
 args = ap.parse_args()
 B = args.batch
-cfg = types.SimpleNamespace(img_dim=(3, 84, 84), sound_dim=(1, 100, 40), representationDim=3)
+cfg = types.SimpleNamespace(img_dim=(3, args.hw, args.hw), sound_dim=(1, 100, 40), representationDim=3)
 torch.manual_seed(453)
 model = var_amd.VARPretextNet(cfg).to("cuda")
 tr = var_amd.VARTrainer(model)
-pool = var_amd.SyntheticTripletPool(int(os.environ.get("KB_POOL", "2048")), hw=84, seed=0, clips_per_class=int(os.environ.get("KB_CPC", "32"))).freeze_pairs()
+pool = var_amd.SyntheticTripletPool(int(os.environ.get("KB_POOL", "2048")), hw=args.hw, seed=0, clips_per_class=int(os.environ.get("KB_CPC", "32"))).freeze_pairs()
 ctx = Context.get(0)
 ctx.set_streams(0)
 

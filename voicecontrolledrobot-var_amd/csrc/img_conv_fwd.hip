@@ -23,13 +23,14 @@ int launch_img_fwd(var_ctx* c, hipStream_t s, const float* params, const void* i
         VAR_SET_ERR(c, "unsupported image size %d (84 or 96)", c->H);
         return VAR_ERR_ARG;
     }
-    // 84 x 84: the role-specialised head (img_head2.hip), act1 band-tiled for img_tail2.hip; 96 x 96: round 2's kernels (NCHW act1)
+    // the role-specialised head (img_head2.hip): at 84 x 84 act1 leaves band-tiled for img_tail2.hip, at 96 x 96 as NCHW + relu1 for
+    // round 2's backward kernels (img_bwd_tail.hip, img_wgrad.hip)
     // (img_head2 walks an image's seven bands inside ONE workgroup -- the right shape for a full batch, the wrong one for the RL
     //  stage's 8 images, where the per-image latency is the kernel time: an inference-only forward of a small batch takes the
     //  round-2 head, which spreads an image's tiles over workgroups; its NCHW act1 is never read by a backward)
-    const bool head2 = c->H == 84 && !(c->fwd_only && B <= 64);
-    c->act1_tiled = head2;
-    if (head2 && B <= kHead2G && c->fuse_fwd) {         // one image per workgroup in both halves: the whole image forward as ONE launch
+    const bool head2 = !(c->fwd_only && B <= 64);
+    c->act1_tiled = head2 && c->H == 84;
+    if (head2 && c->H == 84 && B <= kHead2G && c->fuse_fwd) {         // one image per workgroup in both halves: the whole image forward as ONE launch
         c->head_in_mid = true;
         return launch_img_fwd_all(c, s, params, image, is_u8, bstride, image_index, B);
     }

@@ -1,5 +1,7 @@
 // Head of the image CNN forward, second form: conv 1 (3 -> 32, u8 / f32 image) and conv 2 (32 -> 32), each
-// Conv2d 3x3 stride 2 pad 1 + bias + ReLU (models/pretext/arm_pretext_model.py:9-12), for 84 x 84 inputs.
+// Conv2d 3x3 stride 2 pad 1 + bias + ReLU (models/pretext/arm_pretext_model.py:9-12), for 84 x 84 and 96 x 96 inputs
+// (96 x 96, the reference's img_dim in Envs/pybullet/arms/tasks/fourInARow/kuka/env_config.py:28: six bands of four act2 rows,
+//  4 + 12 waves; 57.7 us alone at 256 images against the first form's 67.1, step 0.3618 -> 0.3538 ms on one box).
 //
 // Why a second form.  The first one (img_fwd_head.hip) is ONE 12-wave workgroup per CU that walks barrier-separated
 // phases in lock step: while the conv-1 epilogue runs on the vector ALU nothing feeds the matrix cores and vice versa
@@ -25,10 +27,12 @@
 namespace {
 typedef float f32x4h __attribute__((ext_vector_type(4)));
 
-template <int H1_, bool U8_, int R2_>
+// TILED_: act1 leaves band-tiled (what img_tail2.hip reads: 84 x 84); otherwise as NCHW rows + the ReLU bit image relu1 of the first
+// form (what img_bwd_tail.hip / img_wgrad.hip read: 96 x 96)
+template <int H1_, bool U8_, int R2_, int NA_, bool TILED_>
 struct Head2Cfg {
     static constexpr int H1 = H1_, W1 = H1_, R2 = R2_;
-    static constexpr bool U8 = U8_;
+    static constexpr bool U8 = U8_, TILED = TILED_;
     static constexpr int CH = 32;
     static constexpr int HI = 2 * H1;                         // image 84
     static constexpr int HO2 = H1 / 2, WO2 = HO2;             // act2 plane 21
@@ -41,12 +45,12 @@ struct Head2Cfg {
     // act1 tile in LDS: per channel [2 pad][row 0 .. IR1-1, W1 floats each, no padding between rows][pad]: rows 1.. are one
     // contiguous 16-byte aligned run (= their run in HBM).  The cell x = -1 of a row is the previous row's last cell:
     // conv 2 zeroes that operand (lanes with ox = 0, taps kx = 0) instead of reading a pad.
-    static constexpr int A1ROW0 = 2;
+    static constexpr int A1ROW0 = (W1 % 4 == 2) ? 2 : 4;
     static constexpr int PLANE_1 = ((A1ROW0 + IR1 * W1 + 7) / 8) * 8 + 4;  // = 4 mod 8: the epilogue's stores (4 q channels apart) fall on disjoint banks
     static constexpr int NPX1 = IR1 * W1, NT1 = (NPX1 + 15) / 16;          // conv-1 pixel tiles per band
     static constexpr int NPX2 = R2 * WO2, NT2 = (NPX2 + 15) / 16;          // conv-2 pixel tiles per band
-    static constexpr int NA = 8, NTA = 64 * NA;               // waves of role A (staging + conv 1)
-    static constexpr int NBW = 8;                             // waves of role B (conv 2): 4 pixel tiles x 2 halves of the output channels
+    static constexpr int NA = NA_, NTA = 64 * NA;             // waves of role A (staging + conv 1): 8 (84 x 84) | 4 (96 x 96)
+    static constexpr int NBW = 2 * NT2;                       // waves of role B (conv 2): 4 | 6 pixel tiles x 2 halves of the output channels
     static constexpr int NT = NTA + 64 * NBW;
     static constexpr int KS1 = 7;                             // conv 1: K = 27 -> 28 = 7 steps of 4
     static constexpr int KS2 = 9 * CH / 4;                    // conv 2: K = 288 = 72 steps of 4
@@ -60,7 +64,8 @@ struct Head2Cfg {
     static constexpr int NLD = 3 * IRI * (HI / 4);            // 4-pixel groups of an image band
         static constexpr int LPT = (NLD + NTA - 1) / NTA;         // per lane of role A
     static_assert(HO2 % R2 == 0 && HI % 4 == 0, "whole bands, 4-pixel groups");
-    static_assert(NT2 == 4 && NBW == 8, "role B: one (conv-2 pixel tile, channel half) per wave");
+    static_assert(NT <= 1024 && NBW % 4 == 0 && NA % 4 == 0, "role B: one (conv-2 pixel tile, channel half) per wave; every role on every SIMD");
+    static_assert(TILED || (2 * R2 * W1) % 4 == 0, "NCHW copy-out: a band's rows of a channel are whole float4");
     static_assert((A1ROW0 + W1) % 4 == 0 && PLANE_1 % 4 == 0 && (BIA % 4) == 0 && (IMG_FLOATS % 4) == 0 && PWI % 4 == 0, "16-byte aligned runs");
     static_assert(A1_FLOATS % 4 == 0, "the tile is whole float4");
     static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
@@ -92,7 +97,7 @@ __device__ __forceinline__ void img_head2_body(const void* __restrict__ image, l
                                                const float* __restrict__ wp1, const float* __restrict__ bias1,
                                                const float* __restrict__ wp2, const float* __restrict__ bias2,
                                                float* __restrict__ y1, float* __restrict__ y2, int B, const int bx, const int G,
-                                               EARLY early) {
+                                               EARLY early, uint16_t* __restrict__ relu_bits = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using XT = typename std::conditional<C::U8, uint8_t, float>::type;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -109,7 +114,7 @@ __device__ __forceinline__ void img_head2_body(const void* __restrict__ image, l
     for (int e = tid; e < 2 * 3 * C::IRI; e += C::NT) lds[C::IMS + e * C::PWI + 3] = 0.f;                     // pad column x = -1
     for (int e = tid; e < 2 * C::CH; e += C::NT) {              // pad cells of the act1 tiles (they travel to HBM with the tile)
         float* pl = lds + C::A1S + e * C::PLANE_1;
-        pl[0] = 0.f; pl[1] = 0.f;
+        for (int k = 0; k < C::A1ROW0; ++k) pl[k] = 0.f;
         for (int k = C::A1ROW0 + C::IR1 * C::W1; k < C::PLANE_1; ++k) pl[k] = 0.f;
     }
     __syncthreads();
@@ -124,6 +129,27 @@ __device__ __forceinline__ void img_head2_body(const void* __restrict__ image, l
         const int band = j % C::NB, b = tile_img(j);
         const float* a1 = lds + C::A1S + (j & 1) * C::A1_FLOATS;
         constexpr int NTC = 64 * C::NBW;                              // lanes of the role that runs the copy
+        if constexpr (!C::TILED) {
+            // NCHW: the band's 2 R2 owned rows of a channel are ONE run in the tile (rows 1.., no padding between rows) and in HBM
+            constexpr int RUN4 = 2 * C::R2 * C::W1 / 4, N4 = C::CH * RUN4, NF = (N4 + NTC - 1) / NTC;
+            float* yb = y1 + (size_t)b * C::CH * C::H1 * C::W1 + (size_t)band * 2 * C::R2 * C::W1;
+            f32x4h cv[NF];
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                int e = atid + NTC * i;
+                if (e >= N4) e = 0;
+                const int ch = e / RUN4, o = e - ch * RUN4;
+                cv[i] = *(const f32x4h*)(a1 + ch * C::PLANE_1 + C::A1ROW0 + C::W1 + 4 * o);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const int e = atid + NTC * i;
+                const int ch = e / RUN4, o = e - ch * RUN4;
+                if (e < N4) *(f32x4h*)(yb + (size_t)ch * C::H1 * C::W1 + 4 * o) = cv[i];
+            }
+            return;
+        }
         float* yb = y1 + (size_t)b * kAct1TiledFloats + (size_t)band * C::A1_FLOATS;
         // (the LDS reads of a group are issued before its first store: left alone hipcc emits read - wait - store chains)
         constexpr int NF4 = (C::A1_FLOATS / 4 + NTC - 1) / NTC;
@@ -254,6 +280,22 @@ __device__ __forceinline__ void img_head2_body(const void* __restrict__ image, l
                         d[(16 + r) * C::PLANE_1] = __builtin_amdgcn_fmed3f(e1[r], 0.f, __builtin_inff());
                     }
                 }
+                if constexpr (!C::TILED) {
+                    // the ReLU bit image of the first form (var_ctx::relu1: [b][half][y][x], bit r <-> channel (r & 3) + 8 (r >> 2) + 4 half):
+                    // this lane holds channels 4 q + r and 16 + 4 q + r = bits 4 (q >> 1) + r and 8 + 4 (q >> 1) + r of half q & 1;
+                    // the lane 32 further on holds the other eight bits of the same half
+                    uint32_t bits = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        bits |= e0[r] > 0.f ? 1u << r : 0u;
+                        bits |= e1[r] > 0.f ? 0x100u << r : 0u;
+                    }
+                    bits <<= 4 * (q >> 1);
+                    bits |= (uint32_t)__shfl_xor((int)bits, 32, 64);
+                    const int rl = p / C::W1, x1 = p - rl * C::W1;
+                    if (q < 2 && p < C::NPX1 && rl >= 1)
+                        relu_bits[((size_t)tile_img(j) * 2 + q) * C::H1 * C::W1 + (band * 2 * C::R2 + rl - 1) * C::W1 + x1] = (uint16_t)bits;
+                }
             }
         };
         // ---- pipeline: step j runs conv 2 of tile j (role B) beside conv 1 of tile j + 1 and the staging of tile j + 2 ----
@@ -280,7 +322,7 @@ __device__ __forceinline__ void img_head2_body(const void* __restrict__ image, l
         // =====================================================================================================
         // role B: conv 2, one 16-pixel tile of the band per wave, all 32 output channels, the whole K = 288
         // =====================================================================================================
-        const int wv = (wave - C::NA) & 3, ct = (wave - C::NA) >> 2;
+        const int wv = (wave - C::NA) % C::NT2, ct = (wave - C::NA) / C::NT2;
 #ifdef VAR_H2_PRIO_B
         __builtin_amdgcn_s_setprio(VAR_H2_PRIO_B);
 #endif
@@ -357,15 +399,18 @@ img_head2_kernel(const void* __restrict__ image, long bstride, const int* __rest
 #if defined(VAR_PHASES) && !defined(VAR_HEAD2_DEVICE_ONLY)
     if (threadIdx.x == 0) g_span_h2[blockIdx.x][0] = wall_clock64();
 #endif
-    img_head2_body<C>(image, bstride, bidx, wp1, bias1, wp2, bias2, y1, y2, B, (int)blockIdx.x, (int)gridDim.x, [](int) {});
+    img_head2_body<C>(image, bstride, bidx, wp1, bias1, wp2, bias2, y1, y2, B, (int)blockIdx.x, (int)gridDim.x, [](int) {}, relu_bits);
 #if defined(VAR_PHASES) && !defined(VAR_HEAD2_DEVICE_ONLY)
     if (threadIdx.x == 0) g_span_h2[blockIdx.x][1] = wall_clock64();
 #endif
 }
 
-//                      H1   U8   R2
-using H2_84u = Head2Cfg<42, true, 3>;
-using H2_84f = Head2Cfg<42, false, 3>;
+//                      H1   U8   R2 NA  TILED
+using H2_84u = Head2Cfg<42, true, 3, 8, true>;
+using H2_84f = Head2Cfg<42, false, 3, 8, true>;
+// 96 x 96: six bands of four act2 rows (96 pixels = six full tiles: twelve waves of role B, three per SIMD, beside four of role A)
+using H2_96u = Head2Cfg<48, true, 4, 4, false>;
+using H2_96f = Head2Cfg<48, false, 4, 4, false>;
 
 #ifndef VAR_HEAD2_DEVICE_ONLY      // img_mid3.hip includes this file for the device code above only
 template <class C>
@@ -408,9 +453,12 @@ int launch_act1_untile(var_ctx* c, hipStream_t s, int B) {
     return VAR_OK;
 }
 
-// conv 1 + conv 2 of the image CNN at 84 x 84; leaves act[1] (band-tiled) and act[2]
+// conv 1 + conv 2 of the image CNN; leaves act[2] and act[1] -- band-tiled at 84 x 84, NCHW + relu1 at 96 x 96
 int launch_img_fwd_head2(var_ctx* c, hipStream_t s, const float* params, const void* image, int is_u8, long bstride,
                          const int* image_index, int B) {
+    if (c->H == 96)
+        return is_u8 ? launch_head2<H2_96u>(c, s, image, bstride, image_index, params, B)
+                     : launch_head2<H2_96f>(c, s, image, bstride, image_index, params, B);
     return is_u8 ? launch_head2<H2_84u>(c, s, image, bstride, image_index, params, B)
                  : launch_head2<H2_84f>(c, s, image, bstride, image_index, params, B);
 }
