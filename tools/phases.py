@@ -5,11 +5,12 @@ import var_amd
 from var_amd._lib import load_library
 which = sys.argv[1]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-cfg = types.SimpleNamespace(img_dim=(3, 84, 84), sound_dim=(1, 100, 40), representationDim=3)
+HW = int(os.environ.get("PH_HW", "84"))      # PH_HW=96: the 96 x 96 forms
+cfg = types.SimpleNamespace(img_dim=(3, HW, HW), sound_dim=(1, 100, 40), representationDim=3)
 torch.manual_seed(453)
 m = var_amd.VARPretextNet(cfg).to("cuda")
 tr = var_amd.VARTrainer(m)
-pool = var_amd.SyntheticTripletPool(1024, hw=84, seed=0, clips_per_class=8).freeze_pairs()
+pool = var_amd.SyntheticTripletPool(1024, hw=HW, seed=0, clips_per_class=8).freeze_pairs()
 tr.ctx.set_streams(0)
 def step():
     i, c, l = pool.next_batch_indices(B)

@@ -66,12 +66,8 @@ int launch_img_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads,
     if ((rc = launch_img_bwd_chain(c, s, B)) != VAR_OK) return rc;
     rc = H == 84 ? launch_wgrad345<W84_2, W84_3, W84_4>(c, s, B) : launch_wgrad345<W96_2, W96_3, W96_4>(c, s, B);
     if (rc != VAR_OK) return rc;
-    if (H == 84) {
-        rc = launch_img_bwd_tail2(c, s, B);      // wgrad 1 + dgrad 1 + wgrad 0 in one role-specialised kernel (img_tail2.hip; act1 band-tiled)
-    } else {
-        if ((rc = launch_img_wgrad1_96(c, s, xin[1], bs[1], c->gact[2], B)) != VAR_OK) return rc;
-        rc = launch_img_bwd_tail(c, s, B);
-    }
+    // wgrad 1 + dgrad 1 + wgrad 0 in one role-specialised kernel (img_tail2.hip; act1 band-tiled at 84 x 84, NCHW at 96 x 96)
+    rc = launch_img_bwd_tail2(c, s, B);
     if (rc != VAR_OK) return rc;
     (void)params;
     return launch_img_wgrad_reduce(c, s, grads, 0, 4);
