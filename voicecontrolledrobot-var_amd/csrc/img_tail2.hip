@@ -75,7 +75,8 @@ struct Tail2Cfg {
     static constexpr int P4 = A1_PLANE / 4;                   // ... of one channel's plane
     static constexpr int N_G2 = CH * G2_ROWS * HO2;           // floats of a gact2 band
     static constexpr int N_IM = 3 * IM_ROWS * (HI / 4);       // 4-pixel groups of an image band
-    static constexpr int L_A1 = (N_A1 + 255) / 256,   /* 1 KiB chunks per wave of role S */ L_G2 = (N_G2 + 255) / 256, L_IM = (N_IM + 255) / 256;
+    static constexpr int L_A1 = TILED ? (N_A1 + 255) / 256 : CH / 4;   /* wave instructions of the band's LDS-DMA per wave of role S (1 KiB chunks | one channel each) */
+    static constexpr int L_G2 = (N_G2 + 255) / 256, L_IM = (N_IM + 255) / 256;
     static constexpr int SLAB0 = 32 * 32 + 32, SLAB1 = 32 * 9 * 32 + 32;
     static_assert(H1 % RB == 0 && RB % 2 == 0 && NPX1 % 4 == 0 && A1_PLANE % 4 == 0 && 4 * SK + DK * ND >= KS_1 && (SK == 8 || SK == 12) && (DK == 0 || DK == 8), "bands, k-step shares");
     static_assert(NT <= 1024 && LDS_BYTES <= 160 * 1024, "one workgroup per CU");
@@ -163,34 +164,32 @@ img_tail2_kernel(const float* __restrict__ gy, const float* __restrict__ wd, con
     // The gact2 rows of a band, global -> registers -> LDS, by NL lanes numbered lt (role S's 256; at 96 x 96 role D's 384: role S is the
     // longest role there, role D waits).  Element e = (channel, row r of the band, ox); a row below the image reads the row above and
     // stores zero.
+    // (a lane keeps its place (row, ox) in a channel's G2_ROWS x HO2 block and walks the channels CPP at a time: per pass one add for the
+    //  global and one for the LDS offset -- element-wise index arithmetic made these few loads the longest stretch of the role)
     auto g2_load = [&](auto nl, float* r, int j, int lt) {
-        constexpr int NL = decltype(nl)::value, L = (C::N_G2 + NL - 1) / NL;
+        constexpr int NL = decltype(nl)::value, WIN = C::G2_ROWS * C::HO2, CPP = NL / WIN, L = (C::CH + CPP - 1) / CPP;
         const int band = j % C::NB, b = tile_img(j);
-        const float* pg = gy + (size_t)b * C::CH * C::HO2 * C::HO2 + C::R2 * band * C::HO2;
+        const int cs = lt / WIN, w = lt - cs * WIN, rr = w / C::HO2;
+        const int back = (C::R2 * band + rr >= C::HO2) ? C::HO2 : 0;
+        const float* pg = gy + (size_t)b * C::CH * C::HO2 * C::HO2 + C::R2 * band * C::HO2 + cs * C::HO2 * C::HO2 + w - back;
 #pragma unroll
         for (int i = 0; i < L; ++i) {
-            const int e = lt + NL * i, ee = e < C::N_G2 ? e : 0;
-            const int ch = ee / (C::G2_ROWS * C::HO2), rem = ee - ch * (C::G2_ROWS * C::HO2);
-            const int rr = rem / C::HO2, ox = rem - rr * C::HO2;
-            const int back = (C::R2 * band + rr >= C::HO2) ? C::HO2 : 0;
-            r[i] = pg[ch * C::HO2 * C::HO2 + rr * C::HO2 + ox - back];
+            const bool ok = cs < CPP && cs + CPP * i < C::CH;
+            r[i] = pg[ok ? CPP * i * C::HO2 * C::HO2 : 0];
         }
     };
     auto g2_store = [&](auto nl, const float* r, int j, int lt) {
-        constexpr int NL = decltype(nl)::value, L = (C::N_G2 + NL - 1) / NL;
+        constexpr int NL = decltype(nl)::value, WIN = C::G2_ROWS * C::HO2, CPP = NL / WIN, L = (C::CH + CPP - 1) / CPP;
         const int band = j % C::NB;
-        float* dg = lds + C::G2S + (j & 1) * C::G2_FLOATS;
+        const int cs = lt / WIN, w = lt - cs * WIN, rr = w / C::HO2, ox = w - rr * C::HO2;
+        float* dg = lds + C::G2S + (j & 1) * C::G2_FLOATS + cs * C::G2_PLANE + rr * C::G2_PITCH + ox;
+        const bool live = C::R2 * band + rr < C::HO2;
 #pragma unroll
-        for (int i = 0; i < L; ++i) {
-            const int e = lt + NL * i;
-            const int ee = e < C::N_G2 ? e : 0;
-            const int ch = ee / (C::G2_ROWS * C::HO2), rem = ee - ch * (C::G2_ROWS * C::HO2);
-            const int rr = rem / C::HO2, ox = rem - rr * C::HO2;
-            if (e < C::N_G2) dg[ch * C::G2_PLANE + rr * C::G2_PITCH + ox] = (C::R2 * band + rr < C::HO2) ? r[i] : 0.f;
-        }
+        for (int i = 0; i < L; ++i)
+            if (cs < CPP && cs + CPP * i < C::CH) dg[CPP * i * C::G2_PLANE] = live ? r[i] : 0.f;
     };
     constexpr bool G2_IN_D = C::DK == 0;                      // (96 x 96)
-    constexpr int NLD_ = 64 * C::ND, L_G2D = (C::N_G2 + NLD_ - 1) / NLD_;
+    constexpr int NLD_ = 64 * C::ND, L_G2D = (C::CH + NLD_ / (C::G2_ROWS * C::HO2) - 1) / (NLD_ / (C::G2_ROWS * C::HO2));
 
     // a wave's K slice of conv 1's weight gradient -> LDS (the act1 buffers, dead by then: behind a workgroup barrier)
     auto park_slices = [&](int sl) {                           // slice = its range of k-steps, ascending
@@ -419,9 +418,12 @@ img_tail2_kernel(const float* __restrict__ gy, const float* __restrict__ wd, con
             for (int i = 0; i < C::L_IM; ++i) t_im[i] = make_im(stid0 + 256 * i);
         }
         auto e_g2 = [&](int i, int stid) -> uint32_t { if constexpr (TAB) return t_g2[i]; else return make_g2(stid + 256 * i); };
-        auto e_im = [&](int i, int stid) -> uint32_t { if constexpr (TAB) return t_im[i]; else return make_im(stid + 256 * i); };
-        const int ch0 = (sw * 64 + lane) / C::P4, o0 = (sw * 64 + lane) - ch0 * C::P4;   // (NCHW gather: this lane's first float4 of a band)
-        static_assert(C::TILED || (256 - 4 * C::P4 >= 0 && 256 - 4 * C::P4 < C::P4), "NCHW gather: a chunk's step in (channel, float4) form");
+        // (96 x 96: lane = (row, 4-pixel group) of a channel's rows, pass i = channel i: one entry per lane, recomputed per band)
+        static_assert(TAB || (C::L_IM == 3 && C::IM_ROWS * (C::HI / 4) <= 256), "image band: a channel per pass");
+        auto e_im = [&](int i, int stid) -> uint32_t {
+            if constexpr (TAB) return t_im[i];
+            else return stid < C::IM_ROWS * (C::HI / 4) ? make_im(stid) : 0x80000000u;
+        };
         auto issue_a1g2 = [&](int j, int stid, bool with_g2 = true) {
             const int band = j % C::NB, b = tile_img(j);
             // the act1 band: ONE contiguous block in HBM in the tile's own layout (img_head2.hip) -> straight into LDS by
@@ -433,7 +435,6 @@ img_tail2_kernel(const float* __restrict__ gy, const float* __restrict__ wd, con
             const float* pa = C::TILED ? act1 + (size_t)b * kAct1TiledFloats + (size_t)band * C::A1_FLOATS
                                        : act1 + (size_t)b * C::CH * C::H1 * C::W1;
             float* da = lds + C::A1S + (j & 1) * C::A1_FLOATS;
-            int gch = 0, go = 0;
 #pragma unroll
             for (int i = 0; i < C::L_A1; ++i) {
                 const int k = sw + 4 * i;                                              // 1 KiB chunk of this wave
@@ -442,15 +443,13 @@ img_tail2_kernel(const float* __restrict__ gy, const float* __restrict__ wd, con
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa + k * 256 + 4 * lane),
                                                          (__attribute__((address_space(3))) void*)(da + k * 256), 16, 0, 0);
                 } else {
-                    // float4 f = 64 k + lane of the tile = (channel gch, float4 go of its plane); a chunk further on: 256 = 4 P4 + 12
-                    if (i == 0) { gch = ch0; go = o0; asm volatile("" : "+v"(gch)); asm volatile("" : "+v"(go)); }   // (opaque per band: see stid)
-                    int off = gch * C::H1 * C::W1 + (C::RB * band - 1) * C::W1 - C::A1_ROW0 + 4 * go;
+                    // one channel's plane (P4 float4: the pad cells + RB + 1 rows) per wave instruction, channel k; lanes >= P4 idle
+                    static_assert(C::TILED || (C::P4 <= 64 && C::L_A1 * 4 == C::CH), "NCHW gather: a channel per instruction");
+                    int off = k * C::H1 * C::W1 + (C::RB * band - 1) * C::W1 - C::A1_ROW0 + 4 * lane;
                     off = off < 0 ? 0 : off;
-                    if (gch < C::CH)
+                    if (lane < C::P4)
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa + off),
-                                                         (__attribute__((address_space(3))) void*)(da + k * 256), 16, 0, 0);
-                    go += 256 - 4 * C::P4; gch += 4;
-                    if (go >= C::P4) { go -= C::P4; ++gch; }
+                                                         (__attribute__((address_space(3))) void*)(da + k * C::A1_PLANE), 16, 0, 0);
                 }
             }
             if (!with_g2) return;
@@ -485,6 +484,7 @@ img_tail2_kernel(const float* __restrict__ gy, const float* __restrict__ wd, con
                 const int iy = iy0 + r;
                 const int fix = iy < 0 ? C::HI : 0;                                   // row -1: read row 0 (discarded)
                 const XT* src = im + (int)(ti & 0x7fff) + iy0 * C::HI + fix;
+                if constexpr (!TAB) src = im + (int)(ti & 0x7fff) + i * C::HI * C::HI + iy0 * C::HI + fix;
                 if constexpr (C::U8) r_u8[i] = *(const uint32_t*)src;
                 else r_f4[i] = *(const float4*)src;
             }
@@ -505,7 +505,7 @@ img_tail2_kernel(const float* __restrict__ gy, const float* __restrict__ wd, con
                 } else {
                     v = rok ? r_f4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-                *(float4*)(lds + C::IMS + ((ti >> 15) & 0xfff)) = v;
+                *(float4*)(lds + C::IMS + ((ti >> 15) & 0xfff) + (TAB ? 0 : i * C::IM_PLANE)) = v;
             }
         };
         // NCHW: the halo row above band 0 (act1 row -1 = conv 2's zero padding), behind the band's LDS-DMA
