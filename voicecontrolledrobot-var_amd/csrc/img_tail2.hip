@@ -55,8 +55,12 @@ struct Tail2Cfg {
     static constexpr int G2_PLANE = ((G2_ROWS * G2_PITCH + 15) / 32) * 32 + 16, G2_FLOATS = CH * G2_PLANE;          // = 16 mod 32
     static constexpr int G1_PLANE = RB * W1 + ((RB * W1) % 32 == 0 ? 4 : 0), G1_FLOATS = CH * G1_PLANE;             // [c][RB x W1]
     static constexpr int IM_ROWS = 2 * RB + 1, IM_PITCH = HI + 4, IM_PLANE = IM_ROWS * IM_PITCH, IM_FLOATS = 3 * IM_PLANE;  // col = x + 4
-    static constexpr int A1S = 0, G2S = A1S + 2 * A1_FLOATS, G1S = G2S + 2 * G2_FLOATS, IMS = G1S + G1_FLOATS;
-    static constexpr int LUT = IMS + IM_FLOATS, ZCELL = LUT + 256;
+    // PIPE (96 x 96): conv 1's weight gradient of band j - 1 (role S) runs beside the data gradient of band j (role D) -- two gact1 and
+    // two image bands in LDS, ONE barrier per band; otherwise role D, which has no share of that product there, idles through it
+    static constexpr bool PIPE = !TILED_;
+    static constexpr int NBUF = PIPE ? 2 : 1;
+    static constexpr int A1S = 0, G2S = A1S + 2 * A1_FLOATS, G1S = G2S + 2 * G2_FLOATS, IMS = G1S + NBUF * G1_FLOATS;
+    static constexpr int LUT = IMS + NBUF * IM_FLOATS, ZCELL = LUT + 256;
     static constexpr int LDS_FLOATS = ZCELL + 4;
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
     static constexpr int NPX2 = R2 * HO2;                     // conv-2 output pixels of a band = pixels of a parity class of its gact1 rows (63 | 48)
@@ -80,6 +84,7 @@ struct Tail2Cfg {
     static constexpr int SLAB0 = 32 * 32 + 32, SLAB1 = 32 * 9 * 32 + 32;
     static_assert(H1 % RB == 0 && RB % 2 == 0 && NPX1 % 4 == 0 && A1_PLANE % 4 == 0 && 4 * SK + DK * ND >= KS_1 && (SK == 8 || SK == 12) && (DK == 0 || DK == 8), "bands, k-step shares");
     static_assert(NT <= 1024 && LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+    static_assert(PIPE == (DK == 0), "the pipelined form is the one where role S holds all of conv 1's weight gradient");
     static_assert(NSL * 1024 + NSL * 32 <= 2 * A1_FLOATS, "the end-of-kernel fold scratch aliases the act1 buffers");
     static_assert(CH * HO2 * HO2 < (1 << 15) && CH * G2_PLANE < (1 << 12) && G2_ROWS <= 4, "role S: packed gact2 element table");
     static_assert(3 * HI * HI < (1 << 15) && 3 * IM_PLANE < (1 << 12) && IM_ROWS <= 16, "role S: packed image group table");
@@ -104,7 +109,7 @@ img_tail2_kernel(const float* __restrict__ gy, const float* __restrict__ wd, con
     if (tid < 256) lds[C::LUT + tid] = (float)tid / 255.f;
     if (tid < 4) lds[C::ZCELL + tid] = 0.f;
     for (int e = tid; e < 2 * C::G2_FLOATS; e += C::NT) lds[C::G2S + e] = 0.f;                                    // (incl. the zero column ox = 21)
-    for (int e = tid; e < 3 * C::IM_ROWS; e += C::NT) lds[C::IMS + e * C::IM_PITCH + 3] = 0.f;                     // x = -1
+    for (int e = tid; e < C::NBUF * 3 * C::IM_ROWS; e += C::NT) lds[C::IMS + e * C::IM_PITCH + 3] = 0.f;           // x = -1
     __syncthreads();                                           // the pad cells are in place before role S stages band 0
 
     float* slab0 = slabs0 + (size_t)blockIdx.x * C::SLAB0;
@@ -130,10 +135,10 @@ img_tail2_kernel(const float* __restrict__ gy, const float* __restrict__ wd, con
     // 2 x + kx - 1.  The operands of the chunk's 8 k-steps are read ahead of its 32 MFMAs.
     // (opq: 0, opaque to the compiler where the caller wants the chunk's twelve addresses recomputed per band instead of hoisted out of
     //  the band loop into registers)
-    auto wgrad1_chunk = [&](auto ck, int s_lo, int s_hi, int opq) {
+    auto wgrad1_chunk = [&](auto ck, int s_lo, int s_hi, int opq, int g1o = 0, int imo = 0) {       // (g1o / imo: the band's gact1 / image buffer, PIPE)
         int m = 4 * s_lo + q + opq;
         int yl = m / C::W1, x = m - yl * C::W1;
-        const int ga = C::G1S + l15 * C::G1_PLANE;
+        const int ga = C::G1S + g1o + l15 * C::G1_PLANE;
         constexpr int CK = decltype(ck)::value;
         float a0[CK], a1v[CK], b0[CK], b1[CK];
 #pragma unroll
@@ -144,8 +149,8 @@ img_tail2_kernel(const float* __restrict__ gy, const float* __restrict__ wd, con
             const int ao = live ? ga + m : C::ZCELL, po = live ? pix : 0;
             a0[u] = lds[ao];
             a1v[u] = lds[live ? ao + 16 * C::G1_PLANE : C::ZCELL];
-            b0[u] = lds[cbase[0] + po];
-            b1[u] = lds[cbase[1] + po];
+            b0[u] = lds[cbase[0] + imo + po];
+            b1[u] = lds[cbase[1] + imo + po];
             m += 4; x += 4;
             if (x >= C::W1) { x -= C::W1; ++yl; }
         }
@@ -291,7 +296,7 @@ img_tail2_kernel(const float* __restrict__ gy, const float* __restrict__ wd, con
                         if constexpr (C::NACC == 2) tot += acc[u * C::NACC + 1];
                         const int yl = 2 * mjb[u] + py, x = 2 * mib[u] + px;
                         const int mo = a1 + (16 * ct + 4 * q) * C::A1_PLANE + C::A1_ROW0 + (yl + 1) * C::A1_PITCH + x;
-                        const int go = C::G1S + (16 * ct + 4 * q) * C::G1_PLANE + yl * C::W1 + x;
+                        const int go = C::G1S + (C::PIPE ? (j & 1) * C::G1_FLOATS : 0) + (16 * ct + 4 * q) * C::G1_PLANE + yl * C::W1 + x;
                         float mv[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) mv[r] = lds[mo + r * C::A1_PLANE];
@@ -309,7 +314,7 @@ img_tail2_kernel(const float* __restrict__ gy, const float* __restrict__ wd, con
                 if (j + 1 < ntl) g2_store(std::integral_constant<int, NLD_>{}, r_g2d, j + 1, dtid);   // (the other gact2 buffer: nobody reads it in this band)
             }
             PHR(2);
-            __syncthreads();                                   // (B) the band of gact1 is complete
+            if constexpr (!C::PIPE) __syncthreads();           // (B) the band of gact1 is complete
             PHR(3);
             // conv 1's weight gradient: this wave's DK k-steps, in chunks of 4 (the filter's 72 registers leave no room for 8)
             if constexpr (C::DK == 8) {
@@ -319,6 +324,7 @@ img_tail2_kernel(const float* __restrict__ gy, const float* __restrict__ wd, con
             PHR(4);
         }
         PHR_FLUSH();
+        if constexpr (C::PIPE) __syncthreads();             // (the last band is complete: role S still has its conv-1 weight gradient to do)
         if constexpr (C::DK == 0) __syncthreads();          // (the fold's first barrier: see below)
     } else if (wave < C::ND + 4) {
         // =====================================================================================================
@@ -367,7 +373,7 @@ img_tail2_kernel(const float* __restrict__ gy, const float* __restrict__ wd, con
 #pragma unroll
                 for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ss & 1], bv[ss & 1][t], acc[t], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (ss + 1 == C::KS_W / 2) { PHR(2); __syncthreads(); PHR(3); }                 // (B): reads only, either side of it
+                if (ss + 1 == C::KS_W / 2) { PHR(2); if constexpr (!C::PIPE) __syncthreads(); PHR(3); }   // (B): reads only, either side of it
             }
             PHR(4);
             // images change every NB bands: nothing to do, the accumulators run on
@@ -381,6 +387,7 @@ img_tail2_kernel(const float* __restrict__ gy, const float* __restrict__ wd, con
         bsum += __shfl_xor(bsum, 32, 64);
         if (ctl == 0 && q == 0) slab1[9216 + 16 * nt + l15] = bsum;
         PHR_FLUSH();
+        if constexpr (C::PIPE) __syncthreads();
         if constexpr (C::DK == 0) __syncthreads();
     } else {
         // =====================================================================================================
@@ -505,7 +512,7 @@ img_tail2_kernel(const float* __restrict__ gy, const float* __restrict__ wd, con
                 } else {
                     v = rok ? r_f4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-                *(float4*)(lds + C::IMS + ((ti >> 15) & 0xfff) + (TAB ? 0 : i * C::IM_PLANE)) = v;
+                *(float4*)(lds + C::IMS + (C::PIPE ? (j & 1) * C::IM_FLOATS : 0) + ((ti >> 15) & 0xfff) + (TAB ? 0 : i * C::IM_PLANE)) = v;
             }
         };
         // NCHW: the halo row above band 0 (act1 row -1 = conv 2's zero padding), behind the band's LDS-DMA
@@ -544,17 +551,19 @@ img_tail2_kernel(const float* __restrict__ gy, const float* __restrict__ wd, con
                 if (j + 1 < ntl) store_a1g2(j + 1, stid);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the band's LDS-DMA has landed (and, with it, the image loads)
             } else {
-                // 96 x 96: the next band's act1 by LDS-DMA and image rows (in flight across the products), ALL of conv 1's weight gradient;
-                // the gact2 rows are role D's there
+                // 96 x 96 (PIPE): the next band's act1 by LDS-DMA and image rows, then ALL of conv 1's weight gradient of the PREVIOUS band
+                // (its gact1 and image bands stay in their buffers for one more step); the gact2 rows are role D's here
                 if (j + 1 < ntl) { issue_img(j + 1, stid); issue_a1g2(j + 1, stid, false); }
                 PHR(2);
-                __syncthreads();                               // (B)
                 PHR(3);
-                int z = 0;
-                asm volatile("" : "+v"(z));
-                wgrad1_chunk(std::integral_constant<int, 4>{}, C::SK * sw, C::SK * sw + 4, z);          // k-steps [0, 4 SK): all of them
-                wgrad1_chunk(std::integral_constant<int, 4>{}, C::SK * sw + 4, C::SK * sw + 8, z);
-                wgrad1_chunk(std::integral_constant<int, 4>{}, C::SK * sw + 8, C::SK * sw + 12, z);
+                if (j > 0) {
+                    int z = 0;
+                    asm volatile("" : "+v"(z));
+                    const int g1o = ((j - 1) & 1) * C::G1_FLOATS, imo = ((j - 1) & 1) * C::IM_FLOATS;
+                    wgrad1_chunk(std::integral_constant<int, 4>{}, C::SK * sw, C::SK * sw + 4, z, g1o, imo);      // k-steps [0, 4 SK): all of them
+                    wgrad1_chunk(std::integral_constant<int, 4>{}, C::SK * sw + 4, C::SK * sw + 8, z, g1o, imo);
+                    wgrad1_chunk(std::integral_constant<int, 4>{}, C::SK * sw + 8, C::SK * sw + 12, z, g1o, imo);
+                }
                 PHR(4);
                 asm volatile("" : "+v"(stid));
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the band's LDS-DMA has landed (and, with it, the image loads)
@@ -563,6 +572,15 @@ img_tail2_kernel(const float* __restrict__ gy, const float* __restrict__ wd, con
             PHR(5);
         }
         PHR_FLUSH();
+        if constexpr (C::PIPE) {
+            __syncthreads();
+            if (ntl > 0) {
+                const int g1o = ((ntl - 1) & 1) * C::G1_FLOATS, imo = ((ntl - 1) & 1) * C::IM_FLOATS;
+                wgrad1_chunk(std::integral_constant<int, 4>{}, C::SK * sw, C::SK * sw + 4, 0, g1o, imo);
+                wgrad1_chunk(std::integral_constant<int, 4>{}, C::SK * sw + 4, C::SK * sw + 8, 0, g1o, imo);
+                wgrad1_chunk(std::integral_constant<int, 4>{}, C::SK * sw + 8, C::SK * sw + 12, 0, g1o, imo);
+            }
+        }
         if constexpr (C::DK == 0) { __syncthreads(); park_slices(sw); }
     }
     // ---- fold the K slices of conv 1's weight gradient (roles S and D) through LDS, fixed order, into this workgroup's
