@@ -288,18 +288,14 @@ def main_ithor(args, rank, local_rank, world, dev):
 
 def tag_kernel(tag, hw):
     """The kernel a profiled conv tag stands for at image size `hw` (its name as rocprofv3 prints it)."""
-    if hw == 84:
-        return {1: "img_head2_kernel<", 2: "img_mid3_kernel<", 7: "img_wgrad345_kernel<", 11: "img_tail2_kernel<",
-                12: "img_chain_kernel", 15: "img_wgrad_reduce_kernel"}.get(tag)
-    return {1: "img_head2_kernel<", 2: "img_mid3_kernel<", 6: "img_wgrad_kernel<", 7: "img_wgrad345_kernel<", 11: "img_bwd_tail_kernel<",
-            12: "img_chain_kernel", 15: "img_wgrad_reduce_kernel"}.get(tag)
+    return {1: "img_head2_kernel<", 2: "img_mid3_kernel<", 7: "img_wgrad345_kernel<", 11: "img_tail2_kernel<",
+            12: "img_chain_kernel", 15: "img_wgrad_reduce_kernel"}.get(tag)          # (the same kernels at 84 x 84 and 96 x 96)
 
 
 def tag_flops(tag):
-    """Algorithmic FLOPs per triplet of a profiled conv launch (csrc/api.hip kTagNames).  84 x 84: tag 1 = conv 1 + conv 2
+    """Algorithmic FLOPs per triplet of a profiled conv launch (csrc/api.hip kTagNames), both image sizes: tag 1 = conv 1 + conv 2
     forward, 2 = conv 3 + 4 + 5 forward (+ image head, not counted), 7 = the weight gradients of conv 3-5, 11 = data gradient
-    of conv 2 + weight gradients of conv 2 and conv 1, 12 = the data gradients of conv 5, 4, 3.  96 x 96: 6 = weight gradient
-    of conv 2, 7 and 12 as at 84 x 84, 11 = data gradient of conv 2 + weight gradient of conv 1.
+    of conv 2 + weight gradients of conv 2 and conv 1, 12 = the data gradients of conv 5, 4, 3.
     Halo recomputation inside the fused kernels is not counted."""
     L = LAYER_FLOPS
     if tag == 1:
@@ -308,11 +304,7 @@ def tag_flops(tag):
         return L[2] + L[3] + L[4]
     if tag in (7, 12):
         return L[2] + L[3] + L[4]
-    if HW == 84:
-        return {11: 2 * L[1] + L[0]}.get(tag, 0)
-    if tag == 11:
-        return L[1] + L[0]
-    return L[tag % 5]
+    return {11: 2 * L[1] + L[0]}.get(tag, 0)
 
 
 def newest_profile(suffix):
@@ -356,25 +348,13 @@ def algorithmic_bytes(tag, B, hw):
         h.append((h[-1] - 1) // 2 + 1)
     act = [B * _CH[l] * h[l] * h[l] * 4 for l in range(6)]     # act[0] as f32; the u8 image is act[0] / 4
     img = act[0] // 4
-    bits = B * h[1] * h[1] * 4
-    if hw == 84:
-        act1 = act[1]
-        return {1: img + act1 + act[2],                          # image in; act1, act2 out
-                2: act[2] + act[3] + act[4] + act[5],
-                7: act[2] + 2 * (act[3] + act[4]) + act[5],      # x of conv 3-5 (act2-4) and their output gradients (gact3-5)
-                11: act1 + act[2] + img,                         # act1 (ReLU gate + conv 2's x), gact2, image
-                12: act[5] + 2 * (act[4] + act[3]) + 2 * act[2]  # gact5 in; act4, act3, act2 (ReLU gates) in; gact4, gact3, gact2 out
-                }.get(tag)
-    if tag == 1:
-        return img + act[1] + act[2] + bits
-    if tag == 2:
-        return act[2] + act[3] + act[4] + act[5]
-    if tag in (7, 8, 9):                      # wgrad l (x, gy) || dgrad l (gy, mask x, gx)
-        l = tag - 5
-        return 2 * act[l + 1] + 3 * act[l]
-    if tag == 11:                             # tail (gact2, bits, image); the weight gradient of conv 2 is tag 6 at this size
-        return act[2] + bits + img
-    return None
+    act1 = act[1]
+    return {1: img + act1 + act[2],                          # image in; act1, act2 out
+            2: act[2] + act[3] + act[4] + act[5],
+            7: act[2] + 2 * (act[3] + act[4]) + act[5],      # x of conv 3-5 (act2-4) and their output gradients (gact3-5)
+            11: act1 + act[2] + img,                         # act1 (ReLU gate + conv 2's x), gact2, image
+            12: act[5] + 2 * (act[4] + act[3]) + 2 * act[2]  # gact5 in; act4, act3, act2 (ReLU gates) in; gact4, gact3, gact2 out
+            }.get(tag)
 
 
 _REAL_STDOUT = None
@@ -635,7 +615,7 @@ def main():
     # the rocprofv3 timeline of the replayed step under profiles/ is the reference for the in-step figure.
     img_us, img_us_side = {}, {}
     if not args.no_roofline and HW in (84, 96):
-        tags = (1, 2, 12, 7, 11, 15) if HW == 84 else (1, 2, 6, 7, 8, 9, 11, 15)
+        tags = (1, 2, 12, 7, 11, 15)
         for serial, dst in ((True, img_us), (False, img_us_side)):
             old_mask = ctx.set_streams(0) if serial else None
             for tag in tags:

@@ -263,8 +263,10 @@ def test_captured_graphs_survive_a_replan(var_amd, golden_dir):
     from var_amd._lib import Context
     ctx = Context.get(0)
     gen0 = ctx.lib.var_plan_generation(ctx.handle)
-    ctx.check(ctx.lib.var_plan(ctx.handle, ctx.plan[0] + 64, 84), "var_plan")      # grows: re-plans
-    ctx.plan = (ctx.plan[0] + 64, 84)
+    # grows past every earlier plan of the process (a 96 x 96 plan holds more per image than an 84 x 84 one: twice the batch is enough): re-plans
+    grown = 2 * ctx.plan[0] + 64
+    ctx.check(ctx.lib.var_plan(ctx.handle, grown, 84), "var_plan")
+    ctx.plan = (grown, 84)
     assert ctx.lib.var_plan_generation(ctx.handle) == gen0 + 1
     trainer_model = make_model(var_amd, load(golden_dir, "kuka_weights2.npz"))
     tr = var_amd.VARTrainer(trainer_model)

@@ -190,7 +190,6 @@ static size_t plan_layout(var_ctx* c, char* base, int max_batch, int img_hw) {
     const size_t n_img_slab = img_slab_floats(), n_snd_slab = snd_slab_floats();
     const size_t o_slab = carve(n_img_slab + n_snd_slab);
     const size_t o_mfcc = carve(2 * B * VAR_MFCC_FRAMES * VAR_MFCC_COEFFS);
-    const size_t o_relu1 = carve(B * hs[1] * hs[1]);          // 2 halves x u16 per pixel
     if (!base) return off;
     c->ws = base;
     c->ws_bytes = off;
@@ -202,7 +201,6 @@ static size_t plan_layout(var_ctx* c, char* base, int max_batch, int img_hw) {
     c->emb = P(o_emb); c->emb_raw = P(o_emb_raw); c->gemb = P(o_gemb); c->ghid = P(o_ghid);
     c->slabs = P(o_slab);
     c->mfcc_buf = P(o_mfcc);
-    c->relu1 = (uint16_t*)P(o_relu1);
     c->slab_floats = n_img_slab + n_snd_slab;
     c->snd_slab_off = n_img_slab;
     c->maxB = max_batch;
@@ -601,9 +599,9 @@ int var_mfcc_ex(var_ctx* c, void* stream, const int16_t* pcm, const int* lens, c
 // what each profiled launch computes (both image sizes; bench.py maps (tag, image size) to the kernel's name)
 static const char* kTagNames[TAG_COUNT] = {
     "(unused)", "img conv1+conv2 forward", "img conv3+4+5 forward + image head", "(unused)",
-    "(unused)", "(unused)", "img conv2 weight gradient (96x96)", "img conv3+4+5 weight gradients",
+    "(unused)", "(unused)", "(unused)", "img conv3+4+5 weight gradients",
     "(unused)", "(unused)", "(unused)",
-    "img conv2 data gradient + conv2, conv1 weight gradients (84x84) / conv2 data + conv1 weight gradient (96x96)",
+    "img conv2 data gradient + conv2, conv1 weight gradients",
     "img conv5-4-3 data gradient chain", "(unused)", "(unused)", "img weight-gradient slab fold",
     "snd_fwd_kernel", "snd_dgrad_kernel", "snd_wgrad_kernel", "snd_reduce_kernel", "heads_fwd_kernel",
     "heads_bwd_rows_kernel", "heads_bwd_gemm_kernel", "triplet_kernel", "adam_kernel", "pack_weights_kernel",
@@ -704,7 +702,6 @@ int var_debug_buffer(var_ctx* c, const char* name, void** ptr, long* nfloats) {
     if (!strcmp(name, "hid_s")) { *ptr = c->hid_s; *nfloats = 2 * (long)B * kHid; return VAR_OK; }
     if (!strcmp(name, "emb")) { *ptr = c->emb; *nfloats = 9 * (long)B; return VAR_OK; }
     if (!strcmp(name, "mfcc")) { *ptr = c->mfcc_buf; *nfloats = 2 * (long)B * VAR_MFCC_FRAMES * VAR_MFCC_COEFFS; return VAR_OK; }
-    if (!strcmp(name, "relu1")) { *ptr = (float*)c->relu1; *nfloats = (long)c->maxB * c->hs[1] * c->hs[1]; return VAR_OK; }
     if (!strcmp(name, "slabs")) { *ptr = c->slabs; *nfloats = (long)c->slab_floats; return VAR_OK; }
     if (!strcmp(name, "gemb")) { *ptr = c->gemb; *nfloats = 9 * (long)B; return VAR_OK; }
     VAR_SET_ERR(c, "var_debug_buffer: unknown buffer '%s'", name);

@@ -2,9 +2,10 @@
 // order of its launches.  Per conv layer  y = relu(conv3x3_s2_p1(x, W) + b):
 //   data gradients of conv 5 -> 4 -> 3: one per-image chain, img_chain.hip (both image sizes);
 //   their weight gradients: ONE grid of img_wgrad.hip's split-K workgroups (below);
-//   conv 2's data gradient + the weight gradients of conv 2 and conv 1: img_tail2.hip (84 x 84), img_wgrad.hip + img_bwd_tail.hip
-//   (96 x 96); then one fixed-order fold of all five layers' slabs (img_wgrad.hip).
-// (Round 2's per-layer data-gradient kernels, paired with the weight gradients in one grid per layer, served 96 x 96 until round 4.)
+//   conv 2's data gradient + the weight gradients of conv 2 and conv 1: img_tail2.hip (both image sizes);
+//   then one fixed-order fold of all five layers' slabs (img_wgrad.hip).
+// (Round 2's kernels -- per-layer data gradients paired with the weight gradients in one grid per layer, img_bwd_tail -- served 96 x 96
+//  until round 4.)
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -58,9 +59,6 @@ static int launch_wgrad345(var_ctx* c, hipStream_t s, int B) {
 int launch_img_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads, int B) {
     int rc;
     const int H = c->H;
-    const long bs[5] = {c->saved_bstride, 32L * c->hs[1] * c->hs[1], 32L * c->hs[2] * c->hs[2],
-                        64L * c->hs[3] * c->hs[3], 64L * c->hs[4] * c->hs[4]};
-    const void* xin[5] = {c->saved_image, c->act[1], c->act[2], c->act[3], c->act[4]};
     if (H != 84 && H != 96) { VAR_SET_ERR(c, "unsupported image size %d (84 or 96)", H); return VAR_ERR_ARG; }
     // data gradients of conv 5 -> 4 -> 3 as one per-image chain (img_chain.hip), then their three weight gradients in one grid
     if ((rc = launch_img_bwd_chain(c, s, B)) != VAR_OK) return rc;

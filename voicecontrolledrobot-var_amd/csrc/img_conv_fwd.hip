@@ -23,8 +23,8 @@ int launch_img_fwd(var_ctx* c, hipStream_t s, const float* params, const void* i
         VAR_SET_ERR(c, "unsupported image size %d (84 or 96)", c->H);
         return VAR_ERR_ARG;
     }
-    // the role-specialised head (img_head2.hip): at 84 x 84 act1 leaves band-tiled for img_tail2.hip, at 96 x 96 as NCHW + relu1 for
-    // round 2's backward kernels (img_bwd_tail.hip, img_wgrad.hip)
+    // the role-specialised head (img_head2.hip): at 84 x 84 act1 leaves band-tiled for img_tail2.hip, at 96 x 96 as NCHW (img_tail2.hip gathers
+    // its bands from the rows)
     // (img_head2 walks an image's seven bands inside ONE workgroup -- the right shape for a full batch, the wrong one for the RL
     //  stage's 8 images, where the per-image latency is the kernel time: an inference-only forward of a small batch takes the
     //  round-2 head, which spreads an image's tiles over workgroups; its NCHW act1 is never read by a backward)

@@ -7,7 +7,7 @@
 //   1. the 2*R2+1 rows of act1 the tile needs, on the matrix cores, from the image band staged in LDS
 //      (D[n][pixel], K = 27 (tap, c) pairs; the u8 -> f32 "/255" of dataset.py:67-68 is a 256-entry LDS table);
 //      bias + ReLU; the tile goes to LDS (the B operand of conv 2), the rows the band owns also go to HBM
-//      (backward needs act1) together with their ReLU bit pattern (img_bwd_tail.hip)
+//      (backward needs act1)
 //   2. conv 2 from that LDS tile: (pixel block) x (filter row ky) wave grid, filter resident in LDS,
 //      the three ky partials folded through LDS in a fixed order; bias + ReLU; act2 to HBM.
 // act1 is written once and not read again in the forward pass.
@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(C::NT)
 img_fwd_head_kernel(const void* __restrict__ image, long bstride, const int* __restrict__ bidx,
                     const float* __restrict__ wp1, const float* __restrict__ bias1,
                     const float* __restrict__ wp2, const float* __restrict__ bias2,
-                    float* __restrict__ y1, uint16_t* __restrict__ relu_bits, float* __restrict__ y2, int B) {
+                    float* __restrict__ y1, float* __restrict__ y2, int B) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NT = C::NT;
     using XT = typename std::conditional<C::U8, uint8_t, float>::type;
@@ -180,7 +180,7 @@ img_fwd_head_kernel(const void* __restrict__ image, long bstride, const int* __r
 #pragma unroll
             for (int s = 0; s < C::KS1; ++s)
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[s], lds[pixoff + osel[s]], acc, 0, 0, 0);
-            // epilogue: bias + ReLU; tile -> LDS, owned rows -> HBM with their ReLU bits
+            // epilogue: bias + ReLU; tile -> LDS, owned rows -> HBM
             const int unit = tile * C::NU + px_u[i];
             const bool uok = unit < total_units;
             const int b = uok ? unit / C::NB : 0, band = uok ? unit - b * C::NB : 0;
@@ -188,13 +188,11 @@ img_fwd_head_kernel(const void* __restrict__ image, long bstride, const int* __r
             const bool live = px_ok[i] && uok && r1 >= 0;
             const bool own = live && px_row[i] >= 1;
             const int lo = C::A1S + px_u[i] * C::UNIT_1 + px_row[i] * C::PW1 + 1 + px_col[i];
-            uint32_t bits = 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = (r & 3) + 8 * (r >> 2) + 4 * half;
                 float v = acc[r] + lds[C::BIA + n];
                 v = (live && v > 0.f) ? v : 0.f;
-                bits |= v > 0.f ? (1u << r) : 0u;
                 acc[r] = v;
             }
             if (px_ok[i]) {
@@ -205,7 +203,6 @@ img_fwd_head_kernel(const void* __restrict__ image, long bstride, const int* __r
                 float* gp = y1 + (size_t)b * C::CH * C::H1 * C::W1 + r1 * C::W1 + px_col[i] + 4 * half * C::H1 * C::W1;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) gp[((r & 3) + 8 * (r >> 2)) * C::H1 * C::W1] = acc[r];
-                relu_bits[((size_t)b * 2 + half) * C::H1 * C::W1 + r1 * C::W1 + px_col[i]] = (uint16_t)bits;
             }
         }
         PH(3);
@@ -295,12 +292,12 @@ static int launch_head(var_ctx* c, hipStream_t s, const void* image, long bstrid
     const PackLayout& K = c->kl;
     hipLaunchKernelGGL(img_fwd_head_kernel<C>, dim3(G), dim3(C::NT), C::LDS_BYTES, s, image, bstride, bidx,
                        c->wpack + K.img_f[0], params + L.img_b[0], c->wpack + K.img_f[1], params + L.img_b[1],
-                       c->act[1], c->relu1, c->act[2], B);
+                       c->act[1], c->act[2], B);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }
 
-// conv 1 + conv 2 of the image CNN; leaves act[1], relu1 and act[2]
+// conv 1 + conv 2 of the image CNN; leaves act[1] and act[2]
 int launch_img_fwd_head(var_ctx* c, hipStream_t s, const float* params, const void* image, int is_u8, long bstride,
                         const int* image_index, int B) {
     if (c->H == 84) return is_u8 ? launch_head<H84u>(c, s, image, bstride, image_index, params, B)

@@ -16,8 +16,8 @@
 //     wave; two independent accumulators per wave cover the instruction's 40-cycle dependent latency;
 //   * the staged image band and the act1 tile are stored column-parity split ([odd columns | even columns] per row), so
 //     the stride-2 taps read consecutive floats (no 2-way bank conflicts on the B operand).
-// Outputs are those of the first form, bit for bit in layout: act1 (NCHW), its ReLU bit pattern relu1 (u16 per pixel
-// and channel half, bit r <-> channel (r & 3) + 8 (r >> 2) + 4 half; img_bwd_tail.hip reads it) and act2.
+// Outputs: act2 (NCHW) and act1 -- band-tiled (84 x 84) or NCHW (96 x 96), see Head2Cfg; img_tail2.hip takes the ReLU mask of the
+// backward from act1 itself (the ReLU bit image of rounds 1-3 is gone).
 #include <stdlib.h>
 
 #include <type_traits>
@@ -27,8 +27,8 @@
 namespace {
 typedef float f32x4h __attribute__((ext_vector_type(4)));
 
-// TILED_: act1 leaves band-tiled (what img_tail2.hip reads: 84 x 84); otherwise as NCHW rows + the ReLU bit image relu1 of the first
-// form (what img_bwd_tail.hip / img_wgrad.hip read: 96 x 96)
+// TILED_: act1 leaves band-tiled (84 x 84: img_tail2.hip's bands are this kernel's); otherwise as NCHW rows (96 x 96: img_tail2.hip's
+// twelve bands of four rows are gathered from them)
 template <int H1_, bool U8_, int R2_, int NA_, bool TILED_>
 struct Head2Cfg {
     static constexpr int H1 = H1_, W1 = H1_, R2 = R2_;
@@ -97,7 +97,7 @@ __device__ __forceinline__ void img_head2_body(const void* __restrict__ image, l
                                                const float* __restrict__ wp1, const float* __restrict__ bias1,
                                                const float* __restrict__ wp2, const float* __restrict__ bias2,
                                                float* __restrict__ y1, float* __restrict__ y2, int B, const int bx, const int G,
-                                               EARLY early, uint16_t* __restrict__ relu_bits = nullptr) {
+                                               EARLY early) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using XT = typename std::conditional<C::U8, uint8_t, float>::type;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -280,22 +280,6 @@ __device__ __forceinline__ void img_head2_body(const void* __restrict__ image, l
                         d[(16 + r) * C::PLANE_1] = __builtin_amdgcn_fmed3f(e1[r], 0.f, __builtin_inff());
                     }
                 }
-                if constexpr (!C::TILED) {
-                    // the ReLU bit image of the first form (var_ctx::relu1: [b][half][y][x], bit r <-> channel (r & 3) + 8 (r >> 2) + 4 half):
-                    // this lane holds channels 4 q + r and 16 + 4 q + r = bits 4 (q >> 1) + r and 8 + 4 (q >> 1) + r of half q & 1;
-                    // the lane 32 further on holds the other eight bits of the same half
-                    uint32_t bits = 0;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        bits |= e0[r] > 0.f ? 1u << r : 0u;
-                        bits |= e1[r] > 0.f ? 0x100u << r : 0u;
-                    }
-                    bits <<= 4 * (q >> 1);
-                    bits |= (uint32_t)__shfl_xor((int)bits, 32, 64);
-                    const int rl = p / C::W1, x1 = p - rl * C::W1;
-                    if (q < 2 && p < C::NPX1 && rl >= 1)
-                        relu_bits[((size_t)tile_img(j) * 2 + q) * C::H1 * C::W1 + (band * 2 * C::R2 + rl - 1) * C::W1 + x1] = (uint16_t)bits;
-                }
             }
         };
         // ---- pipeline: step j runs conv 2 of tile j (role B) beside conv 1 of tile j + 1 and the staging of tile j + 2 ----
@@ -395,11 +379,11 @@ __global__ void __launch_bounds__(C::NT)
 img_head2_kernel(const void* __restrict__ image, long bstride, const int* __restrict__ bidx,
                  const float* __restrict__ wp1, const float* __restrict__ bias1,
                  const float* __restrict__ wp2, const float* __restrict__ bias2,
-                 float* __restrict__ y1, uint16_t* __restrict__ relu_bits, float* __restrict__ y2, int B) {
+                 float* __restrict__ y1, float* __restrict__ y2, int B) {
 #if defined(VAR_PHASES) && !defined(VAR_HEAD2_DEVICE_ONLY)
     if (threadIdx.x == 0) g_span_h2[blockIdx.x][0] = wall_clock64();
 #endif
-    img_head2_body<C>(image, bstride, bidx, wp1, bias1, wp2, bias2, y1, y2, B, (int)blockIdx.x, (int)gridDim.x, [](int) {}, relu_bits);
+    img_head2_body<C>(image, bstride, bidx, wp1, bias1, wp2, bias2, y1, y2, B, (int)blockIdx.x, (int)gridDim.x, [](int) {});
 #if defined(VAR_PHASES) && !defined(VAR_HEAD2_DEVICE_ONLY)
     if (threadIdx.x == 0) g_span_h2[blockIdx.x][1] = wall_clock64();
 #endif
@@ -427,7 +411,7 @@ int launch_head2(var_ctx* c, hipStream_t s, const void* image, long bstride, con
     const PackLayout& K = c->kl;
     hipLaunchKernelGGL(img_head2_kernel<C>, dim3(G), dim3(C::NT), C::LDS_BYTES, s, image, bstride, bidx,
                        c->wpack + K.img_f[0], params + L.img_b[0], c->wpack + K.img_f[1], params + L.img_b[1],
-                       c->act[1], c->relu1, c->act[2], B);
+                       c->act[1], c->act[2], B);
     VAR_HIP_CHECK(c, hipGetLastError());
     return VAR_OK;
 }
@@ -453,7 +437,7 @@ int launch_act1_untile(var_ctx* c, hipStream_t s, int B) {
     return VAR_OK;
 }
 
-// conv 1 + conv 2 of the image CNN; leaves act[2] and act[1] -- band-tiled at 84 x 84, NCHW + relu1 at 96 x 96
+// conv 1 + conv 2 of the image CNN; leaves act[2] and act[1] -- band-tiled at 84 x 84, NCHW at 96 x 96
 int launch_img_fwd_head2(var_ctx* c, hipStream_t s, const float* params, const void* image, int is_u8, long bstride,
                          const int* image_index, int B) {
     if (c->H == 96)

@@ -275,22 +275,10 @@ __device__ __forceinline__ void img_wgrad_body(const void* __restrict__ xin, lon
     PHR_FLUSH();
 }
 
-template <class C>
-__global__ void __launch_bounds__(C::NW * 64)
-img_wgrad_kernel(const void* __restrict__ xin, long bstride, const int* __restrict__ bidx,
-                 const float* __restrict__ gy, float* __restrict__ slabs, int B) {
-    img_wgrad_body<C>(xin, bstride, bidx, gy, slabs, B, blockIdx.x, blockIdx.y, gridDim.x);
-}
-
 //                   CIN COUT  H   U8    R  NU KS
-using W84_0u = WgCfg<3, 32, 84, true, 6, 1, 4>;
-using W84_0f = WgCfg<3, 32, 84, false, 6, 1, 4>;
 using W84_2 = WgCfg<32, 64, 21, false, 11, 1, 4>;
 using W84_3 = WgCfg<64, 64, 11, false, 6, 4, 4>;       // four images per stage: a unit of this layer is too short to cover a load round trip
 using W84_4 = WgCfg<64, 64, 6, false, 3, 4, 4>;
-using W96_0u = WgCfg<3, 32, 96, true, 6, 1, 4>;
-using W96_0f = WgCfg<3, 32, 96, false, 6, 1, 4>;
-using W96_1 = WgCfg<32, 32, 48, false, 3, 1, 4>;
 using W96_2 = WgCfg<32, 64, 24, false, 6, 1, 4>;
 using W96_3 = WgCfg<64, 64, 12, false, 6, 1, 4>;
 using W96_4 = WgCfg<64, 64, 6, false, 3, 4, 4>;
@@ -364,33 +352,6 @@ static size_t slab_offset(int layer) {
     size_t o = 0;
     for (int i = 0; i < layer; i++) o += (size_t)kWgG[i] * kCombo[i] * kSlabSz[i];
     return o;
-}
-
-template <class C>
-static int launch_wgrad(var_ctx* c, hipStream_t s, const void* x, long bstride, const float* gy, int B, int layer) {
-    static_assert(C::NCOMBO * C::SLAB <= 4 * 9248, "slab sizing");
-    const int* bidx = layer == 0 ? c->saved_index : nullptr;
-    ProfScope prof(c, s, TAG_IMG_WGRAD0 + layer);
-    static unsigned attr_set = 0;      // bit d: set on device d (function attributes are per device)
-    if (!(attr_set & var_dev_bit(c))) {
-        VAR_HIP_CHECK(c, hipFuncSetAttribute((const void*)img_wgrad_kernel<C>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-        attr_set |= var_dev_bit(c);
-    }
-    const int need = (B * C::NB + C::NU - 1) / C::NU;
-    const int gmax = kWgG[layer];
-    const int G = need < gmax ? need : gmax;
-    c->wg_groups[layer] = G;
-    hipLaunchKernelGGL(img_wgrad_kernel<C>, dim3(G, C::NCOMBO), dim3(C::NT), C::LDS_BYTES, s, x, bstride, bidx, gy,
-                       c->slabs + slab_offset(layer), B);
-    VAR_HIP_CHECK(c, hipGetLastError());
-    return VAR_OK;
-}
-
-// weight gradient of image conv 2 at 96 x 96 (the only stand-alone weight-gradient launch left: every other one
-// shares a grid with a data gradient, img_conv_bwd.hip): x = act1, gy = gact[2]
-int launch_img_wgrad1_96(var_ctx* c, hipStream_t s, const void* x, long bstride, const float* gy, int B) {
-    return launch_wgrad<W96_1>(c, s, x, bstride, gy, B, 1);
 }
 
 // fixed-order slab sums of layers [lo, hi] into the gradient arena

@@ -145,7 +145,6 @@ struct var_ctx {
     const float* dot_with = nullptr;   // var_set_reward_dot: the next small-batch image-head forward also leaves <emb, dot_with> rows in dot_out
     float* dot_out = nullptr;
     bool dev_join = false;        // this step's forward left the side stream un-joined: the image rows wait on jsig[1]
-    uint16_t* relu1 = nullptr;    // ReLU bits of the first image activation: [b][half][y][x], bit r <-> channel (r&3)+8(r>>2)+4*half
     float* slabs = nullptr;       // split-K partial weight gradients
     size_t slab_floats = 0;
     size_t snd_slab_off = 0;
@@ -296,7 +295,6 @@ int pack_table_upload(var_ctx* c);
 size_t img_slab_floats();
 int img_wgrad_groups(int layer);
 size_t img_slab_offset(int layer);
-int launch_img_wgrad1_96(var_ctx* c, hipStream_t s, const void* x, long bstride, const float* gy, int B);
 int launch_img_wgrad_reduce(var_ctx* c, hipStream_t s, float* grads, int lo, int hi);
 size_t snd_slab_floats();
 
@@ -322,7 +320,6 @@ static constexpr int kHead2G = VAR_HEAD2_G;   // persistent workgroups of img_he
 int launch_img_fwd_mid(var_ctx* c, hipStream_t s, const float* params, int B, bool with_head);
 int launch_img_fwd_all(var_ctx* c, hipStream_t s, const float* params, const void* image, int is_u8, long bstride,
                        const int* image_index, int B);      // img_mid3.hip: conv 1-5 + image head in one launch (84 x 84, B <= 256)
-// (launch_img_fwd also leaves c->relu1)
 // default: the whole sound branch -- MFCC front-end, sound CNN and sound head, forward and backward -- beside the image
 // CNN on one side stream.  (Round 1 kept the 61-us MFCC on the caller's stream, mask 19; with round 2's 43-us kernel the
 // image chain starting at once and the front-end on the side stream is 4-5 us per step faster: 0.346 vs 0.351 ms.)  Measured on MI355X (graph replay):
@@ -335,7 +332,6 @@ int launch_act1_untile(var_ctx* c, hipStream_t s, int B);      // img_head2.hip:
 int launch_img_bwd_chain(var_ctx* c, hipStream_t s, int B);   // img_chain.hip: dgrad 4 -> 3 -> 2 (conv 5, 4, 3) per image, gradients resident in LDS
 static constexpr int kTail2G = 256;   // persistent workgroups (= layer-0 and layer-1 slabs) of img_tail2_kernel: one image each
 int launch_img_bwd_tail2(var_ctx* c, hipStream_t s, int B);   // img_tail2.hip: wgrad 2 + dgrad 2 + wgrad 1 at 84 x 84
-int launch_img_bwd_tail(var_ctx* c, hipStream_t s, int B);
 int launch_img_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads, int B);
 int launch_snd_fwd(var_ctx* c, hipStream_t s, const float* params, const float* pos, const float* neg, int B);
 int launch_snd_bwd(var_ctx* c, hipStream_t s, const float* params, float* grads, int B);
