@@ -545,7 +545,9 @@ img_tail2_kernel(const float* __restrict__ gy, const float* __restrict__ wd, con
                 PHR(2);
                 __syncthreads();                               // (B) gact1 band complete (role D), image band stored (this role)
                 PHR(3);
-                wgrad1_chunk(std::integral_constant<int, 8>{}, 8 * sw, 8 * sw + 8, 0);     // k-steps [0, 32) here, the rest in role D
+                int z8 = 0;
+                asm volatile("" : "+v"(z8));
+                wgrad1_chunk(std::integral_constant<int, 8>{}, 8 * sw, 8 * sw + 8, z8);    // k-steps [0, 32) here, the rest in role D
                 PHR(4);
                 asm volatile("" : "+v"(stid));
                 if (j + 1 < ntl) store_a1g2(j + 1, stid);
