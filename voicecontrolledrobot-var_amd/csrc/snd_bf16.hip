@@ -781,6 +781,9 @@ __global__ void __launch_bounds__(256, 2) snd1_fwd_kernel(const float* __restric
                                                           int nclips) {
     extern __shared__ __align__(16) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p31 = lane & 31;
+    // pixel blocks per pass: the 22 filter fragments (88 registers) and the 32 biases leave room for two blocks' accumulators (64) at two
+    // waves per SIMD -- with four (128) the kernel spilled 88-140 registers
+    constexpr int MB = 2;
     for (int i = tid; i < C1_LDSB / 16; i += 256) ((uint4*)lds)[i] = make_uint4(0, 0, 0, 0);
     u32x4_t wf[11][2];
 #pragma unroll
@@ -795,28 +798,32 @@ __global__ void __launch_bounds__(256, 2) snd1_fwd_kernel(const float* __restric
     for (int clip = blockIdx.x; clip < nclips; clip += gridDim.x) {
         __syncthreads();                                        // (zero fill | the previous clip's reads) before the image changes
         const float4* src = (const float4*)(clip < n0 ? x0 + (long)clip * (C1_H * C1_W) : x1 + (long)(clip - n0) * (C1_H * C1_W));
-        constexpr int NV = (C1_H * C1_W / 4 + 255) / 256;      // 24 float4 per thread, all in flight at once
-        float4 v[NV];
+        constexpr int NV = (C1_H * C1_W / 4 + 255) / 256;      // 24 float4 per thread, in two batches of 12 in flight (beside the filter's 88 registers)
+        static_assert(NV % 2 == 0, "two batches");
 #pragma unroll
-        for (int k = 0; k < NV; ++k) { const int i = tid + 256 * k; v[k] = src[min(i, C1_H * C1_W / 4 - 1)]; }
+        for (int hb = 0; hb < 2; ++hb) {
+            float4 v[NV / 2];
 #pragma unroll
-        for (int k = 0; k < NV; ++k) {                          // row r, columns 4 c4 .. 4 c4 + 3 -> elements 5 + column of row r + 5
-            const int i = tid + 256 * k, r = i / (C1_W / 4), c4 = i - r * (C1_W / 4);
-            if (i < C1_H * C1_W / 4) {                          // (odd first element: a 2-byte, a 4-byte and a 2-byte store)
-                unsigned char* d = lds + (r + 5) * C1_PITCH + 2 * (5 + 4 * c4);
-                *(unsigned short*)d = (unsigned short)bf16_bits(v[k].x);
-                *(unsigned*)(d + 2) = bf16_bits(v[k].y) | (bf16_bits(v[k].z) << 16);
-                *(unsigned short*)(d + 6) = (unsigned short)bf16_bits(v[k].w);
+            for (int k = 0; k < NV / 2; ++k) { const int i = tid + 256 * (k + hb * (NV / 2)); v[k] = src[min(i, C1_H * C1_W / 4 - 1)]; }
+#pragma unroll
+            for (int k = 0; k < NV / 2; ++k) {                  // row r, columns 4 c4 .. 4 c4 + 3 -> elements 5 + column of row r + 5
+                const int i = tid + 256 * (k + hb * (NV / 2)), r = i / (C1_W / 4), c4 = i - r * (C1_W / 4);
+                if (i < C1_H * C1_W / 4) {                      // (odd first element: a 2-byte, a 4-byte and a 2-byte store)
+                    unsigned char* d = lds + (r + 5) * C1_PITCH + 2 * (5 + 4 * c4);
+                    *(unsigned short*)d = (unsigned short)bf16_bits(v[k].x);
+                    *(unsigned*)(d + 2) = bf16_bits(v[k].y) | (bf16_bits(v[k].z) << 16);
+                    *(unsigned short*)(d + 6) = (unsigned short)bf16_bits(v[k].w);
+                }
             }
         }
         __syncthreads();
         const long oclip = clip;
-        for (int g = wave; g < (C1_NBLK + 3) / 4; g += 4) {     // four 32-pixel blocks at a time
-            f32x16_t acc[4][2];
-            int base[4];
+        for (int g = wave; g < (C1_NBLK + MB - 1) / MB; g += 4) {     // MB 32-pixel blocks at a time
+            f32x16_t acc[MB][2];
+            int base[MB];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int P = min(32 * (4 * g + m) + p31, C1_HO * C1_WO - 1), oy = P / C1_WO, ox = P - oy * C1_WO;
+            for (int m = 0; m < MB; ++m) {
+                const int P = min(32 * (MB * g + m) + p31, C1_HO * C1_WO - 1), oy = P / C1_WO, ox = P - oy * C1_WO;
                 base[m] = 2 * oy * C1_PITCH + 4 * ox + 16 * h;
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
@@ -825,22 +832,22 @@ __global__ void __launch_bounds__(256, 2) snd1_fwd_kernel(const float* __restric
             }
 #pragma unroll
             for (int ky = 0; ky < 11; ++ky) {
-                u32x4_t b[4];
+                u32x4_t b[MB];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
+                for (int m = 0; m < MB; ++m) {
                     const unsigned* q = (const unsigned*)(lds + base[m] + ky * C1_PITCH);
                     b[m].x = q[0]; b[m].y = q[1]; b[m].z = q[2]; b[m].w = q[3];
                 }
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < MB; ++m)
 #pragma unroll
                     for (int cb = 0; cb < 2; ++cb)
                         acc[m][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[ky][cb]),
                                                                              __builtin_bit_cast(bf16x8_t, b[m]), acc[m][cb], 0, 0, 0);
             }
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int P = 32 * (4 * g + m) + p31;
+            for (int m = 0; m < MB; ++m) {
+                const int P = 32 * (MB * g + m) + p31;
                 if (P < C1_HO * C1_WO) {
                     unsigned mk = 0u;
 #pragma unroll
