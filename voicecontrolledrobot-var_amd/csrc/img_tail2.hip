@@ -527,7 +527,7 @@ img_tail2_kernel(const float* __restrict__ gy, const float* __restrict__ wd, con
                 }
             }
         };
-        if (ntl > 0) { issue_a1g2(0, stid0); store_a1g2(0, stid0); issue_img(0, stid0); }
+        if (ntl > 0) { issue_a1g2(0, stid0); issue_img(0, stid0); store_a1g2(0, stid0); }     // (every request of band 0 out before the first wait)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (ntl > 0) zero_halo(0, stid0);
         __syncthreads();                                       // (P)
