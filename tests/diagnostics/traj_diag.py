@@ -1,12 +1,12 @@
 """Diagnostic: 10-step trajectory HIP (replayed graph) vs CPU restatement, per-tensor drift, run twice."""
 import os, sys, types
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import var_amd
 from oracle import mfcc_np
 from oracle.torch_oracle import CPUTrainer
 from oracle import var_oracle as orc
-G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+G = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden")
 sd = dict(np.load(os.path.join(G, "kuka_weights.npz")))
 cfg = types.SimpleNamespace(img_dim=(3, 84, 84), sound_dim=(1, 100, 40), representationDim=3)
 B, steps = 256, 10

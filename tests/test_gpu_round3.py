@@ -217,7 +217,7 @@ def test_ithor_bf16_gradient_drift_is_accounted_for(var_amd):
         two forwards must sit at a pre-activation within bf16 rounding of zero, and such units are a small fraction.
     (b) Weight tensors: within 30 % in L2, and any drift above 3 % needs at least one differing gate.
     (c) The image branch's BIAS gradients (32-128 sums over every pixel of the batch) drifted by up to 34 % in round 3 and the
-        bound had been widened to 50 % on the strength of a comment about pool winners.  Traced now (tools/probe/bf16_bias_trace.py):
+        bound had been widened to 50 % on the strength of a comment about pool winners.  Traced now (tests/diagnostics/bf16_bias_trace.py):
         the terms of those sums are the buffers ga1..ga5; split by unit, the part of the difference on units the gradient
         reaches in only ONE of the two runs (gate / pool-winner flips) is 2-15 % of the tensor's norm -- the rest sits on
         units BOTH runs reach and is operand rounding: the sums cancel heavily (sum |g| / |sum g| = 8 ... 270), so a
