@@ -322,11 +322,11 @@ def newest_profile(suffix):
 def pmc_traffic(tag, hw):
     """HBM bytes per launch of the dominant kernel, from the committed PMC pass of THIS round's kernels (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction: FETCH_SIZE x 2; tools/pmc_traffic.sh ->
-    profiles/rNN_pmc_hbm_traffic.json, the newest round present; batch 256, 84 x 84 only).
+    profiles/rNN_pmc_hbm_traffic.json | rNN_hw96_pmc_hbm_traffic.json, the newest round present; batch 256).
     PMC counters cannot be collected from inside this process, so this is the figure of that pass
     (same workload, same kernel); None when the file or the kernel is not in it."""
-    path = newest_profile("pmc_hbm_traffic.json")
-    if hw != 84 or path is None:
+    path = newest_profile("pmc_hbm_traffic.json" if hw == 84 else "hw96_pmc_hbm_traffic.json")
+    if hw not in (84, 96) or path is None:
         return None
     want = tag_kernel(tag, hw)
     if want is None or not os.path.exists(path):
