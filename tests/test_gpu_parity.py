@@ -202,11 +202,13 @@ def test_mfcc_vs_oracle(var_amd):
         assert err < 2e-3, (i, err)                              # f32 front-end vs f64 oracle; |MFCC| up to ~1e2
 
 
-def test_batch_256_properties(var_amd, golden_dir):
-    """Full bench size: per-sample independence of the forward and linearity of the batch gradient."""
+@pytest.mark.parametrize("h", [84, 96])
+def test_batch_256_properties(var_amd, golden_dir, h):
+    """Full bench size, both image sizes: per-sample independence of the forward (the 64-image slice takes the inference path's
+    kernels, the full batch the training path's) and linearity of the batch gradient."""
     sd = load(golden_dir, "kuka_weights2.npz")
-    m = make_model(var_amd, sd, 84)
-    pool = var_amd.SyntheticTripletPool(512, hw=84, seed=3, clips_per_class=8)
+    m = make_model(var_amd, sd, h)
+    pool = var_amd.SyntheticTripletPool(512, hw=h, seed=3, clips_per_class=8)
     idx, cp = pool.sample_indices(256)
     img, pcm, lens = pool.gather(idx, cp)
     feats = var_amd.mfcc(pcm, lens)
@@ -237,7 +239,7 @@ def test_batch_256_properties(var_amd, golden_dir):
     from var_amd._lib import ptr, current_stream_handle
     c.check(c.lib.var_arm_loss_grad_pcm(c.handle, current_stream_handle(), ptr(m.flat_parameters()), ptr(pool.images), 1,
                                         pool.images.stride(0), ptr(idx.to(torch.int32)), ptr(pool.clips),
-                                        pool.clips.stride(0), ptr(clip_id), ptr(lens), 256, 84, 1.0, 1.0 / 256,
+                                        pool.clips.stride(0), ptr(clip_id), ptr(lens), 256, h, 1.0, 1.0 / 256,
                                         ptr(tr2.gbuf), tr2.gbuf.data_ptr() + 4 * var_amd.N_PARAMS, None), "pcm step")
     assert abs(tr2.loss.item() - l_ref2) < 1e-6
     assert torch.equal(tr2.grads, g_ref2)
