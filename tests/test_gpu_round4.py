@@ -31,8 +31,8 @@ def make_model(var_amd, sd, h=84):
     return m.to("cuda")
 
 
-@pytest.mark.parametrize("B", [48, 256])
-def test_device_side_stream_join_equals_the_graph_edge(var_amd, golden_dir, B):
+@pytest.mark.parametrize("B,h", [(48, 84), (256, 84), (256, 96)])
+def test_device_side_stream_join_equals_the_graph_edge(var_amd, golden_dir, B, h):
     """Round 4: inside a training step no graph edge crosses the two streams between the fork and the final join -- a barrier
     packet in front of the first backward kernel cost ~10 us of every replayed step.  The image rows of the heads' backward need
     the sound embeddings' partials, the sound rows the image's: the last workgroup of each producer (sound heads' forward / the
@@ -40,18 +40,18 @@ def test_device_side_stream_join_equals_the_graph_edge(var_amd, golden_dir, B):
     the other stream's partials with agent-scope loads (csrc/var_common.h: join_signal; csrc/heads.hip).  Same arithmetic either
     way: replayed steps with the flags (default) and with the edges (var_set_streams bit 6) from the same start must leave
     bit-identical losses and parameters, eager steps (which always keep the edges) likewise, and no wait may have timed out
-    (var_join_status)."""
+    (var_join_status).  (256, 96): the replayed step on the 96 x 96 forms of the image kernels."""
     from var_amd._lib import Context
     sd = load(golden_dir, "kuka_weights.npz")
     ctx = Context.get(0)
-    pool = var_amd.SyntheticTripletPool(4 * B, hw=84, seed=5, clips_per_class=4).freeze_pairs()
+    pool = var_amd.SyntheticTripletPool(4 * B, hw=h, seed=5, clips_per_class=4).freeze_pairs()
     table = pool.index_table(B, 4)[:4].contiguous()
     before = ctx.join_timeouts()
     out = {}
     for mode, mask in (("flag", 3), ("edge", 3 | 64)):
         old = ctx.set_streams(mask)
         try:
-            m = make_model(var_amd, sd, 84)
+            m = make_model(var_amd, sd, h)
             tr = var_amd.VARTrainer(m, lr=1e-3, weight_decay=1e-6)
             replay, _ = tr.capture_epoch_steps(pool.images, pool.clips, B, table)
             losses = [float(replay().item()) for _ in range(6)]
