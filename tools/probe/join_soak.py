@@ -1,5 +1,5 @@
 """Soak of the replayed training step's device-side stream hand-over: N replays, then var_join_status and the slowest replays
-(a time-out shows as a 5-ms replay)."""
+(a time-out shows as a 5-ms replay).  usage: join_soak.py [replays] [84 | 96]"""
 import os, sys, types, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -7,11 +7,12 @@ import var_amd
 from var_amd._lib import Context
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 B = 256
-cfg = types.SimpleNamespace(img_dim=(3, 84, 84), sound_dim=(1, 100, 40), representationDim=3)
+HW = int(sys.argv[2]) if len(sys.argv) > 2 else 84
+cfg = types.SimpleNamespace(img_dim=(3, HW, HW), sound_dim=(1, 100, 40), representationDim=3)
 torch.manual_seed(1)
 m = var_amd.VARPretextNet(cfg).to("cuda")
 tr = var_amd.VARTrainer(m, lr=1e-4)
-pool = var_amd.SyntheticTripletPool(8192, hw=84, seed=5, clips_per_class=8).freeze_pairs()
+pool = var_amd.SyntheticTripletPool(8192, hw=HW, seed=5, clips_per_class=8).freeze_pairs()
 table = pool.index_table(B, 16)[:16].contiguous()
 ctx = Context.get(0)
 replay, _ = tr.capture_epoch_steps(pool.images, pool.clips, B, table)
